@@ -1,0 +1,478 @@
+"""oracle/reference_math.py — CPU restatement of the GraphTrans forward hot path.
+
+*** TEST INFRASTRUCTURE.  Not product code. ***
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module, and only as the checker / the timed CPU baseline.  The product (`graphtrans_amd/`) never
+imports it and fails loudly when its HIP library is missing.
+
+What it is: a from-the-equations, functional (state_dict in, tensors out) restatement in plain
+fp32 PyTorch-CPU ops of the reference's hot path (SURVEY.md §8a rows a1–a10, a12).  Every
+function cites the reference lines it follows (paths relative to /root/reference).  Autograd of
+these plain ops provides the reference gradients.
+
+Third-party algorithm boundary: the reference delegates gather/scatter to torch-geometric==1.6.3
+`MessagePassing` (requirement.yml:97) and torch-scatter==2.0.6 (requirement.yml:98), which are
+NOT in /root/reference.  Their published semantics (flow="source_to_target":
+x_j = x[edge_index[0]], sum-aggregate at edge_index[1], dim_size=N) are restated here, anchored on
+the reference's own call sites (modules/conv.py:28,63; modules/gnn_module.py:219).
+
+Pinning: the reference has no tests / golden vectors for this path.  This oracle
+is pinned instead against outputs of the reference itself, imported unmodified from
+/root/reference in the build container by `oracle/make_golden.py` (third-party imports satisfied
+by `oracle/stubs/`), committed as `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks
+every one of them (outputs, input grads, parameter grads).
+
+Parameters are addressed by the reference's own state_dict keys, so a reference
+checkpoint drives the oracle directly.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+
+
+def _sub(sd, prefix):
+    """View of a state_dict below `prefix` ('' keeps everything)."""
+    if not prefix:
+        return sd
+    p = prefix if prefix.endswith(".") else prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+def default_args(**kw):
+    """The reference's flag defaults that the hot path reads (main.py:53-58,
+    modules/transformer_encoder.py:13-20, modules/masked_transformer_encoder.py:108-109,
+    models/gnn_transformer.py:25-28)."""
+    a = dict(
+        gnn_virtual_node=False, gnn_num_layer=5, gnn_emb_dim=300, gnn_JK="last", gnn_dropout=0.0,
+        gnn_residual=False, gnn_type="gcn", pretrained_gnn=None, freeze_gnn=None,
+        d_model=128, nhead=4, dim_feedforward=512, transformer_dropout=0.3,
+        transformer_activation="relu", num_encoder_layers=4, max_input_len=1000,
+        transformer_norm_input=False, graph_pooling="mean", num_encoder_layers_masked=0,
+        transformer_prenorm=False, pos_encoder=False, max_seq_len=None,
+    )
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def batch_norm(x, sd, prefix, training, eps=1e-5):
+    """nn.BatchNorm1d forward (gnn_module.py:84,204; conv.py:19): batch statistics (biased
+    variance) in training mode, running statistics in eval mode.  Functional: running stats are
+    not updated here."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if training:
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+    else:
+        mean, var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def layer_norm(x, sd, prefix, eps=1e-5):
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    mean = x.mean(-1, keepdim=True)
+    var = x.var(-1, unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def linear(x, sd, prefix):
+    return x @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
+
+
+def dropout(x, p, training):
+    # parity runs use p == 0 or eval; the CPU-baseline timing run uses the config's p.
+    return F.dropout(x, p, training) if (training and p > 0) else x
+
+
+# --------------------------------------------------------------------------------------------
+# a12: input encoders
+# --------------------------------------------------------------------------------------------
+
+
+def node_encode(sd, prefix, x, node_depth=None):
+    """Node feature encoder, kind inferred from the state_dict keys.
+    ASTNodeEncoder (dataset/utils.py:28-30): type_emb[x[:,0]] + attr_emb[x[:,1]] +
+    depth_emb[min(depth, max_depth)] (max_depth = rows-1; the input is not mutated here).
+    AtomEncoder (ogb; dataset/mol.py:83): sum_i atom_embedding_list[i][x[:,i]].
+    nn.Linear (dataset/tud.py:65)."""
+    s = _sub(sd, prefix)
+    if "type_encoder.weight" in s:
+        max_depth = s["depth_encoder.weight"].shape[0] - 1
+        d = node_depth.view(-1).clamp(max=max_depth)
+        return s["type_encoder.weight"][x[:, 0]] + s["attribute_encoder.weight"][x[:, 1]] + s["depth_encoder.weight"][d]
+    if "atom_embedding_list.0.weight" in s:
+        out = 0
+        for i in range(x.shape[1]):
+            out = out + s[f"atom_embedding_list.{i}.weight"][x[:, i]]
+        return out
+    if "weight" in s:
+        return x @ s["weight"].t() + s["bias"]
+    return x
+
+
+def edge_encode(sd, prefix, edge_attr):
+    """Edge feature encoder (conv.py:27,52).  nn.Linear(2, D) (dataset/code.py:117), ogb
+    BondEncoder (dataset/mol.py:84) or the TU 'zero' callable that returns python 0
+    (dataset/tud.py:67-71) when the conv has no edge_encoder parameters."""
+    s = _sub(sd, prefix)
+    if "weight" in s:
+        return edge_attr.to(s["weight"].dtype) @ s["weight"].t() + s["bias"]
+    if "bond_embedding_list.0.weight" in s:
+        out = 0
+        for i in range(edge_attr.shape[1]):
+            out = out + s[f"bond_embedding_list.{i}.weight"][edge_attr[:, i]]
+        return out
+    return None
+
+
+# --------------------------------------------------------------------------------------------
+# a1 / a2: convolutions
+# --------------------------------------------------------------------------------------------
+
+
+def gcn_degree(edge_index, num_nodes, dtype=torch.float32):
+    """deg[v] = 1 + #{k : row_k == v} with row = edge_index[0] — the SOURCE index
+    (conv.py:54-57)."""
+    row = edge_index[0]
+    deg = torch.zeros(num_nodes, dtype=dtype)
+    deg.index_add_(0, row, torch.ones(row.numel(), dtype=dtype))
+    return deg + 1
+
+
+def gcn_aggregate(h, e, edge_index, root):
+    """The message/aggregate/update part of GCNConv after `x = linear(x)` (conv.py:54-68):
+    out[v] = sum_{k: col_k = v} deg[row_k]^-1/2 deg[col_k]^-1/2 relu(h[row_k] + e_k)
+             + relu(h[v] + root) / deg[v].   `e` may be None (TU: edge embedding 0)."""
+    row, col = edge_index[0], edge_index[1]
+    n = h.shape[0]
+    deg = gcn_degree(edge_index, n, h.dtype)
+    dis = deg.pow(-0.5)
+    norm = dis[row] * dis[col]
+    msg = h[row] if e is None else h[row] + e
+    msg = norm.view(-1, 1) * torch.relu(msg)
+    out = torch.zeros_like(h).index_add_(0, col, msg)
+    return out + torch.relu(h + root) / deg.view(-1, 1)
+
+
+def gin_aggregate(x, e, edge_index):
+    """GINConv.propagate (conv.py:28,33): agg[v] = sum_{k: col_k = v} relu(x[row_k] + e_k)."""
+    row, col = edge_index[0], edge_index[1]
+    msg = x[row] if e is None else x[row] + e
+    return torch.zeros_like(x).index_add_(0, col, torch.relu(msg))
+
+
+def gcn_conv(sd, prefix, x, edge_index, edge_attr):
+    """GCNConv.forward (conv.py:50-65)."""
+    h = linear(x, sd, prefix + ".linear")
+    e = edge_encode(sd, prefix + ".edge_encoder", edge_attr)
+    return gcn_aggregate(h, e, edge_index, sd[prefix + ".root_emb.weight"])
+
+
+def gin_conv(sd, prefix, x, edge_index, edge_attr, training):
+    """GINConv.forward (conv.py:26-30): mlp((1+eps) x + agg), mlp = Linear(D,2D) -> BN ->
+    ReLU -> Linear(2D,D) (conv.py:18-20)."""
+    e = edge_encode(sd, prefix + ".edge_encoder", edge_attr)
+    z = (1 + sd[prefix + ".eps"]) * x + gin_aggregate(x, e, edge_index)
+    z = linear(z, sd, prefix + ".mlp.0")
+    z = torch.relu(batch_norm(z, sd, prefix + ".mlp.1", training))
+    return linear(z, sd, prefix + ".mlp.3")
+
+
+# --------------------------------------------------------------------------------------------
+# a3 / a4: GNN stacks
+# --------------------------------------------------------------------------------------------
+
+
+def segment_sum(x, batch, num_graphs):
+    """global_add_pool (gnn_module.py:219)."""
+    return torch.zeros(num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch, x)
+
+
+def gnn_node(sd, prefix, args, data, perturb=None, training=True):
+    """GNN_node.forward (gnn_module.py:60-107) and GNN_node_Virtualnode.forward
+    (gnn_module.py:172-241), selected by args.gnn_virtual_node (gnn_module.py:244-248)."""
+    s = _sub(sd, prefix)
+    x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
+    node_depth = getattr(data, "node_depth", None)
+    L = args.gnn_num_layer
+    p = args.gnn_dropout
+    has_enc = any(k.startswith("node_encoder.") for k in s)
+    h0 = node_encode(s, "node_encoder", x, node_depth) if has_enc else x
+    if perturb is not None:
+        h0 = h0 + perturb
+    h_list = [h0]
+    vn = None
+    if args.gnn_virtual_node:
+        num_graphs = int(batch[-1]) + 1
+        vn = s["virtualnode_embedding.weight"][torch.zeros(num_graphs, dtype=torch.long)]
+    for layer in range(L):
+        if vn is not None:
+            h_list[layer] = h_list[layer] + vn[batch]  # gnn_module.py:199
+        if args.gnn_type == "gcn":
+            h = gcn_conv(s, f"convs.{layer}", h_list[layer], edge_index, edge_attr)
+        else:
+            h = gin_conv(s, f"convs.{layer}", h_list[layer], edge_index, edge_attr, training)
+        h = batch_norm(h, s, f"batch_norms.{layer}", training)
+        if layer == L - 1:
+            h = dropout(h, p, training)
+        else:
+            h = dropout(torch.relu(h), p, training)
+        if args.gnn_residual:
+            h = h + h_list[layer]
+        h_list.append(h)
+        if vn is not None and layer < L - 1:
+            t = segment_sum(h_list[layer], batch, vn.shape[0]) + vn  # gnn_module.py:219
+            m = f"mlp_virtualnode_list.{layer}"
+            t = linear(t, s, m + ".0")
+            t = torch.relu(batch_norm(t, s, m + ".1", training))
+            t = linear(t, s, m + ".3")
+            t = torch.relu(batch_norm(t, s, m + ".4", training))
+            t = dropout(t, p, training)
+            vn = vn + t if args.gnn_residual else t
+    if args.gnn_JK == "last":
+        return h_list[-1]
+    if args.gnn_JK == "sum":  # excludes the last layer's output (gnn_module.py:100-103)
+        out = 0
+        for layer in range(L):
+            out = out + h_list[layer]
+        return out
+    if args.gnn_JK == "cat":
+        return torch.cat([h_list[0], h_list[-1]], dim=-1)
+    raise ValueError(args.gnn_JK)
+
+
+# --------------------------------------------------------------------------------------------
+# a5 / a6: pad / unpad
+# --------------------------------------------------------------------------------------------
+
+
+def pad_batch(h_node, batch, max_input_len):
+    """pad_batch (modules/utils.py:5-29): left-pad every graph to S = min(max_b n_b,
+    max_input_len) keeping each graph's LAST min(n_b, S) nodes; mask True = padding.
+    Returns (padded (S,B,d), mask (B,S) bool, num_nodes (B,) int64, S)."""
+    B = int(batch[-1]) + 1
+    num_nodes = torch.bincount(batch, minlength=B)
+    S = int(min(int(num_nodes.max()), int(max_input_len)))
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(num_nodes, 0)
+    pos = torch.arange(batch.numel()) - ptr[batch]
+    s = S - num_nodes[batch] + pos
+    keep = s >= 0
+    padded = torch.zeros(S, B, h_node.shape[-1], dtype=h_node.dtype)
+    padded = padded.index_put((s[keep], batch[keep]), h_node[keep])
+    ar = torch.arange(S).view(1, S)
+    mask = ar < (S - torch.clamp(num_nodes, max=S)).view(B, 1)
+    return padded, mask, num_nodes, S
+
+
+def unpad_batch(padded_h_node, prev_h_node, batch, max_num_nodes):
+    """unpad_batch (modules/utils.py:32-53): write the padded rows back to node order; nodes
+    truncated by pad_batch keep their prev_h_node value."""
+    B = int(batch[-1]) + 1
+    num_nodes = torch.bincount(batch, minlength=B)
+    S = max_num_nodes
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(num_nodes, 0)
+    pos = torch.arange(batch.numel()) - ptr[batch]
+    s = S - num_nodes[batch] + pos
+    keep = s >= 0
+    out = prev_h_node.clone()
+    out[keep] = padded_h_node[s[keep], batch[keep]]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# a7: torch nn.TransformerEncoder (post-norm) restated
+# --------------------------------------------------------------------------------------------
+
+
+def _act(name):
+    return torch.relu if name == "relu" else F.gelu
+
+
+def mha_torch(x, key_padding_mask, sd, prefix, nhead, p, training):
+    """nn.MultiheadAttention self-attention as called by nn.TransformerEncoderLayer
+    (transformer_encoder.py:28-32,59; torch F.multi_head_attention_forward): packed in_proj,
+    q scaled by head_dim^-1/2, masked keys -> -inf, softmax, dropout(p), .V, out_proj.
+    x: (S,B,d) seq-first; key_padding_mask: (B,S) True = ignore."""
+    S, B, d = x.shape
+    hd = d // nhead
+    qkv = x @ sd[prefix + ".in_proj_weight"].t() + sd[prefix + ".in_proj_bias"]
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q * (float(hd) ** -0.5)
+
+    def heads(t):  # (S,B,d) -> (B,nhead,S,hd)
+        return t.reshape(S, B, nhead, hd).permute(1, 2, 0, 3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    att = q @ k.transpose(-2, -1)
+    att = att.masked_fill(key_padding_mask.view(B, 1, 1, S), float("-inf"))
+    att = torch.softmax(att, dim=-1)
+    att = dropout(att, p, training)
+    y = att @ v  # (B,nhead,S,hd)
+    y = y.permute(2, 0, 1, 3).reshape(S, B, d)
+    return y @ sd[prefix + ".out_proj.weight"].t() + sd[prefix + ".out_proj.bias"]
+
+
+def transformer_encoder_layer(x, mask, sd, prefix, args, training):
+    """torch nn.TransformerEncoderLayer, post-norm: x = LN1(x + drop(MHA(x)));
+    x = LN2(x + drop(W2 drop(act(W1 x))))."""
+    p = args.transformer_dropout
+    a = mha_torch(x, mask, sd, prefix + ".self_attn", args.nhead, p, training)
+    x = layer_norm(x + dropout(a, p, training), sd, prefix + ".norm1")
+    f = _act(args.transformer_activation)(linear(x, sd, prefix + ".linear1"))
+    f = linear(dropout(f, p, training), sd, prefix + ".linear2")
+    return layer_norm(x + dropout(f, p, training), sd, prefix + ".norm2")
+
+
+def transformer_node_encoder(sd, prefix, args, padded_h_node, src_padding_mask, training=True):
+    """TransformerNodeEncoder.forward (transformer_encoder.py:42-61): CLS appended at the END
+    (:50-52), mask extended with False (:54-55), norm_input over every position (:56-57),
+    L post-norm layers + final LayerNorm (:28-32,59)."""
+    s = _sub(sd, prefix)
+    x, mask = padded_h_node, src_padding_mask
+    if "cls_embedding" in s:
+        cls = s["cls_embedding"].expand(1, x.shape[1], -1)
+        x = torch.cat([x, cls], dim=0)
+        mask = torch.cat([mask, torch.zeros(mask.shape[0], 1, dtype=torch.bool)], dim=1)
+    if "norm_input.weight" in s:
+        x = layer_norm(x, s, "norm_input")
+    for i in range(args.num_encoder_layers):
+        x = transformer_encoder_layer(x, mask, s, f"transformer.layers.{i}", args, training)
+    x = layer_norm(x, s, "transformer.norm")
+    return x, mask
+
+
+# --------------------------------------------------------------------------------------------
+# a8 / a9: the hand-written masked encoder
+# --------------------------------------------------------------------------------------------
+
+
+def causal_self_attention(x, sd, prefix, n_head, attn_mask=None, valid_input_mask=None,
+                          mask_value=-1e6, p=0.0, training=True):
+    """CausalSelfAttention.forward (masked_transformer_encoder.py:32-56). x: (B,T,C) batch-first;
+    attn_mask (B,T,T): entries == 0 are filled with mask_value; valid_input_mask (B,T): entries
+    == 0 mask that KEY column for every query."""
+    B, T, C = x.shape
+    hs = C // n_head
+
+    def proj(name):
+        return linear(x, sd, prefix + "." + name).view(B, T, n_head, hs).transpose(1, 2)
+
+    k, q, v = proj("key"), proj("query"), proj("value")
+    att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs))
+    if attn_mask is not None:
+        att = att.masked_fill(attn_mask.unsqueeze(1) == 0, mask_value)
+    if valid_input_mask is not None:
+        att = att.masked_fill(valid_input_mask.unsqueeze(1).unsqueeze(2) == 0, mask_value)
+    att = torch.softmax(att, dim=-1)
+    att = dropout(att, p, training)
+    y = (att @ v).transpose(1, 2).contiguous().view(B, T, C)
+    return dropout(linear(y, sd, prefix + ".proj"), p, training)
+
+
+def masked_block(x, sd, prefix, n_head, attn_mask, valid_input_mask, p, training, prenorm=True):
+    """Block.forward (masked_transformer_encoder.py:73-80); FFN Linear->GELU->Linear->Dropout
+    (:66-71)."""
+
+    def mlp(t):
+        t = F.gelu(linear(t, sd, prefix + ".mlp.0"))
+        return dropout(linear(t, sd, prefix + ".mlp.2"), p, training)
+
+    def attn(t):
+        return causal_self_attention(t, sd, prefix + ".attn", n_head, attn_mask, valid_input_mask,
+                                     p=p, training=training)
+
+    if prenorm:
+        x = x + attn(layer_norm(x, sd, prefix + ".ln1"))
+        x = x + mlp(layer_norm(x, sd, prefix + ".ln2"))
+    else:
+        x = layer_norm(x + attn(x), sd, prefix + ".ln1")
+        x = layer_norm(x + mlp(x), sd, prefix + ".ln2")
+    return x
+
+
+def masked_only_transformer_encoder(sd, prefix, args, x, attn_mask=None, valid_input_mask=None,
+                                    training=True):
+    """MaskedOnlyTransformerEncoder.forward (masked_transformer_encoder.py:124-130); blocks are
+    always pre-norm because transformer_prenorm is never forwarded (:114-121)."""
+    s = _sub(sd, prefix)
+    for i in range(args.num_encoder_layers_masked):
+        x = masked_block(x, s, f"masked_transformer.blocks.{i}", args.nhead, attn_mask,
+                         valid_input_mask, args.transformer_dropout, training, prenorm=True)
+    return x
+
+
+def positional_encoding(x):
+    """PositionalEncoding.forward (gnn_transformer.py:149-168), dropout 0."""
+    S, _, d = x.shape
+    position = torch.arange(S).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2) * (-math.log(10000.0) / d))
+    pe = torch.zeros(S, 1, d)
+    pe[:, 0, 0::2] = torch.sin(position * div_term)
+    pe[:, 0, 1::2] = torch.cos(position * div_term)
+    return x + pe
+
+
+# --------------------------------------------------------------------------------------------
+# a10: GNNTransformer
+# --------------------------------------------------------------------------------------------
+
+
+def gnn_transformer(sd, args, data, perturb=None, training=True):
+    """GNNTransformer.forward (models/gnn_transformer.py:90-128)."""
+    h = gnn_node(sd, "gnn_node", args, data, perturb, training)
+    h = linear(h, sd, "gnn2transformer")
+    padded, mask, num_nodes, S = pad_batch(h, data.batch, int(args.max_input_len))
+    out = padded
+    if args.pos_encoder:
+        out = positional_encoding(out)
+    if args.num_encoder_layers_masked > 0:
+        adj_list = data.adj_list
+        adj = torch.zeros(len(adj_list), S, S)
+        for i, a in enumerate(adj_list):  # gnn_transformer.py:104-107 (top-left placement)
+            n = a.shape[0]
+            adj[i, :n, :n] = torch.as_tensor(a, dtype=torch.float32)
+        out = masked_only_transformer_encoder(
+            sd, "masked_transformer_encoder", args, out.transpose(0, 1), attn_mask=adj,
+            valid_input_mask=mask, training=training).transpose(0, 1)
+    if args.num_encoder_layers > 0:
+        out, _ = transformer_node_encoder(sd, "transformer_encoder", args, out, mask, training)
+    if args.graph_pooling in ("last", "cls"):
+        h_graph = out[-1]
+    elif args.graph_pooling == "mean":  # divides by #padded positions (gnn_transformer.py:117)
+        h_graph = out.sum(0) / mask.sum(-1, keepdim=True)
+    else:
+        raise NotImplementedError
+    if args.max_seq_len is None:
+        return linear(h_graph, sd, "graph_pred_linear")
+    return [linear(h_graph, sd, f"graph_pred_linear_list.{i}") for i in range(args.max_seq_len)]
+
+
+# --------------------------------------------------------------------------------------------
+# losses (the trainer's calc_loss; defines the backward seed for the fwd+bwd metric)
+# --------------------------------------------------------------------------------------------
+
+
+def code2_loss(pred_list, y_arr):
+    """dataset/code.py:39-45: mean over positions of CrossEntropy(pred_i, y_arr[:, i])."""
+    loss = 0
+    for i, pred in enumerate(pred_list):
+        loss = loss + F.cross_entropy(pred.float(), y_arr[:, i])
+    return loss / len(pred_list)
+
+
+def mol_loss(pred, y):
+    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries."""
+    is_labeled = y == y
+    return F.binary_cross_entropy_with_logits(pred.float()[is_labeled], y.float()[is_labeled])
+
+
+def tud_loss(pred, y):
+    """dataset/tud.py:25-27."""
+    return F.cross_entropy(pred, y)

@@ -1,0 +1,20 @@
+import math
+
+
+def uniform(size, tensor):
+    if tensor is not None:
+        bound = 1.0 / math.sqrt(size)
+        tensor.data.uniform_(-bound, bound)
+
+
+def reset(nn):
+    def _reset(item):
+        if hasattr(item, "reset_parameters"):
+            item.reset_parameters()
+
+    if nn is not None:
+        if hasattr(nn, "children") and len(list(nn.children())) > 0:
+            for item in nn.children():
+                _reset(item)
+        else:
+            _reset(nn)

@@ -1,0 +1,143 @@
+"""Pin the CPU oracle (oracle/reference_math.py, oracle/graph_struct.py) against the golden
+vectors produced by running the reference itself (oracle/make_golden.py).  CPU only.
+
+Tolerance: 1e-4 absolute+relative, fp32 (BASELINE.json north_star); integer structures bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, assert_close, golden_names
+from oracle import reference_math as rm
+from oracle.graph_struct import graph_struct, pad_index
+
+
+def _params(g):
+    sd = {k: v.clone() for k, v in g.sd.items()}
+    for k in g.gsd:
+        sd[k].requires_grad_(True)
+    return sd
+
+
+def _check(g, outs, sd, float_inputs):
+    outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+    assert len(outs) == len(g.out_list)
+    loss = 0
+    for i, o in enumerate(outs):
+        assert_close(o, g.out_list[i], what=f"{g.name} out{i}")
+        loss = loss + (o * g.inputs[f"w{i}"]).sum()
+    if not g.gsd and not g.gin:
+        return
+    loss.backward()
+    for k, v in g.gsd.items():
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(v)
+        assert_close(got, v, what=f"{g.name} grad {k}")
+    for k, v in g.gin.items():
+        assert_close(float_inputs[k].grad, v, what=f"{g.name} grad input {k}")
+
+
+@pytest.mark.parametrize("name", golden_names("G1_") + golden_names("G2_"))
+def test_conv(name):
+    g = Golden(name)
+    sd = _params(g)
+    x = g.inputs["x"].clone().requires_grad_(True)
+    ei, ea = g.inputs["edge_index"], g.inputs.get("edge_attr")
+    if g.meta["conv"] == "gcn":
+        out = rm.gcn_conv({"c." + k: v for k, v in sd.items()}, "c", x, ei, ea)
+    else:
+        out = rm.gin_conv({"c." + k: v for k, v in sd.items()}, "c", x, ei, ea, g.meta["training"])
+    _check(g, out, sd, {"x": x})
+
+
+@pytest.mark.parametrize("name", golden_names("G3_") + golden_names("G4_"))
+def test_gnn_node(name):
+    g = Golden(name)
+    sd = _params(g)
+    b = g.batch()
+    fi = {}
+    if b.x.is_floating_point():
+        b.x = b.x.clone().requires_grad_(True)
+        fi["x"] = b.x
+    perturb = g.inputs.get("perturb")
+    if perturb is not None:
+        perturb = perturb.clone().requires_grad_(True)
+        fi["perturb"] = perturb
+    out = rm.gnn_node(sd, "", g.args(), b, perturb, g.meta["training"])
+    _check(g, out, sd, fi)
+
+
+@pytest.mark.parametrize("name", golden_names("G5_"))
+def test_pad(name):
+    g = Golden(name)
+    h = g.inputs["h"].clone().requires_grad_(True)
+    padded, mask, num_nodes, S = rm.pad_batch(h, g.inputs["batch"], g.meta["max_input_len"])
+    assert torch.equal(padded, g.outs["0"])
+    assert torch.equal(mask, g.outs["1"])
+    (padded * g.inputs["w0"]).sum().backward()
+    assert torch.equal(h.grad, g.gin["h"])
+    unp = rm.unpad_batch(g.inputs["padded_in"], g.inputs["prev"], g.inputs["batch"], S)
+    assert torch.equal(unp, g.outs["2"])
+
+
+@pytest.mark.parametrize("name", golden_names("G6_"))
+def test_transformer_node_encoder(name):
+    g = Golden(name)
+    sd = _params(g)
+    x = g.inputs["padded"].clone().requires_grad_(True)
+    out, mask = rm.transformer_node_encoder(sd, "", g.args(), x, g.inputs["mask"], g.meta["training"])
+    _check(g, out, sd, {"padded": x})
+
+
+@pytest.mark.parametrize("name", golden_names("G7_"))
+def test_masked_encoder(name):
+    g = Golden(name)
+    sd = _params(g)
+    x = g.inputs["x"].clone().requires_grad_(True)
+    adj, valid = g.inputs.get("attn_mask"), g.inputs.get("valid_input_mask")
+    psd = {"m." + k: v for k, v in sd.items()}
+    if g.meta["kind"] == "causal_self_attention":
+        out = rm.causal_self_attention(x, psd, "m", g.meta["n_head"], adj, valid)
+    else:
+        out = rm.masked_block(x, psd, "m", g.meta["n_head"], adj, valid, 0.0, True, prenorm=g.meta["prenorm"])
+    _check(g, out, sd, {"x": x})
+
+
+@pytest.mark.parametrize("name", golden_names("G8_"))
+def test_gnn_transformer(name):
+    g = Golden(name)
+    sd = _params(g)
+    b = g.batch()
+    fi = {}
+    if b.x.is_floating_point():
+        b.x = b.x.clone().requires_grad_(True)
+        fi["x"] = b.x
+    out = rm.gnn_transformer(sd, g.args(), b, None, g.meta["training"])
+    _check(g, out, sd, fi)
+
+
+@pytest.mark.parametrize("name", golden_names("G10_"))
+def test_graph_struct_fixture(name):
+    """The integer oracle reproduces its own committed fixture (guards against drift) and the
+    fixture satisfies the defining properties of a stable counting sort."""
+    g = Golden(name)
+    ei, batch = g.inputs["edge_index"].numpy(), g.inputs["batch"].numpy()
+    s = graph_struct(ei, batch)
+    for k, v in s.items():
+        assert np.array_equal(v, g.outs[k].numpy()), k
+    S, kept, first = pad_index(s["ptr"], g.meta["max_input_len"])
+    assert S == int(g.outs["S"]) and np.array_equal(kept, g.outs["kept"].numpy()) and np.array_equal(first, g.outs["first"].numpy())
+    # defining properties: sorted by key, ties in original order, permutation of all edges
+    for ptr, eid, key in ((s["in_ptr"], s["in_eid"], ei[1]), (s["out_ptr"], s["out_eid"], ei[0])):
+        assert np.array_equal(np.sort(eid), np.arange(ei.shape[1]))
+        k = key[eid]
+        assert np.all(np.diff(k) >= 0)
+        same = np.diff(k) == 0
+        assert np.all(np.diff(eid)[same] > 0)
+        for v in range(len(ptr) - 1):
+            assert np.all(k[ptr[v]:ptr[v + 1]] == v)
+
+
+def test_degree_uses_source_index():
+    """conv.py:57: deg = degree(row) + 1 where row = edge_index[0] (Appendix A)."""
+    ei = torch.tensor([[0, 0, 0, 1], [1, 2, 3, 0]])
+    assert rm.gcn_degree(ei, 4).tolist() == [4.0, 2.0, 1.0, 1.0]
