@@ -1,0 +1,65 @@
+"""ctypes binding of libgraphtrans_hip.so (the C ABI declared in include/graphtrans_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+The product never routes through oracle/ or any CPU/eager re-implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphtrans_hip.so")
+
+GT_F32, GT_BF16 = 0, 1
+GT_CONV_GCN, GT_CONV_GIN = 0, 1
+GT_EDGE_NONE, GT_EDGE_LINEAR, GT_EDGE_TABLES, GT_EDGE_DENSE = 0, 1, 2, 3
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+_u64 = C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/graphtrans_hip.h exactly
+SIGNATURES = {
+    "gt_version": (_i, []),
+    "gt_last_error": (C.c_char_p, []),
+    "gt_graph_prep_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gt_graph_prep": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_aggregate_fwd": (_i, [_i, _i, _i, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
+                              C.POINTER(C.c_int32), _p, _p, _p]),
+    "gt_aggregate_bwd_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
+    "gt_aggregate_bwd": (_i, [_i, _i, _i, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
+                              C.POINTER(C.c_int32), _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_segment_bcast_add": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "gt_segment_sum": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),
+    "gt_seq_scatter": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
+    "gt_attn_fwd": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _f, _f, _u64, _p]),
+    "gt_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _f, _f, _u64, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m graphtrans_amd.build` "
+                "(graphtrans_amd has no CPU or eager fallback)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gt_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,581 @@
+// aggregate.hip — fused GCN / GIN message + scatter-aggregate + self term, forward and backward.
+//
+// Reference math (paths under /root/reference):
+//   GCNConv  modules/conv.py:50-71   out[v] = sum_{k: col_k=v} dis[row_k] dis[col_k] relu(h[row_k] + e_k)
+//                                              + relu(h[v] + root_emb) / deg[v]
+//   GINConv  modules/conv.py:26-36   out[v] = (1 + eps) h[v] + sum_{k: col_k=v} relu(h[row_k] + e_k)
+// The reference materialises x_j, e, the sum, the relu and the scaled message as five E x D
+// tensors and scatter-adds them with atomics (torch-scatter); here one wave-tile per destination
+// node walks the destination-sorted CSR, gathers neighbour rows with 16-byte lane loads, applies
+// edge embedding / relu / norm in registers and writes each output row once: no atomics, fixed
+// summation order (deterministic), E x D never touches memory.
+//
+// Lane mapping: a node row of D (<= 1024, D % 4 == 0) values is covered by LPN lanes x NCH float4
+// chunks.  D <= 64 -> 16 lanes/node (4 nodes per wave), D <= 128 -> 32 lanes/node, else the whole
+// wave with NCH = ceil(D/256) chunks per lane (D = 300 -> 75 chunks: 64 + 11).
+//
+// Backward walks the source-sorted CSC (one wave-tile per SOURCE node u, persistent grid):
+//   t_k = w_k 1[h[u]+e_k>0] g[col_k];  dh[u] = sum_k t_k + self';  edge-parameter gradients are
+//   accumulated in registers (Linear) or per-wave LDS rows (embedding tables), reduced per block
+//   and finished by a second kernel in a fixed order.
+#include "gt_common.h"
+
+namespace {
+
+constexpr int AGG_THREADS = 256;
+constexpr int AGG_WAVES = AGG_THREADS / GT_WAVE;
+constexpr int BWD_BLOCKS = 1024;
+constexpr int MAX_K = 4;
+
+struct AggArgs {
+  int conv, K;
+  int64_t N, E, D;
+  const void* h;
+  const void* g;  // bwd: grad_out
+  const int32_t* ptr;
+  const int32_t* nbr;  // fwd: in_src ; bwd: out_dst
+  const int32_t* eid;
+  const float* deg;
+  const float* dis;
+  const float* self_param;
+  const void* attr;
+  const float* w;  // Linear weight [D][K] or tables [rows][D]
+  const float* b;  // Linear bias [D]
+  int tab_off[MAX_K];
+  int table_rows;
+  const void* dense;
+  void* out;      // fwd: out ; bwd: grad_h
+  void* d_dense;  // bwd
+  float* partial; // bwd: [blocks][slots][D]
+};
+
+template <int LPN, int NCH>
+struct LaneMap {
+  static constexpr int NPW = 64 / LPN;
+  int sub, sl;
+  int col[NCH];
+  bool act[NCH];
+  __device__ __forceinline__ LaneMap(int lane, int64_t D) {
+    sub = lane / LPN;
+    sl = lane % LPN;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      col[j] = (sl + j * 64) * 4;
+      act[j] = col[j] < D;
+      if (!act[j]) col[j] = 0;  // safe address; results discarded
+    }
+  }
+};
+
+// per-lane edge-embedding state
+template <int EDGE, int NCH>
+struct EdgeState {
+  float4 w[EDGE == GT_EDGE_LINEAR ? MAX_K : 1][NCH];
+  float4 b[NCH];
+};
+
+template <int EDGE, int NCH, int LPN>
+__device__ __forceinline__ void edge_state_init(EdgeState<EDGE, NCH>& s, const AggArgs& a, const LaneMap<LPN, NCH>& m) {
+  if constexpr (EDGE == GT_EDGE_LINEAR) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      s.b[j] = m.act[j] ? *reinterpret_cast<const float4*>(a.b + m.col[j]) : gt_zero4();
+#pragma unroll
+      for (int k = 0; k < MAX_K; ++k) {
+        if (k < a.K && m.act[j]) {
+          const float* w = a.w + (int64_t)m.col[j] * a.K + k;  // W[d][k], d = col..col+3
+          s.w[k][j] = make_float4(w[0], w[a.K], w[2 * a.K], w[3 * a.K]);
+        } else {
+          s.w[k][j] = gt_zero4();
+        }
+      }
+    }
+  }
+}
+
+// e_k chunk j for original edge id `eid`
+template <typename T, int EDGE, int NCH, int LPN>
+__device__ __forceinline__ float4 edge_embed(const EdgeState<EDGE, NCH>& s, const AggArgs& a,
+                                             const LaneMap<LPN, NCH>& m, int j, int eid, const float* av,
+                                             const int* ti) {
+  if constexpr (EDGE == GT_EDGE_NONE) {
+    return gt_zero4();
+  } else if constexpr (EDGE == GT_EDGE_LINEAR) {
+    float4 e = s.b[j];
+#pragma unroll
+    for (int k = 0; k < MAX_K; ++k)
+      if (k < a.K) e = gt_fma4(s.w[k][j], av[k], e);
+    return e;
+  } else if constexpr (EDGE == GT_EDGE_TABLES) {
+    float4 e = gt_zero4();
+#pragma unroll
+    for (int k = 0; k < MAX_K; ++k)
+      if (k < a.K) e = gt_add4(e, *reinterpret_cast<const float4*>(a.w + (int64_t)ti[k] * a.D + m.col[j]));
+    return e;
+  } else {
+    return gt_load4<T>(reinterpret_cast<const T*>(a.dense) + (int64_t)eid * a.D + m.col[j]);
+  }
+}
+
+template <int EDGE>
+__device__ __forceinline__ void edge_attr_load(const AggArgs& a, int eid, float* av, int* ti) {
+  if constexpr (EDGE == GT_EDGE_LINEAR) {
+    const float* p = reinterpret_cast<const float*>(a.attr) + (int64_t)eid * a.K;
+#pragma unroll
+    for (int k = 0; k < MAX_K; ++k) av[k] = k < a.K ? p[k] : 0.f;
+  } else if constexpr (EDGE == GT_EDGE_TABLES) {
+    const int64_t* p = reinterpret_cast<const int64_t*>(a.attr) + (int64_t)eid * a.K;
+#pragma unroll
+    for (int k = 0; k < MAX_K; ++k) ti[k] = k < a.K ? a.tab_off[k] + (int)p[k] : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPN, int NCH, int EDGE>
+__global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
+  constexpr int NPW = 64 / LPN;
+  constexpr int U = NCH >= 3 ? 2 : 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * AGG_WAVES + (threadIdx.x >> 6);
+  LaneMap<LPN, NCH> m(lane, a.D);
+  const int64_t v = wave * NPW + m.sub;
+  if (v >= a.N) return;
+  EdgeState<EDGE, NCH> es;
+  edge_state_init<EDGE, NCH, LPN>(es, a, m);
+  const T* h = reinterpret_cast<const T*>(a.h);
+  const bool gcn = a.conv == GT_CONV_GCN;
+  const int beg = a.ptr[v], end = a.ptr[v + 1];
+  float4 acc[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) acc[j] = gt_zero4();
+
+  for (int p = beg; p < end; p += U) {
+    int src[U], eid[U];
+    float wgt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int q = p + u < end ? p + u : end - 1;
+      src[u] = a.nbr[q];
+      eid[u] = a.eid[q];
+    }
+    float4 row[U][NCH];
+    float av[U][MAX_K];
+    int ti[U][MAX_K];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) row[u][j] = gt_load4<T>(h + (int64_t)src[u] * a.D + m.col[j]);
+      wgt[u] = gcn ? a.dis[src[u]] : 1.0f;
+      if (p + u >= end) wgt[u] = 0.f;
+      edge_attr_load<EDGE>(a, eid[u], av[u], ti[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid[u], av[u], ti[u]);
+        acc[j] = gt_fma4(gt_relu4(gt_add4(row[u][j], e)), wgt[u], acc[j]);
+      }
+    }
+  }
+  T* out = reinterpret_cast<T*>(a.out);
+  const float dv = gcn ? a.dis[v] : 1.0f;
+  const float inv_deg = gcn ? 1.0f / a.deg[v] : 0.f;
+  const float one_eps = gcn ? 0.f : 1.0f + a.self_param[0];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (!m.act[j]) continue;
+    float4 hv = gt_load4<T>(h + v * a.D + m.col[j]);
+    float4 r;
+    if (gcn) {
+      float4 root = *reinterpret_cast<const float4*>(a.self_param + m.col[j]);
+      // relu(x + root) * 1.0 / deg   (conv.py:63-65)
+      float4 s = gt_relu4(gt_add4(hv, root));
+      r = make_float4(acc[j].x * dv + s.x * inv_deg, acc[j].y * dv + s.y * inv_deg, acc[j].z * dv + s.z * inv_deg,
+                      acc[j].w * dv + s.w * inv_deg);
+    } else {
+      r = gt_fma4(hv, one_eps, acc[j]);
+    }
+    gt_store4<T>(out + v * a.D + m.col[j], r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 gate4(float4 pre, float4 v) {
+  return make_float4(pre.x > 0.f ? v.x : 0.f, pre.y > 0.f ? v.y : 0.f, pre.z > 0.f ? v.z : 0.f, pre.w > 0.f ? v.w : 0.f);
+}
+
+template <int EDGE>
+__host__ __device__ constexpr int reg_slots() {
+  // register-accumulated D-vectors per lane: [self] (+ K weight columns + bias for Linear)
+  return EDGE == GT_EDGE_LINEAR ? MAX_K + 2 : 1;
+}
+
+template <typename T, int LPN, int NCH, int EDGE>
+__global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
+  constexpr int NPW = 64 / LPN;
+  constexpr int NREG = reg_slots<EDGE>();
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  LaneMap<LPN, NCH> m(lane, a.D);
+  EdgeState<EDGE, NCH> es;
+  edge_state_init<EDGE, NCH, LPN>(es, a, m);
+  const T* h = reinterpret_cast<const T*>(a.h);
+  const T* g = reinterpret_cast<const T*>(a.g);
+  T* dh = reinterpret_cast<T*>(a.out);
+  const bool gcn = a.conv == GT_CONV_GCN;
+  const float one_eps = gcn ? 0.f : 1.0f + a.self_param[0];
+  const int64_t D = a.D;
+  const int nslots = (EDGE == GT_EDGE_LINEAR ? a.K + 2 : 1) + (EDGE == GT_EDGE_TABLES ? a.table_rows : 0);
+
+  // slot order in `partial`: 0 = self ; Linear: 1..K = weight columns, K+1 = bias ; Tables: 1.. = rows
+  float4 racc[NREG][NCH];
+#pragma unroll
+  for (int s = 0; s < NREG; ++s)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) racc[s][j] = gt_zero4();
+
+  float* wl = nullptr;  // per-wave LDS table-gradient rows [table_rows][D]
+  if constexpr (EDGE == GT_EDGE_TABLES) {
+    wl = lds + (int64_t)wid * a.table_rows * D;
+    for (int64_t i = lane; i < (int64_t)a.table_rows * D; i += 64) wl[i] = 0.f;
+  }
+
+  const int64_t total_waves = (int64_t)gridDim.x * AGG_WAVES;
+  const int64_t wave0 = (int64_t)blockIdx.x * AGG_WAVES + wid;
+  for (int64_t base = wave0 * NPW; base < a.N; base += total_waves * NPW) {
+    const int64_t u = base + m.sub;
+    if (u >= a.N) continue;
+    const int beg = a.ptr[u], end = a.ptr[u + 1];
+    float4 hu[NCH], gu[NCH], acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      hu[j] = gt_load4<T>(h + u * D + m.col[j]);
+      gu[j] = gt_load4<T>(g + u * D + m.col[j]);
+      acc[j] = gt_zero4();
+    }
+    const float du = gcn ? a.dis[u] : 1.0f;
+    for (int p = beg; p < end; ++p) {
+      const int dst = a.nbr[p], eid = a.eid[p];
+      float av[MAX_K];
+      int ti[MAX_K];
+      edge_attr_load<EDGE>(a, eid, av, ti);
+      const float wk = gcn ? du * a.dis[dst] : 1.0f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        float4 gd = gt_load4<T>(g + (int64_t)dst * D + m.col[j]);
+        float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid, av, ti);
+        float4 t = gate4(gt_add4(hu[j], e), gt_scale4(gd, wk));
+        acc[j] = gt_add4(acc[j], t);
+        if constexpr (EDGE == GT_EDGE_LINEAR) {
+#pragma unroll
+          for (int k = 0; k < MAX_K; ++k)
+            if (k < a.K) racc[1 + k][j] = gt_fma4(t, av[k], racc[1 + k][j]);
+          racc[MAX_K + 1][j] = gt_add4(racc[MAX_K + 1][j], t);
+        } else if constexpr (EDGE == GT_EDGE_TABLES) {
+          if (m.act[j]) {
+#pragma unroll
+            for (int k = 0; k < MAX_K; ++k)
+              if (k < a.K) {
+                float4* r = reinterpret_cast<float4*>(wl + (int64_t)ti[k] * D + m.col[j]);
+                // lanes of one sub-group own distinct columns; sub-groups of a wave may hit the same
+                // row -> serialise the NPW sub-groups to keep the sum order fixed
+                if constexpr (NPW == 1) {
+                  *r = gt_add4(*r, t);
+                } else {
+#pragma unroll
+                  for (int sg = 0; sg < NPW; ++sg) {
+                    if (m.sub == sg) *r = gt_add4(*r, t);
+                  }
+                }
+              }
+          }
+        } else if constexpr (EDGE == GT_EDGE_DENSE) {
+          if (m.act[j]) gt_store4<T>(reinterpret_cast<T*>(a.d_dense) + (int64_t)eid * D + m.col[j], t);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float4 r;
+      if (gcn) {
+        float4 root = *reinterpret_cast<const float4*>(a.self_param + m.col[j]);
+        float4 s = gate4(gt_add4(hu[j], root), gt_scale4(gu[j], 1.0f / a.deg[u]));
+        racc[0][j] = gt_add4(racc[0][j], s);
+        r = gt_add4(acc[j], s);
+      } else {
+        racc[0][j] = make_float4(fmaf(gu[j].x, hu[j].x, racc[0][j].x), fmaf(gu[j].y, hu[j].y, racc[0][j].y),
+                                 fmaf(gu[j].z, hu[j].z, racc[0][j].z), fmaf(gu[j].w, hu[j].w, racc[0][j].w));
+        r = gt_fma4(gu[j], one_eps, acc[j]);
+      }
+      if (m.act[j]) gt_store4<T>(dh + u * D + m.col[j], r);
+    }
+  }
+
+  // ---- block reduction of the register accumulators: sub-groups (shuffle) -> waves (LDS) -> partial
+  float* stage = lds + (EDGE == GT_EDGE_TABLES ? (int64_t)AGG_WAVES * a.table_rows * D : 0);  // [AGG_WAVES][D]
+  float* part = a.partial + (int64_t)blockIdx.x * nslots * D;
+#pragma unroll
+  for (int s = 0; s < NREG; ++s) {
+    int slot = s;
+    if constexpr (EDGE == GT_EDGE_LINEAR) {
+      if (s >= 1 && s <= MAX_K) {
+        if (s - 1 >= a.K) continue;
+      } else if (s == MAX_K + 1) {
+        slot = a.K + 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float4 x = racc[s][j];
+#pragma unroll
+      for (int o = LPN; o < 64; o <<= 1) {
+        x.x += __shfl_xor(x.x, o, 64);
+        x.y += __shfl_xor(x.y, o, 64);
+        x.z += __shfl_xor(x.z, o, 64);
+        x.w += __shfl_xor(x.w, o, 64);
+      }
+      if (m.sub == 0 && m.act[j]) *reinterpret_cast<float4*>(stage + (int64_t)wid * D + m.col[j]) = x;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += AGG_THREADS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < AGG_WAVES; ++w) t += stage[(int64_t)w * D + c];
+      part[(int64_t)slot * D + c] = t;
+    }
+    __syncthreads();
+  }
+  if constexpr (EDGE == GT_EDGE_TABLES) {
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < (int64_t)a.table_rows * D; i += AGG_THREADS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < AGG_WAVES; ++w) t += lds[(int64_t)w * a.table_rows * D + i];
+      part[D + i] = t;  // slots 1.. = table rows
+    }
+  }
+}
+
+// final fixed-order reduction over the per-block partials.
+// grid (ceil(D/64), nslots); out pointers by slot; GIN self slot is additionally summed over columns.
+struct ReduceArgs {
+  const float* partial;
+  int nblocks, nslots;
+  int64_t D;
+  int conv, edge, K, table_rows;
+  float* d_self;
+  float* d_w;  // Linear [D][K] or tables [rows][D]
+  float* d_b;
+};
+
+__global__ void __launch_bounds__(256) k_agg_reduce(ReduceArgs r) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int slot = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float t = 0.f;
+  if (c < r.D)
+    for (int b = wid; b < r.nblocks; b += 4) t += r.partial[((int64_t)b * r.nslots + slot) * r.D + c];
+  sm[wid][lane] = t;
+  __syncthreads();
+  if (wid != 0) return;
+  t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+  if (slot == 0) {
+    if (r.conv == GT_CONV_GCN) {
+      if (c < r.D && r.d_self) r.d_self[c] = t;
+    } else {
+      // GIN: d_eps = sum over all columns; one block column-tile at a time -> write tile sums to
+      // d_self[1 + blockIdx.x]; the host-side wrapper launches k_eps_finish.
+      if (c >= r.D) t = 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0 && r.d_self) r.d_self[1 + blockIdx.x] = t;
+    }
+    return;
+  }
+  if (c >= r.D) return;
+  if (r.edge == GT_EDGE_LINEAR) {
+    if (slot <= r.K) {
+      if (r.d_w) r.d_w[c * r.K + (slot - 1)] = t;
+    } else if (r.d_b) {
+      r.d_b[c] = t;
+    }
+  } else if (r.edge == GT_EDGE_TABLES) {
+    if (r.d_w) r.d_w[(int64_t)(slot - 1) * r.D + c] = t;
+  }
+}
+
+__global__ void k_eps_finish(float* d_self, int ntiles) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < ntiles; ++i) t += d_self[1 + i];
+    d_self[0] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int EDGE, bool BWD>
+int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t stream) {
+  const int64_t D = a.D;
+#define GT_AGG_LAUNCH(LPN, NCH)                                                                              \
+  do {                                                                                                       \
+    constexpr int NPW = 64 / (LPN);                                                                          \
+    if constexpr (BWD) {                                                                                     \
+      hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(grid_bwd), dim3(AGG_THREADS), lds_bytes,      \
+                         stream, a);                                                                         \
+    } else {                                                                                                 \
+      int64_t waves = gt_cdiv(a.N, NPW);                                                                     \
+      hipLaunchKernelGGL((k_agg_fwd<T, LPN, NCH, EDGE>), dim3((unsigned)gt_cdiv(waves, AGG_WAVES)),         \
+                         dim3(AGG_THREADS), 0, stream, a);                                                   \
+    }                                                                                                        \
+  } while (0)
+  if (D <= 64) GT_AGG_LAUNCH(16, 1);
+  else if (D <= 128) GT_AGG_LAUNCH(32, 1);
+  else if (D <= 256) GT_AGG_LAUNCH(64, 1);
+  else if (D <= 512) GT_AGG_LAUNCH(64, 2);
+  else if (D <= 768) GT_AGG_LAUNCH(64, 3);
+  else GT_AGG_LAUNCH(64, 4);
+#undef GT_AGG_LAUNCH
+  return GT_OK;
+}
+
+template <typename T, bool BWD>
+int launch_edge(int edge_mode, const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t stream) {
+  switch (edge_mode) {
+    case GT_EDGE_NONE: return launch_cfg<T, GT_EDGE_NONE, BWD>(a, lds_bytes, grid_bwd, stream);
+    case GT_EDGE_LINEAR: return launch_cfg<T, GT_EDGE_LINEAR, BWD>(a, lds_bytes, grid_bwd, stream);
+    case GT_EDGE_TABLES: return launch_cfg<T, GT_EDGE_TABLES, BWD>(a, lds_bytes, grid_bwd, stream);
+    case GT_EDGE_DENSE: return launch_cfg<T, GT_EDGE_DENSE, BWD>(a, lds_bytes, grid_bwd, stream);
+  }
+  return GT_ERR_INVALID_ARG;
+}
+
+int check_common(const char* fn, int conv, int edge_mode, int dtype, int64_t N, int64_t E, int64_t D, int64_t K,
+                 const void* attr, const float* w, const float* b, const int32_t* tab_off, const void* dense) {
+  (void)E;
+  if (conv != GT_CONV_GCN && conv != GT_CONV_GIN) { gt_set_error("%s: bad conv %d", fn, conv); return GT_ERR_INVALID_ARG; }
+  if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype %d", fn, dtype); return GT_ERR_INVALID_ARG; }
+  if (N < 0 || D <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (D % 4 != 0 || D > 1024) { gt_set_error("%s: dim %lld unsupported (need dim %% 4 == 0 and dim <= 1024)", fn, (long long)D); return GT_ERR_UNSUPPORTED; }
+  if (edge_mode == GT_EDGE_LINEAR) {
+    if (K < 1 || K > MAX_K) { gt_set_error("%s: Linear edge encoder needs 1 <= K <= %d (got %lld)", fn, MAX_K, (long long)K); return GT_ERR_UNSUPPORTED; }
+    if (!attr || !w || !b) { gt_set_error("%s: null Linear edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
+  } else if (edge_mode == GT_EDGE_TABLES) {
+    if (K < 1 || K > MAX_K) { gt_set_error("%s: table edge encoder needs 1 <= K <= %d", fn, MAX_K); return GT_ERR_UNSUPPORTED; }
+    if (!attr || !w || !tab_off) { gt_set_error("%s: null table edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
+  } else if (edge_mode == GT_EDGE_DENSE) {
+    if (!dense) { gt_set_error("%s: null dense edge embedding", fn); return GT_ERR_INVALID_ARG; }
+  } else if (edge_mode != GT_EDGE_NONE) {
+    gt_set_error("%s: bad edge_mode %d", fn, edge_mode);
+    return GT_ERR_INVALID_ARG;
+  }
+  return GT_OK;
+}
+
+size_t bwd_lds_bytes(int edge_mode, int64_t D, int64_t table_rows) {
+  size_t stage = (size_t)AGG_WAVES * D * sizeof(float);
+  if (edge_mode == GT_EDGE_TABLES) return stage + (size_t)AGG_WAVES * table_rows * D * sizeof(float);
+  return stage;
+}
+
+int bwd_slots(int edge_mode, int64_t K, int64_t table_rows) {
+  if (edge_mode == GT_EDGE_LINEAR) return (int)K + 2;
+  if (edge_mode == GT_EDGE_TABLES) return 1 + (int)table_rows;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* h, int64_t N, int64_t E, int64_t D,
+                                const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const float* deg,
+                                const float* dis, const float* self_param, const void* edge_attr, int64_t K,
+                                const float* edge_w, const float* edge_b, const int32_t* tab_off_host,
+                                const void* edge_dense, void* out, gt_stream_t stream_) {
+  int rc = check_common("gt_aggregate_fwd", conv, edge_mode, dtype, N, E, D, K, edge_attr, edge_w, edge_b,
+                        tab_off_host, edge_dense);
+  if (rc != GT_OK) return rc;
+  GT_CHECK_ARG(h && out && in_ptr && self_param, "null buffer");
+  GT_CHECK_ARG(E == 0 || (in_src && in_eid), "null CSR");
+  GT_CHECK_ARG(conv != GT_CONV_GCN || (deg && dis), "GCN needs deg/dis");
+  if (N == 0) return GT_OK;
+  AggArgs a{};
+  a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.ptr = in_ptr; a.nbr = in_src; a.eid = in_eid;
+  a.deg = deg; a.dis = dis; a.self_param = self_param; a.attr = edge_attr; a.w = edge_w; a.b = edge_b;
+  a.dense = edge_dense; a.out = out;
+  if (edge_mode == GT_EDGE_TABLES)
+    for (int k = 0; k < K; ++k) a.tab_off[k] = tab_off_host[k];
+  hipStream_t stream = (hipStream_t)stream_;
+  rc = dtype == GT_F32 ? launch_edge<float, false>(edge_mode, a, 0, 0, stream)
+                       : launch_edge<gt_bf16, false>(edge_mode, a, 0, 0, stream);
+  if (rc != GT_OK) return rc;
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" size_t gt_aggregate_bwd_workspace_bytes(int conv, int edge_mode, int64_t D, int64_t K, int64_t table_rows) {
+  (void)conv;
+  return (size_t)BWD_BLOCKS * bwd_slots(edge_mode, K, table_rows) * D * sizeof(float) + 256;
+}
+
+extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* h, const void* grad_out, int64_t N,
+                                int64_t E, int64_t D, const int32_t* out_ptr, const int32_t* out_dst,
+                                const int32_t* out_eid, const float* deg, const float* dis, const float* self_param,
+                                const void* edge_attr, int64_t K, const float* edge_w, const float* edge_b,
+                                const int32_t* tab_off_host, int64_t table_rows, const void* edge_dense, void* grad_h,
+                                float* d_self, float* d_edge_w, float* d_edge_b, void* d_dense, void* workspace,
+                                size_t workspace_bytes, gt_stream_t stream_) {
+  int rc = check_common("gt_aggregate_bwd", conv, edge_mode, dtype, N, E, D, K, edge_attr, edge_w, edge_b,
+                        tab_off_host, edge_dense);
+  if (rc != GT_OK) return rc;
+  GT_CHECK_ARG(h && grad_out && grad_h && out_ptr && self_param, "null buffer");
+  GT_CHECK_ARG(E == 0 || (out_dst && out_eid), "null CSC");
+  GT_CHECK_ARG(conv != GT_CONV_GCN || (deg && dis), "GCN needs deg/dis");
+  GT_CHECK_ARG(edge_mode != GT_EDGE_DENSE || d_dense, "dense mode needs d_dense");
+  GT_CHECK_ARG(conv != GT_CONV_GIN || !d_self || true, "");
+  if (edge_mode == GT_EDGE_TABLES) {
+    size_t lds = bwd_lds_bytes(edge_mode, D, table_rows);
+    if (table_rows < 1 || lds > 64 * 1024) {
+      gt_set_error("gt_aggregate_bwd: %lld table rows x dim %lld does not fit the per-wave LDS accumulators",
+                   (long long)table_rows, (long long)D);
+      return GT_ERR_UNSUPPORTED;
+    }
+  }
+  size_t need = gt_aggregate_bwd_workspace_bytes(conv, edge_mode, D, K, table_rows);
+  if (!workspace || workspace_bytes < need) {
+    gt_set_error("gt_aggregate_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return GT_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nslots = bwd_slots(edge_mode, K, table_rows);
+  // persistent grid: enough wave-tiles to cover N, capped at BWD_BLOCKS
+  int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
+  int64_t want = gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw), AGG_WAVES);
+  int grid = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
+  AggArgs a{};
+  a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.g = grad_out; a.ptr = out_ptr; a.nbr = out_dst;
+  a.eid = out_eid; a.deg = deg; a.dis = dis; a.self_param = self_param; a.attr = edge_attr; a.w = edge_w;
+  a.b = edge_b; a.dense = edge_dense; a.out = grad_h; a.d_dense = d_dense; a.partial = (float*)workspace;
+  a.table_rows = (int)table_rows;
+  if (edge_mode == GT_EDGE_TABLES)
+    for (int k = 0; k < K; ++k) a.tab_off[k] = tab_off_host[k];
+  size_t lds = bwd_lds_bytes(edge_mode, D, table_rows);
+  rc = dtype == GT_F32 ? launch_edge<float, true>(edge_mode, a, lds, grid, stream)
+                       : launch_edge<gt_bf16, true>(edge_mode, a, lds, grid, stream);
+  if (rc != GT_OK) return rc;
+  ReduceArgs r{};
+  r.partial = (const float*)workspace; r.nblocks = grid; r.nslots = nslots; r.D = D; r.conv = conv; r.edge = edge_mode;
+  r.K = (int)K; r.table_rows = (int)table_rows; r.d_self = d_self; r.d_w = d_edge_w; r.d_b = d_edge_b;
+  int ctiles = (int)gt_cdiv(D, 64);
+  hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(256), 0, stream, r);
+  if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, stream, d_self, ctiles);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

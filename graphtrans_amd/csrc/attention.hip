@@ -1,0 +1,561 @@
+// attention.hip — fused masked multi-head self-attention over graph-node token rows
+// (flash-style forward + backward on the CDNA4 matrix cores; the S x S scores never reach memory).
+//
+// Reference semantics (paths under /root/reference):
+//   modules/transformer_encoder.py:59  nn.TransformerEncoder -> F.multi_head_attention_forward:
+//       q,k,v = in_proj(x); q *= hd^-1/2; att = bmm(q,k^T); masked_fill(key_padding_mask, -inf);
+//       softmax; dropout(p); bmm(att, v)                       [B*nhead, S, S] fp32 x3 per layer
+//   modules/utils.py:5-29              left-padded sequences: valid keys are a suffix
+// This file replaces everything between in_proj and out_proj.  The padding mask is a per-sequence
+// key range [kv_off, kv_off+kv_len) compared in-register; fully masked key tiles are skipped.
+//
+// Orientation ("everything transposed"): a wave owns 16 queries (fwd / dQ) or 16 keys (dK,dV) as
+// the N (column) index of 16x16 MFMA tiles, so that per-query softmax statistics live in the lane
+// that owns column n = lane & 15 and the score tile S^T[key][query] leaves the MFMA already in
+// the B-operand layout of the following P.V product:
+//     S^T = K Q^T      (A = K rows from LDS, B = Q from registers)
+//     O^T += V^T P^T   (A = V^T via LDS transpose-read, B = P^T straight from the S^T registers)
+// The 16 rows of an S^T tile are mapped to keys g*8 + t*4 + r (pi permutation on the A rows), so
+// the two 16-key tiles of a 32-key step give each lane exactly its 8 consecutive k-slots.
+//
+// dtype GT_BF16: v_mfma_f32_16x16x32_bf16, operands bf16, accumulate fp32.
+// dtype GT_F32 : v_mfma_f32_16x16x4_f32 x8 per 32-deep step: exact fp32 (fma chain), the parity mode.
+#include "gt_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int ATT_THREADS = 256;
+constexpr int TILE = 32;    // keys (fwd, dQ) or queries (dK/dV) per inner step
+constexpr int BLOCK_N = 64; // queries (fwd, dQ) or keys (dK/dV) per block: 4 waves x 16
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ---- 8-slot operand fragments ------------------------------------------------------------------
+template <typename T>
+struct Frag;
+template <>
+struct Frag<gt_bf16> {
+  uint4 v;  // 8 x bf16
+};
+template <>
+struct Frag<float> {
+  float v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_zero();
+template <>
+__device__ __forceinline__ Frag<gt_bf16> frag_zero<gt_bf16>() {
+  Frag<gt_bf16> f;
+  f.v = make_uint4(0, 0, 0, 0);
+  return f;
+}
+template <>
+__device__ __forceinline__ Frag<float> frag_zero<float>() {
+  Frag<float> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = 0.f;
+  return f;
+}
+
+// 8 contiguous elements (row operand), global or LDS
+__device__ __forceinline__ Frag<gt_bf16> frag_load(const gt_bf16* p) {
+  Frag<gt_bf16> f;
+  f.v = *reinterpret_cast<const uint4*>(p);
+  return f;
+}
+__device__ __forceinline__ Frag<float> frag_load(const float* p) {
+  Frag<float> f;
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+
+__device__ __forceinline__ void frag_store_lds(gt_bf16* p, const Frag<gt_bf16>& f) {
+  *reinterpret_cast<uint4*>(p) = f.v;
+}
+__device__ __forceinline__ void frag_store_lds(float* p, const Frag<float>& f) {
+  *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+
+// transposed operand: slot i = tile[(k0 + g*8 + i) * ld + col0 + n]   (n = lane&15, g = lane>>4)
+__device__ __forceinline__ Frag<gt_bf16> frag_load_tr(const gt_bf16* tile, int ld, int k0, int col0, int n, int g) {
+  // ds_read_b64_tr_b16: each lane supplies the address of 4 contiguous bf16; within a 16-lane
+  // group the 16x4 block is returned transposed: lane n gets rows 0..3 of column n.
+  const gt_bf16* p0 = tile + (k0 + g * 8 + (n >> 2)) * ld + col0 + (n & 3) * 4;
+  const gt_bf16* p1 = p0 + 4 * ld;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  Frag<gt_bf16> f;
+  f.v.x = (uint32_t)(uint16_t)a[0] | ((uint32_t)(uint16_t)a[1] << 16);
+  f.v.y = (uint32_t)(uint16_t)a[2] | ((uint32_t)(uint16_t)a[3] << 16);
+  f.v.z = (uint32_t)(uint16_t)b[0] | ((uint32_t)(uint16_t)b[1] << 16);
+  f.v.w = (uint32_t)(uint16_t)b[2] | ((uint32_t)(uint16_t)b[3] << 16);
+  return f;
+}
+__device__ __forceinline__ Frag<float> frag_load_tr(const float* tile, int ld, int k0, int col0, int n, int g) {
+  Frag<float> f;
+  const float* p = tile + (k0 + g * 8) * ld + col0 + n;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = p[i * ld];
+  return f;
+}
+
+// fp32 values -> operand fragment
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_from_f32(const float* x);
+template <>
+__device__ __forceinline__ Frag<gt_bf16> frag_from_f32<gt_bf16>(const float* x) {
+  Frag<gt_bf16> f;
+  f.v.x = (uint32_t)gt_f32_to_bf16(x[0]) | ((uint32_t)gt_f32_to_bf16(x[1]) << 16);
+  f.v.y = (uint32_t)gt_f32_to_bf16(x[2]) | ((uint32_t)gt_f32_to_bf16(x[3]) << 16);
+  f.v.z = (uint32_t)gt_f32_to_bf16(x[4]) | ((uint32_t)gt_f32_to_bf16(x[5]) << 16);
+  f.v.w = (uint32_t)gt_f32_to_bf16(x[6]) | ((uint32_t)gt_f32_to_bf16(x[7]) << 16);
+  return f;
+}
+template <>
+__device__ __forceinline__ Frag<float> frag_from_f32<float>(const float* x) {
+  Frag<float> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = x[i];
+  return f;
+}
+
+// C[16x16] += A[16 x 32slots] B[32slots x 16]
+__device__ __forceinline__ f32x4 mma(const Frag<gt_bf16>& a, const Frag<gt_bf16>& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v),
+                                                 c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[i], b.v[i], c, 0, 0, 0);
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, f32x4 v) {
+  gt_store4<T>(p, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+// ---- dropout RNG: counter-based hash of (seed, seq*nhead+head, query pos, key pos) ---------------
+__device__ __forceinline__ uint32_t rng_hash(uint32_t s0, uint32_t s1, uint32_t bh, uint32_t q, uint32_t k) {
+  uint32_t x = (q * 0x9E3779B1u) ^ (k * 0x85EBCA77u + s0);
+  x ^= bh * 0xC2B2AE3Du + s1;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+struct AttnArgs {
+  const void* qkv;
+  const void* ctx;    // fwd: output ; bwd: saved output
+  const void* d_ctx;  // bwd
+  float* lse;         // [nhead][rows], log2 domain of the scaled scores
+  float* delta;       // [nhead][rows]
+  void* out;          // fwd: ctx ; bwd: d_qkv
+  const int32_t* desc;
+  int64_t rows, d_model, row_stride;
+  int nhead;
+  float scale_log2;   // scale * log2(e)
+  float scale;
+  float inv_keep;     // 1/(1-p)
+  uint32_t drop_thr;  // keep iff hash >= thr ; 0 -> no dropout
+  uint32_t seed0, seed1;
+};
+
+template <int HD, typename T>
+struct Lds {
+  static constexpr int LD = HD + (sizeof(T) == 2 ? 8 : 4);  // row pad: 16 B
+};
+
+// cooperative load of a [TILE][HD] tile of rows (pos0 + r) into LDS, zero-filled outside [lo, hi)
+template <typename T, int HD>
+__device__ __forceinline__ void load_tile(T* lds, const T* src, int64_t src_ld, int64_t row0, int64_t row_stride,
+                                          int pos0, int lo, int hi) {
+  constexpr int LD = Lds<HD, T>::LD;
+  constexpr int CH = HD / 8;
+  for (int c = threadIdx.x; c < TILE * CH; c += ATT_THREADS) {
+    int r = c / CH, col = (c % CH) * 8;
+    int pos = pos0 + r;
+    Frag<T> f = frag_zero<T>();
+    if (pos >= lo && pos < hi) f = frag_load(src + (row0 + (int64_t)pos * row_stride) * src_ld + col);
+    frag_store_lds(lds + r * LD + col, f);
+  }
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <typename T, int HD>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
+  constexpr int LD = Lds<HD, T>::LD;
+  constexpr int KK = HD / 32;  // 32-deep steps over head_dim
+  constexpr int DT = HD / 16;  // 16-wide output dim tiles
+  __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
+            kv_len = a.desc[seq * 4 + 3];
+  const int q_base = blockIdx.x * BLOCK_N;
+  if (q_base >= npos) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int qp = q_base + wid * 16 + n;
+  const bool qvalid = qp < npos;
+  const int64_t ld3 = 3 * a.d_model;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const int64_t qrow = row0 + (int64_t)qp * a.row_stride;
+
+  Frag<T> bq[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+    bq[kk] = qvalid ? frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8) : frag_zero<T>();
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kv_end = kv_off + kv_len;
+  const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
+    __syncthreads();
+    load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
+    load_tile<T, HD>(sV, qkv + 2 * a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
+    __syncthreads();
+    // S^T: two 16-key tiles; row m of tile t <-> key (m>>2)*8 + t*4 + (m&3)
+    float s[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      const int krow = (n >> 2) * 8 + t * 4 + (n & 3);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) c = mma(frag_load(sK + krow * LD + kk * 32 + g * 8), bq[kk], c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t * 4 + r] = c[r];
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kp = k0 + g * 8 + i;
+      s[i] = (kp >= kv_off && kp < kv_end) ? s[i] * a.scale_log2 : -INFINITY;
+      mt = fmaxf(mt, s[i]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m, mt);  // finite: every tile in range holds >= 1 valid key
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    float p[8], psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      p[i] = exp2f(s[i] - m_new);
+      psum += p[i];
+    }
+    lsum = lsum * alpha + psum;
+    if (a.drop_thr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)(k0 + g * 8 + i));
+        p[i] = h >= a.drop_thr ? p[i] * a.inv_keep : 0.f;
+      }
+    }
+    const Frag<T> bp = frag_from_f32<T>(p);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 o = acc[dt];
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+      acc[dt] = mma(frag_load_tr(sV, LD, 0, dt * 16, n, g), bp, o);
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (!qvalid) return;
+  const float inv_l = 1.0f / lsum;
+  T* ctx = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    f32x4 o = acc[dt];
+    o[0] *= inv_l; o[1] *= inv_l; o[2] *= inv_l; o[3] *= inv_l;
+    store4<T>(ctx + qrow * a.d_model + head * HD + dt * 16 + g * 4, o);
+  }
+  if (g == 0) a.lse[(int64_t)head * a.rows + qrow] = m + log2f(lsum);
+}
+
+// =================================================================================================
+// backward, pass 1: delta = rowsum(dO * O) and dQ      (block = 64 queries, loop over key tiles)
+// =================================================================================================
+template <typename T, int HD>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
+  constexpr int LD = Lds<HD, T>::LD;
+  constexpr int KK = HD / 32;
+  constexpr int DT = HD / 16;
+  __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
+            kv_len = a.desc[seq * 4 + 3];
+  const int q_base = blockIdx.x * BLOCK_N;
+  if (q_base >= npos) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int qp = q_base + wid * 16 + n;
+  const bool qvalid = qp < npos;
+  const int64_t ld3 = 3 * a.d_model;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* dctx = reinterpret_cast<const T*>(a.d_ctx);
+  const T* ctx = reinterpret_cast<const T*>(a.ctx);
+  const int64_t qrow = row0 + (int64_t)qp * a.row_stride;
+
+  Frag<T> bq[KK], bdo[KK];
+  float delta = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    if (qvalid) {
+      bq[kk] = frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8);
+      bdo[kk] = frag_load(dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8);
+      // delta partial over this lane's 8 dims
+      const T* po = ctx + qrow * a.d_model + head * HD + kk * 32 + g * 8;
+      const T* pd = dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8;
+      float4 o0 = gt_load4<T>(po), o1 = gt_load4<T>(po + 4), d0 = gt_load4<T>(pd), d1 = gt_load4<T>(pd + 4);
+      delta += o0.x * d0.x + o0.y * d0.y + o0.z * d0.z + o0.w * d0.w + o1.x * d1.x + o1.y * d1.y + o1.z * d1.z +
+               o1.w * d1.w;
+    } else {
+      bq[kk] = frag_zero<T>();
+      bdo[kk] = frag_zero<T>();
+    }
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
+  if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
+
+  f32x4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kv_end = kv_off + kv_len;
+  const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
+    __syncthreads();
+    load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
+    load_tile<T, HD>(sV, qkv + 2 * a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
+    __syncthreads();
+    float ds[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      const int krow = (n >> 2) * 8 + t * 4 + (n & 3);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        c = mma(frag_load(sK + krow * LD + kk * 32 + g * 8), bq[kk], c);
+        dp = mma(frag_load(sV + krow * LD + kk * 32 + g * 8), bdo[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t * 4 + r;
+        const int kp = k0 + g * 8 + i;
+        const bool kvalid = kp >= kv_off && kp < kv_end;
+        const float p = kvalid ? exp2f(c[r] * a.scale_log2 - lse) : 0.f;
+        float dpi = dp[r];
+        if (a.drop_thr) {
+          const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)kp);
+          dpi = h >= a.drop_thr ? dpi * a.inv_keep : 0.f;
+        }
+        ds[i] = p * (dpi - delta);
+      }
+    }
+    const Frag<T> bds = frag_from_f32<T>(ds);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = mma(frag_load_tr(sK, LD, 0, dt * 16, n, g), bds, acc[dt]);
+  }
+  if (!qvalid) return;
+  T* dqkv = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    f32x4 o = acc[dt];
+    o[0] *= a.scale; o[1] *= a.scale; o[2] *= a.scale; o[3] *= a.scale;
+    store4<T>(dqkv + qrow * ld3 + head * HD + dt * 16 + g * 4, o);
+  }
+}
+
+// =================================================================================================
+// backward, pass 2: dK, dV                              (block = 64 keys, loop over query tiles)
+// =================================================================================================
+template <typename T, int HD>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
+  constexpr int LD = Lds<HD, T>::LD;
+  constexpr int KK = HD / 32;
+  constexpr int DT = HD / 16;
+  __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
+  __shared__ float sLse[TILE], sDelta[TILE];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
+            kv_len = a.desc[seq * 4 + 3];
+  const int k_base = blockIdx.x * BLOCK_N;
+  if (k_base >= npos) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int kp = k_base + wid * 16 + n;
+  const int kv_end = kv_off + kv_len;
+  const bool kin = kp < npos;                       // row exists
+  const bool kvalid = kp >= kv_off && kp < kv_end;  // key is not padding
+  const int64_t ld3 = 3 * a.d_model;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* dctx = reinterpret_cast<const T*>(a.d_ctx);
+  const int64_t krow = row0 + (int64_t)kp * a.row_stride;
+
+  Frag<T> bk[KK], bv[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    bk[kk] = kvalid ? frag_load(qkv + krow * ld3 + a.d_model + head * HD + kk * 32 + g * 8) : frag_zero<T>();
+    bv[kk] = kvalid ? frag_load(qkv + krow * ld3 + 2 * a.d_model + head * HD + kk * 32 + g * 8) : frag_zero<T>();
+  }
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  // a block whose 64 keys are all padding only writes zeros
+  const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
+  for (int q0 = 0; any_valid && q0 < npos; q0 += TILE) {
+    __syncthreads();
+    load_tile<T, HD>(sQ, qkv + head * HD, ld3, row0, a.row_stride, q0, 0, npos);
+    load_tile<T, HD>(sDO, dctx + head * HD, a.d_model, row0, a.row_stride, q0, 0, npos);
+    if (threadIdx.x < 2 * TILE) {
+      const int r = threadIdx.x & (TILE - 1);
+      const int pos = q0 + r;
+      const float* src = threadIdx.x < TILE ? a.lse : a.delta;
+      float v = pos < npos ? src[(int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride] : 0.f;
+      (threadIdx.x < TILE ? sLse : sDelta)[r] = v;
+    }
+    __syncthreads();
+    float pd[8], ds[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      const int qr = (n >> 2) * 8 + t * 4 + (n & 3);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        c = mma(frag_load(sQ + qr * LD + kk * 32 + g * 8), bk[kk], c);
+        dp = mma(frag_load(sDO + qr * LD + kk * 32 + g * 8), bv[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t * 4 + r;
+        const int qi = g * 8 + i;  // query row inside the tile owned by this slot
+        const int qpos = q0 + qi;
+        const bool ok = kvalid && qpos < npos;
+        float p = ok ? exp2f(c[r] * a.scale_log2 - sLse[qi]) : 0.f;
+        float dpi = dp[r];
+        float pdrop = p;
+        if (a.drop_thr) {
+          const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qpos, (uint32_t)kp);
+          const bool keep = h >= a.drop_thr;
+          dpi = keep ? dpi * a.inv_keep : 0.f;
+          pdrop = keep ? p * a.inv_keep : 0.f;
+        }
+        pd[i] = pdrop;
+        ds[i] = p * (dpi - sDelta[qi]);
+      }
+    }
+    const Frag<T> bp = frag_from_f32<T>(pd);
+    const Frag<T> bds = frag_from_f32<T>(ds);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dv[dt] = mma(frag_load_tr(sDO, LD, 0, dt * 16, n, g), bp, dv[dt]);
+      dk[dt] = mma(frag_load_tr(sQ, LD, 0, dt * 16, n, g), bds, dk[dt]);
+    }
+  }
+  if (!kin) return;
+  T* dqkv = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    f32x4 o = dk[dt];
+    o[0] *= a.scale; o[1] *= a.scale; o[2] *= a.scale; o[3] *= a.scale;
+    store4<T>(dqkv + krow * ld3 + a.d_model + head * HD + dt * 16 + g * 4, o);
+    store4<T>(dqkv + krow * ld3 + 2 * a.d_model + head * HD + dt * 16 + g * 4, dv[dt]);
+  }
+}
+
+int check_attn(const char* fn, int dtype, int64_t d_model, int nhead, int64_t num_seqs, int64_t max_npos,
+               float dropout_p) {
+  if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (nhead <= 0 || d_model <= 0 || d_model % nhead != 0) { gt_set_error("%s: bad d_model/nhead", fn); return GT_ERR_INVALID_ARG; }
+  int64_t hd = d_model / nhead;
+  if (hd != 32 && hd != 64) { gt_set_error("%s: head_dim %lld unsupported (32 or 64)", fn, (long long)hd); return GT_ERR_UNSUPPORTED; }
+  if (num_seqs < 0 || num_seqs > 65535) { gt_set_error("%s: num_seqs out of range", fn); return GT_ERR_INVALID_ARG; }
+  if (max_npos < 0) { gt_set_error("%s: bad max_npos", fn); return GT_ERR_INVALID_ARG; }
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) { gt_set_error("%s: dropout_p must be in [0,1)", fn); return GT_ERR_INVALID_ARG; }
+  return GT_OK;
+}
+
+AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* lse, float* delta, void* out,
+                   int64_t rows, int64_t d_model, int nhead, const int32_t* desc, int64_t row_stride, float scale,
+                   float dropout_p, uint64_t seed) {
+  AttnArgs a{};
+  a.qkv = qkv; a.ctx = ctx; a.d_ctx = d_ctx; a.lse = lse; a.delta = delta; a.out = out; a.desc = desc;
+  a.rows = rows; a.d_model = d_model; a.row_stride = row_stride; a.nhead = nhead;
+  a.scale = scale; a.scale_log2 = scale * LOG2E;
+  a.inv_keep = 1.0f / (1.0f - dropout_p);
+  double thr = (double)dropout_p * 4294967296.0;
+  a.drop_thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
+  a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
+  return a;
+}
+
+}  // namespace
+
+extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
+                           int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
+                           int64_t max_npos, float scale, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  int rc = check_attn("gt_attn_fwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
+  if (rc) return rc;
+  GT_CHECK_ARG(qkv && ctx && lse && seq_desc, "null buffer");
+  if (num_seqs == 0 || max_npos == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, row_stride,
+                         scale, dropout_p, seed);
+  dim3 grid((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+  const int hd = (int)(d_model / nhead);
+#define GT_LAUNCH(T, HD) hipLaunchKernelGGL((k_attn_fwd<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a)
+  if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64); }
+  else { if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64); }
+#undef GT_LAUNCH
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
+                           float* delta, void* d_qkv, int64_t total_rows, int64_t d_model, int nhead,
+                           const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                           float scale, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  int rc = check_attn("gt_attn_bwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
+  if (rc) return rc;
+  GT_CHECK_ARG(qkv && ctx && d_ctx && lse && delta && d_qkv && seq_desc, "null buffer");
+  if (num_seqs == 0 || max_npos == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnArgs a = make_args(qkv, ctx, d_ctx, const_cast<float*>(lse), delta, d_qkv, total_rows, d_model, nhead, seq_desc,
+                         row_stride, scale, dropout_p, seed);
+  dim3 grid((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+  const int hd = (int)(d_model / nhead);
+#define GT_LAUNCH(T, HD)                                                                        \
+  do {                                                                                          \
+    hipLaunchKernelGGL((k_attn_bwd_dq<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);          \
+    hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);         \
+  } while (0)
+  if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64); }
+  else { if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64); }
+#undef GT_LAUNCH
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -1,0 +1,321 @@
+// graph_prep.hip — per-batch graph structure on device: graph_ptr, CSR-by-destination,
+// CSC-by-source (both stable w.r.t. original edge order), GCN degree / deg^-1/2.
+//
+// Reference semantics being replaced (paths under /root/reference):
+//   modules/conv.py:54-61   deg = degree(row, N) + 1 ; deg_inv_sqrt = deg.pow(-0.5)
+//   modules/conv.py:28,63   MessagePassing.propagate -> scatter-add over UNSORTED edge_index[1]
+//   modules/utils.py:9-13   per-graph `batch.eq(i)` masks
+// Integer outputs are bit-identical to oracle/graph_struct.py (numpy stable argsort).
+//
+// Pipeline (all on `stream`, no host sync): memset counters -> count (atomics on int32: result is
+// order-independent) -> 3-phase exclusive scan -> fill (atomic cursors, arbitrary order inside a
+// row) -> per-row sort by edge id (restores the stable order; rows are short) -> gather src/dst.
+#include "gt_common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 counters per block
+constexpr int SHORT_ROW = 32;
+constexpr int BITONIC_MAX = 4096;
+constexpr int LONG_GRID = 256;
+
+__global__ void k_count(const int64_t* __restrict__ ei, const int64_t* __restrict__ batch, int64_t N, int64_t E,
+                        int64_t B, int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
+                        int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
+                        int32_t* __restrict__ status) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = i; k < E; k += stride) {
+    int64_t r = ei[k], c = ei[E + k];
+    if (r < 0 || r >= N || c < 0 || c >= N) {
+      status[0] = 1;
+      continue;
+    }
+    atomicAdd(&cnt_out[r], 1);
+    atomicAdd(&cnt_in[c], 1);
+  }
+  for (int64_t n = i; n < N; n += stride) {
+    int64_t g = batch[n];
+    int64_t gp = n > 0 ? batch[n - 1] : -1;
+    if (g < gp || g >= B || g < 0) {
+      status[0] = 2;
+      node_graph[n] = 0;
+      continue;
+    }
+    node_graph[n] = (int32_t)g;
+    for (int64_t b = gp + 1; b <= g; ++b) graph_ptr[b] = (int32_t)n;
+    if (n == N - 1)
+      for (int64_t b = g + 1; b <= B; ++b) graph_ptr[b] = (int32_t)N;
+  }
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  // exclusive scan of one int per thread over a 256-thread block (4 waves)
+  __shared__ int wave_sums[SCAN_THREADS / GT_WAVE];
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wave_sums[wid] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / GT_WAVE; ++w) {
+    int s = wave_sums[w];
+    if (w < wid) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+// which = blockIdx.y: 0 -> in (cnt_in -> in_ptr), 1 -> out
+__global__ void k_scan_reduce(const int32_t* __restrict__ cnt_in, const int32_t* __restrict__ cnt_out, int64_t N,
+                              int32_t* __restrict__ bsum, int nb) {
+  const int32_t* cnt = blockIdx.y ? cnt_out : cnt_in;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j)
+    if (base + j < N) s += cnt[base + j];
+  int tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.y * nb + blockIdx.x] = tot;
+}
+
+__global__ void k_scan_blocksums(int32_t* __restrict__ bsum, int nb) {
+  int32_t* s = bsum + blockIdx.x * nb;
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += SCAN_THREADS) {
+    int i = base + threadIdx.x;
+    int v = i < nb ? s[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot);
+    int c = carry;
+    if (i < nb) s[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+}
+
+__global__ void k_scan_final(const int32_t* __restrict__ cnt_in, const int32_t* __restrict__ cnt_out, int64_t N,
+                             int64_t E, const int32_t* __restrict__ bsum, int nb, int32_t* __restrict__ in_ptr,
+                             int32_t* __restrict__ out_ptr, float* __restrict__ deg, float* __restrict__ dis) {
+  const int which = blockIdx.y;
+  const int32_t* cnt = which ? cnt_out : cnt_in;
+  int32_t* ptr = which ? out_ptr : in_ptr;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = (base + j < N) ? cnt[base + j] : 0;
+    s += v[j];
+  }
+  int tot;
+  int ex = block_exclusive_scan(s, &tot) + bsum[which * nb + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < N) {
+      ptr[base + j] = ex;
+      if (which) {
+        float d = (float)(v[j] + 1);  // conv.py:57  degree(row) + 1
+        deg[base + j] = d;
+        dis[base + j] = 1.0f / sqrtf(d);  // conv.py:58  deg.pow(-0.5)   (deg >= 1: never inf)
+      }
+    }
+    ex += v[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) ptr[N] = (int32_t)E;
+}
+
+__global__ void k_fill(const int64_t* __restrict__ ei, int64_t N, int64_t E, const int32_t* __restrict__ in_ptr,
+                       const int32_t* __restrict__ out_ptr, int32_t* __restrict__ cnt_in,
+                       int32_t* __restrict__ cnt_out, int32_t* __restrict__ in_eid, int32_t* __restrict__ out_eid) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = i; k < E; k += stride) {
+    int64_t r = ei[k], c = ei[E + k];
+    if (r < 0 || r >= N || c < 0 || c >= N) continue;
+    int pi = in_ptr[c] + atomicSub(&cnt_in[c], 1) - 1;
+    in_eid[pi] = (int32_t)k;
+    int po = out_ptr[r] + atomicSub(&cnt_out[r], 1) - 1;
+    out_eid[po] = (int32_t)k;
+  }
+}
+
+// thread per row: insertion sort of short rows, long rows go to a worklist
+__global__ void k_sort_short(int64_t N, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ out_ptr,
+                             int32_t* __restrict__ in_eid, int32_t* __restrict__ out_eid,
+                             int32_t* __restrict__ worklist, int32_t* __restrict__ wl_count) {
+  const int which = blockIdx.y;
+  const int32_t* ptr = which ? out_ptr : in_ptr;
+  int32_t* eid = which ? out_eid : in_eid;
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= N) return;
+  int b = ptr[v], e = ptr[v + 1], len = e - b;
+  if (len <= 1) return;
+  if (len > SHORT_ROW) {
+    int slot = atomicAdd(&wl_count[which], 1);
+    worklist[(int64_t)which * N + slot] = (int32_t)v;
+    return;
+  }
+  for (int i = b + 1; i < e; ++i) {
+    int x = eid[i];
+    int j = i - 1;
+    while (j >= b && eid[j] > x) {
+      eid[j + 1] = eid[j];
+      --j;
+    }
+    eid[j + 1] = x;
+  }
+}
+
+// one block per long row (worklist entry): bitonic sort in LDS, or rank-by-counting for huge rows
+__global__ void __launch_bounds__(256) k_sort_long(int64_t N, const int32_t* __restrict__ in_ptr,
+                                                   const int32_t* __restrict__ out_ptr, int32_t* __restrict__ in_eid,
+                                                   int32_t* __restrict__ out_eid, const int32_t* __restrict__ worklist,
+                                                   const int32_t* __restrict__ wl_count, int32_t* __restrict__ tmp,
+                                                   int64_t E) {
+  __shared__ int32_t buf[BITONIC_MAX];
+  const int which = blockIdx.y;
+  const int32_t* ptr = which ? out_ptr : in_ptr;
+  int32_t* eid = which ? out_eid : in_eid;
+  int32_t* scratch = tmp + (int64_t)which * E;
+  const int count = wl_count[which];
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    int v = worklist[(int64_t)which * N + w];
+    int b = ptr[v], len = ptr[v + 1] - b;
+    if (len <= BITONIC_MAX) {
+      int n2 = 1;
+      while (n2 < len) n2 <<= 1;
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = i < len ? eid[b + i] : 0x7fffffff;
+      __syncthreads();
+      for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            int ixj = i ^ j;
+            if (ixj > i) {
+              int a = buf[i], c = buf[ixj];
+              bool up = (i & k) == 0;
+              if ((a > c) == up) {
+                buf[i] = c;
+                buf[ixj] = a;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i = threadIdx.x; i < len; i += blockDim.x) eid[b + i] = buf[i];
+      __syncthreads();
+    } else {
+      // edge ids are distinct: rank = number of smaller ids in the row
+      for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        int x = eid[b + i];
+        int r = 0;
+        for (int j = 0; j < len; ++j) r += (eid[b + j] < x);
+        scratch[b + r] = x;
+      }
+      __syncthreads();
+      __threadfence_block();
+      for (int i = threadIdx.x; i < len; i += blockDim.x) eid[b + i] = scratch[b + i];
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void k_gather(const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ in_eid,
+                         const int32_t* __restrict__ out_eid, int32_t* __restrict__ in_src,
+                         int32_t* __restrict__ out_dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = i; p < E; p += stride) {
+    in_src[p] = (int32_t)ei[in_eid[p]];
+    out_dst[p] = (int32_t)ei[E + out_eid[p]];
+  }
+}
+
+struct PrepWs {
+  int32_t *cnt_in, *cnt_out, *bsum, *worklist, *wl_count, *tmp;
+  size_t bytes;
+};
+
+PrepWs carve(void* ws, int64_t N, int64_t E) {
+  PrepWs w;
+  int64_t nb = gt_cdiv(N > 0 ? N : 1, SCAN_TILE);
+  int32_t* p = (int32_t*)ws;
+  int64_t off = 0;
+  w.cnt_in = p + off; off += N;
+  w.cnt_out = p + off; off += N;
+  w.wl_count = p + off; off += 4;
+  w.bsum = p + off; off += 2 * nb;
+  w.worklist = p + off; off += 2 * N;
+  w.tmp = p + off; off += 2 * E;
+  w.bytes = (size_t)off * sizeof(int32_t);
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t gt_graph_prep_workspace_bytes(int64_t N, int64_t E, int64_t B) {
+  (void)B;
+  return carve(nullptr, N, E).bytes + 64;
+}
+
+extern "C" int gt_graph_prep(const int64_t* edge_index, const int64_t* batch, int64_t N, int64_t E, int64_t B,
+                             int32_t* graph_ptr, int32_t* node_graph, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid,
+                             int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, float* deg, float* dis,
+                             int32_t* status, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GT_CHECK_ARG(N >= 0 && E >= 0 && B >= 0, "negative size");
+  GT_CHECK_ARG(N < (1ll << 31) && E < (1ll << 31), "N and E must fit int32");
+  GT_CHECK_ARG(graph_ptr && node_graph && in_ptr && out_ptr && deg && dis && status, "null output");
+  GT_CHECK_ARG(E == 0 || (edge_index && in_src && in_eid && out_dst && out_eid), "null edge buffer");
+  PrepWs w = carve(workspace, N, E);
+  if (workspace_bytes < w.bytes || !workspace) {
+    gt_set_error("gt_graph_prep: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+    return GT_ERR_WORKSPACE;
+  }
+  // zero: counters (cnt_in, cnt_out, wl_count are contiguous) and the status word
+  (void)hipMemsetAsync(w.cnt_in, 0, (size_t)(2 * N + 4) * sizeof(int32_t), stream);
+  (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+  if (N == 0) {
+    (void)hipMemsetAsync(graph_ptr, 0, (size_t)(B + 1) * sizeof(int32_t), stream);
+    (void)hipMemsetAsync(in_ptr, 0, sizeof(int32_t), stream);
+    (void)hipMemsetAsync(out_ptr, 0, sizeof(int32_t), stream);
+    return GT_OK;
+  }
+  const int threads = 256;
+  int64_t work = E > N ? E : N;
+  int grid = (int)(gt_cdiv(work, threads) < 4096 ? gt_cdiv(work, threads) : 4096);
+  hipLaunchKernelGGL(k_count, dim3(grid), dim3(threads), 0, stream, edge_index, batch, N, E, B, w.cnt_in, w.cnt_out,
+                     graph_ptr, node_graph, status);
+  int nb = (int)gt_cdiv(N, SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb, 2), dim3(SCAN_THREADS), 0, stream, w.cnt_in, w.cnt_out, N, w.bsum, nb);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(2), dim3(SCAN_THREADS), 0, stream, w.bsum, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb, 2), dim3(SCAN_THREADS), 0, stream, w.cnt_in, w.cnt_out, N, E, w.bsum, nb,
+                     in_ptr, out_ptr, deg, dis);
+  if (E > 0) {
+    int egrid = (int)(gt_cdiv(E, threads) < 4096 ? gt_cdiv(E, threads) : 4096);
+    hipLaunchKernelGGL(k_fill, dim3(egrid), dim3(threads), 0, stream, edge_index, N, E, in_ptr, out_ptr, w.cnt_in,
+                       w.cnt_out, in_eid, out_eid);
+    hipLaunchKernelGGL(k_sort_short, dim3((unsigned)gt_cdiv(N, threads), 2), dim3(threads), 0, stream, N, in_ptr,
+                       out_ptr, in_eid, out_eid, w.worklist, w.wl_count);
+    hipLaunchKernelGGL(k_sort_long, dim3(LONG_GRID, 2), dim3(256), 0, stream, N, in_ptr, out_ptr, in_eid, out_eid,
+                       w.worklist, w.wl_count, w.tmp, E);
+    hipLaunchKernelGGL(k_gather, dim3(egrid), dim3(threads), 0, stream, edge_index, E, in_eid, out_eid, in_src,
+                       out_dst);
+  }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -1,0 +1,87 @@
+// gt_common.h — shared helpers for the gfx950 kernels (device code + C-ABI plumbing).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/graphtrans_hip.h"
+
+#define GT_WAVE 64
+
+// thread-local last-error string (C-ABI contract: never throws, never exits)
+void gt_set_error(const char* fmt, ...);
+
+#define GT_CHECK_ARG(cond, msg)                     \
+  do {                                              \
+    if (!(cond)) {                                  \
+      gt_set_error("%s: %s", __func__, msg);        \
+      return GT_ERR_INVALID_ARG;                    \
+    }                                               \
+  } while (0)
+
+#define GT_CHECK_LAUNCH()                                                        \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      gt_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__));   \
+      return GT_ERR_LAUNCH;                                                      \
+    }                                                                            \
+  } while (0)
+
+static inline int64_t gt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 (storage type is a raw 16-bit pattern) -------------------------------------
+typedef uint16_t gt_bf16;
+
+__device__ __forceinline__ float gt_bf16_to_f32(gt_bf16 v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ gt_bf16 gt_f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (gt_bf16)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (gt_bf16)(u >> 16);
+}
+
+struct gt_f4 {
+  float x, y, z, w;
+};
+
+// 4-element vector load/store of a row chunk, converting storage <-> fp32.
+template <typename T>
+__device__ __forceinline__ float4 gt_load4(const T* p);
+template <>
+__device__ __forceinline__ float4 gt_load4<float>(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+template <>
+__device__ __forceinline__ float4 gt_load4<gt_bf16>(const gt_bf16* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  float4 r;
+  r.x = __uint_as_float(u.x << 16);
+  r.y = __uint_as_float(u.x & 0xffff0000u);
+  r.z = __uint_as_float(u.y << 16);
+  r.w = __uint_as_float(u.y & 0xffff0000u);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void gt_store4(T* p, float4 v);
+template <>
+__device__ __forceinline__ void gt_store4<float>(float* p, float4 v) {
+  *reinterpret_cast<float4*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void gt_store4<gt_bf16>(gt_bf16* p, float4 v) {
+  uint2 u;
+  u.x = (uint32_t)gt_f32_to_bf16(v.x) | ((uint32_t)gt_f32_to_bf16(v.y) << 16);
+  u.y = (uint32_t)gt_f32_to_bf16(v.z) | ((uint32_t)gt_f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float4 gt_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 gt_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 gt_scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 gt_fma4(float4 a, float s, float4 c) {
+  return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ float4 gt_relu4(float4 a) {
+  return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+}

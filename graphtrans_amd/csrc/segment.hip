@@ -1,0 +1,227 @@
+// segment.hip — per-graph segment ops and node-row <-> token-row layout kernels.
+//
+// Reference semantics (paths under /root/reference):
+//   h + vn[batch]                         modules/gnn_module.py:199   (index + add)
+//   global_add_pool(h, batch) + vn        modules/gnn_module.py:219   (torch_scatter atomics)
+//   pad_batch / unpad_batch               modules/utils.py:5-53       (python loop over graphs)
+//   CLS concat + mask extend              modules/transformer_encoder.py:50-55
+// `batch` is sorted (PyG collation), so every graph is a contiguous row range [ptr[b], ptr[b+1]):
+// segment sums need no atomics and pad/unpad are pure index arithmetic on graph_ptr.
+#include "gt_common.h"
+
+namespace {
+
+constexpr int SEG_THREADS = 256;
+
+// out[n] = x[n] + seg[node_graph[n]] ; flat over node rows (no per-graph grid: graph sizes are ragged)
+template <typename T>
+__global__ void __launch_bounds__(SEG_THREADS) k_bcast_add(const T* __restrict__ x, const T* __restrict__ seg,
+                                                           const int32_t* __restrict__ node_graph, int64_t N,
+                                                           int64_t D, T* __restrict__ out) {
+  const int64_t C = D / 4;  // float4 chunks per row
+  const int64_t total = N * C;
+  for (int64_t i = (int64_t)blockIdx.x * SEG_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SEG_THREADS) {
+    int64_t r = i / C, c = (i % C) * 4;
+    float4 s = gt_load4<T>(seg + (int64_t)node_graph[r] * D + c);
+    if (x) s = gt_add4(s, gt_load4<T>(x + r * D + c));
+    gt_store4<T>(out + r * D + c, s);
+  }
+}
+
+// out[b] = add[b] + sum_{n in graph b} x[n] ; grid (column tiles of 64 chunks, B); 4 waves stride rows.
+template <typename T>
+__global__ void __launch_bounds__(SEG_THREADS) k_segment_sum(const T* __restrict__ x, const T* __restrict__ add,
+                                                             const int32_t* __restrict__ gptr, int64_t D,
+                                                             T* __restrict__ out) {
+  __shared__ float4 sm[4][64];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  const bool act = c < D;
+  const int beg = gptr[b], end = gptr[b + 1];
+  float4 acc = gt_zero4();
+  if (act) {
+    int r = beg + wid;
+    // 2 independent loads in flight per wave
+    for (; r + 4 < end; r += 8) {
+      float4 a0 = gt_load4<T>(x + (int64_t)r * D + c);
+      float4 a1 = gt_load4<T>(x + (int64_t)(r + 4) * D + c);
+      acc = gt_add4(acc, a0);
+      acc = gt_add4(acc, a1);
+    }
+    for (; r < end; r += 4) acc = gt_add4(acc, gt_load4<T>(x + (int64_t)r * D + c));
+  }
+  sm[wid][lane] = acc;
+  __syncthreads();
+  if (wid == 0 && act) {
+    float4 t = gt_add4(gt_add4(sm[0][lane], sm[1][lane]), gt_add4(sm[2][lane], sm[3][lane]));
+    if (add) t = gt_add4(t, gt_load4<T>(add + (int64_t)b * D + c));
+    gt_store4<T>(out + (int64_t)b * D + c, t);
+  }
+}
+
+// tokens[row(b,p)] <- node row | cls | 0 ; grid (position tiles, B)
+template <typename T>
+__global__ void __launch_bounds__(SEG_THREADS) k_seq_gather(const T* __restrict__ h, const T* __restrict__ cls,
+                                                            const int32_t* __restrict__ gptr,
+                                                            const int32_t* __restrict__ desc, int64_t row_stride,
+                                                            int64_t max_npos, int with_cls, int64_t D,
+                                                            T* __restrict__ tokens, uint8_t* __restrict__ pad_mask,
+                                                            int pos_per_block) {
+  const int b = blockIdx.y;
+  const int row0 = desc[b * 4 + 0], npos = desc[b * 4 + 1], kv_off = desc[b * 4 + 2], kv_len = desc[b * 4 + 3];
+  const int kept = kv_len - with_cls;
+  const int node0 = gptr[b + 1] - kept;  // first kept node (graphs keep their LAST `kept` nodes)
+  const int p0 = blockIdx.x * pos_per_block;
+  if (p0 >= npos) return;
+  const int p1 = p0 + pos_per_block < npos ? p0 + pos_per_block : npos;
+  const int64_t C = D / 4;
+  const int64_t total = (int64_t)(p1 - p0) * C;
+  for (int64_t i = threadIdx.x; i < total; i += SEG_THREADS) {
+    int p = p0 + (int)(i / C);
+    int64_t c = (i % C) * 4;
+    int j = p - kv_off;
+    float4 v = gt_zero4();
+    if (j >= 0 && j < kept) v = gt_load4<T>(h + (int64_t)(node0 + j) * D + c);
+    else if (with_cls && j == kept) v = gt_load4<T>(cls + c);
+    gt_store4<T>(tokens + ((int64_t)row0 + (int64_t)p * row_stride) * D + c, v);
+  }
+  if (pad_mask)
+    for (int p = p0 + threadIdx.x; p < p1; p += SEG_THREADS)
+      pad_mask[(int64_t)b * max_npos + p] = (p < kv_off || p >= kv_off + kv_len) ? 1 : 0;
+}
+
+// adjoint / unpad: node rows <- token rows ; flat over node rows, CLS rows by the first B blocks
+template <typename T>
+__global__ void __launch_bounds__(SEG_THREADS) k_seq_scatter(const T* __restrict__ tokens, const T* __restrict__ base,
+                                                             const int32_t* __restrict__ gptr,
+                                                             const int32_t* __restrict__ node_graph,
+                                                             const int32_t* __restrict__ desc, int64_t num_seqs,
+                                                             int64_t row_stride, int with_cls, int64_t N, int64_t D,
+                                                             T* __restrict__ h_out, T* __restrict__ cls_out) {
+  const int64_t C = D / 4;
+  if (cls_out && with_cls) {
+    for (int64_t i = (int64_t)blockIdx.x * SEG_THREADS + threadIdx.x; i < num_seqs * C;
+         i += (int64_t)gridDim.x * SEG_THREADS) {
+      int64_t b = i / C, c = (i % C) * 4;
+      int row0 = desc[b * 4 + 0], kv_off = desc[b * 4 + 2], kv_len = desc[b * 4 + 3];
+      gt_store4<T>(cls_out + b * D + c,
+                   gt_load4<T>(tokens + ((int64_t)row0 + (int64_t)(kv_off + kv_len - 1) * row_stride) * D + c));
+    }
+  }
+  const int64_t total = N * C;
+  for (int64_t i = (int64_t)blockIdx.x * SEG_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SEG_THREADS) {
+    int64_t r = i / C, c = (i % C) * 4;
+    int b = node_graph[r];
+    int row0 = desc[b * 4 + 0], kv_off = desc[b * 4 + 2], kv_len = desc[b * 4 + 3];
+    int node0 = gptr[b + 1] - (kv_len - with_cls);
+    float4 v;
+    if (r >= node0) v = gt_load4<T>(tokens + ((int64_t)row0 + (int64_t)(kv_off + (int)r - node0) * row_stride) * D + c);
+    else v = base ? gt_load4<T>(base + r * D + c) : gt_zero4();
+    gt_store4<T>(h_out + r * D + c, v);
+  }
+}
+
+int check(const char* fn, int dtype, int64_t D) {
+  if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (D <= 0 || D % 4 != 0) { gt_set_error("%s: dim %lld must be a positive multiple of 4", fn, (long long)D); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
+// rows handled per block so that a block moves ~32 KB
+int rows_per_block(int64_t D, int elt) {
+  int64_t r = (32 * 1024) / (D * elt);
+  return (int)(r < 1 ? 1 : (r > 64 ? 64 : r));
+}
+
+}  // namespace
+
+static int flat_grid(int64_t items) {
+  int64_t g = gt_cdiv(items, SEG_THREADS * 4);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+extern "C" int gt_segment_bcast_add(int dtype, const void* x, const void* seg, const int32_t* node_graph, int64_t N,
+                                    int64_t B, int64_t D, void* out, gt_stream_t stream_) {
+  (void)B;
+  int rc = check("gt_segment_bcast_add", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(seg && node_graph && out, "null buffer");
+  if (N == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(flat_grid(N * (D / 4)));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_bcast_add<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)x, (const float*)seg,
+                       node_graph, N, D, (float*)out);
+  else
+    hipLaunchKernelGGL(k_bcast_add<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)x,
+                       (const gt_bf16*)seg, node_graph, N, D, (gt_bf16*)out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_segment_sum(int dtype, const void* x, const void* add, const int32_t* graph_ptr, int64_t N,
+                              int64_t B, int64_t D, void* out, gt_stream_t stream_) {
+  (void)N;
+  int rc = check("gt_segment_sum", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && graph_ptr && out, "null buffer");
+  if (B == 0) return GT_OK;
+  GT_CHECK_ARG(B <= 65535, "more than 65535 graphs per batch");
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid((unsigned)gt_cdiv(D / 4, 64), (unsigned)B);
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_segment_sum<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)x, (const float*)add,
+                       graph_ptr, D, (float*)out);
+  else
+    hipLaunchKernelGGL(k_segment_sum<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)x,
+                       (const gt_bf16*)add, graph_ptr, D, (gt_bf16*)out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_seq_gather(int dtype, const void* h, const void* cls, const int32_t* graph_ptr,
+                             const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                             int with_cls, int64_t D, void* tokens, uint8_t* pad_mask, gt_stream_t stream_) {
+  int rc = check("gt_seq_gather", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(h && graph_ptr && seq_desc && tokens, "null buffer");
+  GT_CHECK_ARG(!with_cls || cls, "with_cls needs the cls row");
+  if (num_seqs == 0 || max_npos == 0) return GT_OK;
+  GT_CHECK_ARG(num_seqs <= 65535, "more than 65535 sequences");
+  hipStream_t stream = (hipStream_t)stream_;
+  int ppb = rows_per_block(D, dtype == GT_F32 ? 4 : 2);
+  dim3 grid((unsigned)gt_cdiv(max_npos, ppb), (unsigned)num_seqs);
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_seq_gather<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)h, (const float*)cls,
+                       graph_ptr, seq_desc, row_stride, max_npos, with_cls, D, (float*)tokens, pad_mask, ppb);
+  else
+    hipLaunchKernelGGL(k_seq_gather<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)h,
+                       (const gt_bf16*)cls, graph_ptr, seq_desc, row_stride, max_npos, with_cls, D, (gt_bf16*)tokens,
+                       pad_mask, ppb);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_t* graph_ptr,
+                              const int32_t* node_graph, const int32_t* seq_desc, int64_t num_seqs,
+                              int64_t row_stride, int with_cls, int64_t N, int64_t D, void* h_out, void* cls_out,
+                              gt_stream_t stream_) {
+  int rc = check("gt_seq_scatter", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(tokens && graph_ptr && node_graph && seq_desc && h_out, "null buffer");
+  if (num_seqs == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  int64_t items = (N > num_seqs ? N : num_seqs) * (D / 4);
+  dim3 grid(flat_grid(items));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_seq_scatter<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)tokens,
+                       (const float*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
+                       (float*)h_out, (float*)cls_out);
+  else
+    hipLaunchKernelGGL(k_seq_scatter<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)tokens,
+                       (const gt_bf16*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
+                       (gt_bf16*)h_out, (gt_bf16*)cls_out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -1,0 +1,128 @@
+"""Per-batch index structures for the HIP kernels (built once per collated batch on device).
+
+Replaces the reference's per-layer `degree(row)` (modules/conv.py:57), its unsorted scatter
+(conv.py:28,63) and the `batch.eq(i)` loops of pad_batch (modules/utils.py:9-13) with one call to
+`gt_graph_prep`, plus the sequence layouts (`SeqLayout`) that describe how node rows map to
+transformer token rows (padded = the reference's (S,B,d) layout; packed = no padding rows at all).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class GraphStructure:
+    """graph_ptr, node_graph, CSR by destination (in_*), CSC by source (out_*), deg, dis."""
+
+    __slots__ = ("N", "E", "B", "device", "graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr",
+                 "out_dst", "out_eid", "deg", "dis", "status", "_sizes", "_layouts")
+
+    @staticmethod
+    def build(edge_index, batch, num_graphs=None, sizes=None):
+        """edge_index (2,E) int64, batch (N,) int64 sorted; both on the GPU.  `num_graphs` / `sizes`
+        (host values, e.g. PyG Batch.num_graphs / the collater's per-graph node counts) avoid the
+        device sync the reference performs at modules/gnn_module.py:195."""
+        if not edge_index.is_cuda:
+            raise RuntimeError("graphtrans_amd kernels run on the GPU only (no CPU fallback)")
+        gs = GraphStructure()
+        dev = edge_index.device
+        N, E = int(batch.numel()), int(edge_index.shape[1])
+        if num_graphs is None:
+            num_graphs = len(sizes) if sizes is not None else (int(batch[-1].item()) + 1 if N > 0 else 0)
+        B = int(num_graphs)
+        edge_index = edge_index.contiguous()
+        batch = batch.contiguous()
+        if edge_index.dtype != torch.int64 or batch.dtype != torch.int64:
+            raise TypeError("edge_index and batch must be int64 (PyG collation dtype)")
+        i32 = dict(dtype=torch.int32, device=dev)
+        gs.N, gs.E, gs.B, gs.device = N, E, B, dev
+        gs.graph_ptr = torch.empty(B + 1, **i32)
+        gs.node_graph = torch.empty(max(N, 1), **i32)
+        gs.in_ptr = torch.empty(N + 1, **i32)
+        gs.out_ptr = torch.empty(N + 1, **i32)
+        idx = torch.empty(4, max(E, 1), **i32)
+        gs.in_src, gs.in_eid, gs.out_dst, gs.out_eid = idx[0], idx[1], idx[2], idx[3]
+        dd = torch.empty(2, max(N, 1), dtype=torch.float32, device=dev)
+        gs.deg, gs.dis = dd[0], dd[1]
+        gs.status = torch.empty(1, **i32)
+        L = _lib.lib()
+        ws_bytes = L.gt_graph_prep_workspace_bytes(N, E, B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = L.gt_graph_prep(_ptr(edge_index), _ptr(batch), N, E, B, _ptr(gs.graph_ptr), _ptr(gs.node_graph),
+                             _ptr(gs.in_ptr), _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.out_ptr), _ptr(gs.out_dst),
+                             _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes,
+                             _stream())
+        _lib.check(rc, "gt_graph_prep")
+        gs._sizes = None if sizes is None else np.asarray(sizes, dtype=np.int64)
+        gs._layouts = {}
+        return gs
+
+    def validate(self):
+        """Raise if gt_graph_prep saw an out-of-range edge/batch index (device sync)."""
+        s = int(self.status.item())
+        if s:
+            raise ValueError("edge_index / batch out of range or batch not sorted (gt_graph_prep status %d)" % s)
+
+    @property
+    def sizes(self):
+        """Host per-graph node counts (one small D2H copy if the collater did not supply them)."""
+        if self._sizes is None:
+            p = self.graph_ptr.cpu().numpy().astype(np.int64)
+            self._sizes = np.diff(p)
+        return self._sizes
+
+    def layout(self, kind, max_input_len, with_cls):
+        key = (kind, int(max_input_len), bool(with_cls))
+        if key not in self._layouts:
+            self._layouts[key] = SeqLayout(self, kind, int(max_input_len), bool(with_cls))
+        return self._layouts[key]
+
+
+class SeqLayout:
+    """seq_desc[B][4] = {row0, npos, kv_off, kv_len} (see include/graphtrans_hip.h).
+
+    padded: the reference layout of pad_batch + CLS (modules/utils.py:5-29,
+            modules/transformer_encoder.py:50-55): rows = S' x B, position-major, left padded.
+    packed: only real tokens, graph after graph: rows = sum_b (kept_b + cls).
+    """
+
+    def __init__(self, gs, kind, max_input_len, with_cls):
+        n = gs.sizes
+        B = gs.B
+        cls = 1 if with_cls else 0
+        S = int(min(int(n.max()) if B else 0, max_input_len))  # modules/utils.py:16
+        kept = np.minimum(n, S)
+        kv_len = kept + cls
+        desc = np.zeros((B, 4), dtype=np.int32)
+        if kind == "padded":
+            npos = S + cls
+            desc[:, 0] = np.arange(B)
+            desc[:, 1] = npos
+            desc[:, 2] = npos - kv_len
+            desc[:, 3] = kv_len
+            self.row_stride, self.rows, self.max_npos = B, npos * B, npos
+        elif kind == "packed":
+            tok_ptr = np.concatenate([[0], np.cumsum(kv_len)])
+            desc[:, 0] = tok_ptr[:-1]
+            desc[:, 1] = kv_len
+            desc[:, 2] = 0
+            desc[:, 3] = kv_len
+            self.row_stride, self.rows, self.max_npos = 1, int(tok_ptr[-1]), int(kv_len.max()) if B else 0
+            self.tok_ptr = tok_ptr
+        else:
+            raise ValueError(kind)
+        self.kind, self.with_cls, self.S, self.B = kind, with_cls, S, B
+        self.kept = kept
+        self.desc_cpu = desc
+        self.desc = torch.from_numpy(desc).to(gs.device, non_blocking=True)
+        # token row of the last position (CLS / last node) of every sequence: the pooled row
+        last_row = desc[:, 0].astype(np.int64) + (desc[:, 1].astype(np.int64) - 1) * self.row_stride
+        self.last_rows = torch.from_numpy(last_row).to(gs.device, non_blocking=True)

@@ -1,0 +1,145 @@
+"""GNN_node / GNN_node_Virtualnode / GNNNodeEmbedding (modules/gnn_module.py:18-248) on the HIP
+aggregate and segment kernels.  Same ctor arguments, attributes and state_dict keys."""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..graph import GraphStructure
+from .conv import GCNConv, GINConv
+
+
+def batch_structure(batched_data):
+    """GraphStructure of a collated batch, built once and cached on the batch object."""
+    gs = getattr(batched_data, "_gt_structure", None)
+    if gs is None:
+        sizes = getattr(batched_data, "_sizes", None)
+        ng = getattr(batched_data, "_num_graphs", None)
+        if ng is None and sizes is None and hasattr(type(batched_data), "num_graphs"):
+            try:
+                ng = batched_data.num_graphs
+            except Exception:
+                ng = None
+        gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes)
+        try:
+            batched_data._gt_structure = gs
+        except Exception:
+            pass
+    return gs
+
+
+def _encode_nodes(node_encoder, batched_data):
+    x = batched_data.x
+    node_depth = batched_data.node_depth if hasattr(batched_data, "node_depth") else None
+    if node_encoder is None:
+        return x
+    return node_encoder(x) if node_depth is None else node_encoder(x, node_depth.view(-1))
+
+
+def _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type):
+    self.convs = torch.nn.ModuleList()
+    self.batch_norms = torch.nn.ModuleList()
+    for _ in range(num_layer):
+        if gnn_type == "gin":
+            self.convs.append(GINConv(emb_dim, edge_encoder_cls))
+        elif gnn_type == "gcn":
+            self.convs.append(GCNConv(emb_dim, edge_encoder_cls))
+        else:
+            raise ValueError("Undefined GNN type called {}".format(gnn_type))
+        self.batch_norms.append(torch.nn.BatchNorm1d(emb_dim))
+
+
+def _jk(JK, h_list, num_layer):
+    if JK == "last":
+        return h_list[-1]
+    if JK == "sum":  # excludes the final layer's output, as the reference does (gnn_module.py:100-103)
+        out = 0
+        for layer in range(num_layer):
+            out = out + h_list[layer]
+        return out
+    if JK == "cat":
+        return torch.cat([h_list[0], h_list[-1]], dim=-1)
+    raise ValueError(JK)
+
+
+class GNN_node(torch.nn.Module):
+    @staticmethod
+    def need_deg():
+        return False
+
+    def __init__(self, num_layer, emb_dim, node_encoder, edge_encoder_cls, drop_ratio=0.5, JK="last", residual=False,
+                 gnn_type="gin"):
+        super().__init__()
+        self.num_layer, self.drop_ratio, self.JK, self.residual = num_layer, drop_ratio, JK, residual
+        if self.num_layer < 2:
+            raise ValueError("Number of GNN layers must be greater than 1.")
+        self.node_encoder = node_encoder
+        _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type)
+
+    def forward(self, batched_data, perturb=None):
+        gs = batch_structure(batched_data)
+        edge_index, edge_attr = batched_data.edge_index, batched_data.edge_attr
+        encoded = _encode_nodes(self.node_encoder, batched_data)
+        h_list = [encoded + perturb if perturb is not None else encoded]
+        for layer in range(self.num_layer):
+            h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
+            h = self.batch_norms[layer](h)
+            if layer == self.num_layer - 1:
+                h = F.dropout(h, self.drop_ratio, training=self.training)
+            else:
+                h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+            if self.residual:
+                h = h + h_list[layer]
+            h_list.append(h)
+        return _jk(self.JK, h_list, self.num_layer)
+
+
+class GNN_node_Virtualnode(torch.nn.Module):
+    @staticmethod
+    def need_deg():
+        return False
+
+    def __init__(self, num_layer, emb_dim, node_encoder, edge_encoder_cls, drop_ratio=0.5, JK="last", residual=False,
+                 gnn_type="gin"):
+        super().__init__()
+        self.num_layer, self.drop_ratio, self.JK, self.residual = num_layer, drop_ratio, JK, residual
+        if self.num_layer < 2:
+            raise ValueError("Number of GNN layers must be greater than 1.")
+        self.node_encoder = node_encoder
+        self.virtualnode_embedding = torch.nn.Embedding(1, emb_dim)
+        torch.nn.init.constant_(self.virtualnode_embedding.weight.data, 0)
+        _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type)
+        self.mlp_virtualnode_list = torch.nn.ModuleList()
+        for _ in range(num_layer - 1):
+            self.mlp_virtualnode_list.append(torch.nn.Sequential(
+                torch.nn.Linear(emb_dim, 2 * emb_dim), torch.nn.BatchNorm1d(2 * emb_dim), torch.nn.ReLU(),
+                torch.nn.Linear(2 * emb_dim, emb_dim), torch.nn.BatchNorm1d(emb_dim), torch.nn.ReLU()))
+
+    def forward(self, batched_data, perturb=None):
+        gs = batch_structure(batched_data)
+        edge_index, edge_attr = batched_data.edge_index, batched_data.edge_attr
+        encoded = _encode_nodes(self.node_encoder, batched_data)
+        h_list = [encoded + perturb if perturb is not None else encoded]
+        # one zero-initialised embedding row per graph (gnn_module.py:195), without the .item() sync
+        vn = self.virtualnode_embedding.weight.expand(gs.B, -1)
+        for layer in range(self.num_layer):
+            h_list[layer] = ops.segment_bcast_add(h_list[layer], vn, gs)  # + vn[batch]   (:199)
+            h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
+            h = self.batch_norms[layer](h)
+            if layer == self.num_layer - 1:
+                h = F.dropout(h, self.drop_ratio, training=self.training)
+            else:
+                h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+            if self.residual:
+                h = h + h_list[layer]
+            h_list.append(h)
+            if layer < self.num_layer - 1:
+                t = ops.segment_sum(h_list[layer], gs, add=vn)  # global_add_pool + vn   (:219)
+                t = F.dropout(self.mlp_virtualnode_list[layer](t), self.drop_ratio, training=self.training)
+                vn = vn + t if self.residual else t
+        return _jk(self.JK, h_list, self.num_layer)
+
+
+def GNNNodeEmbedding(virtual_node, *args, **kwargs):
+    if virtual_node:
+        return GNN_node_Virtualnode(*args, **kwargs)
+    return GNN_node(*args, **kwargs)

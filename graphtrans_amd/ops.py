@@ -1,0 +1,297 @@
+"""torch.autograd.Function wrappers over the C ABI (include/graphtrans_hip.h).
+
+Every function here launches hand-written gfx950 kernels through ctypes on torch's current
+stream; tensors are only containers for device memory.  No eager/CPU fallback exists: a CPU
+tensor or a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GT_BF16, GT_CONV_GCN, GT_CONV_GIN, GT_EDGE_DENSE, GT_EDGE_LINEAR, GT_EDGE_NONE, GT_EDGE_TABLES, GT_F32
+from .graph import _ptr, _stream
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return GT_F32
+    if t.dtype == torch.bfloat16:
+        return GT_BF16
+    raise TypeError(f"graphtrans_amd kernels take float32 or bfloat16, got {t.dtype}")
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: graphtrans_amd has no CPU fallback")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _f32(t):
+    return None if t is None else _dev(t.detach().float(), "param")
+
+
+# ------------------------------------------------------------------------------------------------
+# fused message passing
+# ------------------------------------------------------------------------------------------------
+class EdgeSpec:
+    """How the kernel obtains e_k.  kind in {none, linear, tables, dense} (gt_edge_mode)."""
+
+    def __init__(self, kind, attr=None, weight=None, bias=None, tables=None, tab_off=None, dense=None):
+        self.kind, self.attr, self.weight, self.bias = kind, attr, weight, bias
+        self.tables, self.tab_off, self.dense = tables, tab_off, dense
+
+
+class _Aggregate(torch.autograd.Function):
+    """out = conv-aggregate(h) (gt_aggregate_fwd / gt_aggregate_bwd).
+    Differentiable inputs: h, self_param (root_emb.weight | eps), and the edge-encoder tensors
+    (Linear weight+bias | concatenated tables | dense edge embedding)."""
+
+    @staticmethod
+    def forward(ctx, h, self_param, ew, eb, dense, gs, conv, mode, attr, tab_off):
+        h = _dev(h, "h")
+        L = _lib.lib()
+        N, D = h.shape
+        out = torch.empty_like(h)
+        sp = _f32(self_param)
+        ew32, eb32 = _f32(ew), _f32(eb)
+        dense_c = None if dense is None else _dev(dense.to(h.dtype), "edge embedding")
+        attr_c = None if attr is None else _dev(attr, "edge_attr")
+        K = 0 if attr_c is None else int(attr_c.shape[1])
+        toff = (C.c_int32 * max(len(tab_off), 1))(*tab_off) if tab_off else None
+        rc = L.gt_aggregate_fwd(conv, mode, _dtype_code(h), _ptr(h), N, gs.E, D, _ptr(gs.in_ptr), _ptr(gs.in_src),
+                                _ptr(gs.in_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp), _ptr(attr_c), K, _ptr(ew32),
+                                _ptr(eb32), toff, _ptr(dense_c), _ptr(out), _stream())
+        _lib.check(rc, "gt_aggregate_fwd")
+        ctx.save_for_backward(h, sp, ew32, eb32, dense_c, attr_c)
+        ctx.gs, ctx.conv, ctx.mode, ctx.tab_off, ctx.K = gs, conv, mode, tab_off, K
+        ctx.param_dtypes = (self_param.dtype, None if ew is None else ew.dtype, None if eb is None else eb.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, sp, ew32, eb32, dense_c, attr_c = ctx.saved_tensors
+        gs, conv, mode, K = ctx.gs, ctx.conv, ctx.mode, ctx.K
+        L = _lib.lib()
+        g = _dev(g.to(h.dtype), "grad_out")
+        N, D = h.shape
+        dh = torch.empty_like(h)
+        dev = h.device
+        rows = 0 if mode != GT_EDGE_TABLES else int(ew32.shape[0])
+        d_self = torch.empty(D if conv == GT_CONV_GCN else 1 + (D + 63) // 64, dtype=torch.float32, device=dev)
+        d_w = torch.empty_like(ew32) if mode in (GT_EDGE_LINEAR, GT_EDGE_TABLES) else None
+        d_b = torch.empty_like(eb32) if mode == GT_EDGE_LINEAR else None
+        d_dense = torch.empty_like(dense_c) if mode == GT_EDGE_DENSE else None
+        ws_bytes = L.gt_aggregate_bwd_workspace_bytes(conv, mode, D, K, rows)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        toff = (C.c_int32 * max(len(ctx.tab_off), 1))(*ctx.tab_off) if ctx.tab_off else None
+        rc = L.gt_aggregate_bwd(conv, mode, _dtype_code(h), _ptr(h), _ptr(g), N, gs.E, D, _ptr(gs.out_ptr),
+                                _ptr(gs.out_dst), _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp),
+                                _ptr(attr_c), K, _ptr(ew32), _ptr(eb32), toff, rows, _ptr(dense_c), _ptr(dh),
+                                _ptr(d_self), _ptr(d_w), _ptr(d_b), _ptr(d_dense), _ptr(ws), ws_bytes, _stream())
+        _lib.check(rc, "gt_aggregate_bwd")
+        sdt, wdt, bdt = ctx.param_dtypes
+        g_self = (d_self if conv == GT_CONV_GCN else d_self[:1]).to(sdt)
+        return (dh, g_self, None if d_w is None else d_w.to(wdt), None if d_b is None else d_b.to(bdt), d_dense,
+                None, None, None, None, None)
+
+
+def aggregate(h, gs, conv, self_param, edge):
+    """conv in {'gcn','gin'}; self_param: root_emb.weight (1,D) | eps (1,); edge: EdgeSpec."""
+    cv = GT_CONV_GCN if conv == "gcn" else GT_CONV_GIN
+    sp = self_param.reshape(-1)
+    if edge.kind == "none":
+        return _Aggregate.apply(h, sp, None, None, None, gs, cv, GT_EDGE_NONE, None, None)
+    if edge.kind == "linear":
+        return _Aggregate.apply(h, sp, edge.weight, edge.bias, None, gs, cv, GT_EDGE_LINEAR, edge.attr.float(), None)
+    if edge.kind == "tables":
+        return _Aggregate.apply(h, sp, edge.tables, None, None, gs, cv, GT_EDGE_TABLES, edge.attr, edge.tab_off)
+    if edge.kind == "dense":
+        return _Aggregate.apply(h, sp, None, None, edge.dense, gs, cv, GT_EDGE_DENSE, None, None)
+    raise ValueError(edge.kind)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-graph segment ops (virtual node)
+# ------------------------------------------------------------------------------------------------
+def _bcast_add_raw(x, seg, gs):
+    seg = _dev(seg, "seg")
+    N, D = gs.N, seg.shape[1]
+    out = torch.empty((N, D), dtype=seg.dtype, device=seg.device)
+    rc = _lib.lib().gt_segment_bcast_add(_dtype_code(seg), _ptr(x), _ptr(seg), _ptr(gs.node_graph), N, gs.B, D,
+                                         _ptr(out), _stream())
+    _lib.check(rc, "gt_segment_bcast_add")
+    return out
+
+
+def _segment_sum_raw(x, add, gs):
+    x = _dev(x, "x")
+    D = x.shape[1]
+    out = torch.empty((gs.B, D), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().gt_segment_sum(_dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
+                                   _stream())
+    _lib.check(rc, "gt_segment_sum")
+    return out
+
+
+class _BcastAdd(torch.autograd.Function):
+    """h + vn[batch]  (modules/gnn_module.py:199)."""
+
+    @staticmethod
+    def forward(ctx, x, seg, gs):
+        ctx.gs = gs
+        return _bcast_add_raw(_dev(x, "x"), seg.to(x.dtype), gs)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        return g, _segment_sum_raw(g, None, ctx.gs), None
+
+
+class _SegmentSum(torch.autograd.Function):
+    """global_add_pool(x, batch) + add  (modules/gnn_module.py:219)."""
+
+    @staticmethod
+    def forward(ctx, x, add, gs):
+        ctx.gs = gs
+        ctx.has_add = add is not None
+        return _segment_sum_raw(x, None if add is None else _dev(add.to(x.dtype), "add"), gs)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        return _bcast_add_raw(None, g, ctx.gs), (g if ctx.has_add else None), None
+
+
+def segment_bcast_add(x, seg, gs):
+    return _BcastAdd.apply(x, seg, gs)
+
+
+def segment_sum(x, gs, add=None):
+    return _SegmentSum.apply(x, add, gs)
+
+
+# ------------------------------------------------------------------------------------------------
+# node rows <-> token rows
+# ------------------------------------------------------------------------------------------------
+def _gather_raw(h, cls, gs, lay, want_mask):
+    D = h.shape[1]
+    tokens = torch.empty((lay.rows, D), dtype=h.dtype, device=h.device)
+    mask = torch.empty((lay.B, lay.max_npos), dtype=torch.bool, device=h.device) if want_mask else None
+    rc = _lib.lib().gt_seq_gather(_dtype_code(h), _ptr(h), _ptr(cls), _ptr(gs.graph_ptr), _ptr(lay.desc), lay.B,
+                                  lay.row_stride, lay.max_npos, 1 if lay.with_cls else 0, D, _ptr(tokens),
+                                  _ptr(mask), _stream())
+    _lib.check(rc, "gt_seq_gather")
+    return tokens, mask
+
+
+def _scatter_raw(tokens, base, gs, lay, want_cls):
+    D = tokens.shape[1]
+    h = torch.empty((gs.N, D), dtype=tokens.dtype, device=tokens.device)
+    cls = torch.empty((lay.B, D), dtype=tokens.dtype, device=tokens.device) if want_cls else None
+    rc = _lib.lib().gt_seq_scatter(_dtype_code(tokens), _ptr(tokens), _ptr(base), _ptr(gs.graph_ptr),
+                                   _ptr(gs.node_graph), _ptr(lay.desc), lay.B, lay.row_stride,
+                                   1 if lay.with_cls else 0, gs.N, D, _ptr(h), _ptr(cls), _stream())
+    _lib.check(rc, "gt_seq_scatter")
+    return h, cls
+
+
+class _SeqGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, cls, gs, lay, want_mask):
+        h = _dev(h, "h")
+        cls_c = None if cls is None else _dev(cls.reshape(-1).to(h.dtype), "cls")
+        tokens, mask = _gather_raw(h, cls_c, gs, lay, want_mask)
+        ctx.gs, ctx.lay = gs, lay
+        ctx.cls_meta = None if cls is None else (cls.shape, cls.dtype)
+        if mask is not None:
+            ctx.mark_non_differentiable(mask)
+        return tokens, mask
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        g = _dev(g, "grad")
+        dh, dcls = _scatter_raw(g, None, ctx.gs, ctx.lay, ctx.cls_meta is not None)
+        if dcls is not None:
+            shape, dt = ctx.cls_meta
+            dcls = dcls.float().sum(0).reshape(shape).to(dt)
+        return dh, dcls, None, None, None
+
+
+def seq_gather(h, cls, gs, lay, want_mask=False):
+    """tokens (lay.rows, d) [+ padding mask (B, max_npos), True = padding] from node rows."""
+    return _SeqGather.apply(h, cls, gs, lay, want_mask)
+
+
+class _SeqScatter(torch.autograd.Function):
+    """unpad_batch (modules/utils.py:32-53): node rows <- token rows, truncated nodes keep `base`."""
+
+    @staticmethod
+    def forward(ctx, tokens, base, gs, lay):
+        tokens = _dev(tokens, "tokens")
+        base_c = None if base is None else _dev(base.to(tokens.dtype), "base")
+        h, _ = _scatter_raw(tokens, base_c, gs, lay, False)
+        ctx.gs, ctx.lay, ctx.has_base = gs, lay, base is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        gs, lay = ctx.gs, ctx.lay
+        zero_cls = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device) if lay.with_cls else None
+        dtok, _ = _gather_raw(g, zero_cls, gs, lay, False)
+        dbase = None
+        if ctx.has_base:  # rows that were NOT overwritten keep their gradient
+            keep = torch.zeros_like(g)
+            kept_h, _ = _scatter_raw(torch.ones_like(dtok), None, gs, lay, False)
+            dbase = g * (1 - kept_h) + keep
+        return dtok, dbase, None, None
+
+
+def seq_scatter(tokens, base, gs, lay):
+    return _SeqScatter.apply(tokens, base, gs, lay)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused attention
+# ------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, lay, nhead, scale, dropout_p, seed):
+        qkv = _dev(qkv, "qkv")
+        rows, d3 = qkv.shape
+        d = d3 // 3
+        out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
+        rc = _lib.lib().gt_attn_fwd(_dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
+                                    lay.B, lay.row_stride, lay.max_npos, scale, dropout_p, seed, _stream())
+        _lib.check(rc, "gt_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (lay, nhead, scale, dropout_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse = ctx.saved_tensors
+        lay, nhead, scale, dropout_p, seed = ctx.cfg
+        g = _dev(g.to(qkv.dtype), "grad")
+        rows, d3 = qkv.shape
+        # rows that belong to no sequence position do not exist in either layout -> fully written
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        rc = _lib.lib().gt_attn_bwd(_dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
+                                    _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride,
+                                    lay.max_npos, scale, dropout_p, seed, _stream())
+        _lib.check(rc, "gt_attn_bwd")
+        return dqkv, None, None, None, None, None
+
+
+def attention(qkv, lay, nhead, dropout_p=0.0, seed=0, scale=None):
+    """ctx rows = softmax(mask(scale q k^T)) v per (sequence, head); qkv (rows, 3*d_model)."""
+    d = qkv.shape[1] // 3
+    if scale is None:
+        scale = float(d // nhead) ** -0.5
+    return _Attention.apply(qkv, lay, nhead, float(scale), float(dropout_p), int(seed))

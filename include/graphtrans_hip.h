@@ -1,0 +1,170 @@
+/*
+ * graphtrans_hip.h — C ABI of libgraphtrans_hip.so (MI355X / gfx950 kernels for the GraphTrans
+ * forward/backward hot path).
+ *
+ * The reference (ucbrise/graphtrans) is pure Python and has NO FFI / plugin registry; its hot path
+ * bottoms out in third-party native ops.  Each entry point below names the
+ * reference call site (file:line under /root/reference) and the third-party op it replaces; a
+ * maintainer binds them with ctypes.
+ *
+ * Conventions (every function):
+ *   - extern "C", plain pointers and sizes only; every pointer is a DEVICE pointer unless named
+ *     `*_host`.  All buffers (inputs, outputs, workspaces) are caller-owned: the library never
+ *     allocates/frees device memory, never synchronises the device and enqueues work only on the
+ *     `stream` argument (a hipStream_t passed as void*; NULL = the null stream).
+ *   - returns GT_OK (0) or a negative gt_status; `gt_last_error()` (thread-local) describes it.
+ *   - re-entrant, no mutable global state (autograd calls backward from a second host thread).
+ *   - matrices are row-major and contiguous; index arrays produced by gt_graph_prep are int32.
+ *   - `dtype`: GT_F32 or GT_BF16 storage; accumulation is always fp32.
+ */
+#ifndef GRAPHTRANS_HIP_H
+#define GRAPHTRANS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gt_stream_t; /* hipStream_t */
+
+enum gt_status {
+  GT_OK = 0,
+  GT_ERR_INVALID_ARG = -1,
+  GT_ERR_UNSUPPORTED = -2,
+  GT_ERR_WORKSPACE = -3,
+  GT_ERR_LAUNCH = -4
+};
+
+enum gt_dtype { GT_F32 = 0, GT_BF16 = 1 };
+enum gt_conv { GT_CONV_GCN = 0, GT_CONV_GIN = 1 };
+enum gt_edge_mode {
+  GT_EDGE_NONE = 0,   /* edge embedding == 0          (dataset/tud.py:67-71)            */
+  GT_EDGE_LINEAR = 1, /* nn.Linear(K, D) on f32 attrs (dataset/code.py:117), K <= 4     */
+  GT_EDGE_TABLES = 2, /* sum of K embedding rows      (ogb BondEncoder, dataset/mol.py:84) */
+  GT_EDGE_DENSE = 3   /* caller-computed (E, D) edge embedding, any edge_encoder module */
+};
+
+int gt_version(void);
+const char* gt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph structure, built once per collated batch.
+ * Replaces: the per-layer `degree(row, N)` (modules/conv.py:57, PyG degree -> scatter_add) and the
+ * unsorted atomic scatter of torch-scatter (conv.py:28,63 via MessagePassing.aggregate) with a
+ * destination-sorted CSR / source-sorted CSC that is bit-identical to a stable sort of edge_index
+ * (oracle/graph_struct.py); also the `batch.eq(i)` loop of pad_batch (modules/utils.py:9-13).
+ *
+ *   edge_index [2][E] int64 (row 0 = source `row`, row 1 = destination `col`), batch [N] int64
+ *   sorted non-decreasing.  Outputs:
+ *   graph_ptr[B+1]; node_graph[N] (= batch as int32); in_ptr[N+1], in_src[E], in_eid[E] (CSR by destination, ties in edge order);
+ *   out_ptr[N+1], out_dst[E], out_eid[E] (CSC by source); deg[N] = 1 + out-degree (float, the
+ *   GCN `deg`, conv.py:57); dis[N] = deg^-1/2 (conv.py:58).
+ *   status[0] is set non-zero on device if an index is out of range (checked by the caller).
+ */
+size_t gt_graph_prep_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
+int gt_graph_prep(const int64_t* edge_index, const int64_t* batch, int64_t num_nodes, int64_t num_edges,
+                  int64_t num_graphs, int32_t* graph_ptr, int32_t* node_graph, int32_t* in_ptr, int32_t* in_src,
+                  int32_t* in_eid,
+                  int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, float* deg, float* dis,
+                  int32_t* status, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused message + aggregate + update of GCNConv / GINConv.
+ * Replaces (per layer): index_select x[row], edge_encoder GEMM / embedding gathers, add, relu,
+ * mul-by-norm, torch_scatter.scatter(sum), and the self term (modules/conv.py:26-36, :50-71).
+ *
+ *   GCN: out[v] = dis[v] * sum_{k in in(v)} dis[src_k] * relu(h[src_k] + e_k) + relu(h[v] + root) / deg[v]
+ *   GIN: out[v] = (1 + eps) * h[v] + sum_{k in in(v)} relu(h[src_k] + e_k)
+ *   e_k by edge_mode: 0 | sum_j attr[k][j] * W[:, j] + b | sum_j T[tab_off[j] + attr[k][j]] | dense[k]
+ *   edge_attr is indexed by ORIGINAL edge id (in_eid); GT_EDGE_LINEAR: float attr[E][K], W [D][K]
+ *   (nn.Linear.weight layout), b [D]; GT_EDGE_TABLES: int64 attr[E][K], tables [rows][D],
+ *   tab_off[K] int32 (host pointer); GT_EDGE_DENSE: dense [E][D] (same dtype as h).
+ *   `self_param`: GCN root_emb.weight [D] (float32); GIN eps [1] (float32).  Parameters are fp32.
+ */
+int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* h, int64_t num_nodes, int64_t num_edges,
+                     int64_t dim, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
+                     const float* deg, const float* dis, const float* self_param, const void* edge_attr,
+                     int64_t edge_attr_cols, const float* edge_w, const float* edge_b,
+                     const int32_t* tab_off_host, const void* edge_dense, void* out, gt_stream_t stream);
+
+/* Backward of gt_aggregate_fwd (autograd of the ops above in the reference).
+ *   t_k   = w_k * 1[h[row_k] + e_k > 0] * g[col_k]            (w_k = dis[row_k] dis[col_k] | 1)
+ *   dh[u] = sum_{k in out(u)} t_k + (GCN: 1[h[u]+root>0] g[u]/deg[u] | GIN: (1+eps) g[u])
+ *   GT_EDGE_LINEAR: d_edge_w[D][K] = sum_k t_k (x) attr_k, d_edge_b[D] = sum_k t_k
+ *   GT_EDGE_TABLES: d_tables[rows][D]: row r gets sum of t_k over edges/columns that index it
+ *   GT_EDGE_DENSE : d_dense[E][D] = t_k (original edge order)
+ *   GCN: d_self[D] = sum_u 1[h[u]+root>0] g[u]/deg[u];  GIN: d_self[0] = sum_{u,c} g[u][c] h[u][c]
+ *   (GIN: d_self must hold 1 + ceil(D/64) floats; entries past [0] are scratch)
+ * Parameter gradients are fp32 and OVERWRITTEN (not accumulated); reduction order is fixed
+ * (deterministic).  `table_rows` = total rows of `tables`.
+ */
+size_t gt_aggregate_bwd_workspace_bytes(int conv, int edge_mode, int64_t dim, int64_t edge_attr_cols,
+                                        int64_t table_rows);
+int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* h, const void* grad_out, int64_t num_nodes,
+                     int64_t num_edges, int64_t dim, const int32_t* out_ptr, const int32_t* out_dst,
+                     const int32_t* out_eid, const float* deg, const float* dis, const float* self_param,
+                     const void* edge_attr, int64_t edge_attr_cols, const float* edge_w, const float* edge_b,
+                     const int32_t* tab_off_host, int64_t table_rows, const void* edge_dense, void* grad_h,
+                     float* d_self, float* d_edge_w, float* d_edge_b, void* d_dense, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-graph segment ops on the sorted `batch` vector (virtual node + pooling).
+ * gt_segment_bcast_add: out[n] = (x ? x[n] : 0) + seg[g(n)]      -- `h + vn[batch]`
+ *   (modules/gnn_module.py:199); also the backward of global_add_pool.
+ * gt_segment_sum:       out[g] = (add ? add[g] : 0) + sum_{n in g} x[n]   -- global_add_pool + vn
+ *   (modules/gnn_module.py:219, PyG global_add_pool -> torch_scatter); also d(vn) of the bcast.
+ */
+int gt_segment_bcast_add(int dtype, const void* x, const void* seg, const int32_t* node_graph, int64_t num_nodes,
+                         int64_t num_graphs, int64_t dim, void* out, gt_stream_t stream);
+int gt_segment_sum(int dtype, const void* x, const void* add, const int32_t* graph_ptr, int64_t num_nodes,
+                   int64_t num_graphs, int64_t dim, void* out, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sequence layout: flat node rows <-> transformer token rows.
+ * Replaces pad_batch / unpad_batch (modules/utils.py:5-53) and the CLS concat
+ * (modules/transformer_encoder.py:50-55).  A layout is described by seq_desc[B][4] int32 =
+ * {row0, npos, kv_off, kv_len}: position p of sequence b lives at token row row0 + p*row_stride;
+ * positions [kv_off, kv_off+kv_len) are real (node or CLS) tokens, the rest is padding.
+ *   padded (reference) layout: row0 = b, row_stride = B, npos = S(+1), kv_off = npos - kv_len
+ *   packed (fast) layout     : row0 = tok_ptr[b], row_stride = 1, npos = kv_len, kv_off = 0
+ * gt_seq_gather: tokens[row(b,p)] = node row (graph_ptr[b+1] - kept_b + j) for the j-th kept node,
+ *   `cls` [dim] for the CLS position (if with_cls), 0 for padding.  kept_b = kv_len - with_cls.
+ * gt_seq_scatter: the adjoint (grad_h[N][dim] zero for truncated nodes; d_cls[B][dim] per-graph,
+ *   reduced by the caller) and also unpad_batch when `base` (N rows kept for truncated nodes) is given.
+ */
+int gt_seq_gather(int dtype, const void* h, const void* cls, const int32_t* graph_ptr, const int32_t* seq_desc,
+                  int64_t num_seqs, int64_t row_stride, int64_t max_npos, int with_cls, int64_t dim,
+                  void* tokens, uint8_t* pad_mask /* [B][max_npos] or NULL */, gt_stream_t stream);
+int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_t* graph_ptr,
+                   const int32_t* node_graph, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
+                   int with_cls, int64_t num_nodes, int64_t dim, void* h_out, void* cls_out /* [B][dim] or NULL */,
+                   gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused masked multi-head self-attention over the token rows (flash-style, never materialises
+ * the S x S scores).  Replaces F.multi_head_attention_forward's bmm / masked_fill(-inf) / softmax
+ * / dropout / bmm (modules/transformer_encoder.py:59) between in_proj and out_proj.
+ *   qkv [rows][3*d_model] (torch packed in_proj order q|k|v), ctx [rows][d_model],
+ *   lse [nhead][rows] fp32 (saved for backward).  head_dim = d_model/nhead in {32, 64}.
+ *   Keys outside [kv_off, kv_off+kv_len) are masked (the key_padding_mask); every query position
+ *   in [0, npos) is computed.  P = softmax(scale * q k^T); dropout(P, p) with a counter-based RNG
+ *   keyed by (seed, seq, head, query, key) so backward replays it.
+ *   dtype GT_BF16 -> v_mfma_f32_16x16x32_bf16; GT_F32 -> v_mfma_f32_16x16x4_f32 (exact fp32).
+ */
+int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model, int nhead,
+                const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale,
+                float dropout_p, uint64_t seed, gt_stream_t stream);
+/* d_qkv [rows][3*d_model] is fully written for every row belonging to a sequence position.
+ * delta [nhead][rows] fp32 workspace (rowsum(dO*O)). */
+int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse, float* delta,
+                void* d_qkv, int64_t total_rows, int64_t d_model, int nhead, const int32_t* seq_desc,
+                int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale, float dropout_p,
+                uint64_t seed, gt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHTRANS_HIP_H */
