@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""bench.py — GraphTrans training-step throughput on MI355X (driver contract).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload code2|molpcba|nci1|er] [--dtype bf16|fp32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256.  One "step" = the whole
+hot path over one synthetic, HBM-resident, pre-collated batch of 256 graphs PER GPU (weak scaling):
+    zero grads -> graph_prep -> GNNTransformer forward -> loss (dataset/code.py:39-45) -> backward
+    -> [RCCL gradient all-reduce, overlapped] -> fused AdamW step
+Nothing is skipped or cached across steps (the per-batch graph structure is rebuilt every step;
+dropout runs at the reference's configured rates).  Inputs rotate over 4 seeded batches.
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  "roofline":     the dominant hand-written kernel (largest total HIP-event time inside the timed
+                  region): algorithmic bytes|flops per launch (SURVEY.md §8d formulas) / avg launch time,
+  "kernels":      the same for every timed C-ABI entry point,
+  "cpu_baseline": the CPU oracle (oracle/reference_math.py, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
+MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA
+
+
+def model_args(workload, dtype):
+    """Reference hyper-parameters (SURVEY.md §8a sizes; main.py:53-58, transformer_encoder.py:13-20,
+    configs/code2/gnn-transformer/JK=cat/pooling=cls+norm_input.yml, configs/molpcba/...+gin+norm_input.yml)."""
+    from types import SimpleNamespace
+
+    a = dict(gnn_virtual_node=True, gnn_num_layer=5, gnn_emb_dim=300, gnn_JK="cat", gnn_dropout=0.0,
+             gnn_residual=False, gnn_type="gcn", pretrained_gnn=None, freeze_gnn=None, d_model=128, nhead=4,
+             dim_feedforward=512, transformer_dropout=0.3, transformer_activation="relu", num_encoder_layers=4,
+             max_input_len=1000, transformer_norm_input=True, graph_pooling="cls", num_encoder_layers_masked=0,
+             transformer_prenorm=False, pos_encoder=False, max_seq_len=5, compute_dtype=dtype, token_layout="auto")
+    if workload == "molpcba":
+        a.update(gnn_type="gin", gnn_dropout=0.3, max_seq_len=None)
+    elif workload == "nci1":
+        a.update(gnn_virtual_node=False, gnn_num_layer=3, gnn_emb_dim=128, gnn_JK="last", gnn_dropout=0.5,
+                 dim_feedforward=256, transformer_dropout=0.1, num_encoder_layers=3, transformer_norm_input=False,
+                 max_seq_len=None)
+    elif workload == "er":
+        a.update(gnn_virtual_node=False, gnn_num_layer=4, gnn_emb_dim=256, gnn_JK="last", d_model=256,
+                 dim_feedforward=1024, transformer_dropout=0.0, max_seq_len=None)
+    return SimpleNamespace(**a)
+
+
+def build(workload, dtype, device, batch_graphs):
+    from graphtrans_amd import losses, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder, AtomEncoder, BondEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+
+    args = model_args(workload, dtype)
+    D = args.gnn_emb_dim
+    if workload == "code2":
+        model = GNNTransformer(5002, ASTNodeEncoder(D, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), args)
+        gen = lambda seed: synth.code2_like(B=batch_graphs, seed=seed)
+        loss = lambda out, b: losses.code2_loss(out, b.y_arr)
+        name = "OGBG-Code2-like synthetic, GraphTrans GCN-Virtual L5 D300 JK=cat cls norm_input, 4 enc layers d128"
+    elif workload == "molpcba":
+        model = GNNTransformer(128, AtomEncoder(D), lambda d: BondEncoder(d), args)
+        gen = lambda seed: synth.molpcba_like(B=batch_graphs, seed=seed)
+        loss = lambda out, b: losses.mol_loss(out, b.y)
+        name = "OGBG-Molpcba-like synthetic, GraphTrans GIN-Virtual L5 D300 JK=cat cls norm_input"
+    elif workload == "nci1":
+        def zero_cls(_):
+            return lambda _x: 0
+        model = GNNTransformer(2, torch.nn.Linear(37, D), zero_cls, args)
+        gen = lambda seed: synth.nci1_like(B=batch_graphs, seed=seed)
+        loss = lambda out, b: losses.tud_loss(out, b.y)
+        name = "NCI1-like synthetic, GraphTrans(small, GCN) d128, 3 GNN layers"
+    elif workload == "er":
+        model = GNNTransformer(2, torch.nn.Linear(256, D), lambda d: torch.nn.Linear(2, d), args)
+        gen = lambda seed: synth.er_stress(B=batch_graphs, seed=seed)
+        loss = lambda out, b: losses.tud_loss(out, b.y)
+        name = "Erdos-Renyi G(512, 8/511) stress, 4 GCN + 4 encoder layers d256"
+    else:
+        raise ValueError(workload)
+    return args, model.to(device), gen, loss, name
+
+
+def attach_sizes(b):
+    b._sizes = torch.bincount(b.batch, minlength=b.num_graphs).numpy()
+    return b
+
+
+# ---- algorithmic work per launch ---------------------------------------------------
+def agg_bytes(meta, bwd):
+    N, E, D, s, a = meta["N"], meta["E"], meta["D"], meta["elt"], meta["attr_bytes"]
+    if not bwd:   # E*8 + (N+1)*8 + E*a + E*D*s + N*D*s + N*4 + N*D*s
+        return E * 8 + (N + 1) * 8 + E * a + E * D * s + N * D * s + N * 4 + N * D * s
+    return E * 8 + (N + 1) * 8 + E * a + E * D * s + 2 * N * D * s + N * D * s
+
+
+def attn_flops(meta, bwd):
+    lay, d = meta["lay"], meta["d"]
+    desc = getattr(lay, "desc_cpu", None)
+    if desc is None:
+        return 0.0
+    n = desc[:, 3].astype(np.float64)   # valid keys per sequence (incl. CLS)
+    q = desc[:, 1].astype(np.float64)   # query positions computed
+    f = float((4.0 * q * n * d).sum())  # QK^T + PV over valid keys: 4*n^2*d per graph
+    return f * (2.5 if bwd else 1.0)
+
+
+def kernel_report(summary, dtype):
+    rep = {}
+    for name, d in summary.items():
+        if name.startswith("gt_aggregate"):
+            bwd = name.endswith("bwd")
+            per = float(np.mean([agg_bytes(m, bwd) for m in d["metas"]]))
+            gbs = per / (d["avg_us"] * 1e-6) / 1e9
+            rep[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, avg_us=round(d["avg_us"], 2),
+                             calls=d["calls"], total_ms=round(d["total_ms"], 3), algorithmic_bytes=int(per))
+        elif name.startswith("gt_attn"):
+            bwd = name.endswith("bwd")
+            per = float(np.mean([attn_flops(m, bwd) for m in d["metas"]]))
+            tf = per / (d["avg_us"] * 1e-6) / 1e12
+            peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
+            rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 5),
+                             traffic=None, avg_us=round(d["avg_us"], 2), calls=d["calls"],
+                             total_ms=round(d["total_ms"], 3), algorithmic_flops=int(per))
+    return rep
+
+
+# ---- CPU baseline (the oracle as a timed port) --------------------------------------------------
+def cpu_baseline(workload, model, args, sample_graphs=64, iters=2):
+    from graphtrans_amd import synth
+    from oracle import reference_math as rm
+
+    if workload != "code2":
+        return None
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    b = synth.code2_like(B=sample_graphs, seed=0)
+    times = []
+    for it in range(iters + 1):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = rm.gnn_transformer(sd, args, b, None, True)
+        rm.code2_loss(out, b.y_arr).backward()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return dict(value=round(sample_graphs / t, 2), unit="graphs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on the first "
+                       f"{sample_graphs} graphs of the seed-0 Code2-like batch, median of {iters} after 1 warm-up; "
+                       f"padded layout like the reference (S = max nodes of the sample)",
+                s_per_step=round(t, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er"])
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    opt = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if opt.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {opt.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from graphtrans_amd import _lib
+    from graphtrans_amd.dist import GradSync
+
+    dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
+    per_gpu = opt.batch or (32 if opt.workload == "nci1" else 256)
+    torch.manual_seed(1234)  # identical initial parameters on every rank
+    args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
+    model.train()
+    sync = GradSync(model.parameters(), world_size=world)
+    optim = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0, fused=True)
+    torch.manual_seed(1234 + rank)  # per-rank dropout streams
+    batches = [attach_sizes(gen(1000 * rank + i)).to(device) for i in range(4)]  # .to() keeps the host-side sizes
+
+    def step(i):
+        b = batches[i % len(batches)]
+        b.__dict__.pop("_gt_structure", None)  # graph_prep is part of the step
+        sync.zero()
+        out = model(b)
+        loss = loss_fn(out, b)
+        loss.backward()
+        sync.finish()
+        if not opt.no_optimizer:
+            optim.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(opt.warmup):
+        step(i)
+    timed = ["gt_aggregate_fwd", "gt_aggregate_bwd", "gt_attn_fwd", "gt_attn_bwd"]
+    timer = None if opt.no_kernel_timing else _lib.KernelTimer(timed)
+    _lib.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(opt.steps):
+        loss = step(opt.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER = None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        total_graphs = per_gpu * world * opt.steps
+        nodes = int(np.mean([b.num_nodes for b in batches]))
+        edges = int(np.mean([b.edge_index.shape[1] for b in batches]))
+        res = {
+            "metric": "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}",
+            "value": round(total_graphs / elapsed, 1), "unit": "graphs/s", "n_gpus": world, "steps": opt.steps,
+            "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
+            "config": {"workload": wl_name, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
+                       "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
+                       "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
+                       "step": "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
+                       "gnn_dtype": "fp32", "transformer_dtype": opt.dtype,
+                       "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
+            "final_loss": round(final_loss, 5),
+        }
+        if timer is not None:
+            rep = kernel_report(timer.summary(), dtype)
+            if rep:
+                dom = max(rep, key=lambda k: rep[k]["total_ms"])
+                r = dict(rep[dom])
+                r["kernel"] = dom
+                res["roofline"] = r
+                res["kernels"] = rep
+        if world == 1 and not opt.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(opt.workload, model, args)
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,10 @@ The product never routes through oracle/ or any CPU/eager re-implementation.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  must come first: PyTorch-ROCm bundles its own libamdhip64 (soname
+#               libamdhip64.so.7); loading it before our library makes both share ONE HIP runtime
+#               (same device context, streams and allocations).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphtrans_hip.so")
 
@@ -57,6 +61,47 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+class KernelTimer:
+    """Optional HIP-event timing of individual C-ABI launches (used by bench.py for the roofline
+    object).  Events are recorded on torch's current stream = the stream the kernels are enqueued
+    on.  `names`: entry points to time; every timed launch appends (name, start, end, meta)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []
+
+    def summary(self):
+        """name -> dict(calls, total_ms, avg_us, metas); synchronises the device."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, meta in self.records:
+            d = out.setdefault(name, dict(calls=0, total_ms=0.0, metas=[]))
+            d["calls"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["metas"].append(meta)
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / max(d["calls"], 1)
+        return out
+
+
+TIMER = None
+
+
+def launch(name, *args, meta=None):
+    """Call entry point `name`, raise on a non-zero status; timed when TIMER selects it."""
+    fn = getattr(lib(), name)
+    t = TIMER
+    if t is not None and name in t.names:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        t.records.append((name, s, e, meta))
+    else:
+        rc = fn(*args)
+    check(rc, name)
 
 
 def check(rc, what):

@@ -288,9 +288,13 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
                 if constexpr (NPW == 1) {
                   *r = gt_add4(*r, t);
                 } else {
+                  // the compiler reasons per thread and would merge these predicated updates into
+                  // one wave-wide read-modify-write (a cross-lane race on a shared row): fence each.
 #pragma unroll
                   for (int sg = 0; sg < NPW; ++sg) {
                     if (m.sub == sg) *r = gt_add4(*r, t);
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                   }
                 }
               }
@@ -429,6 +433,9 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
   do {                                                                                                       \
     constexpr int NPW = 64 / (LPN);                                                                          \
     if constexpr (BWD) {                                                                                     \
+      if (lds_bytes > 48 * 1024)                                                                             \
+        (void)hipFuncSetAttribute((const void*)(k_agg_bwd<T, LPN, NCH, EDGE>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
       hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(grid_bwd), dim3(AGG_THREADS), lds_bytes,      \
                          stream, a);                                                                         \
     } else {                                                                                                 \
@@ -542,7 +549,7 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   GT_CHECK_ARG(conv != GT_CONV_GIN || !d_self || true, "");
   if (edge_mode == GT_EDGE_TABLES) {
     size_t lds = bwd_lds_bytes(edge_mode, D, table_rows);
-    if (table_rows < 1 || lds > 64 * 1024) {
+    if (table_rows < 1 || lds > 160 * 1024) {
       gt_set_error("gt_aggregate_bwd: %lld table rows x dim %lld does not fit the per-wave LDS accumulators",
                    (long long)table_rows, (long long)D);
       return GT_ERR_UNSUPPORTED;

@@ -170,10 +170,27 @@ struct AttnArgs {
   uint32_t seed0, seed1;
 };
 
+// head dims 8 / 16 are zero-padded to one 32-deep MFMA step (HDP); LDS rows are HDP wide + 16 B pad
 template <int HD, typename T>
 struct Lds {
-  static constexpr int LD = HD + (sizeof(T) == 2 ? 8 : 4);  // row pad: 16 B
+  static constexpr int HDP = HD < 32 ? 32 : HD;
+  static constexpr int LD = HDP + (sizeof(T) == 2 ? 8 : 4);
 };
+
+// zero the LDS columns [HD, LD) that load_tile never writes (only needed when HD < 32)
+template <typename T, int HD>
+__device__ __forceinline__ void zero_pad_cols(T* lds) {
+  constexpr int LD = Lds<HD, T>::LD;
+  if constexpr (HD < 32) {
+    for (int i = threadIdx.x; i < TILE * LD; i += ATT_THREADS) lds[i] = (T)0;
+  }
+}
+
+// operand row fragment from global memory: dims [c0, c0+8) of a head row, zero beyond HD
+template <typename T, int HD>
+__device__ __forceinline__ Frag<T> frag_load_head(const T* head_row, int c0, bool valid) {
+  return (valid && c0 < HD) ? frag_load(head_row + c0) : frag_zero<T>();
+}
 
 // cooperative load of a [TILE][HD] tile of rows (pos0 + r) into LDS, zero-filled outside [lo, hi)
 template <typename T, int HD>
@@ -196,8 +213,8 @@ __device__ __forceinline__ void load_tile(T* lds, const T* src, int64_t src_ld, 
 template <typename T, int HD>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
-  constexpr int KK = HD / 32;  // 32-deep steps over head_dim
-  constexpr int DT = HD / 16;  // 16-wide output dim tiles
+  constexpr int KK = Lds<HD, T>::HDP / 32;  // 32-deep steps over head_dim
+  constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
   const int seq = blockIdx.z, head = blockIdx.y;
@@ -216,7 +233,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   Frag<T> bq[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
-    bq[kk] = qvalid ? frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8) : frag_zero<T>();
+    bq[kk] = frag_load_head<T, HD>(qkv + qrow * ld3 + head * HD, kk * 32 + g * 8, qvalid);
+  zero_pad_cols<T, HD>(sK);
+  zero_pad_cols<T, HD>(sV);
 
   float m = -INFINITY, lsum = 0.f;
   f32x4 acc[DT];
@@ -284,7 +303,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt) {
     f32x4 o = acc[dt];
     o[0] *= inv_l; o[1] *= inv_l; o[2] *= inv_l; o[3] *= inv_l;
-    store4<T>(ctx + qrow * a.d_model + head * HD + dt * 16 + g * 4, o);
+    if (dt * 16 + g * 4 < HD) store4<T>(ctx + qrow * a.d_model + head * HD + dt * 16 + g * 4, o);
   }
   if (g == 0) a.lse[(int64_t)head * a.rows + qrow] = m + log2f(lsum);
 }
@@ -295,8 +314,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 template <typename T, int HD>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
-  constexpr int KK = HD / 32;
-  constexpr int DT = HD / 16;
+  constexpr int KK = Lds<HD, T>::HDP / 32;
+  constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
   const int seq = blockIdx.z, head = blockIdx.y;
@@ -318,7 +337,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   float delta = 0.f;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    if (qvalid) {
+    if (qvalid && kk * 32 + g * 8 < HD) {
       bq[kk] = frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8);
       bdo[kk] = frag_load(dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8);
       // delta partial over this lane's 8 dims
@@ -336,6 +355,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   delta += __shfl_xor(delta, 32, 64);
   const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
+  zero_pad_cols<T, HD>(sK);
+  zero_pad_cols<T, HD>(sV);
 
   f32x4 acc[DT];
 #pragma unroll
@@ -381,7 +402,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt) {
     f32x4 o = acc[dt];
     o[0] *= a.scale; o[1] *= a.scale; o[2] *= a.scale; o[3] *= a.scale;
-    store4<T>(dqkv + qrow * ld3 + head * HD + dt * 16 + g * 4, o);
+    if (dt * 16 + g * 4 < HD) store4<T>(dqkv + qrow * ld3 + head * HD + dt * 16 + g * 4, o);
   }
 }
 
@@ -391,8 +412,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
 template <typename T, int HD>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
-  constexpr int KK = HD / 32;
-  constexpr int DT = HD / 16;
+  constexpr int KK = Lds<HD, T>::HDP / 32;
+  constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
   __shared__ float sLse[TILE], sDelta[TILE];
@@ -415,9 +436,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   Frag<T> bk[KK], bv[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    bk[kk] = kvalid ? frag_load(qkv + krow * ld3 + a.d_model + head * HD + kk * 32 + g * 8) : frag_zero<T>();
-    bv[kk] = kvalid ? frag_load(qkv + krow * ld3 + 2 * a.d_model + head * HD + kk * 32 + g * 8) : frag_zero<T>();
+    bk[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + a.d_model + head * HD, kk * 32 + g * 8, kvalid);
+    bv[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + 2 * a.d_model + head * HD, kk * 32 + g * 8, kvalid);
   }
+  zero_pad_cols<T, HD>(sQ);
+  zero_pad_cols<T, HD>(sDO);
   f32x4 dk[DT], dv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -482,8 +505,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt) {
     f32x4 o = dk[dt];
     o[0] *= a.scale; o[1] *= a.scale; o[2] *= a.scale; o[3] *= a.scale;
-    store4<T>(dqkv + krow * ld3 + a.d_model + head * HD + dt * 16 + g * 4, o);
-    store4<T>(dqkv + krow * ld3 + 2 * a.d_model + head * HD + dt * 16 + g * 4, dv[dt]);
+    if (dt * 16 + g * 4 < HD) {
+      store4<T>(dqkv + krow * ld3 + a.d_model + head * HD + dt * 16 + g * 4, o);
+      store4<T>(dqkv + krow * ld3 + 2 * a.d_model + head * HD + dt * 16 + g * 4, dv[dt]);
+    }
   }
 }
 
@@ -492,7 +517,7 @@ int check_attn(const char* fn, int dtype, int64_t d_model, int nhead, int64_t nu
   if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
   if (nhead <= 0 || d_model <= 0 || d_model % nhead != 0) { gt_set_error("%s: bad d_model/nhead", fn); return GT_ERR_INVALID_ARG; }
   int64_t hd = d_model / nhead;
-  if (hd != 32 && hd != 64) { gt_set_error("%s: head_dim %lld unsupported (32 or 64)", fn, (long long)hd); return GT_ERR_UNSUPPORTED; }
+  if (hd != 8 && hd != 16 && hd != 32 && hd != 64) { gt_set_error("%s: head_dim %lld unsupported (8, 16, 32 or 64)", fn, (long long)hd); return GT_ERR_UNSUPPORTED; }
   if (num_seqs < 0 || num_seqs > 65535) { gt_set_error("%s: num_seqs out of range", fn); return GT_ERR_INVALID_ARG; }
   if (max_npos < 0) { gt_set_error("%s: bad max_npos", fn); return GT_ERR_INVALID_ARG; }
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) { gt_set_error("%s: dropout_p must be in [0,1)", fn); return GT_ERR_INVALID_ARG; }
@@ -528,8 +553,13 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   dim3 grid((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
 #define GT_LAUNCH(T, HD) hipLaunchKernelGGL((k_attn_fwd<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a)
-  if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64); }
-  else { if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64); }
+  if (dtype == GT_F32) {
+    if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
+    else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
+  } else {
+    if (hd == 8) GT_LAUNCH(gt_bf16, 8); else if (hd == 16) GT_LAUNCH(gt_bf16, 16);
+    else if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64);
+  }
 #undef GT_LAUNCH
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -553,8 +583,13 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     hipLaunchKernelGGL((k_attn_bwd_dq<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);          \
     hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);         \
   } while (0)
-  if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64); }
-  else { if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64); }
+  if (dtype == GT_F32) {
+    if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
+    else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
+  } else {
+    if (hd == 8) GT_LAUNCH(gt_bf16, 8); else if (hd == 16) GT_LAUNCH(gt_bf16, 16);
+    else if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64);
+  }
 #undef GT_LAUNCH
   GT_CHECK_LAUNCH();
   return GT_OK;

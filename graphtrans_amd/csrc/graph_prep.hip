@@ -134,8 +134,8 @@ __global__ void k_scan_final(const int32_t* __restrict__ cnt_in, const int32_t* 
       }
     }
     ex += v[j];
+    if (base + j == N - 1) ptr[N] = ex;  // = number of in-range edges (== E for valid input)
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) ptr[N] = (int32_t)E;
 }
 
 __global__ void k_fill(const int64_t* __restrict__ ei, int64_t N, int64_t E, const int32_t* __restrict__ in_ptr,
@@ -234,12 +234,14 @@ __global__ void __launch_bounds__(256) k_sort_long(int64_t N, const int32_t* __r
   }
 }
 
-__global__ void k_gather(const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ in_eid,
+__global__ void k_gather(const int64_t* __restrict__ ei, int64_t N, int64_t E, const int32_t* __restrict__ in_ptr,
+                         const int32_t* __restrict__ in_eid,
                          const int32_t* __restrict__ out_eid, int32_t* __restrict__ in_src,
                          int32_t* __restrict__ out_dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = i; p < E; p += stride) {
+  const int64_t valid = in_ptr[N];  // edges with out-of-range endpoints were dropped (status != 0)
+  for (int64_t p = i; p < valid; p += stride) {
     in_src[p] = (int32_t)ei[in_eid[p]];
     out_dst[p] = (int32_t)ei[E + out_eid[p]];
   }
@@ -313,8 +315,8 @@ extern "C" int gt_graph_prep(const int64_t* edge_index, const int64_t* batch, in
                        out_ptr, in_eid, out_eid, w.worklist, w.wl_count);
     hipLaunchKernelGGL(k_sort_long, dim3(LONG_GRID, 2), dim3(256), 0, stream, N, in_ptr, out_ptr, in_eid, out_eid,
                        w.worklist, w.wl_count, w.tmp, E);
-    hipLaunchKernelGGL(k_gather, dim3(egrid), dim3(threads), 0, stream, edge_index, E, in_eid, out_eid, in_src,
-                       out_dst);
+    hipLaunchKernelGGL(k_gather, dim3(egrid), dim3(threads), 0, stream, edge_index, N, E, in_ptr, in_eid, out_eid,
+                       in_src, out_dst);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;

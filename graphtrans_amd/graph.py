@@ -56,11 +56,9 @@ class GraphStructure:
         L = _lib.lib()
         ws_bytes = L.gt_graph_prep_workspace_bytes(N, E, B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = L.gt_graph_prep(_ptr(edge_index), _ptr(batch), N, E, B, _ptr(gs.graph_ptr), _ptr(gs.node_graph),
-                             _ptr(gs.in_ptr), _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.out_ptr), _ptr(gs.out_dst),
-                             _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes,
-                             _stream())
-        _lib.check(rc, "gt_graph_prep")
+        _lib.launch("gt_graph_prep", _ptr(edge_index), _ptr(batch), N, E, B, _ptr(gs.graph_ptr), _ptr(gs.node_graph),
+                    _ptr(gs.in_ptr), _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.out_ptr), _ptr(gs.out_dst),
+                    _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes, _stream())
         gs._sizes = None if sizes is None else np.asarray(sizes, dtype=np.int64)
         gs._layouts = {}
         return gs

@@ -1,0 +1,22 @@
+"""The trainers' calc_loss functions (define the backward seed of the fwd+bwd metric)."""
+import torch
+import torch.nn.functional as F
+
+
+def code2_loss(pred_list, y_arr):
+    """dataset/code.py:39-45: mean over the max_seq_len heads of CrossEntropy(pred_i, y_arr[:, i])."""
+    loss = 0
+    for i, pred in enumerate(pred_list):
+        loss = loss + F.cross_entropy(pred.to(torch.float32), y_arr[:, i])
+    return loss / len(pred_list)
+
+
+def mol_loss(pred, y):
+    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries only."""
+    is_labeled = y == y
+    return F.binary_cross_entropy_with_logits(pred.to(torch.float32)[is_labeled], y.to(torch.float32)[is_labeled])
+
+
+def tud_loss(pred, y):
+    """dataset/tud.py:25-27."""
+    return F.cross_entropy(pred, y)

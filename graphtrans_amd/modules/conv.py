@@ -6,7 +6,7 @@ import torch
 from .. import ops
 from ..graph import GraphStructure
 
-_LDS_TABLE_BUDGET = 64 * 1024  # per-wave table-gradient rows in the backward kernel
+_LDS_TABLE_BUDGET = 160 * 1024  # per-wave table-gradient rows in the backward kernel (LDS per CU)
 
 
 def edge_spec(edge_encoder, edge_attr, emb_dim):

@@ -62,10 +62,12 @@ class _Aggregate(torch.autograd.Function):
         attr_c = None if attr is None else _dev(attr, "edge_attr")
         K = 0 if attr_c is None else int(attr_c.shape[1])
         toff = (C.c_int32 * max(len(tab_off), 1))(*tab_off) if tab_off else None
-        rc = L.gt_aggregate_fwd(conv, mode, _dtype_code(h), _ptr(h), N, gs.E, D, _ptr(gs.in_ptr), _ptr(gs.in_src),
-                                _ptr(gs.in_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp), _ptr(attr_c), K, _ptr(ew32),
-                                _ptr(eb32), toff, _ptr(dense_c), _ptr(out), _stream())
-        _lib.check(rc, "gt_aggregate_fwd")
+        meta = dict(N=N, E=gs.E, D=D, elt=h.element_size(),
+                    attr_bytes=0 if attr_c is None else attr_c.shape[1] * attr_c.element_size())
+        _lib.launch("gt_aggregate_fwd", conv, mode, _dtype_code(h), _ptr(h), N, gs.E, D, _ptr(gs.in_ptr),
+                    _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp), _ptr(attr_c), K,
+                    _ptr(ew32), _ptr(eb32), toff, _ptr(dense_c), _ptr(out), _stream(), meta=meta)
+        ctx.meta = meta
         ctx.save_for_backward(h, sp, ew32, eb32, dense_c, attr_c)
         ctx.gs, ctx.conv, ctx.mode, ctx.tab_off, ctx.K = gs, conv, mode, tab_off, K
         ctx.param_dtypes = (self_param.dtype, None if ew is None else ew.dtype, None if eb is None else eb.dtype)
@@ -88,11 +90,10 @@ class _Aggregate(torch.autograd.Function):
         ws_bytes = L.gt_aggregate_bwd_workspace_bytes(conv, mode, D, K, rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         toff = (C.c_int32 * max(len(ctx.tab_off), 1))(*ctx.tab_off) if ctx.tab_off else None
-        rc = L.gt_aggregate_bwd(conv, mode, _dtype_code(h), _ptr(h), _ptr(g), N, gs.E, D, _ptr(gs.out_ptr),
-                                _ptr(gs.out_dst), _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp),
-                                _ptr(attr_c), K, _ptr(ew32), _ptr(eb32), toff, rows, _ptr(dense_c), _ptr(dh),
-                                _ptr(d_self), _ptr(d_w), _ptr(d_b), _ptr(d_dense), _ptr(ws), ws_bytes, _stream())
-        _lib.check(rc, "gt_aggregate_bwd")
+        _lib.launch("gt_aggregate_bwd", conv, mode, _dtype_code(h), _ptr(h), _ptr(g), N, gs.E, D, _ptr(gs.out_ptr),
+                    _ptr(gs.out_dst), _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp), _ptr(attr_c), K,
+                    _ptr(ew32), _ptr(eb32), toff, rows, _ptr(dense_c), _ptr(dh), _ptr(d_self), _ptr(d_w), _ptr(d_b),
+                    _ptr(d_dense), _ptr(ws), ws_bytes, _stream(), meta=ctx.meta)
         sdt, wdt, bdt = ctx.param_dtypes
         g_self = (d_self if conv == GT_CONV_GCN else d_self[:1]).to(sdt)
         return (dh, g_self, None if d_w is None else d_w.to(wdt), None if d_b is None else d_b.to(bdt), d_dense,
@@ -121,9 +122,8 @@ def _bcast_add_raw(x, seg, gs):
     seg = _dev(seg, "seg")
     N, D = gs.N, seg.shape[1]
     out = torch.empty((N, D), dtype=seg.dtype, device=seg.device)
-    rc = _lib.lib().gt_segment_bcast_add(_dtype_code(seg), _ptr(x), _ptr(seg), _ptr(gs.node_graph), N, gs.B, D,
-                                         _ptr(out), _stream())
-    _lib.check(rc, "gt_segment_bcast_add")
+    _lib.launch("gt_segment_bcast_add", _dtype_code(seg), _ptr(x), _ptr(seg), _ptr(gs.node_graph), N, gs.B, D,
+                _ptr(out), _stream())
     return out
 
 
@@ -131,9 +131,8 @@ def _segment_sum_raw(x, add, gs):
     x = _dev(x, "x")
     D = x.shape[1]
     out = torch.empty((gs.B, D), dtype=x.dtype, device=x.device)
-    rc = _lib.lib().gt_segment_sum(_dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
-                                   _stream())
-    _lib.check(rc, "gt_segment_sum")
+    _lib.launch("gt_segment_sum", _dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
+                _stream())
     return out
 
 
@@ -181,10 +180,8 @@ def _gather_raw(h, cls, gs, lay, want_mask):
     D = h.shape[1]
     tokens = torch.empty((lay.rows, D), dtype=h.dtype, device=h.device)
     mask = torch.empty((lay.B, lay.max_npos), dtype=torch.bool, device=h.device) if want_mask else None
-    rc = _lib.lib().gt_seq_gather(_dtype_code(h), _ptr(h), _ptr(cls), _ptr(gs.graph_ptr), _ptr(lay.desc), lay.B,
-                                  lay.row_stride, lay.max_npos, 1 if lay.with_cls else 0, D, _ptr(tokens),
-                                  _ptr(mask), _stream())
-    _lib.check(rc, "gt_seq_gather")
+    _lib.launch("gt_seq_gather", _dtype_code(h), _ptr(h), _ptr(cls), _ptr(gs.graph_ptr), _ptr(lay.desc), lay.B,
+                lay.row_stride, lay.max_npos, 1 if lay.with_cls else 0, D, _ptr(tokens), _ptr(mask), _stream())
     return tokens, mask
 
 
@@ -192,10 +189,9 @@ def _scatter_raw(tokens, base, gs, lay, want_cls):
     D = tokens.shape[1]
     h = torch.empty((gs.N, D), dtype=tokens.dtype, device=tokens.device)
     cls = torch.empty((lay.B, D), dtype=tokens.dtype, device=tokens.device) if want_cls else None
-    rc = _lib.lib().gt_seq_scatter(_dtype_code(tokens), _ptr(tokens), _ptr(base), _ptr(gs.graph_ptr),
-                                   _ptr(gs.node_graph), _ptr(lay.desc), lay.B, lay.row_stride,
-                                   1 if lay.with_cls else 0, gs.N, D, _ptr(h), _ptr(cls), _stream())
-    _lib.check(rc, "gt_seq_scatter")
+    _lib.launch("gt_seq_scatter", _dtype_code(tokens), _ptr(tokens), _ptr(base), _ptr(gs.graph_ptr),
+                _ptr(gs.node_graph), _ptr(lay.desc), lay.B, lay.row_stride, 1 if lay.with_cls else 0, gs.N, D, _ptr(h),
+                _ptr(cls), _stream())
     return h, cls
 
 
@@ -266,9 +262,10 @@ class _Attention(torch.autograd.Function):
         d = d3 // 3
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
-        rc = _lib.lib().gt_attn_fwd(_dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
-                                    lay.B, lay.row_stride, lay.max_npos, scale, dropout_p, seed, _stream())
-        _lib.check(rc, "gt_attn_fwd")
+        meta = dict(lay=lay, d=d, nhead=nhead, elt=qkv.element_size())
+        _lib.launch("gt_attn_fwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
+                    lay.B, lay.row_stride, lay.max_npos, scale, dropout_p, seed, _stream(), meta=meta)
+        ctx.meta = meta
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (lay, nhead, scale, dropout_p, seed)
         return out
@@ -282,10 +279,9 @@ class _Attention(torch.autograd.Function):
         # rows that belong to no sequence position do not exist in either layout -> fully written
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        rc = _lib.lib().gt_attn_bwd(_dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
-                                    _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride,
-                                    lay.max_npos, scale, dropout_p, seed, _stream())
-        _lib.check(rc, "gt_attn_bwd")
+        _lib.launch("gt_attn_bwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
+                    _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos, scale,
+                    dropout_p, seed, _stream(), meta=ctx.meta)
         return dqkv, None, None, None, None, None
 
 

@@ -125,7 +125,7 @@ def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     torch.manual_seed(0)
     b = synth.molpcba_like(B=24, seed=3) if edge == "bond" else synth.code2_like(B=12, seed=3)
     N = b.num_nodes
-    h = torch.randn(N, D)
+    h = torch.randn(N, D).to(dtype).float()  # the oracle sees the same (storage-rounded) inputs
     w = torch.randn(N, D)
     enc = None
     if edge == "linear":
