@@ -384,8 +384,20 @@ __global__ void __launch_bounds__(256) k_agg_reduce(ReduceArgs r) {
   const int slot = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
   float t = 0.f;
-  if (c < r.D)
-    for (int b = wid; b < r.nblocks; b += 4) t += r.partial[((int64_t)b * r.nslots + slot) * r.D + c];
+  if (c < r.D) {
+    // fixed order, 8 independent loads in flight per thread (a serial chain of L2 round trips made
+    // this kernel cost as much as the main pass: profiles/r01a)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* p = r.partial + (int64_t)slot * r.D + c;
+    const int64_t stride = (int64_t)r.nslots * r.D;
+    int b = wid;
+    for (; b + 28 < r.nblocks; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(b + 4 * u) * stride];
+    }
+    for (; b < r.nblocks; b += 4) acc[0] += p[(int64_t)b * stride];
+    t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
   sm[wid][lane] = t;
   __syncthreads();
   if (wid != 0) return;

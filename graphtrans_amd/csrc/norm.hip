@@ -1,0 +1,615 @@
+// norm.hip — BatchNorm1d (train/eval, optional fused ReLU) and residual + dropout + LayerNorm,
+// forward and backward, for the node/token row matrices of the GraphTrans hot path.
+//
+// Reference call sites (paths under /root/reference):
+//   modules/gnn_module.py:84,204  h = batch_norms[layer](h) ; :86-90,205-209  F.relu / dropout
+//   modules/gnn_module.py:161-170 virtual-node MLP BatchNorm1d(2D) / BatchNorm1d(D) + ReLU
+//   modules/conv.py:18-20         GIN mlp BatchNorm1d(2D) + ReLU
+//   modules/transformer_encoder.py:28-32,56-59  nn.TransformerEncoderLayer: x = LN(x + dropout(sub(x)));
+//                                 norm_input / final LayerNorm
+// torch's BatchNorm kernels dominated the first profile (25 % of GPU time at N = 32 k rows x 300
+// channels, profiles/r01a): column statistics here are one streaming pass (shifted sums: pivot =
+// row 0 of every column, so sum / sum-of-squares do not cancel), deterministic block partials, a
+// latency-hidden fixed-order finish, then one apply pass with ReLU fused.
+#include "gt_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_PART = 512;  // column-partial blocks
+
+// thread -> (chunk column, row lane) mapping for an [rows][D] matrix walked by a 256-thread block
+struct ColMap {
+  int C, CW, R, tc, tr;
+  __device__ __forceinline__ ColMap(int64_t D) {
+    C = (int)(D / 4);
+    CW = C < NT ? C : NT;
+    R = NT / CW;
+    tc = threadIdx.x % CW;
+    tr = threadIdx.x / CW;  // >= R for the idle tail threads
+  }
+};
+
+// reduce `nv` float4 accumulators over the R row-lanes of a block through LDS and hand the result
+// to row-lane 0 (fixed order)
+template <int NV>
+__device__ __forceinline__ void block_rowlane_reduce(float4 (&v)[NV], const ColMap& m, float4* sm) {
+  // sm: [R][CW][NV]
+  if (m.tr < m.R) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[(m.tr * m.CW + m.tc) * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (m.tr == 0) {
+    for (int r = 1; r < m.R; ++r)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = gt_add4(v[i], sm[(r * m.CW + m.tc) * NV + i]);
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------------------
+// pass 1: per-block shifted sums  part[blk][0][D] = sum(x - pivot), part[blk][1][D] = sum((x-pivot)^2)
+template <typename T>
+__global__ void __launch_bounds__(NT) k_bn_stats_partial(const T* __restrict__ x, int64_t N, int64_t D,
+                                                         float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm4[];
+  ColMap m(D);
+  const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int64_t r1 = r0 + rows_per < N ? r0 + rows_per : N;
+  for (int c0 = 0; c0 < m.C; c0 += m.CW) {  // uniform trip count (block-wide barriers inside)
+    const int c = c0 + m.tc;
+    const bool cact = c < m.C;
+    float4 acc[2] = {gt_zero4(), gt_zero4()};
+    if (m.tr < m.R && cact) {
+      const float4 piv = gt_load4<T>(x + (int64_t)c * 4);  // row 0
+      for (int64_t r = r0 + m.tr; r < r1; r += m.R) {
+        float4 v = gt_load4<T>(x + r * D + (int64_t)c * 4);
+        v = make_float4(v.x - piv.x, v.y - piv.y, v.z - piv.z, v.w - piv.w);
+        acc[0] = gt_add4(acc[0], v);
+        acc[1] = make_float4(fmaf(v.x, v.x, acc[1].x), fmaf(v.y, v.y, acc[1].y), fmaf(v.z, v.z, acc[1].z),
+                             fmaf(v.w, v.w, acc[1].w));
+      }
+    }
+    block_rowlane_reduce<2>(acc, m, sm4);
+    if (m.tr == 0 && cact) {
+      float* p = part + (int64_t)blockIdx.x * 2 * D + (int64_t)c * 4;
+      *reinterpret_cast<float4*>(p) = acc[0];
+      *reinterpret_cast<float4*>(p + D) = acc[1];
+    }
+  }
+}
+
+// fixed-order sum over `nblk` partial rows of `nv` D-vectors: thread per (vector, column), 8 loads in flight
+__device__ __forceinline__ float partial_sum(const float* __restrict__ part, int nblk, int64_t stride, int64_t off) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(b + u) * stride + off];
+  }
+  for (; b < nblk; ++b) a[0] += part[(int64_t)b * stride + off];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+// pass 2: mean / rstd per column (+ running-stat update, torch semantics: unbiased running_var)
+template <typename T>
+__global__ void k_bn_stats_finish(const T* __restrict__ x, const float* __restrict__ part, int nblk, int64_t N,
+                                  int64_t D, float eps, float momentum, float* __restrict__ mean,
+                                  float* __restrict__ rstd, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  if (c >= D) return;
+  const float s1 = partial_sum(part, nblk, 2 * D, c);
+  const float s2 = partial_sum(part, nblk, 2 * D, D + c);
+  const float piv = sizeof(T) == 4 ? (float)reinterpret_cast<const float*>(x)[c]
+                                   : gt_bf16_to_f32(reinterpret_cast<const gt_bf16*>(x)[c]);
+  const float inv_n = 1.0f / (float)N;
+  const float m1 = s1 * inv_n;
+  float var = s2 * inv_n - m1 * m1;
+  var = var < 0.f ? 0.f : var;
+  const float mu = piv + m1;
+  mean[c] = mu;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    const float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// eval mode: mean = running_mean, rstd = (running_var + eps)^-1/2
+__global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                int64_t D, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  mean[c] = running_mean[c];
+  rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// pass 3: y = (x - mean) * rstd * w + b  [relu]
+template <typename T>
+__global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, const float* __restrict__ w,
+                                                 const float* __restrict__ b, int relu, int64_t N, int64_t D,
+                                                 T* __restrict__ y) {
+  const int64_t C = D / 4, total = N * C;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t c = (i % C) * 4;
+    float4 v = gt_load4<T>(x + i * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+    v = make_float4((v.x - mu.x) * rs.x * ww.x + bb.x, (v.y - mu.y) * rs.y * ww.y + bb.y,
+                    (v.z - mu.z) * rs.z * ww.z + bb.z, (v.w - mu.w) * rs.w * ww.w + bb.w);
+    if (relu) v = gt_relu4(v);
+    gt_store4<T>(y + i * 4, v);
+  }
+}
+
+// backward pass 1: part[blk][0][D] = sum(dy'), part[blk][1][D] = sum(dy' * xhat),  dy' = dy * 1[y > 0] if relu
+template <typename T>
+__global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const T* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int relu, int64_t N, int64_t D,
+                                                       float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm4[];
+  ColMap m(D);
+  const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int64_t r1 = r0 + rows_per < N ? r0 + rows_per : N;
+  for (int c0 = 0; c0 < m.C; c0 += m.CW) {
+    const int c = c0 + m.tc;
+    const bool cact = c < m.C;
+    float4 acc[2] = {gt_zero4(), gt_zero4()};
+    if (m.tr < m.R && cact) {
+      const float4 mu = *reinterpret_cast<const float4*>(mean + c * 4), rs = *reinterpret_cast<const float4*>(rstd + c * 4);
+      for (int64_t r = r0 + m.tr; r < r1; r += m.R) {
+        const int64_t o = r * D + (int64_t)c * 4;
+        float4 g = gt_load4<T>(dy + o);
+        const float4 v = gt_load4<T>(x + o);
+        if (relu) {
+          const float4 yy = gt_load4<T>(y + o);
+          g = make_float4(yy.x > 0.f ? g.x : 0.f, yy.y > 0.f ? g.y : 0.f, yy.z > 0.f ? g.z : 0.f, yy.w > 0.f ? g.w : 0.f);
+        }
+        acc[0] = gt_add4(acc[0], g);
+        acc[1] = make_float4(fmaf(g.x, (v.x - mu.x) * rs.x, acc[1].x), fmaf(g.y, (v.y - mu.y) * rs.y, acc[1].y),
+                             fmaf(g.z, (v.z - mu.z) * rs.z, acc[1].z), fmaf(g.w, (v.w - mu.w) * rs.w, acc[1].w));
+      }
+    }
+    block_rowlane_reduce<2>(acc, m, sm4);
+    if (m.tr == 0 && cact) {
+      float* p = part + (int64_t)blockIdx.x * 2 * D + (int64_t)c * 4;
+      *reinterpret_cast<float4*>(p) = acc[0];
+      *reinterpret_cast<float4*>(p + D) = acc[1];
+    }
+  }
+}
+
+__global__ void k_bn_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dbias,
+                                float* __restrict__ dweight) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  dbias[c] = partial_sum(part, nblk, 2 * D, c);
+  dweight[c] = partial_sum(part, nblk, 2 * D, D + c);
+}
+
+// backward pass 3: train: dx = w rstd (dy' - dbias/N - xhat dweight/N) ; eval: dx = w rstd dy'
+template <typename T>
+__global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
+                                                     const T* __restrict__ y, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ w,
+                                                     const float* __restrict__ dbias, const float* __restrict__ dweight,
+                                                     int relu, int training, int64_t N, int64_t D, T* __restrict__ dx) {
+  const int64_t C = D / 4, total = N * C;
+  const float inv_n = training ? 1.0f / (float)N : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t c = (i % C) * 4;
+    float4 g = gt_load4<T>(dy + i * 4);
+    const float4 v = gt_load4<T>(x + i * 4);
+    if (relu) {
+      const float4 yy = gt_load4<T>(y + i * 4);
+      g = make_float4(yy.x > 0.f ? g.x : 0.f, yy.y > 0.f ? g.y : 0.f, yy.z > 0.f ? g.z : 0.f, yy.w > 0.f ? g.w : 0.f);
+    }
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    const float4 db = *reinterpret_cast<const float4*>(dbias + c), dw = *reinterpret_cast<const float4*>(dweight + c);
+    float4 r;
+    r.x = ww.x * rs.x * (g.x - db.x * inv_n - (v.x - mu.x) * rs.x * dw.x * inv_n);
+    r.y = ww.y * rs.y * (g.y - db.y * inv_n - (v.y - mu.y) * rs.y * dw.y * inv_n);
+    r.z = ww.z * rs.z * (g.z - db.z * inv_n - (v.z - mu.z) * rs.z * dw.z * inv_n);
+    r.w = ww.w * rs.w * (g.w - db.w * inv_n - (v.w - mu.w) * rs.w * dw.w * inv_n);
+    gt_store4<T>(dx + i * 4, r);
+  }
+}
+
+int part_blocks(int64_t N) {
+  int64_t b = gt_cdiv(N, 64);
+  return (int)(b < 1 ? 1 : (b > MAX_PART ? MAX_PART : b));
+}
+int flat_blocks(int64_t items) {
+  int64_t g = gt_cdiv(items, NT * 2);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+size_t rowlane_lds(int64_t D, int nv) {
+  int C = (int)(D / 4);
+  int CW = C < NT ? C : NT;
+  int R = NT / CW;
+  return (size_t)R * CW * nv * sizeof(float4);
+}
+
+int check_norm(const char* fn, int dtype, int64_t rows, int64_t D) {
+  if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (rows < 0 || D <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (D % 4 != 0 || D > 4096) { gt_set_error("%s: dim %lld unsupported (dim %% 4 == 0, dim <= 4096)", fn, (long long)D); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual + dropout + LayerNorm   (one 16/32/64-lane group per row)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ln_hash(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col) {
+  uint32_t x = (row * 0x9E3779B1u + s0) ^ (col * 0x85EBCA77u + s1);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+struct LnArgs {
+  const void* x;      // sub-layer output (dropout applies to it) or the only input
+  const void* resid;  // optional residual stream
+  const float* w;
+  const float* b;
+  void* y;
+  float* mean;
+  float* rstd;
+  const void* dy;     // bwd
+  void* dx;           // bwd: grad wrt x (through dropout); may be null when x has no grad
+  void* dresid;       // bwd: grad wrt resid (= dz); null when no residual
+  float* part;        // bwd: [blocks][2][D]
+  int64_t rows, D;
+  float eps, inv_keep;
+  uint32_t thr, s0, s1;
+};
+
+template <typename T, int LPN, int NCH>
+__device__ __forceinline__ void ln_load_z(const LnArgs& a, int64_t row, int sl, float4 (&z)[NCH], bool (&keep)[NCH][4]) {
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* rs = reinterpret_cast<const T*>(a.resid);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (sl + j * 64) * 4;
+    keep[j][0] = keep[j][1] = keep[j][2] = keep[j][3] = true;
+    if (col >= a.D) {
+      z[j] = gt_zero4();
+      continue;
+    }
+    float4 v = gt_load4<T>(x + row * a.D + col);
+    if (a.thr) {
+      float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        keep[j][e] = ln_hash(a.s0, a.s1, (uint32_t)row, (uint32_t)(col + e)) >= a.thr;
+        vv[e] = keep[j][e] ? vv[e] * a.inv_keep : 0.f;
+      }
+    }
+    if (rs) v = gt_add4(v, gt_load4<T>(rs + row * a.D + col));
+    z[j] = v;
+  }
+}
+
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPN; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPN, int NCH>
+__global__ void __launch_bounds__(NT) k_ln_fwd(LnArgs a) {
+  constexpr int NPW = 64 / LPN;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPN, sl = lane % LPN;
+  const int64_t row = ((int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * NPW + sub;
+  if (row >= a.rows) return;
+  float4 z[NCH];
+  bool keep[NCH][4];
+  ln_load_z<T, LPN, NCH>(a, row, sl, z, keep);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
+  const float mu = group_sum<LPN>(s) / (float)a.D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (sl + j * 64) * 4;
+    if (col < a.D) {
+      const float dx = z[j].x - mu, dy = z[j].y - mu, dz = z[j].z - mu, dw = z[j].w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rs = 1.0f / sqrtf(group_sum<LPN>(q) / (float)a.D + a.eps);
+  T* y = reinterpret_cast<T*>(a.y);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (sl + j * 64) * 4;
+    if (col >= a.D) continue;
+    const float4 w = *reinterpret_cast<const float4*>(a.w + col), b = *reinterpret_cast<const float4*>(a.b + col);
+    gt_store4<T>(y + row * a.D + col, make_float4((z[j].x - mu) * rs * w.x + b.x, (z[j].y - mu) * rs * w.y + b.y,
+                                                  (z[j].z - mu) * rs * w.z + b.z, (z[j].w - mu) * rs * w.w + b.w));
+  }
+  if (sl == 0) {
+    a.mean[row] = mu;
+    a.rstd[row] = rs;
+  }
+}
+
+// backward: persistent grid; per-lane column accumulators for dw/db, block partials, fixed-order finish
+template <typename T, int LPN, int NCH>
+__global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
+  constexpr int NPW = 64 / LPN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane / LPN, sl = lane % LPN;
+  float4 aw[NCH], ab[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) aw[j] = ab[j] = gt_zero4();
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const int64_t total_waves = (int64_t)gridDim.x * (NT / 64);
+  for (int64_t base = ((int64_t)blockIdx.x * (NT / 64) + wid) * NPW; base < a.rows; base += total_waves * NPW) {
+    const int64_t row = base + sub;
+    if (row >= a.rows) continue;
+    float4 z[NCH];
+    bool keep[NCH][4];
+    ln_load_z<T, LPN, NCH>(a, row, sl, z, keep);
+    const float mu = a.mean[row], rs = a.rstd[row];
+    float4 g[NCH], xh[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int col = (sl + j * 64) * 4;
+      if (col >= a.D) {
+        g[j] = xh[j] = gt_zero4();
+        continue;
+      }
+      const float4 d = gt_load4<T>(dy + row * a.D + col);
+      const float4 w = *reinterpret_cast<const float4*>(a.w + col);
+      xh[j] = make_float4((z[j].x - mu) * rs, (z[j].y - mu) * rs, (z[j].z - mu) * rs, (z[j].w - mu) * rs);
+      ab[j] = gt_add4(ab[j], d);
+      aw[j] = make_float4(fmaf(d.x, xh[j].x, aw[j].x), fmaf(d.y, xh[j].y, aw[j].y), fmaf(d.z, xh[j].z, aw[j].z),
+                          fmaf(d.w, xh[j].w, aw[j].w));
+      g[j] = make_float4(d.x * w.x, d.y * w.y, d.z * w.z, d.w * w.w);
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float m1 = group_sum<LPN>(s1) / (float)a.D, m2 = group_sum<LPN>(s2) / (float)a.D;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int col = (sl + j * 64) * 4;
+      if (col >= a.D) continue;
+      float4 dz = make_float4(rs * (g[j].x - m1 - xh[j].x * m2), rs * (g[j].y - m1 - xh[j].y * m2),
+                              rs * (g[j].z - m1 - xh[j].z * m2), rs * (g[j].w - m1 - xh[j].w * m2));
+      if (a.dresid) gt_store4<T>(reinterpret_cast<T*>(a.dresid) + row * a.D + col, dz);
+      if (a.dx) {
+        if (a.thr) {
+          dz.x = keep[j][0] ? dz.x * a.inv_keep : 0.f;
+          dz.y = keep[j][1] ? dz.y * a.inv_keep : 0.f;
+          dz.z = keep[j][2] ? dz.z * a.inv_keep : 0.f;
+          dz.w = keep[j][3] ? dz.w * a.inv_keep : 0.f;
+        }
+        gt_store4<T>(reinterpret_cast<T*>(a.dx) + row * a.D + col, dz);
+      }
+    }
+  }
+  // reduce (sub-groups -> waves -> block partial)
+  float* part = a.part + (int64_t)blockIdx.x * 2 * a.D;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (sl + j * 64) * 4;
+    float4 w4 = aw[j], b4 = ab[j];
+#pragma unroll
+    for (int o = LPN; o < 64; o <<= 1) {
+      w4.x += __shfl_xor(w4.x, o, 64); w4.y += __shfl_xor(w4.y, o, 64); w4.z += __shfl_xor(w4.z, o, 64); w4.w += __shfl_xor(w4.w, o, 64);
+      b4.x += __shfl_xor(b4.x, o, 64); b4.y += __shfl_xor(b4.y, o, 64); b4.z += __shfl_xor(b4.z, o, 64); b4.w += __shfl_xor(b4.w, o, 64);
+    }
+    if (sub == 0 && col < a.D) {
+      *reinterpret_cast<float4*>(lds + ((int64_t)wid * 2 + 0) * a.D + col) = w4;
+      *reinterpret_cast<float4*>(lds + ((int64_t)wid * 2 + 1) * a.D + col) = b4;
+    }
+  }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < 2 * a.D; i += NT) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += lds[(int64_t)w * 2 * a.D + i];
+    part[i] = t;  // [0][D] = dweight partial, [1][D] = dbias partial
+  }
+}
+
+__global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dweight,
+                                float* __restrict__ dbias) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  dweight[c] = partial_sum(part, nblk, 2 * D, c);
+  dbias[c] = partial_sum(part, nblk, 2 * D, D + c);
+}
+
+constexpr int LN_BWD_BLOCKS = 512;
+
+template <typename T, bool BWD>
+void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
+  const int64_t D = a.D;
+#define GT_LN(LPN, NCH)                                                                                      \
+  do {                                                                                                       \
+    if constexpr (BWD) {                                                                                     \
+      hipLaunchKernelGGL((k_ln_bwd<T, LPN, NCH>), dim3(grid_bwd), dim3(NT), (size_t)(NT / 64) * 2 * D * 4,   \
+                         stream, a);                                                                         \
+    } else {                                                                                                 \
+      int64_t waves = gt_cdiv(a.rows, 64 / (LPN));                                                           \
+      hipLaunchKernelGGL((k_ln_fwd<T, LPN, NCH>), dim3((unsigned)gt_cdiv(waves, NT / 64)), dim3(NT), 0,      \
+                         stream, a);                                                                         \
+    }                                                                                                        \
+  } while (0)
+  if (D <= 64) GT_LN(16, 1);
+  else if (D <= 128) GT_LN(32, 1);
+  else if (D <= 256) GT_LN(64, 1);
+  else if (D <= 512) GT_LN(64, 2);
+  else if (D <= 768) GT_LN(64, 3);
+  else GT_LN(64, 4);
+#undef GT_LN
+}
+
+void fill_drop(LnArgs& a, float dropout_p, uint64_t seed) {
+  a.inv_keep = 1.0f / (1.0f - dropout_p);
+  double thr = (double)dropout_p * 4294967296.0;
+  a.thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
+  a.s0 = (uint32_t)seed;
+  a.s1 = (uint32_t)(seed >> 32);
+}
+
+}  // namespace
+
+// ---- C ABI -----------------------------------------------------------------------------------------
+extern "C" size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim) {
+  return (size_t)part_blocks(rows) * 2 * dim * sizeof(float) + 256;
+}
+
+extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float momentum, float eps, int training, int relu, int64_t rows, int64_t dim, void* y,
+                                float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                gt_stream_t stream_) {
+  int rc = check_norm("gt_batchnorm_fwd", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && weight && bias && y && save_mean && save_rstd, "null buffer");
+  GT_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
+  if (rows == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int cgrid = (int)gt_cdiv(dim, 256);
+  if (training) {
+    GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
+    const int nb = part_blocks(rows);
+    if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
+      gt_set_error("gt_batchnorm_fwd: workspace too small");
+      return GT_ERR_WORKSPACE;
+    }
+    float* part = (float*)workspace;
+    size_t lds = rowlane_lds(dim, 2);
+    if (dtype == GT_F32) {
+      hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
+      hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(256), 0, stream, (const float*)x, part, nb, rows,
+                         dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
+    } else {
+      hipLaunchKernelGGL(k_bn_stats_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, rows, dim, part);
+      hipLaunchKernelGGL(k_bn_stats_finish<gt_bf16>, dim3(cgrid), dim3(256), 0, stream, (const gt_bf16*)x, part, nb,
+                         rows, dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
+    }
+  } else {
+    hipLaunchKernelGGL(k_bn_eval_stats, dim3(cgrid), dim3(256), 0, stream, running_mean, running_var, dim, eps, save_mean,
+                       save_rstd);
+  }
+  const int g = flat_blocks(rows * (dim / 4));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, save_mean, save_rstd, weight,
+                       bias, relu, rows, dim, (float*)y);
+  else
+    hipLaunchKernelGGL(k_bn_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, save_mean, save_rstd, weight,
+                       bias, relu, rows, dim, (gt_bf16*)y);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const void* y, const float* weight,
+                                const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
+                                int64_t dim, void* dx, float* dweight, float* dbias, void* workspace,
+                                size_t workspace_bytes, gt_stream_t stream_) {
+  int rc = check_norm("gt_batchnorm_bwd", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && dy && weight && save_mean && save_rstd && dx && dweight && dbias, "null buffer");
+  GT_CHECK_ARG(!relu || y, "relu backward needs the forward output");
+  if (rows == 0) return GT_OK;
+  if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
+    gt_set_error("gt_batchnorm_bwd: workspace too small");
+    return GT_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nb = part_blocks(rows);
+  float* part = (float*)workspace;
+  const size_t lds = rowlane_lds(dim, 2);
+  const int cgrid = (int)gt_cdiv(dim, 256);
+  const int g = flat_blocks(rows * (dim / 4));
+  if (dtype == GT_F32) {
+    hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
+                       (const float*)y, save_mean, save_rstd, relu, rows, dim, part);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
+                       (const float*)y, save_mean, save_rstd, weight, dbias, dweight, relu, training, rows, dim, (float*)dx);
+  } else {
+    hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
+                       (const gt_bf16*)y, save_mean, save_rstd, relu, rows, dim, part);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
+    hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
+                       (const gt_bf16*)y, save_mean, save_rstd, weight, dbias, dweight, relu, training, rows, dim,
+                       (gt_bf16*)dx);
+  }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_layernorm_fwd(int dtype, const void* x, const void* resid, const float* weight, const float* bias,
+                                float eps, float dropout_p, uint64_t seed, int64_t rows, int64_t dim, void* y,
+                                float* save_mean, float* save_rstd, gt_stream_t stream_) {
+  int rc = check_norm("gt_layernorm_fwd", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(dim <= 1024, "LayerNorm dim > 1024 unsupported");
+  GT_CHECK_ARG(x && weight && bias && y && save_mean && save_rstd, "null buffer");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  if (rows == 0) return GT_OK;
+  LnArgs a{};
+  a.x = x; a.resid = resid; a.w = weight; a.b = bias; a.y = y; a.mean = save_mean; a.rstd = save_rstd;
+  a.rows = rows; a.D = dim; a.eps = eps;
+  fill_drop(a, dropout_p, seed);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (dtype == GT_F32) ln_launch<float, false>(a, 0, stream);
+  else ln_launch<gt_bf16, false>(a, 0, stream);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" size_t gt_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
+  (void)rows;
+  return (size_t)LN_BWD_BLOCKS * 2 * dim * sizeof(float) + 256;
+}
+
+extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy, const float* weight,
+                                const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed,
+                                int64_t rows, int64_t dim, void* dx, void* dresid, float* dweight, float* dbias,
+                                void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  int rc = check_norm("gt_layernorm_bwd", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(dim <= 1024, "LayerNorm dim > 1024 unsupported");
+  GT_CHECK_ARG(x && dy && weight && save_mean && save_rstd && dweight && dbias, "null buffer");
+  GT_CHECK_ARG(dx || dresid, "nothing to compute");
+  if (!workspace || workspace_bytes < gt_layernorm_bwd_workspace_bytes(rows, dim)) {
+    gt_set_error("gt_layernorm_bwd: workspace too small");
+    return GT_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  LnArgs a{};
+  a.x = x; a.resid = resid; a.w = weight; a.dy = dy; a.dx = dx; a.dresid = dresid; a.mean = const_cast<float*>(save_mean);
+  a.rstd = const_cast<float*>(save_rstd); a.rows = rows; a.D = dim; a.part = (float*)workspace;
+  fill_drop(a, dropout_p, seed);
+  const int64_t npw = dim <= 64 ? 4 : (dim <= 128 ? 2 : 1);
+  int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), NT / 64);
+  const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
+  if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
+  else ln_launch<gt_bf16, true>(a, grid, stream);
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, 256)), dim3(256), 0, stream, (const float*)workspace, grid,
+                     dim, dweight, dbias);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

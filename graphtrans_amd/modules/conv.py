@@ -5,6 +5,7 @@ import torch
 
 from .. import ops
 from ..graph import GraphStructure
+from .norm import BatchNorm1d, mlp_bn_relu
 
 _LDS_TABLE_BUDGET = 160 * 1024  # per-wave table-gradient rows in the backward kernel (LDS per CU)
 
@@ -43,7 +44,7 @@ class GINConv(torch.nn.Module):
     def __init__(self, emb_dim: int, edge_encoder_cls):
         super().__init__()
         self.mlp = torch.nn.Sequential(
-            torch.nn.Linear(emb_dim, 2 * emb_dim), torch.nn.BatchNorm1d(2 * emb_dim), torch.nn.ReLU(),
+            torch.nn.Linear(emb_dim, 2 * emb_dim), BatchNorm1d(2 * emb_dim), torch.nn.ReLU(),
             torch.nn.Linear(2 * emb_dim, emb_dim))
         self.eps = torch.nn.Parameter(torch.Tensor([0]))
         self.edge_encoder = edge_encoder_cls(emb_dim)
@@ -53,7 +54,7 @@ class GINConv(torch.nn.Module):
         gs = _structure(x, edge_index, graph)
         spec = edge_spec(self.edge_encoder, edge_attr, self.emb_dim)
         # (1 + eps) * x + sum_k relu(x_j + e_k), fused  (conv.py:28,33)
-        return self.mlp(ops.aggregate(x, gs, "gin", self.eps, spec))
+        return mlp_bn_relu(self.mlp, ops.aggregate(x, gs, "gin", self.eps, spec))
 
 
 class GCNConv(torch.nn.Module):

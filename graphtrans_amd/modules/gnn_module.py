@@ -6,6 +6,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..graph import GraphStructure
 from .conv import GCNConv, GINConv
+from .norm import BatchNorm1d, mlp_bn_relu
 
 
 def batch_structure(batched_data):
@@ -45,7 +46,7 @@ def _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type):
             self.convs.append(GCNConv(emb_dim, edge_encoder_cls))
         else:
             raise ValueError("Undefined GNN type called {}".format(gnn_type))
-        self.batch_norms.append(torch.nn.BatchNorm1d(emb_dim))
+        self.batch_norms.append(BatchNorm1d(emb_dim))
 
 
 def _jk(JK, h_list, num_layer):
@@ -82,11 +83,9 @@ class GNN_node(torch.nn.Module):
         h_list = [encoded + perturb if perturb is not None else encoded]
         for layer in range(self.num_layer):
             h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
-            h = self.batch_norms[layer](h)
-            if layer == self.num_layer - 1:
-                h = F.dropout(h, self.drop_ratio, training=self.training)
-            else:
-                h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+            # BN (+ReLU except on the last layer) fused, then dropout
+            h = self.batch_norms[layer](h, relu=(layer != self.num_layer - 1))
+            h = F.dropout(h, self.drop_ratio, training=self.training)
             if self.residual:
                 h = h + h_list[layer]
             h_list.append(h)
@@ -111,8 +110,8 @@ class GNN_node_Virtualnode(torch.nn.Module):
         self.mlp_virtualnode_list = torch.nn.ModuleList()
         for _ in range(num_layer - 1):
             self.mlp_virtualnode_list.append(torch.nn.Sequential(
-                torch.nn.Linear(emb_dim, 2 * emb_dim), torch.nn.BatchNorm1d(2 * emb_dim), torch.nn.ReLU(),
-                torch.nn.Linear(2 * emb_dim, emb_dim), torch.nn.BatchNorm1d(emb_dim), torch.nn.ReLU()))
+                torch.nn.Linear(emb_dim, 2 * emb_dim), BatchNorm1d(2 * emb_dim), torch.nn.ReLU(),
+                torch.nn.Linear(2 * emb_dim, emb_dim), BatchNorm1d(emb_dim), torch.nn.ReLU()))
 
     def forward(self, batched_data, perturb=None):
         gs = batch_structure(batched_data)
@@ -124,17 +123,15 @@ class GNN_node_Virtualnode(torch.nn.Module):
         for layer in range(self.num_layer):
             h_list[layer] = ops.segment_bcast_add(h_list[layer], vn, gs)  # + vn[batch]   (:199)
             h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
-            h = self.batch_norms[layer](h)
-            if layer == self.num_layer - 1:
-                h = F.dropout(h, self.drop_ratio, training=self.training)
-            else:
-                h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+            # BN (+ReLU except on the last layer) fused, then dropout
+            h = self.batch_norms[layer](h, relu=(layer != self.num_layer - 1))
+            h = F.dropout(h, self.drop_ratio, training=self.training)
             if self.residual:
                 h = h + h_list[layer]
             h_list.append(h)
             if layer < self.num_layer - 1:
                 t = ops.segment_sum(h_list[layer], gs, add=vn)  # global_add_pool + vn   (:219)
-                t = F.dropout(self.mlp_virtualnode_list[layer](t), self.drop_ratio, training=self.training)
+                t = F.dropout(mlp_bn_relu(self.mlp_virtualnode_list[layer], t), self.drop_ratio, training=self.training)
                 vn = vn + t if self.residual else t
         return _jk(self.JK, h_list, self.num_layer)
 

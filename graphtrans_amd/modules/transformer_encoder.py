@@ -68,8 +68,10 @@ class TransformerNodeEncoder(nn.Module):
     def _w(self, p):
         return p if p.dtype == self.compute_dtype else p.to(self.compute_dtype)
 
-    def _ln(self, x, ln):
-        return F.layer_norm(x, (self.d_model,), self._w(ln.weight), self._w(ln.bias), ln.eps)
+    def _ln(self, x, ln, resid=None, seed=0):
+        """LN(resid + dropout(x)) in one kernel (gt_layernorm_fwd); plain LN when resid is None."""
+        p = self.dropout_p if (self.training and resid is not None) else 0.0
+        return ops.layer_norm(x, ln.weight, ln.bias, ln.eps, resid=resid, dropout_p=p, seed=seed)
 
     def _drop(self, x):
         return F.dropout(x, self.dropout_p, self.training) if (self.training and self.dropout_p > 0) else x
@@ -80,11 +82,11 @@ class TransformerNodeEncoder(nn.Module):
         p = self.dropout_p if self.training else 0.0
         ctx = ops.attention(qkv, lay, self.nhead, dropout_p=p, seed=seed)
         a = F.linear(ctx, self._w(sa.out_proj.weight), self._w(sa.out_proj.bias))
-        x = self._ln(x + self._drop(a), mod.norm1)
+        x = self._ln(a, mod.norm1, resid=x, seed=seed ^ 0x5851F42D4C957F2D)
         act = F.relu if self.activation == "relu" else F.gelu
         f = act(F.linear(x, self._w(mod.linear1.weight), self._w(mod.linear1.bias)))
         f = F.linear(self._drop(f), self._w(mod.linear2.weight), self._w(mod.linear2.bias))
-        return self._ln(x + self._drop(f), mod.norm2)
+        return self._ln(f, mod.norm2, resid=x, seed=seed ^ 0x14057B7EF767814F)
 
     def forward_tokens(self, tokens, lay):
         """tokens (lay.rows, d) already containing the CLS rows -> (lay.rows, d)."""

@@ -291,3 +291,88 @@ def attention(qkv, lay, nhead, dropout_p=0.0, seed=0, scale=None):
     if scale is None:
         scale = float(d // nhead) ** -0.5
     return _Attention.apply(qkv, lay, nhead, float(scale), float(dropout_p), int(seed))
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, training, relu):
+        x = _dev(x, "x")
+        rows, D = x.shape
+        dev = x.device
+        w32, b32 = _f32(weight), _f32(bias)
+        y = torch.empty_like(x)
+        stats = torch.empty((2, D), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.launch("gt_batchnorm_fwd", _dtype_code(x), _ptr(x), _ptr(w32), _ptr(b32), _ptr(running_mean),
+                    _ptr(running_var), _ptr(nbt), float(momentum), float(eps), 1 if training else 0, 1 if relu else 0,
+                    rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws_bytes, _stream())
+        ctx.save_for_backward(x, y if relu else None, w32, stats)
+        ctx.cfg = (training, relu, weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w32, stats = ctx.saved_tensors
+        training, relu, wdt, bdt = ctx.cfg
+        dy = _dev(dy.to(x.dtype), "grad")
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        dwb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(y), _ptr(w32), _ptr(stats[0]),
+                    _ptr(stats[1]), 1 if training else 0, 1 if relu else 0, rows, D, _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]),
+                    _ptr(ws), ws_bytes, _stream())
+        return dx, dwb[0].to(wdt), dwb[1].to(bdt), None, None, None, None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu=False):
+    """BatchNorm1d over rows of (rows, dim) with optional fused ReLU (gt_batchnorm_fwd/bwd)."""
+    return _BatchNorm.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, resid, weight, bias, eps, dropout_p, seed):
+        x = _dev(x, "x")
+        resid_c = None if resid is None else _dev(resid.to(x.dtype), "resid")
+        rows, D = x.shape
+        w32, b32 = _f32(weight), _f32(bias)
+        y = torch.empty_like(x)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        _lib.launch("gt_layernorm_fwd", _dtype_code(x), _ptr(x), _ptr(resid_c), _ptr(w32), _ptr(b32), float(eps),
+                    float(dropout_p), int(seed), rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _stream())
+        ctx.save_for_backward(x, resid_c, w32, stats)
+        ctx.cfg = (dropout_p, seed, weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, resid, w32, stats = ctx.saved_tensors
+        dropout_p, seed, wdt, bdt = ctx.cfg
+        dy = _dev(dy.to(x.dtype), "grad")
+        rows, D = x.shape
+        need_x, need_r = ctx.needs_input_grad[0], resid is not None and ctx.needs_input_grad[1]
+        if not (need_x or need_r):
+            need_x = True
+        dx = torch.empty_like(x) if need_x else None
+        dres = torch.empty_like(x) if need_r else None
+        dwb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws_bytes = L.gt_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _lib.launch("gt_layernorm_bwd", _dtype_code(x), _ptr(x), _ptr(resid), _ptr(dy), _ptr(w32), _ptr(stats[0]),
+                    _ptr(stats[1]), float(dropout_p), int(seed), rows, D, _ptr(dx), _ptr(dres), _ptr(dwb[0]),
+                    _ptr(dwb[1]), _ptr(ws), ws_bytes, _stream())
+        return dx, dres, dwb[0].to(wdt), dwb[1].to(bdt), None, None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, resid=None, dropout_p=0.0, seed=0):
+    """LayerNorm(resid + dropout(x)) over rows of (rows, dim) (gt_layernorm_fwd/bwd)."""
+    return _LayerNorm.apply(x, resid, weight, bias, eps, dropout_p, seed)

@@ -164,6 +164,43 @@ int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, 
                 int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale, float dropout_p,
                 uint64_t seed, gt_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d over the rows of an [rows][dim] matrix (channels = columns), optional fused ReLU.
+ * Replaces nn.BatchNorm1d (+ F.relu) at modules/gnn_module.py:84-90,204-209 (node BN),
+ * :161-170 (virtual-node MLP) and modules/conv.py:18-20 (GIN mlp).  torch semantics: training ->
+ * batch mean / biased variance, running stats updated with `momentum` (unbiased variance) and
+ * num_batches_tracked += 1; eval -> running stats.  weight/bias/stat buffers are fp32.
+ * save_mean/save_rstd [dim] are written for backward.  Deterministic (fixed reduction order).
+ */
+size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim);
+int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
+                     int relu, int64_t rows, int64_t dim, void* y, float* save_mean, float* save_rstd,
+                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* `y` (the forward output) is only read when relu != 0 (mask = y > 0). */
+int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const void* y, const float* weight,
+                     const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
+                     int64_t dim, void* dx, float* dweight, float* dbias, void* workspace, size_t workspace_bytes,
+                     gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y = LayerNorm(resid + dropout(x)) over the last dim of [rows][dim] token rows (dim <= 1024).
+ * Replaces the `x = norm(x + dropout(sublayer(x)))` pairs of nn.TransformerEncoderLayer and the
+ * norm_input / final LayerNorm (modules/transformer_encoder.py:28-32,56-59).  resid may be NULL
+ * (plain LayerNorm, dropout_p = 0).  Dropout is a counter hash of (seed, row, column), replayed
+ * by the backward.  save_mean/save_rstd [rows] fp32.
+ * Backward: dresid = d(resid + dropout(x)), dx = dresid through the dropout mask; either may be
+ * NULL.  dweight/dbias [dim] fp32, deterministic.
+ */
+int gt_layernorm_fwd(int dtype, const void* x, const void* resid, const float* weight, const float* bias, float eps,
+                     float dropout_p, uint64_t seed, int64_t rows, int64_t dim, void* y, float* save_mean,
+                     float* save_rstd, gt_stream_t stream);
+size_t gt_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy, const float* weight,
+                     const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed, int64_t rows,
+                     int64_t dim, void* dx, void* dresid, float* dweight, float* dbias, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
