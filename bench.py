@@ -201,6 +201,8 @@ def main():
     from graphtrans_amd.dist import GradSync
 
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
+    from graphtrans_amd import ops as gt_ops
+    gt_ops.set_matmul_dtype(dtype)  # GNN linears: fp32 storage, MFMA compute type follows --dtype
     per_gpu = opt.batch or (32 if opt.workload == "nci1" else 256)
     torch.manual_seed(1234)  # identical initial parameters on every rank
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
@@ -260,7 +262,7 @@ def main():
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
                        "step": "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
-                       "gnn_dtype": "fp32", "transformer_dtype": opt.dtype,
+                       "gnn_dtype": "fp32 storage, %s MFMA linears" % opt.dtype, "transformer_dtype": opt.dtype,
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
             "final_loss": round(final_loss, 5),
         }

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libgraphtrans_hip.so")
-SOURCES = ["common.hip", "graph_prep.hip", "aggregate.hip", "segment.hip", "attention.hip", "norm.hip"]
+SOURCES = ["common.hip", "graph_prep.hip", "aggregate.hip", "segment.hip", "attention.hip", "norm.hip", "linear.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -27,7 +27,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "gt_common.h"), os.path.join(INCLUDE, "graphtrans_hip.h")]
+    headers = [os.path.join(CSRC, "gt_common.h"), os.path.join(CSRC, "mfma_frag.h"), os.path.join(INCLUDE, "graphtrans_hip.h")]
     hdr_m = max(os.path.getmtime(h) for h in headers)
     objs, rebuilt = [], False
     procs = []

@@ -1,0 +1,399 @@
+// linear.hip — nn.Linear forward / backward on the CDNA4 matrix cores for the skinny GEMMs of the
+// GraphTrans hot path (M = nodes or tokens ~ 3e4, K and N in 128..600), with the surrounding
+// elementwise work fused in.
+//
+// Reference call sites (paths under /root/reference): GCNConv.linear modules/conv.py:44,51; GIN mlp
+// conv.py:18-20; virtual-node MLP modules/gnn_module.py:161-170; gnn2transformer
+// models/gnn_transformer.py:69-70,92; nn.TransformerEncoderLayer in_proj / out_proj / linear1 (+act
+// +dropout) / linear2 modules/transformer_encoder.py:28-32 — cuBLAS GEMM + bias + relu + dropout
+// as separate launches in the reference; the first profile here (profiles/r01a) showed the library
+// GEMMs at 2-4 % of the MFMA rate on these shapes and ~450 elementwise/cast/reduce launches per step.
+//
+//   fwd : Y[M][N]  = act(X[M][K] W[N][K]^T + b) (* dropout)           k_linear_fwd   ("NT")
+//   dX  : dX[M][K] = dZ[M][N] W[N][K],  dZ = dY * 1[Y>0] * inv_keep   k_linear_dx    ("NN")
+//   dW  : dW[N][K] = dZ^T X,  db[N] = colsum(dZ)                      k_linear_dw    ("TN", split over M)
+// W is always the fp32 master weight (converted while staging: no cast pass); X / Y storage fp32 or
+// bf16; compute type bf16 (v_mfma_f32_16x16x32_bf16) or fp32 (v_mfma_f32_16x16x4_f32, exact).
+// Orientation: every lane owns an output ROW index as its MFMA column (n = lane & 15) and 4
+// consecutive output columns as accumulator registers -> 8/16-byte stores, float4 bias loads.
+#include "gt_common.h"
+#include "mfma_frag.h"
+
+namespace {
+using namespace gtf;
+
+constexpr int LT = 256;  // threads
+constexpr int BM = 128, BN = 128;
+
+struct LinArgs {
+  const void* a;      // fwd: X[M][K]; dx: dY[M][N]; dw: dY[M][N]
+  const float* w;     // W[N][K] fp32
+  const float* bias;  // [N] or null
+  const void* x;      // dw: X[M][K]
+  const void* ymask;  // dx/dw: forward output Y[M][N] when the forward fused relu(/dropout): dZ = dY*(Y>0)*inv_keep
+  void* out;          // fwd: Y; dx: dX; dw: partial [splits][N][K] fp32
+  float* dbpart;      // dw: [splits][N]
+  int64_t M, N, K;
+  int act;            // 0 none, 1 relu
+  float inv_keep;     // 1/(1-p)
+  uint32_t thr, s0, s1;
+  int splits;
+  int64_t m_per_split;
+};
+
+__device__ __forceinline__ uint32_t lin_hash(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col) {
+  uint32_t x = (row * 0x9E3779B1u + s0) ^ (col * 0x85EBCA77u + s1);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+template <typename TC>
+struct Tile {
+  static constexpr int BK = sizeof(TC) == 2 ? 64 : 32;  // contraction elements per LDS stage (128 B rows)
+  static constexpr int PAD = sizeof(TC) == 2 ? 8 : 4;   // 16 B row pad
+  static constexpr int LD = BK + PAD;
+};
+
+// 4 consecutive fp32 values -> compute-type LDS store
+__device__ __forceinline__ void lds_store4(gt_bf16* p, float4 v) { gt_store4<gt_bf16>(p, v); }
+__device__ __forceinline__ void lds_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Stage a [ROWS][COLS] tile (row-major source, leading dim ld) into LDS [ROWS][LDS_LD], zero-filling
+// outside [0,nrows) x [0,ncols); optional dZ prologue: v = (mask > 0) ? v * inv_keep : 0.
+template <typename TS, typename TC, int ROWS, int COLS, int LDS_LD>
+__device__ __forceinline__ void stage(TC* lds, const TS* src, int64_t ld, int64_t row0, int64_t nrows, int64_t col0,
+                                      int64_t ncols, const TS* mask, float inv_keep) {
+  constexpr int CH = COLS / 4;
+  for (int c = threadIdx.x; c < ROWS * CH; c += LT) {
+    const int r = c / CH, cc = (c % CH) * 4;
+    const int64_t gr = row0 + r, gc = col0 + cc;
+    float4 v = gt_zero4();
+    if (gr < nrows && gc < ncols) {
+      v = gt_load4<TS>(src + gr * ld + gc);
+      if (mask) {
+        const float4 y = gt_load4<TS>(mask + gr * ld + gc);
+        v = make_float4(y.x > 0.f ? v.x * inv_keep : 0.f, y.y > 0.f ? v.y * inv_keep : 0.f,
+                        y.z > 0.f ? v.z * inv_keep : 0.f, y.w > 0.f ? v.w * inv_keep : 0.f);
+      }
+    }
+    lds_store4(lds + r * LDS_LD + cc, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: Y = act(X W^T + b) [dropout]
+// MFMA rows = output columns n (W rows), MFMA cols = output rows m (X rows).
+// ------------------------------------------------------------------------------------------------
+template <typename TX, typename TY, typename TC>
+__global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
+  constexpr int BK = Tile<TC>::BK, LD = Tile<TC>::LD;
+  __shared__ __attribute__((aligned(16))) TC sX[BM * LD];
+  __shared__ __attribute__((aligned(16))) TC sW[BN * LD];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int wm = wid & 1, wn = wid >> 1;  // wave tile: rows wm*64.., cols wn*64..
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const TX* X = reinterpret_cast<const TX*>(a.a);
+  f32x4 acc[4][4];  // [n tile j][m tile i]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
+    __syncthreads();
+    stage<TX, TC, BM, BK, LD>(sX, X, a.K, m0, a.M, k0, a.K, nullptr, 1.f);
+    stage<float, TC, BN, BK, LD>(sW, a.w, a.K, n0, a.N, k0, a.K, nullptr, 1.f);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      Frag<TC> fx[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fx[i] = frag_load(sX + (wm * 64 + i * 16 + n) * LD + kk * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[j] = frag_load(sW + (wn * 64 + j * 16 + n) * LD + kk * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fx[i], acc[j][i]);
+    }
+  }
+  TY* Y = reinterpret_cast<TY*>(a.out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + n;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = n0 + wn * 64 + j * 16 + g * 4;  // 4 consecutive output columns
+      if (c >= a.N) continue;                           // N % 4 == 0
+      float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+      if (a.bias) v = gt_add4(v, *reinterpret_cast<const float4*>(a.bias + c));
+      if (a.act == 1) v = gt_relu4(v);
+      if (a.thr) {
+        float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(c + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+      }
+      gt_store4<TY>(Y + m * a.N + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dX[M][K] = dZ[M][N] W[N][K]      (contraction over n)
+// MFMA rows = output columns k (A operand = W^T via transposed LDS read), MFMA cols = rows m.
+// ------------------------------------------------------------------------------------------------
+template <typename TY, typename TX, typename TC>
+__global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
+  constexpr int BKc = Tile<TC>::BK;            // n-slots per stage
+  constexpr int LDZ = Tile<TC>::LD;            // dZ tile [BM][BKc]
+  constexpr int LDW = BN + Tile<TC>::PAD;      // W tile [BKc n][BN k]
+  __shared__ __attribute__((aligned(16))) TC sZ[BM * LDZ];
+  __shared__ __attribute__((aligned(16))) TC sW[BKc * LDW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int wm = wid & 1, wk = wid >> 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, kk0 = (int64_t)blockIdx.y * BN;  // output column tile (k)
+  const TY* dY = reinterpret_cast<const TY*>(a.a);
+  const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
+  f32x4 acc[4][4];  // [k tile j][m tile i]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t c0 = 0; c0 < a.N; c0 += BKc) {
+    __syncthreads();
+    stage<TY, TC, BM, BKc, LDZ>(sZ, dY, a.N, m0, a.M, c0, a.N, Ym, a.inv_keep);
+    stage<float, TC, BKc, BN, LDW>(sW, a.w, a.K, c0, a.N, kk0, a.K, nullptr, 1.f);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < BKc / 32; ++s) {
+      Frag<TC> fz[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fz[i] = frag_load(sZ + (wm * 64 + i * 16 + n) * LDZ + s * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[j] = frag_load_tr(sW, LDW, s * 32, wk * 64 + j * 16, n, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fz[i], acc[j][i]);
+    }
+  }
+  TX* dX = reinterpret_cast<TX*>(a.out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + n;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = kk0 + wk * 64 + j * 16 + g * 4;
+      if (c >= a.K) continue;
+      gt_store4<TX>(dX + m * a.K + c, make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW[N][K] = dZ^T X, db = colsum(dZ)      (contraction over m, split across blockIdx.z)
+// MFMA rows = n (A = dZ^T via transposed LDS read), MFMA cols = k (B = X^T... via transposed read).
+// ------------------------------------------------------------------------------------------------
+template <typename TY, typename TX, typename TC>
+__global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
+  constexpr int BMc = Tile<TC>::BK;            // m-slots per stage
+  constexpr int LDZ = BN + Tile<TC>::PAD;      // dZ tile [BMc m][BN n]
+  constexpr int LDX = BN + Tile<TC>::PAD;      // X tile  [BMc m][BN k]
+  __shared__ __attribute__((aligned(16))) TC sZ[BMc * LDZ];
+  __shared__ __attribute__((aligned(16))) TC sX[BMc * LDX];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int wn = wid & 1, wk = wid >> 1;
+  const int64_t n0 = (int64_t)blockIdx.x * BN, k0 = (int64_t)blockIdx.y * BN;
+  const int split = blockIdx.z;
+  const int64_t mb = (int64_t)split * a.m_per_split;
+  const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
+  const TY* dY = reinterpret_cast<const TY*>(a.a);
+  const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
+  const TX* X = reinterpret_cast<const TX*>(a.x);
+  f32x4 acc[4][4];  // [n tile j][k tile i]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;  // thread t < BN: column n0 + t
+  for (int64_t m0 = mb; m0 < me; m0 += BMc) {
+    __syncthreads();
+    stage<TY, TC, BMc, BN, LDZ>(sZ, dY, a.N, m0, me, n0, a.N, Ym, a.inv_keep);
+    stage<TX, TC, BMc, BN, LDX>(sX, X, a.K, m0, me, k0, a.K, nullptr, 1.f);
+    __syncthreads();
+    if (blockIdx.y == 0 && threadIdx.x < BN) {
+#pragma unroll 8
+      for (int r = 0; r < BMc; ++r) {
+        const TC v = sZ[r * LDZ + threadIdx.x];
+        if constexpr (sizeof(TC) == 2) dbacc += gt_bf16_to_f32((gt_bf16)v);
+        else dbacc += (float)v;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < BMc / 32; ++s) {
+      Frag<TC> fz[4], fx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fz[j] = frag_load_tr(sZ, LDZ, s * 32, wn * 64 + j * 16, n, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fx[i] = frag_load_tr(sX, LDX, s * 32, wk * 64 + i * 16, n, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mma(fz[j], fx[i], acc[j][i]);
+    }
+  }
+  // C[row = n-index (g*4+r)][col = k-index (lane&15)]
+  float* part = reinterpret_cast<float*>(a.out) + (int64_t)split * a.N * a.K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = n0 + wn * 64 + j * 16 + g * 4 + r;
+      if (row >= a.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t col = k0 + wk * 64 + i * 16 + n;
+        if (col < a.K) part[row * a.K + col] = acc[j][i][r];
+      }
+    }
+  }
+  if (blockIdx.y == 0 && threadIdx.x < BN && n0 + threadIdx.x < a.N && a.dbpart)
+    a.dbpart[(int64_t)split * a.N + n0 + threadIdx.x] = dbacc;
+}
+
+// out[i] = sum_s part[s][i]  (fixed order, 8 loads in flight); used for dW (len N*K) and db (len N)
+__global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ part, int splits, int64_t len,
+                                                      float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += part[(int64_t)(s + u) * len + i];
+    }
+    for (; s < splits; ++s) acc[0] += part[(int64_t)s * len + i];
+    out[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+}
+
+int check_lin(const char* fn, int x_dtype, int y_dtype, int compute, int64_t M, int64_t N, int64_t K) {
+  if ((x_dtype != GT_F32 && x_dtype != GT_BF16) || (y_dtype != GT_F32 && y_dtype != GT_BF16) ||
+      (compute != GT_F32 && compute != GT_BF16)) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (compute == GT_F32 && (x_dtype != GT_F32 || y_dtype != GT_F32)) { gt_set_error("%s: fp32 compute needs fp32 storage", fn); return GT_ERR_UNSUPPORTED; }
+  if (M < 0 || N <= 0 || K <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (N % 4 != 0 || K % 4 != 0) { gt_set_error("%s: N and K must be multiples of 4 (got %lld, %lld)", fn, (long long)N, (long long)K); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
+void fill_drop(LinArgs& a, float dropout_p, uint64_t seed) {
+  a.inv_keep = 1.0f / (1.0f - dropout_p);
+  double thr = (double)dropout_p * 4294967296.0;
+  a.thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
+  a.s0 = (uint32_t)seed;
+  a.s1 = (uint32_t)(seed >> 32);
+}
+
+int dw_splits(int64_t M, int64_t N, int64_t K, int compute) {
+  const int64_t bmc = compute == GT_BF16 ? 64 : 32;
+  int64_t tiles = gt_cdiv(N, BN) * gt_cdiv(K, BN);
+  int64_t s = 1024 / tiles;
+  int64_t maxs = gt_cdiv(M, bmc * 4);  // at least 4 stages per split
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+// dispatch over (storage of the M-sized operands, compute type)
+#define GT_LIN_DISPATCH(KERNEL, grid, args)                                                                        \
+  do {                                                                                                             \
+    if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float>), grid, dim3(LT), 0, stream, args);     \
+    else if (t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, gt_bf16>), grid, dim3(LT), 0, stream, args);   \
+    else if (t0 == GT_F32 && t1 == GT_BF16) hipLaunchKernelGGL((KERNEL<float, gt_bf16, gt_bf16>), grid, dim3(LT), 0, stream, args); \
+    else if (t0 == GT_BF16 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, gt_bf16>), grid, dim3(LT), 0, stream, args); \
+    else hipLaunchKernelGGL((KERNEL<gt_bf16, gt_bf16, gt_bf16>), grid, dim3(LT), 0, stream, args);                 \
+  } while (0)
+
+}  // namespace
+
+extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
+                             const float* bias, void* y, int64_t M, int64_t N, int64_t K, int act, float dropout_p,
+                             uint64_t seed, gt_stream_t stream_) {
+  int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && weight && y, "null buffer");
+  GT_CHECK_ARG(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  GT_CHECK_ARG(dropout_p == 0.f || act == 1, "fused dropout requires the fused relu (mask is recovered from Y > 0)");
+  if (M == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  LinArgs a{};
+  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.act = act;
+  fill_drop(a, dropout_p, seed);
+  dim3 grid((unsigned)gt_cdiv(M, BM), (unsigned)gt_cdiv(N, BN));
+  const int t0 = x_dtype, t1 = y_dtype;
+  GT_LIN_DISPATCH(k_linear_fwd, grid, a);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K) {
+  return (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float) + 256;
+}
+
+extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                             const void* y_for_mask, void* dx, float* dweight, float* dbias, int64_t M, int64_t N,
+                             int64_t K, float dropout_p, void* workspace, size_t workspace_bytes,
+                             gt_stream_t stream_) {
+  int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K);
+  if (rc) return rc;
+  GT_CHECK_ARG(weight && dy, "null buffer");
+  GT_CHECK_ARG(dx || dweight, "nothing to compute");
+  GT_CHECK_ARG(!dweight || x, "dweight needs x");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  hipStream_t stream = (hipStream_t)stream_;
+  LinArgs a{};
+  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K;
+  a.inv_keep = 1.0f / (1.0f - dropout_p);
+  if (M == 0) {
+    if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)N * K * sizeof(float), stream);
+    if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream);
+    return GT_OK;
+  }
+  if (dx) {
+    a.out = dx;
+    dim3 grid((unsigned)gt_cdiv(M, BM), (unsigned)gt_cdiv(K, BN));
+    const int t0 = y_dtype, t1 = x_dtype;
+    GT_LIN_DISPATCH(k_linear_dx, grid, a);
+  }
+  if (dweight) {
+    const int splits = dw_splits(M, N, K, compute);
+    size_t need = gt_linear_bwd_workspace_bytes(compute, M, N, K);
+    if (!workspace || workspace_bytes < need) {
+      gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return GT_ERR_WORKSPACE;
+    }
+    const int64_t bmc = compute == GT_BF16 ? 64 : 32;
+    a.splits = splits;
+    a.m_per_split = gt_cdiv(gt_cdiv(M, splits), bmc) * bmc;
+    a.out = workspace;
+    a.dbpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)splits * N * K : nullptr;
+    dim3 grid((unsigned)gt_cdiv(N, BN), (unsigned)gt_cdiv(K, BN), (unsigned)splits);
+    const int t0 = y_dtype, t1 = x_dtype;
+    GT_LIN_DISPATCH(k_linear_dw, grid, a);
+    int64_t len = N * K;
+    int rg = (int)(gt_cdiv(len, 256) < 2048 ? gt_cdiv(len, 256) : 2048);
+    hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight);
+    if (dbias)
+      hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)gt_cdiv(N, 256)), dim3(256), 0, stream, a.dbpart, splits, N, dbias);
+  }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -83,16 +83,31 @@ __global__ void __launch_bounds__(NT) k_bn_stats_partial(const T* __restrict__ x
   }
 }
 
-// fixed-order sum over `nblk` partial rows of `nv` D-vectors: thread per (vector, column), 8 loads in flight
-__device__ __forceinline__ float partial_sum(const float* __restrict__ part, int nblk, int64_t stride, int64_t off) {
+// Fixed-order column sums over `nblk` partial rows.  Block = 32 columns x 8 partial-lanes: lane p
+// sums partial rows p, p+8, ... (8 independent loads in flight), then the 8 lanes are combined in a
+// fixed order through LDS.  Returns the total to the threads with p == 0 (others get garbage).
+constexpr int FIN_COLS = 32, FIN_LANES = 8;
+__device__ __forceinline__ float finish_sum(const float* __restrict__ part, int nblk, int64_t stride, int64_t off,
+                                            bool active, float* sm /* [FIN_LANES][FIN_COLS] */) {
+  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int b = 0;
-  for (; b + 8 <= nblk; b += 8) {
+  if (active) {
+    int b = p;
+    for (; b + 7 * FIN_LANES < nblk; b += 8 * FIN_LANES) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(b + u) * stride + off];
+      for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(b + u * FIN_LANES) * stride + off];
+    }
+    for (; b < nblk; b += FIN_LANES) a[0] += part[(int64_t)b * stride + off];
   }
-  for (; b < nblk; ++b) a[0] += part[(int64_t)b * stride + off];
-  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  sm[p * FIN_COLS + cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  float t = 0.f;
+  if (p == 0) {
+#pragma unroll
+    for (int q = 0; q < FIN_LANES; ++q) t += sm[q * FIN_COLS + cl];
+  }
+  __syncthreads();
+  return t;
 }
 
 // pass 2: mean / rstd per column (+ running-stat update, torch semantics: unbiased running_var)
@@ -101,11 +116,12 @@ __global__ void k_bn_stats_finish(const T* __restrict__ x, const float* __restri
                                   int64_t D, float eps, float momentum, float* __restrict__ mean,
                                   float* __restrict__ rstd, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-  if (c >= D) return;
-  const float s1 = partial_sum(part, nblk, 2 * D, c);
-  const float s2 = partial_sum(part, nblk, 2 * D, D + c);
+  __shared__ float sm[FIN_LANES * FIN_COLS];
+  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  if (c >= D || threadIdx.x >= FIN_COLS) return;
   const float piv = sizeof(T) == 4 ? (float)reinterpret_cast<const float*>(x)[c]
                                    : gt_bf16_to_f32(reinterpret_cast<const gt_bf16*>(x)[c]);
   const float inv_n = 1.0f / (float)N;
@@ -191,10 +207,13 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
 
 __global__ void k_bn_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dbias,
                                 float* __restrict__ dweight) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  dbias[c] = partial_sum(part, nblk, 2 * D, c);
-  dweight[c] = partial_sum(part, nblk, 2 * D, D + c);
+  __shared__ float sm[FIN_LANES * FIN_COLS];
+  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  if (c >= D || threadIdx.x >= FIN_COLS) return;
+  dbias[c] = s1;
+  dweight[c] = s2;
 }
 
 // backward pass 3: train: dx = w rstd (dy' - dbias/N - xhat dweight/N) ; eval: dx = w rstd dy'
@@ -432,10 +451,13 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
 
 __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dweight,
                                 float* __restrict__ dbias) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  dweight[c] = partial_sum(part, nblk, 2 * D, c);
-  dbias[c] = partial_sum(part, nblk, 2 * D, D + c);
+  __shared__ float sm[FIN_LANES * FIN_COLS];
+  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  if (c >= D || threadIdx.x >= FIN_COLS) return;
+  dweight[c] = s1;
+  dbias[c] = s2;
 }
 
 constexpr int LN_BWD_BLOCKS = 512;
@@ -489,7 +511,7 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
   GT_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
   if (rows == 0) return GT_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  const int cgrid = (int)gt_cdiv(dim, 256);
+  const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   if (training) {
     GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
     const int nb = part_blocks(rows);
@@ -540,7 +562,7 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const int nb = part_blocks(rows);
   float* part = (float*)workspace;
   const size_t lds = rowlane_lds(dim, 2);
-  const int cgrid = (int)gt_cdiv(dim, 256);
+  const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   const int g = flat_blocks(rows * (dim / 4));
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
@@ -608,7 +630,7 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
-  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, 256)), dim3(256), 0, stream, (const float*)workspace, grid,
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(256), 0, stream, (const float*)workspace, grid,
                      dim, dweight, dbias);
   GT_CHECK_LAUNCH();
   return GT_OK;

@@ -104,7 +104,7 @@ class GNNTransformer(BaseModel):
         if perturb is not None and perturb.shape[0] != batched_data.batch.numel():
             raise ValueError("perturb must have one row per node")
         h_node = self.gnn_node(batched_data, perturb)
-        h_node = self.gnn2transformer(h_node)
+        h_node = ops.linear_module(self.gnn2transformer, h_node)
         gs = batch_structure(batched_data)
         enc = self.transformer_encoder
         max_len = int(enc.max_input_len)

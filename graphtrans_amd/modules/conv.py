@@ -67,7 +67,7 @@ class GCNConv(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, graph=None):
         gs = _structure(x, edge_index, graph)
-        x = self.linear(x)
+        x = ops.linear_module(self.linear, x)
         spec = edge_spec(self.edge_encoder, edge_attr, self.emb_dim)
         # sum_k norm_k relu(x_j + e_k) + relu(x + root_emb) / deg, fused  (conv.py:54-68)
         return ops.aggregate(x, gs, "gcn", self.root_emb.weight, spec)

@@ -27,6 +27,9 @@ def mlp_bn_relu(seq, x):
         if isinstance(m, BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
             x = m(x, relu=True)
             i += 2
+        elif isinstance(m, torch.nn.Linear):
+            x = ops.linear_module(m, x)
+            i += 1
         else:
             x = m(x)
             i += 1

@@ -78,14 +78,17 @@ class TransformerNodeEncoder(nn.Module):
 
     def _layer(self, x, mod, lay, seed):
         sa = mod.self_attn
-        qkv = F.linear(x, self._w(sa.in_proj_weight), self._w(sa.in_proj_bias))
         p = self.dropout_p if self.training else 0.0
+        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         ctx = ops.attention(qkv, lay, self.nhead, dropout_p=p, seed=seed)
-        a = F.linear(ctx, self._w(sa.out_proj.weight), self._w(sa.out_proj.bias))
+        a = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias)
         x = self._ln(a, mod.norm1, resid=x, seed=seed ^ 0x5851F42D4C957F2D)
-        act = F.relu if self.activation == "relu" else F.gelu
-        f = act(F.linear(x, self._w(mod.linear1.weight), self._w(mod.linear1.bias)))
-        f = F.linear(self._drop(f), self._w(mod.linear2.weight), self._w(mod.linear2.bias))
+        if self.activation == "relu":  # relu + dropout fused into linear1's epilogue
+            f = ops.linear(x, mod.linear1.weight, mod.linear1.bias, act="relu", dropout_p=p,
+                           seed=seed ^ 0x2545F4914F6CDD1D)
+        else:
+            f = self._drop(F.gelu(ops.linear(x, mod.linear1.weight, mod.linear1.bias)))
+        f = ops.linear(f, mod.linear2.weight, mod.linear2.bias)
         return self._ln(f, mod.norm2, resid=x, seed=seed ^ 0x14057B7EF767814F)
 
     def forward_tokens(self, tokens, lay):

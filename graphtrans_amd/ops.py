@@ -376,3 +376,100 @@ class _LayerNorm(torch.autograd.Function):
 def layer_norm(x, weight, bias, eps=1e-5, resid=None, dropout_p=0.0, seed=0):
     """LayerNorm(resid + dropout(x)) over rows of (rows, dim) (gt_layernorm_fwd/bwd)."""
     return _LayerNorm.apply(x, resid, weight, bias, eps, dropout_p, seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.Linear on the matrix cores (fused bias / relu / dropout)
+# ------------------------------------------------------------------------------------------------
+_MATMUL_DTYPE = torch.float32
+
+
+def set_matmul_dtype(dtype):
+    """Compute type of fp32-STORED linears (the GNN side): torch.float32 = v_mfma_f32_16x16x4_f32
+    (exact fp32, the parity mode) or torch.bfloat16 = bf16 MFMA with fp32 accumulate (operands are
+    rounded to bf16 while staging; storage and master weights stay fp32)."""
+    global _MATMUL_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(dtype)
+    _MATMUL_DTYPE = dtype
+
+
+def get_matmul_dtype():
+    return _MATMUL_DTYPE
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, dropout_p, seed, compute, out_dtype):
+        x2 = _dev(x.reshape(-1, x.shape[-1]), "x")
+        M, K = x2.shape
+        N = weight.shape[0]
+        w32 = _f32(weight)
+        b32 = _f32(bias)
+        y = torch.empty((M, N), dtype=out_dtype, device=x2.device)
+        _lib.launch("gt_linear_fwd", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
+                    M, N, K, act, float(dropout_p), int(seed), _stream())
+        fused = act == 1
+        ctx.save_for_backward(x2, w32, y if fused else None)
+        ctx.cfg = (compute, dropout_p if fused else 0.0, x.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w32, ymask = ctx.saved_tensors
+        compute, dropout_p, xshape, wdt, bdt = ctx.cfg
+        M, K = x2.shape
+        N = w32.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], bdt is not None and ctx.needs_input_grad[2]
+        ydt = ymask.dtype if ymask is not None else (dy.dtype if dy.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        if compute == GT_F32:
+            ydt = torch.float32
+        dy2 = _dev(dy.reshape(-1, N).to(ydt), "grad")
+        dev = x2.device
+        dx = torch.empty_like(x2) if need_x else None
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev) if (need_w or need_b) else None
+        db = torch.empty(N, dtype=torch.float32, device=dev) if need_b else None
+        L = _lib.lib()
+        ws_bytes = L.gt_linear_bwd_workspace_bytes(compute, M, N, K) if dw is not None else 0
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        _lib.launch("gt_linear_bwd", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
+                    _ptr(ymask), _ptr(dx), _ptr(dw), _ptr(db), M, N, K, float(dropout_p), _ptr(ws), ws_bytes, _stream())
+        return (None if dx is None else dx.view(xshape), None if not need_w else dw.to(wdt),
+                None if db is None else db.to(bdt), None, None, None, None, None)
+
+
+def linear_supported(x, weight):
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.shape[0] % 4 == 0
+            and weight.shape[1] % 4 == 0 and x.shape[-1] == weight.shape[1])
+
+
+def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None):
+    """act in {None, 'relu'}; dropout_p > 0 only together with relu (mask recovered from y > 0).
+    bf16-stored x always computes in bf16; fp32-stored x computes in get_matmul_dtype()."""
+    if x.dtype == torch.bfloat16:
+        compute = GT_BF16
+    else:
+        compute = GT_BF16 if _MATMUL_DTYPE == torch.bfloat16 else GT_F32
+    if out_dtype is None:
+        out_dtype = x.dtype
+    if compute == GT_F32 and out_dtype != torch.float32:
+        raise ValueError("fp32 compute writes fp32")
+    a = 1 if act == "relu" else 0
+    if act not in (None, "relu"):
+        raise ValueError(act)
+    if dropout_p > 0 and a == 0:
+        raise ValueError("fused dropout needs act='relu'")
+    return _Linear.apply(x, weight, bias, a, float(dropout_p), int(seed), compute, out_dtype)
+
+
+def linear_module(mod, x, act=None, dropout_p=0.0, seed=0):
+    """Apply an nn.Linear through the HIP kernel when its shape is supported (N, K multiples of 4),
+    else through torch's GEMM (odd shapes: e.g. the 37-feature TU node encoder, the 5002-way heads)."""
+    if linear_supported(x, mod.weight):
+        return linear(x, mod.weight, mod.bias, act=act, dropout_p=dropout_p, seed=seed)
+    y = torch.nn.functional.linear(x, mod.weight.to(x.dtype), None if mod.bias is None else mod.bias.to(x.dtype))
+    if act == "relu":
+        y = torch.relu(y)
+    if dropout_p > 0:
+        y = torch.nn.functional.dropout(y, dropout_p, True)
+    return y

@@ -201,6 +201,28 @@ int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy
                      int64_t dim, void* dx, void* dresid, float* dweight, float* dbias, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * nn.Linear on the matrix cores with fused bias / ReLU / dropout, forward and backward.
+ * Replaces F.linear (+ relu, dropout, bias-grad reductions, dtype casts) at modules/conv.py:44,51
+ * (GCN linear), conv.py:18-20 (GIN mlp), modules/gnn_module.py:161-170 (virtual-node MLP),
+ * models/gnn_transformer.py:69-70,92 (gnn2transformer) and inside nn.TransformerEncoderLayer
+ * (in_proj, out_proj, linear1+activation+dropout, linear2; modules/transformer_encoder.py:28-32).
+ *   fwd: y[M][N] = dropout(act(x[M][K] weight[N][K]^T + bias))      act: 0 none | 1 relu
+ *   bwd: dz = dy * 1[y > 0] / (1 - p) when y_for_mask != NULL (the forward fused relu[/dropout]),
+ *        else dz = dy;  dx = dz weight;  dweight = dz^T x;  dbias = colsum(dz)   (any may be NULL)
+ * weight/bias and their gradients are fp32 (master weights are converted while staging: no cast
+ * pass).  x_dtype / y_dtype: storage of x (and dx) / y (and dy); compute: GT_BF16
+ * (v_mfma_f32_16x16x32_bf16) or GT_F32 (v_mfma_f32_16x16x4_f32, needs fp32 storage).
+ * N % 4 == 0 and K % 4 == 0.  Fused dropout requires act == relu.  Deterministic.
+ */
+int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                  void* y, int64_t M, int64_t N, int64_t K, int act, float dropout_p, uint64_t seed,
+                  gt_stream_t stream);
+size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K);
+int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                  const void* y_for_mask, void* dx, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K,
+                  float dropout_p, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,12 @@ def test_batchnorm_matches_torch(rows, D, relu, training):
     yd = m(xd, relu=relu)
     (yd * w.to(DEV)).sum().backward()
     assert_close(yd.cpu(), yr.detach(), what="y")
-    assert_close(xd.grad.cpu(), xr.grad, what="dx")
+    gx, gx_ref = xd.grad.cpu(), xr.grad.clone()
+    if relu:  # the ReLU gate of an output within fp32 rounding of 0 is a coin flip: exclude those elements
+        tie = yr.detach().abs() < 1e-4
+        gx = gx.masked_fill(tie, 0.0)
+        gx_ref = gx_ref.masked_fill(tie, 0.0)
+    assert_close(gx, gx_ref, what="dx")
     assert_close(m.weight.grad.cpu(), ref.weight.grad, what="dweight")
     assert_close(m.bias.grad.cpu(), ref.bias.grad, what="dbias")
     assert_close(m.running_mean.cpu(), ref.running_mean, what="running_mean")
