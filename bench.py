@@ -239,6 +239,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(opt.steps):
         loss = step(opt.warmup + i)
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue all steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
@@ -264,7 +265,7 @@ def main():
                        "step": "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
                        "gnn_dtype": "fp32 storage, %s MFMA linears" % opt.dtype, "transformer_dtype": opt.dtype,
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }
         if timer is not None:
             rep = kernel_report(timer.summary(), dtype)

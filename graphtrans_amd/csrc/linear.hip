@@ -56,31 +56,96 @@ struct Tile {
   static constexpr int LD = BK + PAD;
 };
 
-// 4 consecutive fp32 values -> compute-type LDS store
-__device__ __forceinline__ void lds_store4(gt_bf16* p, float4 v) { gt_store4<gt_bf16>(p, v); }
-__device__ __forceinline__ void lds_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// ---- register-staged tile loader (global -> registers -> LDS), 16-byte chunks -------------------
+// load() issues every global load of the tile (and of the optional dZ mask tile) before anything
+// consumes them; store() converts to the compute type and writes LDS.  Splitting the two lets the
+// next stage's loads fly while the current stage's MFMAs run (T14 "issue early / write late").
+template <typename TS, typename TC, int ROWS, int COLS, int LDS_LD, bool MASK>
+struct Loader {
+  static constexpr int EPC = 16 / sizeof(TS);  // elements per 16-byte chunk
+  static constexpr int CH = COLS / EPC;
+  static constexpr int NIT = ROWS * CH / LT;
+  static_assert(ROWS * CH % LT == 0, "tile must be a multiple of the block's chunk count");
+  uint4 v[NIT];
+  uint4 m[MASK ? NIT : 1];
 
-// Stage a [ROWS][COLS] tile (row-major source, leading dim ld) into LDS [ROWS][LDS_LD], zero-filling
-// outside [0,nrows) x [0,ncols); optional dZ prologue: v = (mask > 0) ? v * inv_keep : 0.
-template <typename TS, typename TC, int ROWS, int COLS, int LDS_LD>
-__device__ __forceinline__ void stage(TC* lds, const TS* src, int64_t ld, int64_t row0, int64_t nrows, int64_t col0,
-                                      int64_t ncols, const TS* mask, float inv_keep) {
-  constexpr int CH = COLS / 4;
-  for (int c = threadIdx.x; c < ROWS * CH; c += LT) {
-    const int r = c / CH, cc = (c % CH) * 4;
-    const int64_t gr = row0 + r, gc = col0 + cc;
-    float4 v = gt_zero4();
-    if (gr < nrows && gc < ncols) {
-      v = gt_load4<TS>(src + gr * ld + gc);
-      if (mask) {
-        const float4 y = gt_load4<TS>(mask + gr * ld + gc);
-        v = make_float4(y.x > 0.f ? v.x * inv_keep : 0.f, y.y > 0.f ? v.y * inv_keep : 0.f,
-                        y.z > 0.f ? v.z * inv_keep : 0.f, y.w > 0.f ? v.w * inv_keep : 0.f);
+  __device__ __forceinline__ void load(const TS* src, int64_t ld, int64_t row0, int64_t nrows, int64_t col0,
+                                       int64_t ncols, const TS* mask) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = threadIdx.x + i * LT;
+      const int r = c / CH, cc = (c % CH) * EPC;
+      const int64_t gr = row0 + r, gc = col0 + cc;
+      const bool ok = gr < nrows && gc < ncols;
+      v[i] = ok ? *reinterpret_cast<const uint4*>(src + gr * ld + gc) : make_uint4(0, 0, 0, 0);
+      if constexpr (MASK) m[i] = (ok && mask) ? *reinterpret_cast<const uint4*>(mask + gr * ld + gc) : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  __device__ __forceinline__ void store(TC* lds, bool has_mask, float inv_keep) const {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = threadIdx.x + i * LT;
+      const int r = c / CH, cc = (c % CH) * EPC;
+      float f[EPC];
+      if constexpr (sizeof(TS) == 4) {
+        f[0] = __uint_as_float(v[i].x); f[1] = __uint_as_float(v[i].y);
+        f[2] = __uint_as_float(v[i].z); f[3] = __uint_as_float(v[i].w);
+      } else {
+        const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f[2 * q] = __uint_as_float(u[q] << 16);
+          f[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u);
+        }
+      }
+      if constexpr (MASK) {
+        if (has_mask) {
+          float y[EPC];
+          if constexpr (sizeof(TS) == 4) {
+            y[0] = __uint_as_float(m[i].x); y[1] = __uint_as_float(m[i].y);
+            y[2] = __uint_as_float(m[i].z); y[3] = __uint_as_float(m[i].w);
+          } else {
+            const uint32_t u[4] = {m[i].x, m[i].y, m[i].z, m[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              y[2 * q] = __uint_as_float(u[q] << 16);
+              y[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) f[e] = y[e] > 0.f ? f[e] * inv_keep : 0.f;
+        }
+      }
+      TC* dst = lds + r * LDS_LD + cc;
+      if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+      } else if constexpr (sizeof(TS) == 2) {
+        // bf16 -> bf16 with no mask is a plain copy; with a mask the values were re-rounded above
+        uint4 o;
+        o.x = (uint32_t)gt_f32_to_bf16(f[0]) | ((uint32_t)gt_f32_to_bf16(f[1]) << 16);
+        o.y = (uint32_t)gt_f32_to_bf16(f[2]) | ((uint32_t)gt_f32_to_bf16(f[3]) << 16);
+        o.z = (uint32_t)gt_f32_to_bf16(f[4]) | ((uint32_t)gt_f32_to_bf16(f[5]) << 16);
+        o.w = (uint32_t)gt_f32_to_bf16(f[6]) | ((uint32_t)gt_f32_to_bf16(f[7]) << 16);
+        *reinterpret_cast<uint4*>(dst) = o;
+      } else {
+        uint2 o;
+        o.x = (uint32_t)gt_f32_to_bf16(f[0]) | ((uint32_t)gt_f32_to_bf16(f[1]) << 16);
+        o.y = (uint32_t)gt_f32_to_bf16(f[2]) | ((uint32_t)gt_f32_to_bf16(f[3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = o;
       }
     }
-    lds_store4(lds + r * LDS_LD + cc, v);
   }
-}
+};
+
+// Per-wave epilogue patch: 16 output rows x 64 output columns of fp32 staged through LDS so that the
+// global stores are whole 256-byte row segments (the MFMA accumulator layout alone gives 32 B).
+constexpr int PATCH_LD = 64 + 4;
+constexpr int PATCH_FLOATS = 16 * PATCH_LD;
+
+template <typename TO>
+__device__ __forceinline__ void store_chunk(TO* p, float4 v) { gt_store4<TO>(p, v); }
 
 // ------------------------------------------------------------------------------------------------
 // forward: Y = act(X W^T + b) [dropout]
@@ -89,8 +154,11 @@ __device__ __forceinline__ void stage(TC* lds, const TS* src, int64_t ld, int64_
 template <typename TX, typename TY, typename TC>
 __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   constexpr int BK = Tile<TC>::BK, LD = Tile<TC>::LD;
-  __shared__ __attribute__((aligned(16))) TC sX[BM * LD];
-  __shared__ __attribute__((aligned(16))) TC sW[BN * LD];
+  constexpr int LDS_ELEMS = (BM + BN) * LD;
+  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
+  TC* sX = smem;
+  TC* sW = smem + BM * LD;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int wm = wid & 1, wn = wid >> 1;  // wave tile: rows wm*64.., cols wn*64..
@@ -101,11 +169,19 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Loader<TX, TC, BM, BK, LD, false> lx;
+  Loader<float, TC, BN, BK, LD, false> lw;
+  lx.load(X, a.K, m0, a.M, 0, a.K, nullptr);
+  lw.load(a.w, a.K, n0, a.N, 0, a.K, nullptr);
   for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
     __syncthreads();
-    stage<TX, TC, BM, BK, LD>(sX, X, a.K, m0, a.M, k0, a.K, nullptr, 1.f);
-    stage<float, TC, BN, BK, LD>(sW, a.w, a.K, n0, a.N, k0, a.K, nullptr, 1.f);
+    lx.store(sX, false, 1.f);
+    lw.store(sW, false, 1.f);
     __syncthreads();
+    if (k0 + BK < a.K) {
+      lx.load(X, a.K, m0, a.M, k0 + BK, a.K, nullptr);
+      lw.load(a.w, a.K, n0, a.N, k0 + BK, a.K, nullptr);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       Frag<TC> fx[4], fw[4];
@@ -119,26 +195,39 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
         for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fx[i], acc[j][i]);
     }
   }
+  __syncthreads();
+  // epilogue: acc[j][i][r] = C[col n0+wn*64+j*16+g*4+r][row m0+wm*64+i*16+n] -> patch[row n][col ...]
+  float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TY* Y = reinterpret_cast<TY*>(a.out);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + n;
-    if (m >= a.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t c = n0 + wn * 64 + j * 16 + g * 4;  // 4 consecutive output columns
-      if (c >= a.N) continue;                           // N % 4 == 0
-      float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-      if (a.bias) v = gt_add4(v, *reinterpret_cast<const float4*>(a.bias + c));
-      if (a.act == 1) v = gt_relu4(v);
-      if (a.thr) {
-        float* vv = reinterpret_cast<float*>(&v);
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + n * PATCH_LD + j * 16 + g * 4) =
+          make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(c + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + q * 64;       // 256 float4 chunks: row = c / 16, col4 = c % 16
+      const int r = c >> 4, c4 = (c & 15) * 4;
+      const int64_t m = m0 + wm * 64 + i * 16 + r;
+      const int64_t col = n0 + wn * 64 + c4;
+      if (m < a.M && col < a.N) {
+        float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
+        if (a.bias) v = gt_add4(v, *reinterpret_cast<const float4*>(a.bias + col));
+        if (a.act == 1) v = gt_relu4(v);
+        if (a.thr) {
+          float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+        }
+        store_chunk<TY>(Y + m * a.N + col, v);
       }
-      gt_store4<TY>(Y + m * a.N + c, v);
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -151,24 +240,36 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
   constexpr int BKc = Tile<TC>::BK;            // n-slots per stage
   constexpr int LDZ = Tile<TC>::LD;            // dZ tile [BM][BKc]
   constexpr int LDW = BN + Tile<TC>::PAD;      // W tile [BKc n][BN k]
-  __shared__ __attribute__((aligned(16))) TC sZ[BM * LDZ];
-  __shared__ __attribute__((aligned(16))) TC sW[BKc * LDW];
+  constexpr int LDS_ELEMS = BM * LDZ + BKc * LDW;
+  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
+  TC* sZ = smem;
+  TC* sW = smem + BM * LDZ;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int wm = wid & 1, wk = wid >> 1;
   const int64_t m0 = (int64_t)blockIdx.x * BM, kk0 = (int64_t)blockIdx.y * BN;  // output column tile (k)
   const TY* dY = reinterpret_cast<const TY*>(a.a);
   const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
+  const bool has_mask = Ym != nullptr;
   f32x4 acc[4][4];  // [k tile j][m tile i]
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Loader<TY, TC, BM, BKc, LDZ, true> lz;
+  Loader<float, TC, BKc, BN, LDW, false> lw;
+  lz.load(dY, a.N, m0, a.M, 0, a.N, Ym);
+  lw.load(a.w, a.K, 0, a.N, kk0, a.K, nullptr);
   for (int64_t c0 = 0; c0 < a.N; c0 += BKc) {
     __syncthreads();
-    stage<TY, TC, BM, BKc, LDZ>(sZ, dY, a.N, m0, a.M, c0, a.N, Ym, a.inv_keep);
-    stage<float, TC, BKc, BN, LDW>(sW, a.w, a.K, c0, a.N, kk0, a.K, nullptr, 1.f);
+    lz.store(sZ, has_mask, a.inv_keep);
+    lw.store(sW, false, 1.f);
     __syncthreads();
+    if (c0 + BKc < a.N) {
+      lz.load(dY, a.N, m0, a.M, c0 + BKc, a.N, Ym);
+      lw.load(a.w, a.K, c0 + BKc, a.N, kk0, a.K, nullptr);
+    }
 #pragma unroll
     for (int s = 0; s < BKc / 32; ++s) {
       Frag<TC> fz[4], fw[4];
@@ -182,31 +283,45 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
         for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fz[i], acc[j][i]);
     }
   }
+  __syncthreads();
+  float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TX* dX = reinterpret_cast<TX*>(a.out);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + n;
-    if (m >= a.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t c = kk0 + wk * 64 + j * 16 + g * 4;
-      if (c >= a.K) continue;
-      gt_store4<TX>(dX + m * a.K + c, make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]));
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + n * PATCH_LD + j * 16 + g * 4) =
+          make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + q * 64;
+      const int r = c >> 4, c4 = (c & 15) * 4;
+      const int64_t m = m0 + wm * 64 + i * 16 + r;
+      const int64_t col = kk0 + wk * 64 + c4;
+      if (m < a.M && col < a.K)
+        store_chunk<TX>(dX + m * a.K + col, *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4));
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // dW[N][K] = dZ^T X, db = colsum(dZ)      (contraction over m, split across blockIdx.z)
-// MFMA rows = n (A = dZ^T via transposed LDS read), MFMA cols = k (B = X^T... via transposed read).
+// MFMA rows = n (A = dZ^T via transposed LDS read), MFMA cols = k (B = X^T via transposed read).
 // ------------------------------------------------------------------------------------------------
 template <typename TY, typename TX, typename TC>
 __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   constexpr int BMc = Tile<TC>::BK;            // m-slots per stage
   constexpr int LDZ = BN + Tile<TC>::PAD;      // dZ tile [BMc m][BN n]
   constexpr int LDX = BN + Tile<TC>::PAD;      // X tile  [BMc m][BN k]
-  __shared__ __attribute__((aligned(16))) TC sZ[BMc * LDZ];
-  __shared__ __attribute__((aligned(16))) TC sX[BMc * LDX];
+  constexpr int LDS_ELEMS = BMc * (LDZ + LDX);
+  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
+  TC* sZ = smem;
+  TC* sX = smem + BMc * LDZ;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int wn = wid & 1, wk = wid >> 1;
@@ -216,6 +331,7 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
   const TY* dY = reinterpret_cast<const TY*>(a.a);
   const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
+  const bool has_mask = Ym != nullptr;
   const TX* X = reinterpret_cast<const TX*>(a.x);
   f32x4 acc[4][4];  // [n tile j][k tile i]
 #pragma unroll
@@ -223,11 +339,21 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbacc = 0.f;  // thread t < BN: column n0 + t
+  Loader<TY, TC, BMc, BN, LDZ, true> lz;
+  Loader<TX, TC, BMc, BN, LDX, false> lx;
+  if (mb < me) {
+    lz.load(dY, a.N, mb, me, n0, a.N, Ym);
+    lx.load(X, a.K, mb, me, k0, a.K, nullptr);
+  }
   for (int64_t m0 = mb; m0 < me; m0 += BMc) {
     __syncthreads();
-    stage<TY, TC, BMc, BN, LDZ>(sZ, dY, a.N, m0, me, n0, a.N, Ym, a.inv_keep);
-    stage<TX, TC, BMc, BN, LDX>(sX, X, a.K, m0, me, k0, a.K, nullptr, 1.f);
+    lz.store(sZ, has_mask, a.inv_keep);
+    lx.store(sX, false, 1.f);
     __syncthreads();
+    if (m0 + BMc < me) {
+      lz.load(dY, a.N, m0 + BMc, me, n0, a.N, Ym);
+      lx.load(X, a.K, m0 + BMc, me, k0, a.K, nullptr);
+    }
     if (blockIdx.y == 0 && threadIdx.x < BN) {
 #pragma unroll 8
       for (int r = 0; r < BMc; ++r) {
@@ -249,20 +375,29 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
         for (int i = 0; i < 4; ++i) acc[j][i] = mma(fz[j], fx[i], acc[j][i]);
     }
   }
-  // C[row = n-index (g*4+r)][col = k-index (lane&15)]
+  __syncthreads();
+  // acc[j][i][r] = C[row n-index wn*64+j*16+g*4+r][col k-index wk*64+i*16+n] -> patch[16 n rows][64 k cols]
+  float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   float* part = reinterpret_cast<float*>(a.out) + (int64_t)split * a.N * a.K;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = n0 + wn * 64 + j * 16 + g * 4 + r;
-      if (row >= a.N) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t col = k0 + wk * 64 + i * 16 + n;
-        if (col < a.K) part[row * a.K + col] = acc[j][i][r];
-      }
+      for (int r = 0; r < 4; ++r) patch[(g * 4 + r) * PATCH_LD + i * 16 + n] = acc[j][i][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + q * 64;
+      const int r = c >> 4, c4 = (c & 15) * 4;
+      const int64_t row = n0 + wn * 64 + j * 16 + r;
+      const int64_t col = k0 + wk * 64 + c4;
+      if (row < a.N && col < a.K)
+        *reinterpret_cast<float4*>(part + row * a.K + col) = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if (blockIdx.y == 0 && threadIdx.x < BN && n0 + threadIdx.x < a.N && a.dbpart)
     a.dbpart[(int64_t)split * a.N + n0 + threadIdx.x] = dbacc;
@@ -289,6 +424,7 @@ int check_lin(const char* fn, int x_dtype, int y_dtype, int compute, int64_t M, 
   if (compute == GT_F32 && (x_dtype != GT_F32 || y_dtype != GT_F32)) { gt_set_error("%s: fp32 compute needs fp32 storage", fn); return GT_ERR_UNSUPPORTED; }
   if (M < 0 || N <= 0 || K <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
   if (N % 4 != 0 || K % 4 != 0) { gt_set_error("%s: N and K must be multiples of 4 (got %lld, %lld)", fn, (long long)N, (long long)K); return GT_ERR_UNSUPPORTED; }
+  if ((x_dtype == GT_BF16 && K % 8 != 0) || (y_dtype == GT_BF16 && N % 8 != 0)) { gt_set_error("%s: bf16 storage needs K (x) / N (y) to be multiples of 8", fn); return GT_ERR_UNSUPPORTED; }
   return GT_OK;
 }
 

@@ -5,9 +5,9 @@ The reference has no parallelism at all (main.py:109,174); this 
 never exchange messages (edge_index is block diagonal, attention is per graph), so the ONLY
 collective on the path is the gradient all-reduce.  Parameters (9.05 M for the Code2 config,
 36 MB fp32) are replicated; gradients live in a few flat buckets so that
-  * zeroing them is one memset per bucket instead of ~140 per-parameter kernels,
-  * each bucket is reduced as soon as autograd has produced all of its gradients (buckets are
-    filled in reverse parameter order = the order backward produces them), on RCCL's own stream,
+  * gradients are never zeroed or accumulated (set to None, then assigned by autograd),
+  * after backward each bucket is packed with one multi-tensor copy and reduced asynchronously on
+    RCCL's own stream while the next bucket is being packed,
   * xGMI is a point-to-point mesh: few, large messages (default 16 MB buckets) keep every link busy.
 BatchNorm statistics stay per rank (what torch DDP does); see DESIGN.md for the consequences.
 """
@@ -16,14 +16,23 @@ import torch.distributed as dist
 
 
 class GradSync:
+    """zero() / finish() around backward.
+
+    world == 1: gradients are simply dropped to None before backward (autograd then ASSIGNS each
+    produced gradient instead of launching one accumulate kernel per parameter, ~140 launches per
+    step) and finish() is a no-op.
+    world  > 1: same, plus after backward the gradients are packed into flat buckets with one
+    multi-tensor copy per bucket, all-reduced asynchronously (bucket k+1 is packed while bucket k
+    is on the wire), averaged, and `.grad` is re-pointed at the reduced bucket views.
+    """
+
     def __init__(self, params, world_size=None, bucket_bytes=16 << 20, group=None):
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []  # dict(flat, params, pending, handle)
-        self._bucket_of = {}
+        self.buckets = []  # dict(flat, params, views)
         cur, cur_bytes = [], 0
-        for p in reversed(self.params):
+        for p in reversed(self.params):  # reverse registration order = the order backward produces them
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
                 self._make_bucket(cur)
@@ -32,49 +41,37 @@ class GradSync:
             cur_bytes += nbytes
         if cur:
             self._make_bucket(cur)
-        self._hooks = []
-        if self.world > 1:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _make_bucket(self, ps):
         total = sum(p.numel() for p in ps)
         flat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
-        off = 0
+        views, off = [], 0
         for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the view
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        b = dict(flat=flat, params=ps, pending=len(ps), handle=None)
-        for p in ps:
-            self._bucket_of[p] = b
-        self.buckets.append(b)
+        self.buckets.append(dict(flat=flat, params=ps, views=views))
 
     def zero(self):
-        """Replaces optimizer.zero_grad(): one memset per bucket; keeps .grad views alive."""
-        for b in self.buckets:
-            b["flat"].zero_()
-            b["pending"] = len(b["params"])
-            b["handle"] = None
-
-    def _launch(self, b):
-        if self.world > 1 and b["handle"] is None:
-            b["flat"].div_(self.world)  # average (gloo has no AVG op; pre-scaling keeps fp32 range)
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def _on_grad(self, p):
-        b = self._bucket_of[p]
-        b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        """Replaces optimizer.zero_grad(set_to_none=True)."""
+        for p in self.params:
+            p.grad = None
 
     def finish(self):
-        """Reduce buckets whose parameters got no gradient this step, then wait for all."""
         if self.world == 1:
             return
+        handles = []
         for b in self.buckets:
-            self._launch(b)
-        for b in self.buckets:
-            b["handle"].wait()
+            have = [(v, p.grad) for v, p in zip(b["views"], b["params"]) if p.grad is not None]
+            if len(have) != len(b["params"]):
+                b["flat"].zero_()  # parameters unused this step contribute zeros
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            b["flat"].div_(self.world)  # average (gloo has no AVG op; pre-scaling keeps fp32 range)
+            handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for b, h in zip(self.buckets, handles):
+            h.wait()
+            for v, p in zip(b["views"], b["params"]):
+                p.grad = v
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)

@@ -120,7 +120,13 @@ class SeqLayout:
         self.kind, self.with_cls, self.S, self.B = kind, with_cls, S, B
         self.kept = kept
         self.desc_cpu = desc
-        self.desc = torch.from_numpy(desc).to(gs.device, non_blocking=True)
         # token row of the last position (CLS / last node) of every sequence: the pooled row
         last_row = desc[:, 0].astype(np.int64) + (desc[:, 1].astype(np.int64) - 1) * self.row_stride
-        self.last_rows = torch.from_numpy(last_row).to(gs.device, non_blocking=True)
+        if torch.device(gs.device).type == "cuda":
+            # pinned staging + non_blocking: a pageable H2D copy blocks the host until everything
+            # already queued on the stream has drained (it showed up as a 10 ms/step stall)
+            self.desc = torch.from_numpy(desc).pin_memory().to(gs.device, non_blocking=True)
+            self.last_rows = torch.from_numpy(last_row).pin_memory().to(gs.device, non_blocking=True)
+        else:
+            self.desc = torch.from_numpy(desc)
+            self.last_rows = torch.from_numpy(last_row)

@@ -439,8 +439,9 @@ class _Linear(torch.autograd.Function):
 
 
 def linear_supported(x, weight):
-    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.shape[0] % 4 == 0
-            and weight.shape[1] % 4 == 0 and x.shape[-1] == weight.shape[1])
+    q = 8 if x.dtype == torch.bfloat16 else 4  # 16-byte chunks of the storage type
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.shape[0] % q == 0
+            and weight.shape[1] % q == 0 and x.shape[-1] == weight.shape[1])
 
 
 def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None):

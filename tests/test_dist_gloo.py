@@ -44,7 +44,7 @@ def _worker(rank, world, port, out):
         sync.zero()
         ((m(xs) - ys) ** 2).mean().backward()
         sync.finish()
-    out[rank] = [p.grad.clone() for p in m.parameters()]
+    out[rank] = [p.grad.clone() for p in m.parameters()]  # unused params hold the (zero) reduced bucket view
     dist.destroy_process_group()
 
 
@@ -72,7 +72,6 @@ def test_gradsync_single_process_views():
     sync.zero()
     ((m(x) - y) ** 2).mean().backward()
     sync.finish()
-    flat = torch.cat([b["flat"] for b in sync.buckets])
-    assert flat.abs().sum() > 0 and all(p.grad.data_ptr() >= 0 for p in m.parameters())
+    assert all(p.grad is not None for p in m.body.parameters()) and all(p.grad is None for p in m.unused.parameters())
     sync.zero()
-    assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+    assert all(p.grad is None for p in m.parameters())

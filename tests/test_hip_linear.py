@@ -20,6 +20,8 @@ SHAPES = [(31598, 300, 300), (31855, 384, 128), (31855, 512, 128), (31855, 128, 
 def test_linear_fwd_bwd(M, N, K, mode, act):
     from graphtrans_amd import ops
 
+    if mode == "bf16" and (K % 8 or N % 8):
+        pytest.skip("bf16 storage needs 16-byte rows (K, N multiples of 8); such shapes go to torch's GEMM")
     torch.manual_seed(0)
     x = torch.randn(M, K)
     w = torch.randn(N, K) / K ** 0.5

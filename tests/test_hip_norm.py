@@ -31,6 +31,13 @@ def test_batchnorm_matches_torch(rows, D, relu, training):
     m = m.to(DEV)
     ref.train(training)
     m.train(training)
+    if relu:  # the ReLU gate of an output within fp32 rounding of 0 is a coin flip: give those elements no upstream grad
+        with torch.no_grad():
+            tie = ref(x.double()).abs() < 1e-4
+            ref.running_mean.copy_(m.running_mean.double().cpu())  # undo the extra stat update of the probe call
+            ref.running_var.copy_(m.running_var.double().cpu())
+            ref.num_batches_tracked.copy_(m.num_batches_tracked.cpu())
+        w = w.masked_fill(tie, 0.0)
     xr = x.double().requires_grad_(True)
     yr = ref(xr)
     yr = F.relu(yr) if relu else yr
@@ -39,12 +46,7 @@ def test_batchnorm_matches_torch(rows, D, relu, training):
     yd = m(xd, relu=relu)
     (yd * w.to(DEV)).sum().backward()
     assert_close(yd.cpu(), yr.detach(), what="y")
-    gx, gx_ref = xd.grad.cpu(), xr.grad.clone()
-    if relu:  # the ReLU gate of an output within fp32 rounding of 0 is a coin flip: exclude those elements
-        tie = yr.detach().abs() < 1e-4
-        gx = gx.masked_fill(tie, 0.0)
-        gx_ref = gx_ref.masked_fill(tie, 0.0)
-    assert_close(gx, gx_ref, what="dx")
+    assert_close(xd.grad.cpu(), xr.grad, what="dx")
     assert_close(m.weight.grad.cpu(), ref.weight.grad, what="dweight")
     assert_close(m.bias.grad.cpu(), ref.bias.grad, what="dbias")
     assert_close(m.running_mean.cpu(), ref.running_mean, what="running_mean")
