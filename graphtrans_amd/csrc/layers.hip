@@ -1,0 +1,406 @@
+// layers.hip — composite layer entry points: one C call enqueues every kernel of a GraphTrans layer
+// (forward or backward), so the host issues ~10 launches back to back instead of going through
+// ~10 Python/autograd round trips per layer (the step was host-bound at ~530 launches,
+// profiles/r01d).  Pure host code: it only sequences the gt_* primitives of this library on the
+// caller's stream and carves caller-owned buffers; nothing is allocated or synchronised here.
+//
+// Reference structure being sequenced (paths under /root/reference):
+//   encoder layer  torch nn.TransformerEncoderLayer (post-norm) via modules/transformer_encoder.py:28-32,59
+//   GCN layer      modules/gnn_module.py:199-212 (vn add, conv, batch_norm, relu, residual) + modules/conv.py:50-71
+//   VN update      modules/gnn_module.py:217-229 (global_add_pool + vn -> MLP)
+#include "gt_common.h"
+
+namespace {
+
+struct Bump {
+  char* base;
+  size_t off;
+  explicit Bump(void* p) : base(reinterpret_cast<char*>(p)), off(0) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+size_t elt(int dtype) { return dtype == GT_BF16 ? 2 : 4; }
+
+#define GT_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != GT_OK) return rc__; \
+  } while (0)
+
+// ---------------------------------------------------------------- encoder layer
+struct EncSaved {
+  void *qkv, *ctx, *a, *x1, *f1, *f2;
+  float *lse, *st1, *st2;
+  size_t bytes;
+};
+EncSaved enc_saved(const gt_encoder_layer* L, void* p) {
+  Bump b(p);
+  const size_t e = elt(L->dtype);
+  EncSaved s;
+  s.qkv = b.take((size_t)L->rows * 3 * L->d_model * e);
+  s.ctx = b.take((size_t)L->rows * L->d_model * e);
+  s.a = b.take((size_t)L->rows * L->d_model * e);
+  s.x1 = b.take((size_t)L->rows * L->d_model * e);
+  s.f1 = b.take((size_t)L->rows * L->ffn * e);
+  s.f2 = b.take((size_t)L->rows * L->d_model * e);
+  s.lse = (float*)b.take((size_t)L->nhead * L->rows * 4);
+  s.st1 = (float*)b.take((size_t)2 * L->rows * 4);
+  s.st2 = (float*)b.take((size_t)2 * L->rows * 4);
+  s.bytes = b.off;
+  return s;
+}
+struct EncWork {
+  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctx, *d_qkv, *lin_ws, *ln_ws;
+  float* delta;
+  size_t lin_ws_bytes, ln_ws_bytes, bytes;
+};
+EncWork enc_work(const gt_encoder_layer* L, void* p) {
+  Bump b(p);
+  const size_t e = elt(L->dtype);
+  EncWork w;
+  w.d_f2 = b.take((size_t)L->rows * L->d_model * e);
+  w.d_x1 = b.take((size_t)L->rows * L->d_model * e);
+  w.d_f1 = b.take((size_t)L->rows * L->ffn * e);
+  w.d_a = b.take((size_t)L->rows * L->d_model * e);
+  w.d_ctx = b.take((size_t)L->rows * L->d_model * e);
+  w.d_qkv = b.take((size_t)L->rows * 3 * L->d_model * e);
+  w.delta = (float*)b.take((size_t)L->nhead * L->rows * 4);
+  size_t m = 0;
+  const int64_t d = L->d_model, F = L->ffn, R = L->rows;
+  const int c = L->dtype == GT_BF16 ? GT_BF16 : L->compute;
+  size_t q;
+  q = gt_linear_bwd_workspace_bytes(c, R, 3 * d, d); m = q > m ? q : m;
+  q = gt_linear_bwd_workspace_bytes(c, R, d, d); m = q > m ? q : m;
+  q = gt_linear_bwd_workspace_bytes(c, R, F, d); m = q > m ? q : m;
+  q = gt_linear_bwd_workspace_bytes(c, R, d, F); m = q > m ? q : m;
+  w.lin_ws_bytes = m;
+  w.lin_ws = b.take(m);
+  w.ln_ws_bytes = gt_layernorm_bwd_workspace_bytes(R, d);
+  w.ln_ws = b.take(w.ln_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+// flat gradient layout (floats), parameter order of the header
+struct EncGrads {
+  float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+};
+EncGrads enc_grads(const gt_encoder_layer* L, float* g) {
+  const int64_t d = L->d_model, F = L->ffn;
+  EncGrads r;
+  r.in_w = g; g += 3 * d * d;
+  r.in_b = g; g += 3 * d;
+  r.out_w = g; g += d * d;
+  r.out_b = g; g += d;
+  r.l1_w = g; g += F * d;
+  r.l1_b = g; g += F;
+  r.l2_w = g; g += d * F;
+  r.l2_b = g; g += d;
+  r.n1_w = g; g += d;
+  r.n1_b = g; g += d;
+  r.n2_w = g; g += d;
+  r.n2_b = g; g += d;
+  return r;
+}
+
+int enc_check(const char* fn, const gt_encoder_layer* L) {
+  if (!L) { gt_set_error("%s: null descriptor", fn); return GT_ERR_INVALID_ARG; }
+  if (L->dtype != GT_F32 && L->dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (L->rows < 0 || L->d_model <= 0 || L->ffn <= 0 || L->nhead <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (L->d_model % 8 || L->ffn % 8) { gt_set_error("%s: d_model and ffn must be multiples of 8", fn); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
+// ---------------------------------------------------------------- GCN layer
+struct GcnSaved {
+  void *lin, *agg;
+  float* stats;
+  size_t bytes;
+};
+GcnSaved gcn_saved(const gt_gcn_layer* L, void* p) {
+  Bump b(p);
+  GcnSaved s;
+  s.lin = b.take((size_t)L->N * L->D * 4);
+  s.agg = b.take((size_t)L->N * L->D * 4);
+  s.stats = (float*)b.take((size_t)2 * L->D * 4);
+  s.bytes = b.off;
+  return s;
+}
+int64_t gcn_edge_w_elems(const gt_gcn_layer* L) {
+  if (L->edge_mode == GT_EDGE_LINEAR) return L->D * L->edge_cols;
+  if (L->edge_mode == GT_EDGE_TABLES) return L->table_rows * L->D;
+  return 0;
+}
+struct GcnGrads {
+  float *lin_w, *lin_b, *root, *edge_w, *edge_b, *bn_w, *bn_b;
+};
+GcnGrads gcn_grads(const gt_gcn_layer* L, float* g) {
+  GcnGrads r;
+  r.lin_w = g; g += L->D * L->D;
+  r.lin_b = g; g += L->D;
+  r.root = g; g += L->D;
+  r.edge_w = g; g += gcn_edge_w_elems(L);
+  r.edge_b = g; g += (L->edge_mode == GT_EDGE_LINEAR ? L->D : 0);
+  r.bn_w = g; g += L->D;
+  r.bn_b = g; g += L->D;
+  return r;
+}
+struct GcnWork {
+  void *d_agg, *d_lin, *bn_ws, *agg_ws, *lin_ws;
+  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, bytes;
+};
+GcnWork gcn_work(const gt_gcn_layer* L, void* p) {
+  Bump b(p);
+  GcnWork w;
+  w.d_agg = b.take((size_t)L->N * L->D * 4);
+  w.d_lin = b.take((size_t)L->N * L->D * 4);
+  w.bn_ws_bytes = gt_batchnorm_workspace_bytes(L->N, L->D);
+  w.bn_ws = b.take(w.bn_ws_bytes);
+  w.agg_ws_bytes = gt_aggregate_bwd_workspace_bytes(GT_CONV_GCN, L->edge_mode, L->D, L->edge_cols, L->table_rows);
+  w.agg_ws = b.take(w.agg_ws_bytes);
+  w.lin_ws_bytes = gt_linear_bwd_workspace_bytes(L->compute, L->N, L->D, L->D);
+  w.lin_ws = b.take(w.lin_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+int gcn_check(const char* fn, const gt_gcn_layer* L) {
+  if (!L) { gt_set_error("%s: null descriptor", fn); return GT_ERR_INVALID_ARG; }
+  if (L->N < 0 || L->D <= 0 || L->D % 4) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (L->edge_mode == GT_EDGE_DENSE) { gt_set_error("%s: dense edge embeddings use the un-fused ops", fn); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
+// ---------------------------------------------------------------- virtual-node update
+struct VnSaved {
+  void *t0, *z1, *a1, *z2;
+  float *st1, *st2;
+  size_t bytes;
+};
+VnSaved vn_saved(const gt_vn_update* L, void* p) {
+  Bump b(p);
+  VnSaved s;
+  s.t0 = b.take((size_t)L->B * L->D * 4);
+  s.z1 = b.take((size_t)L->B * 2 * L->D * 4);
+  s.a1 = b.take((size_t)L->B * 2 * L->D * 4);
+  s.z2 = b.take((size_t)L->B * L->D * 4);
+  s.st1 = (float*)b.take((size_t)2 * 2 * L->D * 4);
+  s.st2 = (float*)b.take((size_t)2 * L->D * 4);
+  s.bytes = b.off;
+  return s;
+}
+struct VnGrads {
+  float *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn2_w, *bn2_b;
+};
+VnGrads vn_grads(const gt_vn_update* L, float* g) {
+  const int64_t D = L->D;
+  VnGrads r;
+  r.w1 = g; g += 2 * D * D;
+  r.b1 = g; g += 2 * D;
+  r.bn1_w = g; g += 2 * D;
+  r.bn1_b = g; g += 2 * D;
+  r.w2 = g; g += 2 * D * D;
+  r.b2 = g; g += D;
+  r.bn2_w = g; g += D;
+  r.bn2_b = g; g += D;
+  return r;
+}
+struct VnWork {
+  void *d_z2, *d_a1, *d_z1, *d_t0, *bn_ws, *lin_ws;
+  size_t bn_ws_bytes, lin_ws_bytes, bytes;
+};
+VnWork vn_work(const gt_vn_update* L, void* p) {
+  Bump b(p);
+  VnWork w;
+  w.d_z2 = b.take((size_t)L->B * L->D * 4);
+  w.d_a1 = b.take((size_t)L->B * 2 * L->D * 4);
+  w.d_z1 = b.take((size_t)L->B * 2 * L->D * 4);
+  w.d_t0 = b.take((size_t)L->B * L->D * 4);
+  w.bn_ws_bytes = gt_batchnorm_workspace_bytes(L->B, 2 * L->D);
+  w.bn_ws = b.take(w.bn_ws_bytes);
+  size_t a = gt_linear_bwd_workspace_bytes(L->compute, L->B, 2 * L->D, L->D);
+  size_t c = gt_linear_bwd_workspace_bytes(L->compute, L->B, L->D, 2 * L->D);
+  w.lin_ws_bytes = a > c ? a : c;
+  w.lin_ws = b.take(w.lin_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" size_t gt_encoder_layer_saved_bytes(const gt_encoder_layer* L) { return L ? enc_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_encoder_layer_workspace_bytes(const gt_encoder_layer* L) { return L ? enc_work(L, nullptr).bytes : 0; }
+extern "C" int64_t gt_encoder_layer_grad_elems(const gt_encoder_layer* L) {
+  if (!L) return 0;
+  const int64_t d = L->d_model, F = L->ffn;
+  return 3 * d * d + 3 * d + d * d + d + F * d + F + d * F + d + 4 * d;
+}
+
+extern "C" int gt_encoder_layer_fwd(const gt_encoder_layer* L, const void* x, void* y, void* saved, gt_stream_t st) {
+  GT_TRY(enc_check("gt_encoder_layer_fwd", L));
+  GT_CHECK_ARG(x && y && saved, "null buffer");
+  if (L->rows == 0) return GT_OK;
+  const EncSaved s = enc_saved(L, saved);
+  const int t = L->dtype, c = t == GT_BF16 ? GT_BF16 : L->compute;
+  const int64_t R = L->rows, d = L->d_model, F = L->ffn;
+  const float p = L->training ? L->dropout_p : 0.f;
+  const float scale = 1.0f / sqrtf((float)(d / L->nhead));
+  GT_TRY(gt_linear_fwd(t, t, c, x, L->in_w, L->in_b, s.qkv, R, 3 * d, d, 0, 0.f, 0, st));
+  GT_TRY(gt_attn_fwd(t, s.qkv, s.ctx, s.lse, R, d, L->nhead, L->seq_desc, L->num_seqs, L->row_stride, L->max_npos, scale,
+                     p, L->seed, st));
+  GT_TRY(gt_linear_fwd(t, t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, 0, 0.f, 0, st));
+  GT_TRY(gt_layernorm_fwd(t, s.a, x, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, s.x1, s.st1,
+                          s.st1 + R, st));
+  GT_TRY(gt_linear_fwd(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, R, F, d, 1, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
+  GT_TRY(gt_linear_fwd(t, t, c, s.f1, L->l2_w, L->l2_b, s.f2, R, d, F, 0, 0.f, 0, st));
+  GT_TRY(gt_layernorm_fwd(t, s.f2, s.x1, L->n2_w, L->n2_b, L->ln_eps, p, L->seed ^ 0x14057B7EF767814FULL, R, d, y, s.st2,
+                          s.st2 + R, st));
+  return GT_OK;
+}
+
+extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, const void* dy, const void* saved, void* dx,
+                                    float* grads, void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(enc_check("gt_encoder_layer_bwd", L));
+  GT_CHECK_ARG(x && dy && saved && dx && grads && workspace, "null buffer");
+  const EncWork w = enc_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_encoder_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->rows == 0) return GT_OK;
+  const EncSaved s = enc_saved(L, const_cast<void*>(saved));
+  const EncGrads g = enc_grads(L, grads);
+  const int t = L->dtype, c = t == GT_BF16 ? GT_BF16 : L->compute;
+  const int64_t R = L->rows, d = L->d_model, F = L->ffn;
+  const float p = L->training ? L->dropout_p : 0.f;
+  const float scale = 1.0f / sqrtf((float)(d / L->nhead));
+  // x2 = LN2(x1 + drop(f2))
+  GT_TRY(gt_layernorm_bwd(t, s.f2, s.x1, dy, L->n2_w, s.st2, s.st2 + R, p, L->seed ^ 0x14057B7EF767814FULL, R, d, w.d_f2,
+                          w.d_x1, g.n2_w, g.n2_b, w.ln_ws, w.ln_ws_bytes, st));
+  // f2 = f1 W2^T + b2
+  GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F, 0.f,
+                       w.lin_ws, w.lin_ws_bytes, st));
+  // f1 = drop(relu(x1 W1^T + b1)) ; d_x1 += ...
+  GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, p, w.lin_ws,
+                       w.lin_ws_bytes, st));
+  // x1 = LN1(x + drop(a))
+  GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
+                          g.n1_w, g.n1_b, w.ln_ws, w.ln_ws_bytes, st));
+  // a = ctx Wo^T + bo
+  GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
+                       w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_attn_bwd(t, s.qkv, s.ctx, w.d_ctx, s.lse, w.delta, w.d_qkv, R, d, L->nhead, L->seq_desc, L->num_seqs,
+                     L->row_stride, L->max_npos, scale, p, L->seed, st));
+  // qkv = x Win^T + bin ; dx += ...
+  GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, g.in_w, g.in_b, R, 3 * d, d, 0.f, w.lin_ws,
+                       w.lin_ws_bytes, st));
+  return GT_OK;
+}
+
+// =================================================================================================
+extern "C" size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* L) { return L ? gcn_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* L) { return L ? gcn_work(L, nullptr).bytes : 0; }
+extern "C" int64_t gt_gcn_layer_grad_elems(const gt_gcn_layer* L) {
+  if (!L) return 0;
+  return L->D * L->D + 2 * L->D + gcn_edge_w_elems(L) + (L->edge_mode == GT_EDGE_LINEAR ? L->D : 0) + 2 * L->D;
+}
+
+extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const void* vn, void* x_out, void* y, void* saved,
+                                void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(gcn_check("gt_gcn_layer_fwd", L));
+  GT_CHECK_ARG(h_in && y && saved && workspace, "null buffer");
+  GT_CHECK_ARG(!L->has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
+  const GcnWork w = gcn_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_gcn_layer_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const GcnSaved s = gcn_saved(L, saved);
+  const void* x = h_in;
+  if (L->has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
+    GT_TRY(gt_segment_bcast_add(GT_F32, h_in, vn, L->node_graph, L->N, L->B, L->D, x_out, st));
+    x = x_out;
+  }
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_b, s.lin, L->N, L->D, L->D, 0, 0.f, 0, st));
+  GT_TRY(gt_aggregate_fwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, L->N, L->E, L->D, L->in_ptr, L->in_src, L->in_eid, L->deg,
+                          L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, nullptr, s.agg, st));
+  // h = batch_norm(h) [relu] [+ h_list[layer]]   (gnn_module.py:204-212; dropout p = 0 or eval here)
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.agg, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr,
+                          L->bn_momentum, L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->N, L->D, y, s.stats,
+                          s.stats + L->D, w.bn_ws, w.bn_ws_bytes, st));
+  return GT_OK;
+}
+
+extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void* dy, const void* dx_extra,
+                                const void* saved, void* d_h_in, void* d_vn, float* grads, void* workspace,
+                                size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(gcn_check("gt_gcn_layer_bwd", L));
+  GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
+  GT_CHECK_ARG(!L->has_vn || d_vn, "virtual-node layer needs d_vn");
+  const GcnWork w = gcn_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_gcn_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const GcnSaved s = gcn_saved(L, const_cast<void*>(saved));
+  const GcnGrads g = gcn_grads(L, grads);
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.agg, dy, L->bn_w, L->bn_b, s.stats, s.stats + L->D, L->training, L->relu, L->N, L->D,
+                          w.d_agg, g.bn_w, g.bn_b, w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_aggregate_bwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, w.d_agg, L->N, L->E, L->D, L->out_ptr, L->out_dst,
+                          L->out_eid, L->deg, L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off,
+                          L->table_rows, nullptr, w.d_lin, g.root, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
+  // d_x = d_lin W (+ grads reaching x from its other consumers) (+ dy through the residual branch)
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, x, L->lin_w, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr, d_h_in,
+                       g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  if (L->has_vn) GT_TRY(gt_segment_sum(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, st));
+  return GT_OK;
+}
+
+// =================================================================================================
+extern "C" size_t gt_vn_update_saved_bytes(const gt_vn_update* L) { return L ? vn_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_vn_update_workspace_bytes(const gt_vn_update* L) { return L ? vn_work(L, nullptr).bytes : 0; }
+extern "C" int64_t gt_vn_update_grad_elems(const gt_vn_update* L) { return L ? 4 * L->D * L->D + 9 * L->D : 0; }
+
+extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void* vn, void* vn_out, void* saved,
+                                void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_CHECK_ARG(L && x && vn && vn_out && saved && workspace, "null buffer");
+  GT_CHECK_ARG(L->D > 0 && L->D % 4 == 0 && L->B > 0, "bad sizes");
+  const VnWork w = vn_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_vn_update_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  const VnSaved s = vn_saved(L, saved);
+  const int64_t B = L->B, D = L->D;
+  // global_add_pool(h_list[layer], batch) + vn   (gnn_module.py:219)
+  GT_TRY(gt_segment_sum(GT_F32, x, vn, L->graph_ptr, L->N, B, D, s.t0, st));
+  // mlp_virtualnode_list[layer]: Linear(D,2D) BN ReLU Linear(2D,D) BN ReLU   (gnn_module.py:161-170)
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, L->b1, s.z1, B, 2 * D, D, 0, 0.f, 0, st));
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
+                          L->bn_momentum, L->bn_eps, L->training, 1, nullptr, B, 2 * D, s.a1, s.st1, s.st1 + 2 * D, w.bn_ws,
+                          w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, L->b2, s.z2, B, D, 2 * D, 0, 0.f, 0, st));
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z2, L->bn2_w, L->bn2_b, L->bn2_rm, L->bn2_rv, L->training ? L->bn2_nbt : nullptr,
+                          L->bn_momentum, L->bn_eps, L->training, 1, L->residual ? vn : nullptr, B, D, vn_out, s.st2,
+                          s.st2 + D, w.bn_ws, w.bn_ws_bytes, st));
+  return GT_OK;
+}
+
+extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, const void* saved, void* d_x, void* d_vn,
+                                float* grads, void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_CHECK_ARG(L && d_vn_out && saved && d_x && d_vn && grads && workspace, "null buffer");
+  const VnWork w = vn_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_vn_update_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  const VnSaved s = vn_saved(L, const_cast<void*>(saved));
+  const VnGrads g = vn_grads(L, grads);
+  const int64_t B = L->B, D = L->D;
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, d_vn_out, L->bn2_w, L->bn2_b, s.st2, s.st2 + D, L->training, 1, B, D, w.d_z2, g.bn2_w,
+                          g.bn2_b, w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, B, D,
+                       2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, B, 2 * D, w.d_z1,
+                          g.bn1_w, g.bn1_b, w.bn_ws, w.bn_ws_bytes, st));
+  // d_t0 = d_z1 W1 ; d_vn = d_t0 (+ d_vn_out through the residual branch)
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, g.w1, g.b1, B,
+                       2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  // d_x[n] = d_t0[graph(n)]
+  GT_TRY(gt_segment_bcast_add(GT_F32, nullptr, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
+  if (L->residual)
+    GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
+  else
+    (void)hipMemcpyAsync(d_vn, w.d_t0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
+  return GT_OK;
+}

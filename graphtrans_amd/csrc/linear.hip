@@ -31,6 +31,8 @@ struct LinArgs {
   const float* bias;  // [N] or null
   const void* x;      // dw: X[M][K]
   const void* ymask;  // dx/dw: forward output Y[M][N] when the forward fused relu(/dropout): dZ = dY*(Y>0)*inv_keep
+  const void* add1;   // dx: optional addends [M][K] (storage type of dX): dX = dZ W + add1 + add2
+  const void* add2;
   void* out;          // fwd: Y; dx: dX; dw: partial [splits][N][K] fp32
   float* dbpart;      // dw: [splits][N]
   int64_t M, N, K;
@@ -300,8 +302,12 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
       const int r = c >> 4, c4 = (c & 15) * 4;
       const int64_t m = m0 + wm * 64 + i * 16 + r;
       const int64_t col = kk0 + wk * 64 + c4;
-      if (m < a.M && col < a.K)
-        store_chunk<TX>(dX + m * a.K + col, *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4));
+      if (m < a.M && col < a.K) {
+        float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
+        if (a.add1) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add1) + m * a.K + col));
+        if (a.add2) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add2) + m * a.K + col));
+        store_chunk<TX>(dX + m * a.K + col, v);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -485,9 +491,9 @@ extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t 
 }
 
 extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
-                             const void* y_for_mask, void* dx, float* dweight, float* dbias, int64_t M, int64_t N,
-                             int64_t K, float dropout_p, void* workspace, size_t workspace_bytes,
-                             gt_stream_t stream_) {
+                             const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                             float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
+                             size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K);
   if (rc) return rc;
   GT_CHECK_ARG(weight && dy, "null buffer");
@@ -496,7 +502,7 @@ extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* 
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
-  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K;
+  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.add1 = dx_add1; a.add2 = dx_add2;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
   if (M == 0) {
     if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)N * K * sizeof(float), stream);

@@ -151,8 +151,8 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ w,
-                                                 const float* __restrict__ b, int relu, int64_t N, int64_t D,
-                                                 T* __restrict__ y) {
+                                                 const float* __restrict__ b, const T* __restrict__ resid, int relu,
+                                                 int64_t N, int64_t D, T* __restrict__ y) {
   const int64_t C = D / 4, total = N * C;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t c = (i % C) * 4;
@@ -162,16 +162,23 @@ __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const 
     v = make_float4((v.x - mu.x) * rs.x * ww.x + bb.x, (v.y - mu.y) * rs.y * ww.y + bb.y,
                     (v.z - mu.z) * rs.z * ww.z + bb.z, (v.w - mu.w) * rs.w * ww.w + bb.w);
     if (relu) v = gt_relu4(v);
+    if (resid) v = gt_add4(v, gt_load4<T>(resid + i * 4));
     gt_store4<T>(y + i * 4, v);
   }
+}
+
+// relu gate recomputed from the BN input: 1[(x - mean) * rstd * w + b > 0]
+__device__ __forceinline__ float4 bn_gate(float4 g, float4 v, float4 mu, float4 rs, float4 w, float4 b) {
+  return make_float4((v.x - mu.x) * rs.x * w.x + b.x > 0.f ? g.x : 0.f, (v.y - mu.y) * rs.y * w.y + b.y > 0.f ? g.y : 0.f,
+                     (v.z - mu.z) * rs.z * w.z + b.z > 0.f ? g.z : 0.f, (v.w - mu.w) * rs.w * w.w + b.w > 0.f ? g.w : 0.f);
 }
 
 // backward pass 1: part[blk][0][D] = sum(dy'), part[blk][1][D] = sum(dy' * xhat),  dy' = dy * 1[y > 0] if relu
 template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, const T* __restrict__ dy,
-                                                       const T* __restrict__ y, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, int relu, int64_t N, int64_t D,
-                                                       float* __restrict__ part) {
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int relu, int64_t N, int64_t D, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   ColMap m(D);
   const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
@@ -183,14 +190,12 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
     float4 acc[2] = {gt_zero4(), gt_zero4()};
     if (m.tr < m.R && cact) {
       const float4 mu = *reinterpret_cast<const float4*>(mean + c * 4), rs = *reinterpret_cast<const float4*>(rstd + c * 4);
+      const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(b + c * 4);
       for (int64_t r = r0 + m.tr; r < r1; r += m.R) {
         const int64_t o = r * D + (int64_t)c * 4;
         float4 g = gt_load4<T>(dy + o);
         const float4 v = gt_load4<T>(x + o);
-        if (relu) {
-          const float4 yy = gt_load4<T>(y + o);
-          g = make_float4(yy.x > 0.f ? g.x : 0.f, yy.y > 0.f ? g.y : 0.f, yy.z > 0.f ? g.z : 0.f, yy.w > 0.f ? g.w : 0.f);
-        }
+        if (relu) g = bn_gate(g, v, mu, rs, ww, bb);
         acc[0] = gt_add4(acc[0], g);
         acc[1] = make_float4(fmaf(g.x, (v.x - mu.x) * rs.x, acc[1].x), fmaf(g.y, (v.y - mu.y) * rs.y, acc[1].y),
                              fmaf(g.z, (v.z - mu.z) * rs.z, acc[1].z), fmaf(g.w, (v.w - mu.w) * rs.w, acc[1].w));
@@ -219,8 +224,8 @@ __global__ void k_bn_bwd_finish(const float* __restrict__ part, int nblk, int64_
 // backward pass 3: train: dx = w rstd (dy' - dbias/N - xhat dweight/N) ; eval: dx = w rstd dy'
 template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
-                                                     const T* __restrict__ y, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ w,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ dbias, const float* __restrict__ dweight,
                                                      int relu, int training, int64_t N, int64_t D, T* __restrict__ dx) {
   const int64_t C = D / 4, total = N * C;
@@ -229,12 +234,9 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
     const int64_t c = (i % C) * 4;
     float4 g = gt_load4<T>(dy + i * 4);
     const float4 v = gt_load4<T>(x + i * 4);
-    if (relu) {
-      const float4 yy = gt_load4<T>(y + i * 4);
-      g = make_float4(yy.x > 0.f ? g.x : 0.f, yy.y > 0.f ? g.y : 0.f, yy.z > 0.f ? g.z : 0.f, yy.w > 0.f ? g.w : 0.f);
-    }
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
     const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    if (relu) g = bn_gate(g, v, mu, rs, ww, *reinterpret_cast<const float4*>(b + c));
     const float4 db = *reinterpret_cast<const float4*>(dbias + c), dw = *reinterpret_cast<const float4*>(dweight + c);
     float4 r;
     r.x = ww.x * rs.x * (g.x - db.x * inv_n - (v.x - mu.x) * rs.x * dw.x * inv_n);
@@ -502,9 +504,9 @@ extern "C" size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim) {
 
 extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                float momentum, float eps, int training, int relu, int64_t rows, int64_t dim, void* y,
-                                float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                                gt_stream_t stream_) {
+                                float momentum, float eps, int training, int relu, const void* resid, int64_t rows,
+                                int64_t dim, void* y, float* save_mean, float* save_rstd, void* workspace,
+                                size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_norm("gt_batchnorm_fwd", dtype, rows, dim);
   if (rc) return rc;
   GT_CHECK_ARG(x && weight && bias && y && save_mean && save_rstd, "null buffer");
@@ -537,22 +539,21 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
   const int g = flat_blocks(rows * (dim / 4));
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, save_mean, save_rstd, weight,
-                       bias, relu, rows, dim, (float*)y);
+                       bias, (const float*)resid, relu, rows, dim, (float*)y);
   else
     hipLaunchKernelGGL(k_bn_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, save_mean, save_rstd, weight,
-                       bias, relu, rows, dim, (gt_bf16*)y);
+                       bias, (const gt_bf16*)resid, relu, rows, dim, (gt_bf16*)y);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
 
-extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const void* y, const float* weight,
+extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
                                 const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
                                 int64_t dim, void* dx, float* dweight, float* dbias, void* workspace,
                                 size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_norm("gt_batchnorm_bwd", dtype, rows, dim);
   if (rc) return rc;
-  GT_CHECK_ARG(x && dy && weight && save_mean && save_rstd && dx && dweight && dbias, "null buffer");
-  GT_CHECK_ARG(!relu || y, "relu backward needs the forward output");
+  GT_CHECK_ARG(x && dy && weight && bias && save_mean && save_rstd && dx && dweight && dbias, "null buffer");
   if (rows == 0) return GT_OK;
   if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
     gt_set_error("gt_batchnorm_bwd: workspace too small");
@@ -566,17 +567,16 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const int g = flat_blocks(rows * (dim / 4));
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
-                       (const float*)y, save_mean, save_rstd, relu, rows, dim, part);
+                       weight, bias, save_mean, save_rstd, relu, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
-                       (const float*)y, save_mean, save_rstd, weight, dbias, dweight, relu, training, rows, dim, (float*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, rows, dim, (float*)dx);
   } else {
     hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       (const gt_bf16*)y, save_mean, save_rstd, relu, rows, dim, part);
+                       weight, bias, save_mean, save_rstd, relu, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       (const gt_bf16*)y, save_mean, save_rstd, weight, dbias, dweight, relu, training, rows, dim,
-                       (gt_bf16*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, rows, dim, (gt_bf16*)dx);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;

@@ -28,9 +28,17 @@ def edge_spec(edge_encoder, edge_attr, emb_dim):
             for t in list(tabs)[:k]:
                 off.append(acc)
                 acc += int(t.weight.shape[0])
-            tables = torch.cat([t.weight for t in list(tabs)[:k]], dim=0)
-            return ops.EdgeSpec("tables", attr=edge_attr, tables=tables, tab_off=off)
+            spec = ops.EdgeSpec("tables", attr=edge_attr, tables=None, tab_off=off)
+            spec.table_list = [t.weight for t in list(tabs)[:k]]
+            return spec
     return ops.EdgeSpec("dense", dense=edge_encoder(edge_attr))
+
+
+def _materialize(spec):
+    """Concatenate the embedding tables for the fine-grained kernel call (autograd splits the grad)."""
+    if spec.kind == "tables" and spec.tables is None:
+        spec.tables = torch.cat(spec.table_list, dim=0)
+    return spec
 
 
 def _structure(x, edge_index, graph):
@@ -54,7 +62,7 @@ class GINConv(torch.nn.Module):
         gs = _structure(x, edge_index, graph)
         spec = edge_spec(self.edge_encoder, edge_attr, self.emb_dim)
         # (1 + eps) * x + sum_k relu(x_j + e_k), fused  (conv.py:28,33)
-        return mlp_bn_relu(self.mlp, ops.aggregate(x, gs, "gin", self.eps, spec))
+        return mlp_bn_relu(self.mlp, ops.aggregate(x, gs, "gin", self.eps, _materialize(spec)))
 
 
 class GCNConv(torch.nn.Module):
@@ -70,4 +78,4 @@ class GCNConv(torch.nn.Module):
         x = ops.linear_module(self.linear, x)
         spec = edge_spec(self.edge_encoder, edge_attr, self.emb_dim)
         # sum_k norm_k relu(x_j + e_k) + relu(x + root_emb) / deg, fused  (conv.py:54-68)
-        return ops.aggregate(x, gs, "gcn", self.root_emb.weight, spec)
+        return ops.aggregate(x, gs, "gcn", self.root_emb.weight, _materialize(spec))

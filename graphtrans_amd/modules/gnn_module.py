@@ -3,9 +3,9 @@ aggregate and segment kernels.  Same ctor arguments, attributes and state_dict k
 import torch
 import torch.nn.functional as F
 
-from .. import ops
+from .. import layers, ops
 from ..graph import GraphStructure
-from .conv import GCNConv, GINConv
+from .conv import GCNConv, GINConv, edge_spec
 from .norm import BatchNorm1d, mlp_bn_relu
 
 
@@ -49,6 +49,26 @@ def _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type):
         self.batch_norms.append(BatchNorm1d(emb_dim))
 
 
+def _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr):
+    """One message-passing layer: [x = h + vn[batch]] -> conv -> BN (+ReLU except on the last layer)
+    -> dropout -> [+ x].  Returns (x, h).  GCN layers in the covered configuration run as ONE
+    composite op (layers.gcn_layer); everything else through the fine-grained ops."""
+    conv, bn = self.convs[layer], self.batch_norms[layer]
+    relu = layer != self.num_layer - 1
+    h_in = h_list[layer]
+    if isinstance(conv, GCNConv):
+        spec = edge_spec(conv.edge_encoder, edge_attr, conv.emb_dim)
+        if layers.gcn_layer_eligible(conv, bn, h_in, spec, self.drop_ratio, self.training):
+            return layers.gcn_layer(h_in, vn, gs, conv, bn, spec, relu, self.residual, self.training)
+    x = ops.segment_bcast_add(h_in, vn, gs) if vn is not None else h_in  # + vn[batch]   (:199)
+    h = conv(x, edge_index, edge_attr, graph=gs)
+    h = bn(h, relu=relu)
+    h = F.dropout(h, self.drop_ratio, training=self.training)
+    if self.residual:
+        h = h + x
+    return x, h
+
+
 def _jk(JK, h_list, num_layer):
     if JK == "last":
         return h_list[-1]
@@ -82,13 +102,7 @@ class GNN_node(torch.nn.Module):
         encoded = _encode_nodes(self.node_encoder, batched_data)
         h_list = [encoded + perturb if perturb is not None else encoded]
         for layer in range(self.num_layer):
-            h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
-            # BN (+ReLU except on the last layer) fused, then dropout
-            h = self.batch_norms[layer](h, relu=(layer != self.num_layer - 1))
-            h = F.dropout(h, self.drop_ratio, training=self.training)
-            if self.residual:
-                h = h + h_list[layer]
-            h_list.append(h)
+            h_list.append(_conv_bn_layer(self, layer, h_list, None, gs, edge_index, edge_attr)[1])
         return _jk(self.JK, h_list, self.num_layer)
 
 
@@ -121,18 +135,16 @@ class GNN_node_Virtualnode(torch.nn.Module):
         # one zero-initialised embedding row per graph (gnn_module.py:195), without the .item() sync
         vn = self.virtualnode_embedding.weight.expand(gs.B, -1)
         for layer in range(self.num_layer):
-            h_list[layer] = ops.segment_bcast_add(h_list[layer], vn, gs)  # + vn[batch]   (:199)
-            h = self.convs[layer](h_list[layer], edge_index, edge_attr, graph=gs)
-            # BN (+ReLU except on the last layer) fused, then dropout
-            h = self.batch_norms[layer](h, relu=(layer != self.num_layer - 1))
-            h = F.dropout(h, self.drop_ratio, training=self.training)
-            if self.residual:
-                h = h + h_list[layer]
+            h_list[layer], h = _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr)
             h_list.append(h)
             if layer < self.num_layer - 1:
-                t = ops.segment_sum(h_list[layer], gs, add=vn)  # global_add_pool + vn   (:219)
-                t = F.dropout(mlp_bn_relu(self.mlp_virtualnode_list[layer], t), self.drop_ratio, training=self.training)
-                vn = vn + t if self.residual else t
+                seq = self.mlp_virtualnode_list[layer]
+                if layers.vn_update_eligible(seq, h_list[layer], self.drop_ratio, self.training):
+                    vn = layers.vn_update(h_list[layer], vn, gs, seq, self.residual, self.training)
+                else:
+                    t = ops.segment_sum(h_list[layer], gs, add=vn)  # global_add_pool + vn   (:219)
+                    t = F.dropout(mlp_bn_relu(seq, t), self.drop_ratio, training=self.training)
+                    vn = vn + t if self.residual else t
         return _jk(self.JK, h_list, self.num_layer)
 
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import layers, ops
 
 
 class _MaskLayout:
@@ -79,6 +79,8 @@ class TransformerNodeEncoder(nn.Module):
     def _layer(self, x, mod, lay, seed):
         sa = mod.self_attn
         p = self.dropout_p if self.training else 0.0
+        if layers.encoder_layer_eligible(mod, x, self.activation):  # one composite op per layer
+            return layers.encoder_layer(x, mod, lay, self.nhead, p, seed, self.training)
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         ctx = ops.attention(qkv, lay, self.nhead, dropout_p=p, seed=seed)
         a = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias)

@@ -310,14 +310,14 @@ class _BatchNorm(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.launch("gt_batchnorm_fwd", _dtype_code(x), _ptr(x), _ptr(w32), _ptr(b32), _ptr(running_mean),
                     _ptr(running_var), _ptr(nbt), float(momentum), float(eps), 1 if training else 0, 1 if relu else 0,
-                    rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws_bytes, _stream())
-        ctx.save_for_backward(x, y if relu else None, w32, stats)
+                    None, rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws_bytes, _stream())
+        ctx.save_for_backward(x, b32, w32, stats)
         ctx.cfg = (training, relu, weight.dtype, bias.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, w32, stats = ctx.saved_tensors
+        x, b32, w32, stats = ctx.saved_tensors
         training, relu, wdt, bdt = ctx.cfg
         dy = _dev(dy.to(x.dtype), "grad")
         rows, D = x.shape
@@ -326,7 +326,7 @@ class _BatchNorm(torch.autograd.Function):
         L = _lib.lib()
         ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(y), _ptr(w32), _ptr(stats[0]),
+        _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(w32), _ptr(b32), _ptr(stats[0]),
                     _ptr(stats[1]), 1 if training else 0, 1 if relu else 0, rows, D, _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]),
                     _ptr(ws), ws_bytes, _stream())
         return dx, dwb[0].to(wdt), dwb[1].to(bdt), None, None, None, None, None, None, None
@@ -433,7 +433,8 @@ class _Linear(torch.autograd.Function):
         ws_bytes = L.gt_linear_bwd_workspace_bytes(compute, M, N, K) if dw is not None else 0
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
         _lib.launch("gt_linear_bwd", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
-                    _ptr(ymask), _ptr(dx), _ptr(dw), _ptr(db), M, N, K, float(dropout_p), _ptr(ws), ws_bytes, _stream())
+                    _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, float(dropout_p), _ptr(ws), ws_bytes,
+                    _stream())
         return (None if dx is None else dx.view(xshape), None if not need_w else dw.to(wdt),
                 None if db is None else db.to(bdt), None, None, None, None, None)
 

@@ -175,10 +175,12 @@ int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, 
 size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim);
 int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
-                     int relu, int64_t rows, int64_t dim, void* y, float* save_mean, float* save_rstd,
-                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
-/* `y` (the forward output) is only read when relu != 0 (mask = y > 0). */
-int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const void* y, const float* weight,
+                     int relu, const void* resid /* optional: y = bn(x)[relu] + resid */, int64_t rows, int64_t dim,
+                     void* y, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                     gt_stream_t stream);
+/* dx w.r.t. the BN input (the residual branch's gradient is dy itself).  The ReLU gate is recomputed
+ * from x, the saved statistics, weight and bias: the forward output is not needed. */
+int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
                      const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
                      int64_t dim, void* dx, float* dweight, float* dbias, void* workspace, size_t workspace_bytes,
                      gt_stream_t stream);
@@ -209,7 +211,8 @@ int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy
  * (in_proj, out_proj, linear1+activation+dropout, linear2; modules/transformer_encoder.py:28-32).
  *   fwd: y[M][N] = dropout(act(x[M][K] weight[N][K]^T + bias))      act: 0 none | 1 relu
  *   bwd: dz = dy * 1[y > 0] / (1 - p) when y_for_mask != NULL (the forward fused relu[/dropout]),
- *        else dz = dy;  dx = dz weight;  dweight = dz^T x;  dbias = colsum(dz)   (any may be NULL)
+ *        else dz = dy;  dx = dz weight [+ dx_add1 + dx_add2];  dweight = dz^T x;  dbias = colsum(dz)
+ *        (any output may be NULL; dx_add* are optional [M][K] addends in x's storage type)
  * weight/bias and their gradients are fp32 (master weights are converted while staging: no cast
  * pass).  x_dtype / y_dtype: storage of x (and dx) / y (and dy); compute: GT_BF16
  * (v_mfma_f32_16x16x32_bf16) or GT_F32 (v_mfma_f32_16x16x4_f32, needs fp32 storage).
@@ -220,8 +223,77 @@ int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const fl
                   gt_stream_t stream);
 size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K);
 int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
-                  const void* y_for_mask, void* dx, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K,
-                  float dropout_p, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                  float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
+                  size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite layer entry points: ONE call enqueues every kernel of a layer's forward or backward
+ * (the gt_* primitives above, in order, on `stream`).  Purpose: host cost — a training step is
+ * ~500 kernel launches; issued from C back to back instead of through per-op Python/autograd
+ * round trips.  `saved` keeps the activations the backward needs (gt_*_saved_bytes), `workspace`
+ * is scratch (gt_*_workspace_bytes), `grads` is one flat fp32 buffer holding every parameter
+ * gradient of the layer in the order of the descriptor's parameter fields (gt_*_grad_elems);
+ * gradients are overwritten.  All parameters are fp32.
+ */
+typedef struct gt_encoder_layer {  /* torch nn.TransformerEncoderLayer, post-norm, ReLU FFN */
+  int64_t rows, d_model, ffn;
+  int32_t nhead, dtype /* token storage */, compute /* fp32 storage only: GT_F32 | GT_BF16 */, training;
+  const int32_t* seq_desc;
+  int64_t num_seqs, row_stride, max_npos;
+  float dropout_p, ln_eps;
+  uint64_t seed;
+  const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+} gt_encoder_layer;
+size_t gt_encoder_layer_saved_bytes(const gt_encoder_layer* layer);
+size_t gt_encoder_layer_workspace_bytes(const gt_encoder_layer* layer);
+int64_t gt_encoder_layer_grad_elems(const gt_encoder_layer* layer);
+int gt_encoder_layer_fwd(const gt_encoder_layer* layer, const void* x, void* y, void* saved, gt_stream_t stream);
+int gt_encoder_layer_bwd(const gt_encoder_layer* layer, const void* x, const void* dy, const void* saved, void* dx,
+                         float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+
+typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [relu] [+ x]; fp32 rows */
+  int64_t N, E, B, D;
+  int32_t edge_mode /* NONE | LINEAR | TABLES */, has_vn, relu, residual, training, compute;
+  int64_t edge_cols, table_rows;
+  int32_t tab_off[4];
+  float bn_momentum, bn_eps;
+  const int32_t *graph_ptr, *node_graph, *in_ptr, *in_src, *in_eid, *out_ptr, *out_dst, *out_eid;
+  const float *deg, *dis;
+  const void* edge_attr;
+  const float *lin_w, *lin_b, *root, *edge_w, *edge_b, *bn_w, *bn_b; /* gradient order: these 7 */
+  float *bn_rm, *bn_rv;
+  int64_t* bn_nbt;
+} gt_gcn_layer;
+size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
+size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
+int64_t gt_gcn_layer_grad_elems(const gt_gcn_layer* layer);
+/* x_out [N][D] receives h_in + vn[batch] when has_vn (the reference's updated h_list[layer]). */
+int gt_gcn_layer_fwd(const gt_gcn_layer* layer, const void* h_in, const void* vn, void* x_out, void* y, void* saved,
+                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* x: the forward's x_out (or h_in without vn); dx_extra: optional gradient reaching x from its other
+ * consumers (JK / virtual-node pooling); d_vn [B][D] = per-graph sum of d_h_in when has_vn. */
+int gt_gcn_layer_bwd(const gt_gcn_layer* layer, const void* x, const void* dy, const void* dx_extra, const void* saved,
+                     void* d_h_in, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
+                     gt_stream_t stream);
+
+typedef struct gt_vn_update {  /* vn_out = ReLU(BN(W2 ReLU(BN(W1 (pool(x) + vn))))) [+ vn]; fp32 */
+  int64_t N, B, D;
+  int32_t residual, training, compute, pad_;
+  float bn_momentum, bn_eps;
+  const int32_t *graph_ptr, *node_graph, *identity_graph /* [B] = 0..B-1 */;
+  const float *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn2_w, *bn2_b; /* gradient order: these 8 */
+  float *bn1_rm, *bn1_rv, *bn2_rm, *bn2_rv;
+  int64_t *bn1_nbt, *bn2_nbt;
+} gt_vn_update;
+size_t gt_vn_update_saved_bytes(const gt_vn_update* layer);
+size_t gt_vn_update_workspace_bytes(const gt_vn_update* layer);
+int64_t gt_vn_update_grad_elems(const gt_vn_update* layer);
+int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, void* vn_out, void* saved,
+                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* d_x [N][D] = d(pooled)[graph(n)], d_vn [B][D]. */
+int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, void* d_x, void* d_vn,
+                     float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
 #ifdef __cplusplus
 }

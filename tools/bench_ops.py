@@ -45,8 +45,8 @@ def bench_linear():
             ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
             xd, wd, bd = x.detach(), w.detach(), b.detach()
             f_fwd = lambda: lib.gt_linear_fwd(_dtype_code(xd), _dtype_code(y), cc, _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), M, N, K, 0, 0.0, 0, _stream())
-            f_dx = lambda: lib.gt_linear_bwd(_dtype_code(xd), _dtype_code(g), cc, _ptr(xd), _ptr(wd), _ptr(g), None, _ptr(dx), None, None, M, N, K, 0.0, _ptr(ws), wsb, _stream())
-            f_dw = lambda: lib.gt_linear_bwd(_dtype_code(xd), _dtype_code(g), cc, _ptr(xd), _ptr(wd), _ptr(g), None, None, _ptr(dw), _ptr(db), M, N, K, 0.0, _ptr(ws), wsb, _stream())
+            f_dx = lambda: lib.gt_linear_bwd(_dtype_code(xd), _dtype_code(g), cc, _ptr(xd), _ptr(wd), _ptr(g), None, None, None, _ptr(dx), None, None, M, N, K, 0.0, _ptr(ws), wsb, _stream())
+            f_dw = lambda: lib.gt_linear_bwd(_dtype_code(xd), _dtype_code(g), cc, _ptr(xd), _ptr(wd), _ptr(g), None, None, None, None, _ptr(dw), _ptr(db), M, N, K, 0.0, _ptr(ws), wsb, _stream())
             t_f, t_dx, t_dw = timeit(f_fwd), timeit(f_dx), timeit(f_dw)
             wt = wd.to(sdt); bt = bd.to(sdt)
             t_tf = timeit(lambda: torch.nn.functional.linear(xd, wt, bt))
