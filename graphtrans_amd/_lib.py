@@ -48,6 +48,22 @@ SIGNATURES = {
     "gt_linear_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "gt_linear_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
+    # composite layers (descriptor structs are passed by pointer; see graphtrans_amd/layers.py)
+    "gt_encoder_layer_saved_bytes": (_sz, [_p]),
+    "gt_encoder_layer_workspace_bytes": (_sz, [_p]),
+    "gt_encoder_layer_grad_elems": (_i64, [_p]),
+    "gt_encoder_layer_fwd": (_i, [_p, _p, _p, _p, _p]),
+    "gt_encoder_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_gcn_layer_saved_bytes": (_sz, [_p]),
+    "gt_gcn_layer_workspace_bytes": (_sz, [_p]),
+    "gt_gcn_layer_grad_elems": (_i64, [_p]),
+    "gt_gcn_layer_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_gcn_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_vn_update_saved_bytes": (_sz, [_p]),
+    "gt_vn_update_workspace_bytes": (_sz, [_p]),
+    "gt_vn_update_grad_elems": (_i64, [_p]),
+    "gt_vn_update_fwd": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_vn_update_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_attn_fwd": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _f, _f, _u64, _p]),
     "gt_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _f, _f, _u64, _p]),
 }

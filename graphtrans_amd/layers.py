@@ -44,31 +44,7 @@ class VnUpdateDesc(C.Structure):
 
 
 def _bind():
-    L = _lib.lib()
-    if getattr(L, "_layers_bound", False):
-        return L
-    P = C.POINTER
-    for name, desc in (("encoder_layer", EncoderLayerDesc), ("gcn_layer", GcnLayerDesc), ("vn_update", VnUpdateDesc)):
-        getattr(L, f"gt_{name}_saved_bytes").restype = C.c_size_t
-        getattr(L, f"gt_{name}_saved_bytes").argtypes = [P(desc)]
-        getattr(L, f"gt_{name}_workspace_bytes").restype = C.c_size_t
-        getattr(L, f"gt_{name}_workspace_bytes").argtypes = [P(desc)]
-        getattr(L, f"gt_{name}_grad_elems").restype = C.c_int64
-        getattr(L, f"gt_{name}_grad_elems").argtypes = [P(desc)]
-    L.gt_encoder_layer_fwd.restype = C.c_int
-    L.gt_encoder_layer_fwd.argtypes = [P(EncoderLayerDesc), _fp, _fp, _fp, _fp]
-    L.gt_encoder_layer_bwd.restype = C.c_int
-    L.gt_encoder_layer_bwd.argtypes = [P(EncoderLayerDesc), _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
-    L.gt_gcn_layer_fwd.restype = C.c_int
-    L.gt_gcn_layer_fwd.argtypes = [P(GcnLayerDesc), _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
-    L.gt_gcn_layer_bwd.restype = C.c_int
-    L.gt_gcn_layer_bwd.argtypes = [P(GcnLayerDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
-    L.gt_vn_update_fwd.restype = C.c_int
-    L.gt_vn_update_fwd.argtypes = [P(VnUpdateDesc), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
-    L.gt_vn_update_bwd.restype = C.c_int
-    L.gt_vn_update_bwd.argtypes = [P(VnUpdateDesc), _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
-    L._layers_bound = True
-    return L
+    return _lib.lib()  # signatures are declared in _lib.SIGNATURES (descriptor pointers as void*)
 
 
 def _bytes(n, dev):

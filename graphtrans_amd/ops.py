@@ -43,6 +43,7 @@ class EdgeSpec:
     def __init__(self, kind, attr=None, weight=None, bias=None, tables=None, tab_off=None, dense=None):
         self.kind, self.attr, self.weight, self.bias = kind, attr, weight, bias
         self.tables, self.tab_off, self.dense = tables, tab_off, dense
+        self.table_list = None
 
 
 class _Aggregate(torch.autograd.Function):
@@ -109,6 +110,8 @@ def aggregate(h, gs, conv, self_param, edge):
     if edge.kind == "linear":
         return _Aggregate.apply(h, sp, edge.weight, edge.bias, None, gs, cv, GT_EDGE_LINEAR, edge.attr.float(), None)
     if edge.kind == "tables":
+        if edge.tables is None:  # concatenated view of the embedding tables (autograd splits the gradient)
+            edge.tables = torch.cat(edge.table_list, dim=0)
         return _Aggregate.apply(h, sp, edge.tables, None, None, gs, cv, GT_EDGE_TABLES, edge.attr, edge.tab_off)
     if edge.kind == "dense":
         return _Aggregate.apply(h, sp, None, None, edge.dense, gs, cv, GT_EDGE_DENSE, None, None)
