@@ -26,6 +26,13 @@ constexpr int AGG_THREADS = 256;
 constexpr int AGG_WAVES = AGG_THREADS / GT_WAVE;
 constexpr int BWD_BLOCKS = 1024;
 constexpr int MAX_K = 4;
+// internal edge mode: Linear edge encoder with K <= 2 (the Code2 case, dataset/code.py:117): half the
+// weight registers / accumulators of the generic K <= 4 variant -> higher occupancy
+constexpr int EDGE_LINEAR2 = 4;
+template <int EDGE>
+__host__ __device__ constexpr bool is_linear() { return EDGE == GT_EDGE_LINEAR || EDGE == EDGE_LINEAR2; }
+template <int EDGE>
+__host__ __device__ constexpr int kmax() { return EDGE == EDGE_LINEAR2 ? 2 : MAX_K; }
 
 struct AggArgs {
   int conv, K;
@@ -70,18 +77,18 @@ struct LaneMap {
 // per-lane edge-embedding state
 template <int EDGE, int NCH>
 struct EdgeState {
-  float4 w[EDGE == GT_EDGE_LINEAR ? MAX_K : 1][NCH];
+  float4 w[is_linear<EDGE>() ? kmax<EDGE>() : 1][NCH];
   float4 b[NCH];
 };
 
 template <int EDGE, int NCH, int LPN>
 __device__ __forceinline__ void edge_state_init(EdgeState<EDGE, NCH>& s, const AggArgs& a, const LaneMap<LPN, NCH>& m) {
-  if constexpr (EDGE == GT_EDGE_LINEAR) {
+  if constexpr (is_linear<EDGE>()) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       s.b[j] = m.act[j] ? *reinterpret_cast<const float4*>(a.b + m.col[j]) : gt_zero4();
 #pragma unroll
-      for (int k = 0; k < MAX_K; ++k) {
+      for (int k = 0; k < kmax<EDGE>(); ++k) {
         if (k < a.K && m.act[j]) {
           const float* w = a.w + (int64_t)m.col[j] * a.K + k;  // W[d][k], d = col..col+3
           s.w[k][j] = make_float4(w[0], w[a.K], w[2 * a.K], w[3 * a.K]);
@@ -100,10 +107,10 @@ __device__ __forceinline__ float4 edge_embed(const EdgeState<EDGE, NCH>& s, cons
                                              const int* ti) {
   if constexpr (EDGE == GT_EDGE_NONE) {
     return gt_zero4();
-  } else if constexpr (EDGE == GT_EDGE_LINEAR) {
+  } else if constexpr (is_linear<EDGE>()) {
     float4 e = s.b[j];
 #pragma unroll
-    for (int k = 0; k < MAX_K; ++k)
+    for (int k = 0; k < kmax<EDGE>(); ++k)
       if (k < a.K) e = gt_fma4(s.w[k][j], av[k], e);
     return e;
   } else if constexpr (EDGE == GT_EDGE_TABLES) {
@@ -119,10 +126,10 @@ __device__ __forceinline__ float4 edge_embed(const EdgeState<EDGE, NCH>& s, cons
 
 template <int EDGE>
 __device__ __forceinline__ void edge_attr_load(const AggArgs& a, int eid, float* av, int* ti) {
-  if constexpr (EDGE == GT_EDGE_LINEAR) {
+  if constexpr (is_linear<EDGE>()) {
     const float* p = reinterpret_cast<const float*>(a.attr) + (int64_t)eid * a.K;
 #pragma unroll
-    for (int k = 0; k < MAX_K; ++k) av[k] = k < a.K ? p[k] : 0.f;
+    for (int k = 0; k < kmax<EDGE>(); ++k) av[k] = k < a.K ? p[k] : 0.f;
   } else if constexpr (EDGE == GT_EDGE_TABLES) {
     const int64_t* p = reinterpret_cast<const int64_t*>(a.attr) + (int64_t)eid * a.K;
 #pragma unroll
@@ -212,7 +219,7 @@ __device__ __forceinline__ float4 gate4(float4 pre, float4 v) {
 template <int EDGE>
 __host__ __device__ constexpr int reg_slots() {
   // register-accumulated D-vectors per lane: [self] (+ K weight columns + bias for Linear)
-  return EDGE == GT_EDGE_LINEAR ? MAX_K + 2 : 1;
+  return is_linear<EDGE>() ? kmax<EDGE>() + 2 : 1;
 }
 
 template <typename T, int LPN, int NCH, int EDGE>
@@ -231,7 +238,7 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   const bool gcn = a.conv == GT_CONV_GCN;
   const float one_eps = gcn ? 0.f : 1.0f + a.self_param[0];
   const int64_t D = a.D;
-  const int nslots = (EDGE == GT_EDGE_LINEAR ? a.K + 2 : 1) + (EDGE == GT_EDGE_TABLES ? a.table_rows : 0);
+  const int nslots = (is_linear<EDGE>() ? a.K + 2 : 1) + (EDGE == GT_EDGE_TABLES ? a.table_rows : 0);
 
   // slot order in `partial`: 0 = self ; Linear: 1..K = weight columns, K+1 = bias ; Tables: 1.. = rows
   float4 racc[NREG][NCH];
@@ -272,11 +279,11 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
         float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid, av, ti);
         float4 t = gate4(gt_add4(hu[j], e), gt_scale4(gd, wk));
         acc[j] = gt_add4(acc[j], t);
-        if constexpr (EDGE == GT_EDGE_LINEAR) {
+        if constexpr (is_linear<EDGE>()) {
 #pragma unroll
-          for (int k = 0; k < MAX_K; ++k)
+          for (int k = 0; k < kmax<EDGE>(); ++k)
             if (k < a.K) racc[1 + k][j] = gt_fma4(t, av[k], racc[1 + k][j]);
-          racc[MAX_K + 1][j] = gt_add4(racc[MAX_K + 1][j], t);
+          racc[kmax<EDGE>() + 1][j] = gt_add4(racc[kmax<EDGE>() + 1][j], t);
         } else if constexpr (EDGE == GT_EDGE_TABLES) {
           if (m.act[j]) {
 #pragma unroll
@@ -327,10 +334,10 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
 #pragma unroll
   for (int s = 0; s < NREG; ++s) {
     int slot = s;
-    if constexpr (EDGE == GT_EDGE_LINEAR) {
-      if (s >= 1 && s <= MAX_K) {
+    if constexpr (is_linear<EDGE>()) {
+      if (s >= 1 && s <= kmax<EDGE>()) {
         if (s - 1 >= a.K) continue;
-      } else if (s == MAX_K + 1) {
+      } else if (s == kmax<EDGE>() + 1) {
         slot = a.K + 1;
       }
     }
@@ -470,7 +477,9 @@ template <typename T, bool BWD>
 int launch_edge(int edge_mode, const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t stream) {
   switch (edge_mode) {
     case GT_EDGE_NONE: return launch_cfg<T, GT_EDGE_NONE, BWD>(a, lds_bytes, grid_bwd, stream);
-    case GT_EDGE_LINEAR: return launch_cfg<T, GT_EDGE_LINEAR, BWD>(a, lds_bytes, grid_bwd, stream);
+    case GT_EDGE_LINEAR:
+      if (a.K <= 2) return launch_cfg<T, EDGE_LINEAR2, BWD>(a, lds_bytes, grid_bwd, stream);
+      return launch_cfg<T, GT_EDGE_LINEAR, BWD>(a, lds_bytes, grid_bwd, stream);
     case GT_EDGE_TABLES: return launch_cfg<T, GT_EDGE_TABLES, BWD>(a, lds_bytes, grid_bwd, stream);
     case GT_EDGE_DENSE: return launch_cfg<T, GT_EDGE_DENSE, BWD>(a, lds_bytes, grid_bwd, stream);
   }

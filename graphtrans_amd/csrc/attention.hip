@@ -49,6 +49,7 @@ struct AttnArgs {
   float* delta;       // [nhead][rows]
   void* out;          // fwd: ctx ; bwd: d_qkv
   const int32_t* desc;
+  const int32_t* work;  // optional [num_work][2] = {sequence, 64-row tile}: 1-D grid over real tiles only
   int64_t rows, d_model, row_stride;
   int nhead;
   float scale_log2;   // scale * log2(e)
@@ -105,10 +106,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const int head = blockIdx.y;
+  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int q_base = blockIdx.x * BLOCK_N;
+  const int q_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -206,10 +208,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const int head = blockIdx.y;
+  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int q_base = blockIdx.x * BLOCK_N;
+  const int q_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -305,10 +308,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
   __shared__ float sLse[TILE], sDelta[TILE];
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const int head = blockIdx.y;
+  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int k_base = blockIdx.x * BLOCK_N;
+  const int k_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
   if (k_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -413,10 +417,10 @@ int check_attn(const char* fn, int dtype, int64_t d_model, int nhead, int64_t nu
 }
 
 AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* lse, float* delta, void* out,
-                   int64_t rows, int64_t d_model, int nhead, const int32_t* desc, int64_t row_stride, float scale,
-                   float dropout_p, uint64_t seed) {
+                   int64_t rows, int64_t d_model, int nhead, const int32_t* desc, const int32_t* work,
+                   int64_t row_stride, float scale, float dropout_p, uint64_t seed) {
   AttnArgs a{};
-  a.qkv = qkv; a.ctx = ctx; a.d_ctx = d_ctx; a.lse = lse; a.delta = delta; a.out = out; a.desc = desc;
+  a.qkv = qkv; a.ctx = ctx; a.d_ctx = d_ctx; a.lse = lse; a.delta = delta; a.out = out; a.desc = desc; a.work = work;
   a.rows = rows; a.d_model = d_model; a.row_stride = row_stride; a.nhead = nhead;
   a.scale = scale; a.scale_log2 = scale * LOG2E;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
@@ -430,15 +434,18 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
 
 extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
                            int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
-                           int64_t max_npos, float scale, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+                           int64_t max_npos, const int32_t* work_items, int64_t num_work, float scale,
+                           float dropout_p, uint64_t seed, gt_stream_t stream_) {
   int rc = check_attn("gt_attn_fwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
   if (rc) return rc;
   GT_CHECK_ARG(qkv && ctx && lse && seq_desc, "null buffer");
   if (num_seqs == 0 || max_npos == 0) return GT_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, row_stride,
-                         scale, dropout_p, seed);
-  dim3 grid((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+  if (work_items && num_work == 0) return GT_OK;
+  AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, work_items,
+                         row_stride, scale, dropout_p, seed);
+  dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
+                         : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
 #define GT_LAUNCH(T, HD) hipLaunchKernelGGL((k_attn_fwd<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a)
   if (dtype == GT_F32) {
@@ -456,15 +463,18 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
 extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
                            float* delta, void* d_qkv, int64_t total_rows, int64_t d_model, int nhead,
                            const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
-                           float scale, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+                           const int32_t* work_items, int64_t num_work, float scale, float dropout_p, uint64_t seed,
+                           gt_stream_t stream_) {
   int rc = check_attn("gt_attn_bwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
   if (rc) return rc;
   GT_CHECK_ARG(qkv && ctx && d_ctx && lse && delta && d_qkv && seq_desc, "null buffer");
   if (num_seqs == 0 || max_npos == 0) return GT_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, ctx, d_ctx, const_cast<float*>(lse), delta, d_qkv, total_rows, d_model, nhead, seq_desc,
-                         row_stride, scale, dropout_p, seed);
-  dim3 grid((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+                         work_items, row_stride, scale, dropout_p, seed);
+  dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
+                         : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
 #define GT_LAUNCH(T, HD)                                                                        \
   do {                                                                                          \

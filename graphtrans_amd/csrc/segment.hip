@@ -42,12 +42,13 @@ __global__ void __launch_bounds__(SEG_THREADS) k_segment_sum(const T* __restrict
   float4 acc = gt_zero4();
   if (act) {
     int r = beg + wid;
-    // 2 independent loads in flight per wave
-    for (; r + 4 < end; r += 8) {
-      float4 a0 = gt_load4<T>(x + (int64_t)r * D + c);
-      float4 a1 = gt_load4<T>(x + (int64_t)(r + 4) * D + c);
-      acc = gt_add4(acc, a0);
-      acc = gt_add4(acc, a1);
+    // 8 independent row loads in flight per wave (a serial chain of L2 round trips otherwise)
+    for (; r + 28 < end; r += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = gt_load4<T>(x + (int64_t)(r + 4 * u) * D + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = gt_add4(acc, v[u]);
     }
     for (; r < end; r += 4) acc = gt_add4(acc, gt_load4<T>(x + (int64_t)r * D + c));
   }

@@ -120,6 +120,12 @@ class SeqLayout:
         self.kind, self.with_cls, self.S, self.B = kind, with_cls, S, B
         self.kept = kept
         self.desc_cpu = desc
+        # attention tile list: (sequence, 64-position tile) for every tile that exists (ragged sizes)
+        tiles = (desc[:, 1].astype(np.int64) + 63) // 64
+        wseq = np.repeat(np.arange(B, dtype=np.int32), tiles)
+        wtile = (np.arange(int(tiles.sum()), dtype=np.int64) - np.repeat(np.cumsum(tiles) - tiles, tiles)).astype(np.int32)
+        work = np.stack([wseq, wtile], axis=1).astype(np.int32) if B else np.zeros((0, 2), np.int32)
+        self.num_work = int(work.shape[0])
         # token row of the last position (CLS / last node) of every sequence: the pooled row
         last_row = desc[:, 0].astype(np.int64) + (desc[:, 1].astype(np.int64) - 1) * self.row_stride
         if torch.device(gs.device).type == "cuda":
@@ -127,6 +133,8 @@ class SeqLayout:
             # already queued on the stream has drained (it showed up as a 10 ms/step stall)
             self.desc = torch.from_numpy(desc).pin_memory().to(gs.device, non_blocking=True)
             self.last_rows = torch.from_numpy(last_row).pin_memory().to(gs.device, non_blocking=True)
+            self.work = torch.from_numpy(work).pin_memory().to(gs.device, non_blocking=True) if self.num_work else None
         else:
+            self.work = torch.from_numpy(work)
             self.desc = torch.from_numpy(desc)
             self.last_rows = torch.from_numpy(last_row)

@@ -19,7 +19,7 @@ class EncoderLayerDesc(C.Structure):
     _fields_ = [("rows", C.c_int64), ("d_model", C.c_int64), ("ffn", C.c_int64),
                 ("nhead", C.c_int32), ("dtype", C.c_int32), ("compute", C.c_int32), ("training", C.c_int32),
                 ("seq_desc", _fp), ("num_seqs", C.c_int64), ("row_stride", C.c_int64), ("max_npos", C.c_int64),
-                ("dropout_p", C.c_float), ("ln_eps", C.c_float), ("seed", C.c_uint64)] + \
+                ("work_items", _fp), ("num_work", C.c_int64), ("dropout_p", C.c_float), ("ln_eps", C.c_float), ("seed", C.c_uint64)] + \
                [(n, _fp) for n in ("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b",
                                    "n2_w", "n2_b")]
 
@@ -99,6 +99,7 @@ class _EncoderLayer(torch.autograd.Function):
         desc.training = 1 if training else 0
         desc.seq_desc = _ptr(lay.desc)
         desc.num_seqs, desc.row_stride, desc.max_npos = lay.B, lay.row_stride, lay.max_npos
+        desc.work_items, desc.num_work = _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0)
         desc.dropout_p, desc.ln_eps, desc.seed = float(dropout_p), float(ln_eps), int(seed)
         for name, p in zip(("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w",
                             "n2_b"), params):

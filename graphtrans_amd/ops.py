@@ -267,7 +267,8 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
         meta = dict(lay=lay, d=d, nhead=nhead, elt=qkv.element_size())
         _lib.launch("gt_attn_fwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
-                    lay.B, lay.row_stride, lay.max_npos, scale, dropout_p, seed, _stream(), meta=meta)
+                    lay.B, lay.row_stride, lay.max_npos, _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), scale,
+                    dropout_p, seed, _stream(), meta=meta)
         ctx.meta = meta
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (lay, nhead, scale, dropout_p, seed)
@@ -283,8 +284,9 @@ class _Attention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
         _lib.launch("gt_attn_bwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
-                    _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos, scale,
-                    dropout_p, seed, _stream(), meta=ctx.meta)
+                    _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos,
+                    _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), scale, dropout_p, seed, _stream(),
+                    meta=ctx.meta)
         return dqkv, None, None, None, None, None
 
 

@@ -153,16 +153,20 @@ int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_
  *   in [0, npos) is computed.  P = softmax(scale * q k^T); dropout(P, p) with a counter-based RNG
  *   keyed by (seed, seq, head, query, key) so backward replays it.
  *   dtype GT_BF16 -> v_mfma_f32_16x16x32_bf16; GT_F32 -> v_mfma_f32_16x16x4_f32 (exact fp32).
+ *   work_items (optional) [num_work][2] int32 = {sequence, 64-position tile}: when given, the grid
+ *   covers exactly these tiles (ragged graph sizes: most sequences need 2 of the max_npos/64 tiles);
+ *   NULL -> dense grid (max tiles x heads x sequences, empty tiles exit).
  */
 int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model, int nhead,
-                const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale,
-                float dropout_p, uint64_t seed, gt_stream_t stream);
+                const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                const int32_t* work_items, int64_t num_work, float scale, float dropout_p, uint64_t seed,
+                gt_stream_t stream);
 /* d_qkv [rows][3*d_model] is fully written for every row belonging to a sequence position.
  * delta [nhead][rows] fp32 workspace (rowsum(dO*O)). */
 int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse, float* delta,
                 void* d_qkv, int64_t total_rows, int64_t d_model, int nhead, const int32_t* seq_desc,
-                int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale, float dropout_p,
-                uint64_t seed, gt_stream_t stream);
+                int64_t num_seqs, int64_t row_stride, int64_t max_npos, const int32_t* work_items, int64_t num_work,
+                float scale, float dropout_p, uint64_t seed, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d over the rows of an [rows][dim] matrix (channels = columns), optional fused ReLU.
@@ -241,6 +245,8 @@ typedef struct gt_encoder_layer {  /* torch nn.TransformerEncoderLayer, post-nor
   int32_t nhead, dtype /* token storage */, compute /* fp32 storage only: GT_F32 | GT_BF16 */, training;
   const int32_t* seq_desc;
   int64_t num_seqs, row_stride, max_npos;
+  const int32_t* work_items; /* optional attention tile list, see gt_attn_fwd */
+  int64_t num_work;
   float dropout_p, ln_eps;
   uint64_t seed;
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
