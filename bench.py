@@ -105,7 +105,7 @@ def agg_bytes(meta, bwd):
     return E * 8 + (N + 1) * 8 + E * a + E * D * s + 2 * N * D * s + N * D * s
 
 
-def attn_flops(meta, bwd):
+def _unused_attn_flops(meta, bwd):
     lay, d = meta["lay"], meta["d"]
     desc = getattr(lay, "desc_cpu", None)
     if desc is None:
@@ -116,24 +116,43 @@ def attn_flops(meta, bwd):
     return f * (2.5 if bwd else 1.0)
 
 
-def kernel_report(summary, dtype):
+def kernel_report(records, attn_flops_fwd, dtype):
+    """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the launch stream,
+    recorded inside the timed region).  -> per entry point roofline dicts."""
+    groups = {}
+    for name, ms, dims in records:
+        groups.setdefault(name, []).append((ms, dims))
     rep = {}
-    for name, d in summary.items():
+    for name, items in groups.items():
+        calls = len(items)
+        total_ms = sum(ms for ms, _ in items)
+        avg_us = 1e3 * total_ms / calls
+        base = dict(avg_us=round(avg_us, 2), calls=calls, total_ms=round(total_ms, 3), traffic=None)
         if name.startswith("gt_aggregate"):
             bwd = name.endswith("bwd")
-            per = float(np.mean([agg_bytes(m, bwd) for m in d["metas"]]))
-            gbs = per / (d["avg_us"] * 1e-6) / 1e9
+            per = float(np.mean([agg_bytes(dict(N=d[0], E=d[1], D=d[2], elt=d[3], attr_bytes=d[4]), bwd) for _, d in items]))
+            gbs = per / (avg_us * 1e-6) / 1e9
             rep[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, avg_us=round(d["avg_us"], 2),
-                             calls=d["calls"], total_ms=round(d["total_ms"], 3), algorithmic_bytes=int(per))
+                             frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=int(per), **base)
         elif name.startswith("gt_attn"):
-            bwd = name.endswith("bwd")
-            per = float(np.mean([attn_flops(m, bwd) for m in d["metas"]]))
-            tf = per / (d["avg_us"] * 1e-6) / 1e12
+            per = attn_flops_fwd * (2.5 if name.endswith("bwd") else 1.0)
+            tf = per / (avg_us * 1e-6) / 1e12
             peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
             rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 5),
-                             traffic=None, avg_us=round(d["avg_us"], 2), calls=d["calls"],
-                             total_ms=round(d["total_ms"], 3), algorithmic_flops=int(per))
+                             algorithmic_flops=int(per), **base)
+        elif name.startswith("gt_linear"):
+            # skinny GEMMs (K, N <= 600): arithmetic intensity < 100 flop/B, i.e. HBM-bound on this chip
+            def lin_bytes(d):
+                M, N, K, xd, yd, _ = d
+                ex, ey = (2 if xd == 1 else 4), (2 if yd == 1 else 4)
+                b = M * K * ex + M * N * ey + N * K * 4
+                return b if name == "gt_linear_fwd" else (b + M * N * ey if name == "gt_linear_bwd" else b)
+            per = float(np.mean([lin_bytes(d) for _, d in items]))
+            gbs = per / (avg_us * 1e-6) / 1e9
+            fl = float(np.mean([2.0 * d[0] * d[1] * d[2] * (2 if name == "gt_linear_bwd" else 1) for _, d in items]))
+            rep[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=int(per),
+                             tflops=round(fl / (avg_us * 1e-6) / 1e12, 1), **base)
     return rep
 
 
@@ -232,17 +251,18 @@ def main():
 
     for i in range(opt.warmup):
         step(i)
-    timed = ["gt_aggregate_fwd", "gt_aggregate_bwd", "gt_attn_fwd", "gt_attn_bwd"]
-    timer = None if opt.no_kernel_timing else _lib.KernelTimer(timed)
-    _lib.TIMER = timer
     barrier()
+    if not opt.no_kernel_timing:
+        _lib.profile_enable(1 | 2 | 4)  # HIP events around the aggregate / attention / linear launches
+
     t0 = time.perf_counter()
     for i in range(opt.steps):
         loss = step(opt.warmup + i)
     t_enqueued = time.perf_counter() - t0  # host time to enqueue all steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
-    _lib.TIMER = None
+    records = [] if opt.no_kernel_timing else _lib.profile_records()
+    _lib.profile_enable(0)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -267,8 +287,13 @@ def main():
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }
-        if timer is not None:
-            rep = kernel_report(timer.summary(), dtype)
+        if records:
+            d_model, max_len = args.d_model, int(args.max_input_len)
+            fl = []
+            for b in batches:  # attention core flops over VALID lengths: 4 n^2 d per graph and layer
+                n = np.minimum(np.asarray(b._sizes, dtype=np.float64), max_len) + (1 if args.graph_pooling == "cls" else 0)
+                fl.append(float((4.0 * n * n * d_model).sum()))
+            rep = kernel_report(records, float(np.mean(fl)), dtype)
             if rep:
                 dom = max(rep, key=lambda k: rep[k]["total_ms"])
                 r = dict(rep[dom])

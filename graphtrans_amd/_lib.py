@@ -28,6 +28,9 @@ _u64 = C.c_uint64
 SIGNATURES = {
     "gt_version": (_i, []),
     "gt_last_error": (C.c_char_p, []),
+    "gt_profile_enable": (_i, [C.c_uint]),
+    "gt_profile_count": (_i64, []),
+    "gt_profile_get": (_i, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "gt_graph_prep_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gt_graph_prep": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_aggregate_fwd": (_i, [_i, _i, _i, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
@@ -112,6 +115,25 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+def profile_enable(mask):
+    """C-side launch profiler (common.hip): 1 aggregate | 2 attention | 4 linear; 0 = stop."""
+    check(lib().gt_profile_enable(int(mask)), "gt_profile_enable")
+
+
+def profile_records():
+    """[(name, ms, dims[6])] of every launch recorded since profile_enable(mask); synchronises."""
+    torch.cuda.synchronize()
+    L = lib()
+    out = []
+    name = C.create_string_buffer(64)
+    ms = C.c_float()
+    dims = (C.c_int64 * 6)()
+    for i in range(L.gt_profile_count()):
+        check(L.gt_profile_get(i, name, 64, C.byref(ms), dims), "gt_profile_get")
+        out.append((name.value.decode(), float(ms.value), list(dims)))
+    return out
 
 
 def launch(name, *args, meta=None):

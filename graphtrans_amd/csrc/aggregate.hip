@@ -534,6 +534,8 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
   GT_CHECK_ARG(E == 0 || (in_src && in_eid), "null CSR");
   GT_CHECK_ARG(conv != GT_CONV_GCN || (deg && dis), "GCN needs deg/dis");
   if (N == 0) return GT_OK;
+  GtProfScope prof__(GT_PROF_AGGREGATE, "gt_aggregate_fwd", stream_, {N, E, D, dtype == GT_F32 ? 4 : 2,
+                     edge_mode == GT_EDGE_LINEAR ? K * 4 : (edge_mode == GT_EDGE_TABLES ? K * 8 : 0), edge_mode});
   AggArgs a{};
   a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.ptr = in_ptr; a.nbr = in_src; a.eid = in_eid;
   a.deg = deg; a.dis = dis; a.self_param = self_param; a.attr = edge_attr; a.w = edge_w; a.b = edge_b;
@@ -582,6 +584,8 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
     return GT_ERR_WORKSPACE;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  GtProfScope prof__(GT_PROF_AGGREGATE, "gt_aggregate_bwd", stream_, {N, E, D, dtype == GT_F32 ? 4 : 2,
+                     edge_mode == GT_EDGE_LINEAR ? K * 4 : (edge_mode == GT_EDGE_TABLES ? K * 8 : 0), edge_mode});
   const int nslots = bwd_slots(edge_mode, K, table_rows);
   // persistent grid: enough wave-tiles to cover N, capped at BWD_BLOCKS
   int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);

@@ -440,6 +440,7 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   if (rc) return rc;
   GT_CHECK_ARG(qkv && ctx && lse && seq_desc, "null buffer");
   if (num_seqs == 0 || max_npos == 0) return GT_OK;
+  GtProfScope prof__(GT_PROF_ATTENTION, "gt_attn_fwd", stream_, {total_rows, d_model, nhead, dtype == GT_F32 ? 4 : 2, num_seqs, num_work});
   hipStream_t stream = (hipStream_t)stream_;
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, work_items,
@@ -469,6 +470,7 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   if (rc) return rc;
   GT_CHECK_ARG(qkv && ctx && d_ctx && lse && delta && d_qkv && seq_desc, "null buffer");
   if (num_seqs == 0 || max_npos == 0) return GT_OK;
+  GtProfScope prof__(GT_PROF_ATTENTION, "gt_attn_bwd", stream_, {total_rows, d_model, nhead, dtype == GT_F32 ? 4 : 2, num_seqs, num_work});
   hipStream_t stream = (hipStream_t)stream_;
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, ctx, d_ctx, const_cast<float*>(lse), delta, d_qkv, total_rows, d_model, nhead, seq_desc,

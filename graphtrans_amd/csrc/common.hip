@@ -15,3 +15,75 @@ void gt_set_error(const char* fmt, ...) {
 
 extern "C" int gt_version(void) { return 100; /* 0.1.0 */ }
 extern "C" const char* gt_last_error(void) { return g_err; }
+
+// ---- opt-in launch profiler ----------------------------------------------------------------------
+// HIP events recorded on the launch stream around selected entry points (bench.py's roofline
+// object needs per-kernel durations measured inside the timed region, also when the kernels are
+// enqueued by the composite layer calls).  Off by default; guarded by a mutex; never synchronises.
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ProfRecord {
+  const char* name;
+  hipEvent_t e0, e1;
+  int64_t dims[6];
+};
+std::mutex g_prof_mu;
+std::vector<ProfRecord> g_prof;
+std::vector<hipEvent_t> g_pool;  // events are created when profiling is switched on, not per launch
+size_t g_pool_next = 0;
+unsigned g_prof_mask = 0;
+constexpr size_t POOL_EVENTS = 16384;
+}  // namespace
+
+unsigned gt_prof_mask() { return g_prof_mask; }
+
+int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims) {
+  ProfRecord r{};
+  r.name = name;
+  for (int i = 0; i < 6; ++i) r.dims[i] = i < ndims ? dims[i] : 0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_pool_next + 2 > g_pool.size()) return -1;  // pool exhausted: stop recording, never allocate here
+  r.e0 = g_pool[g_pool_next++];
+  r.e1 = g_pool[g_pool_next++];
+  (void)hipEventRecord(r.e0, stream);
+  g_prof.push_back(r);
+  return (int64_t)g_prof.size() - 1;
+}
+
+void gt_prof_end(int64_t id, hipStream_t stream) {
+  if (id < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if ((size_t)id < g_prof.size()) (void)hipEventRecord(g_prof[id].e1, stream);
+}
+
+extern "C" int gt_profile_enable(unsigned mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (mask) {
+    g_prof.clear();
+    g_pool_next = 0;
+    while (g_pool.size() < POOL_EVENTS) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      g_pool.push_back(e);
+    }
+  }
+  g_prof_mask = mask;
+  return GT_OK;
+}
+
+extern "C" int64_t gt_profile_count(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  return (int64_t)g_prof.size();
+}
+
+extern "C" int gt_profile_get(int64_t i, char* name_out, int64_t name_cap, float* ms, int64_t* dims6) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (i < 0 || (size_t)i >= g_prof.size() || !name_out || !ms || !dims6) return GT_ERR_INVALID_ARG;
+  const ProfRecord& r = g_prof[i];
+  snprintf(name_out, (size_t)name_cap, "%s", r.name);
+  if (hipEventElapsedTime(ms, r.e0, r.e1) != hipSuccess) return GT_ERR_LAUNCH;  // caller synchronises first
+  for (int k = 0; k < 6; ++k) dims6[k] = r.dims[k];
+  return GT_OK;
+}

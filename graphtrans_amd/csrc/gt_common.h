@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <initializer_list>
+
 #include "../../include/graphtrans_hip.h"
 
 #define GT_WAVE 64
@@ -27,6 +29,21 @@ void gt_set_error(const char* fmt, ...);
       return GT_ERR_LAUNCH;                                                      \
     }                                                                            \
   } while (0)
+
+// opt-in launch profiler (common.hip): categories for gt_profile_enable's mask
+enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF_NORM = 8, GT_PROF_SEGMENT = 16 };
+unsigned gt_prof_mask();
+int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims);
+void gt_prof_end(int64_t id, hipStream_t stream);
+struct GtProfScope {
+  int64_t id;
+  hipStream_t stream;
+  GtProfScope(unsigned cat, const char* name, gt_stream_t st, std::initializer_list<int64_t> dims)
+      : id(-1), stream((hipStream_t)st) {
+    if (gt_prof_mask() & cat) id = gt_prof_begin(name, stream, dims.begin(), (int)dims.size());
+  }
+  ~GtProfScope() { gt_prof_end(id, stream); }
+};
 
 static inline int64_t gt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

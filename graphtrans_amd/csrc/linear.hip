@@ -475,6 +475,7 @@ extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* 
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
   GT_CHECK_ARG(dropout_p == 0.f || act == 1, "fused dropout requires the fused relu (mask is recovered from Y > 0)");
   if (M == 0) return GT_OK;
+  GtProfScope prof__(GT_PROF_LINEAR, "gt_linear_fwd", stream_, {M, N, K, x_dtype, y_dtype, compute});
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.act = act;
@@ -501,6 +502,8 @@ extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* 
   GT_CHECK_ARG(!dweight || x, "dweight needs x");
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
   hipStream_t stream = (hipStream_t)stream_;
+  GtProfScope prof__(GT_PROF_LINEAR, dx ? (dweight ? "gt_linear_bwd" : "gt_linear_bwd_dx") : "gt_linear_bwd_dw", stream_,
+                     {M, N, K, x_dtype, y_dtype, compute});
   LinArgs a{};
   a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.add1 = dx_add1; a.add2 = dx_add2;
   a.inv_keep = 1.0f / (1.0f - dropout_p);

@@ -49,6 +49,14 @@ enum gt_edge_mode {
 int gt_version(void);
 const char* gt_last_error(void);
 
+/* Opt-in launch profiler: HIP events on the launch stream around the selected entry points
+ * (mask: 1 aggregate, 2 attention, 4 linear).  gt_profile_enable(mask != 0) clears old records and
+ * starts recording, (0) stops; after a device synchronisation gt_profile_get returns the entry
+ * point name, its elapsed milliseconds and the 6 size fields it was called with. */
+int gt_profile_enable(unsigned mask);
+int64_t gt_profile_count(void);
+int gt_profile_get(int64_t index, char* name_out, int64_t name_cap, float* ms, int64_t* dims6);
+
 /* ---------------------------------------------------------------------------------------------
  * Graph structure, built once per collated batch.
  * Replaces: the per-layer `degree(row, N)` (modules/conv.py:57, PyG degree -> scatter_add) and the
