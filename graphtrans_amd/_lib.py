@@ -29,6 +29,7 @@ SIGNATURES = {
     "gt_version": (_i, []),
     "gt_last_error": (C.c_char_p, []),
     "gt_profile_enable": (_i, [C.c_uint]),
+    "gt_profile_resume": (_i, [C.c_uint]),
     "gt_profile_count": (_i64, []),
     "gt_profile_get": (_i, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "gt_graph_prep_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -73,6 +73,12 @@ extern "C" int gt_profile_enable(unsigned mask) {
   return GT_OK;
 }
 
+extern "C" int gt_profile_resume(unsigned mask) {  // toggle recording without clearing the records
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_mask = mask;
+  return GT_OK;
+}
+
 extern "C" int64_t gt_profile_count(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   return (int64_t)g_prof.size();

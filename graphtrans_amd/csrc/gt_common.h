@@ -58,6 +58,14 @@ __device__ __forceinline__ gt_bf16 gt_f32_to_bf16(float f) {  // round-to-neares
   return (gt_bf16)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 0..15) in ONE instruction: v_cvt_pk_bf16_f32 (gfx950, RNE).
+// The software sequence above costs ~7 VALU per element and made the GEMM staging VALU-bound.
+__device__ __forceinline__ uint32_t gt_pack_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 struct gt_f4 {
   float x, y, z, w;
 };
@@ -88,8 +96,8 @@ __device__ __forceinline__ void gt_store4<float>(float* p, float4 v) {
 template <>
 __device__ __forceinline__ void gt_store4<gt_bf16>(gt_bf16* p, float4 v) {
   uint2 u;
-  u.x = (uint32_t)gt_f32_to_bf16(v.x) | ((uint32_t)gt_f32_to_bf16(v.y) << 16);
-  u.y = (uint32_t)gt_f32_to_bf16(v.z) | ((uint32_t)gt_f32_to_bf16(v.w) << 16);
+  u.x = gt_pack_bf16(v.x, v.y);
+  u.y = gt_pack_bf16(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = u;
 }
 

@@ -18,12 +18,14 @@
 // consecutive output columns as accumulator registers -> 8/16-byte stores, float4 bias loads.
 #include "gt_common.h"
 #include "mfma_frag.h"
+#include <stdlib.h>
 
 namespace {
 using namespace gtf;
 
 constexpr int LT = 256;  // threads
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;
+int g_bm_override = 0;  // tuning knob (GT_LINEAR_BM env): rows per block for fwd/dx, 64 or 128
 
 struct LinArgs {
   const void* a;      // fwd: X[M][K]; dx: dY[M][N]; dw: dY[M][N]
@@ -41,6 +43,7 @@ struct LinArgs {
   uint32_t thr, s0, s1;
   int splits;
   int64_t m_per_split;
+  int dbg;  // ablation bits (GT_LINEAR_DBG): 1 no W loads, 2 no X loads, 4 no stores, 8 no MFMA
 };
 
 __device__ __forceinline__ uint32_t lin_hash(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col) {
@@ -70,17 +73,26 @@ struct Loader {
   static_assert(ROWS * CH % LT == 0, "tile must be a multiple of the block's chunk count");
   uint4 v[NIT];
   uint4 m[MASK ? NIT : 1];
+  int off[NIT];  // element offset of this thread's chunks relative to the tile origin (r * ld + cc)
 
-  __device__ __forceinline__ void load(const TS* src, int64_t ld, int64_t row0, int64_t nrows, int64_t col0,
-                                       int64_t ncols, const TS* mask) {
+  __device__ __forceinline__ void init(int64_t ld) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = threadIdx.x + i * LT;
+      off[i] = (c / CH) * (int)ld + (c % CH) * EPC;
+    }
+  }
+
+  // origin = address of tile element (0,0); rows_rem / cols_rem = valid extent from the origin
+  __device__ __forceinline__ void load(const TS* origin, int64_t rows_rem, int64_t cols_rem, const TS* mask_origin) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int c = threadIdx.x + i * LT;
       const int r = c / CH, cc = (c % CH) * EPC;
-      const int64_t gr = row0 + r, gc = col0 + cc;
-      const bool ok = gr < nrows && gc < ncols;
-      v[i] = ok ? *reinterpret_cast<const uint4*>(src + gr * ld + gc) : make_uint4(0, 0, 0, 0);
-      if constexpr (MASK) m[i] = (ok && mask) ? *reinterpret_cast<const uint4*>(mask + gr * ld + gc) : make_uint4(0, 0, 0, 0);
+      const bool ok = r < rows_rem && cc < cols_rem;
+      v[i] = ok ? *reinterpret_cast<const uint4*>(origin + off[i]) : make_uint4(0, 0, 0, 0);
+      if constexpr (MASK)
+        m[i] = (ok && mask_origin) ? *reinterpret_cast<const uint4*>(mask_origin + off[i]) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -125,16 +137,20 @@ struct Loader {
         for (int e = 0; e < EPC; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
       } else if constexpr (sizeof(TS) == 2) {
         // bf16 -> bf16 with no mask is a plain copy; with a mask the values were re-rounded above
-        uint4 o;
-        o.x = (uint32_t)gt_f32_to_bf16(f[0]) | ((uint32_t)gt_f32_to_bf16(f[1]) << 16);
-        o.y = (uint32_t)gt_f32_to_bf16(f[2]) | ((uint32_t)gt_f32_to_bf16(f[3]) << 16);
-        o.z = (uint32_t)gt_f32_to_bf16(f[4]) | ((uint32_t)gt_f32_to_bf16(f[5]) << 16);
-        o.w = (uint32_t)gt_f32_to_bf16(f[6]) | ((uint32_t)gt_f32_to_bf16(f[7]) << 16);
-        *reinterpret_cast<uint4*>(dst) = o;
+        if (!MASK || !has_mask) {
+          *reinterpret_cast<uint4*>(dst) = v[i];  // bf16 -> bf16: plain copy
+        } else {
+          uint4 o;
+          o.x = gt_pack_bf16(f[0], f[1]);
+          o.y = gt_pack_bf16(f[2], f[3]);
+          o.z = gt_pack_bf16(f[4], f[5]);
+          o.w = gt_pack_bf16(f[6], f[7]);
+          *reinterpret_cast<uint4*>(dst) = o;
+        }
       } else {
         uint2 o;
-        o.x = (uint32_t)gt_f32_to_bf16(f[0]) | ((uint32_t)gt_f32_to_bf16(f[1]) << 16);
-        o.y = (uint32_t)gt_f32_to_bf16(f[2]) | ((uint32_t)gt_f32_to_bf16(f[3]) << 16);
+        o.x = gt_pack_bf16(f[0], f[1]);
+        o.y = gt_pack_bf16(f[2], f[3]);
         *reinterpret_cast<uint2*>(dst) = o;
       }
     }
@@ -153,9 +169,10 @@ __device__ __forceinline__ void store_chunk(TO* p, float4 v) { gt_store4<TO>(p, 
 // forward: Y = act(X W^T + b) [dropout]
 // MFMA rows = output columns n (W rows), MFMA cols = output rows m (X rows).
 // ------------------------------------------------------------------------------------------------
-template <typename TX, typename TY, typename TC>
+template <typename TX, typename TY, typename TC, int BMT>
 __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   constexpr int BK = Tile<TC>::BK, LD = Tile<TC>::LD;
+  constexpr int BM = BMT, MI = BMT / 32;  // rows per block, m16-tiles per wave
   constexpr int LDS_ELEMS = (BM + BN) * LD;
   static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
@@ -166,35 +183,41 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   const int wm = wid & 1, wn = wid >> 1;  // wave tile: rows wm*64.., cols wn*64..
   const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
   const TX* X = reinterpret_cast<const TX*>(a.a);
-  f32x4 acc[4][4];  // [n tile j][m tile i]
+  f32x4 acc[4][MI];  // [n tile j][m tile i]
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   Loader<TX, TC, BM, BK, LD, false> lx;
   Loader<float, TC, BN, BK, LD, false> lw;
-  lx.load(X, a.K, m0, a.M, 0, a.K, nullptr);
-  lw.load(a.w, a.K, n0, a.N, 0, a.K, nullptr);
+  const int64_t Mx = (a.dbg & 2) ? 0 : a.M - m0, Nw = (a.dbg & 1) ? 0 : a.N - n0;
+  const TX* xo = X + m0 * a.K;
+  const float* wo = a.w + n0 * a.K;
+  lx.init(a.K);
+  lw.init(a.K);
+  lx.load(xo, Mx, a.K, nullptr);
+  lw.load(wo, Nw, a.K, nullptr);
   for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
     __syncthreads();
     lx.store(sX, false, 1.f);
     lw.store(sW, false, 1.f);
     __syncthreads();
     if (k0 + BK < a.K) {
-      lx.load(X, a.K, m0, a.M, k0 + BK, a.K, nullptr);
-      lw.load(a.w, a.K, n0, a.N, k0 + BK, a.K, nullptr);
+      lx.load(xo + k0 + BK, Mx, a.K - k0 - BK, nullptr);
+      lw.load(wo + k0 + BK, Nw, a.K - k0 - BK, nullptr);
     }
+    if (a.dbg & 8) continue;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      Frag<TC> fx[4], fw[4];
+      Frag<TC> fx[MI], fw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fx[i] = frag_load(sX + (wm * 64 + i * 16 + n) * LD + kk * 32 + g * 8);
+      for (int i = 0; i < MI; ++i) fx[i] = frag_load(sX + (wm * (BM / 2) + i * 16 + n) * LD + kk * 32 + g * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fw[j] = frag_load(sW + (wn * 64 + j * 16 + n) * LD + kk * 32 + g * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fx[i], acc[j][i]);
+        for (int i = 0; i < MI; ++i) acc[j][i] = mma(fw[j], fx[i], acc[j][i]);
     }
   }
   __syncthreads();
@@ -202,7 +225,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TY* Y = reinterpret_cast<TY*>(a.out);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + n * PATCH_LD + j * 16 + g * 4) =
@@ -213,9 +236,9 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int c = lane + q * 64;       // 256 float4 chunks: row = c / 16, col4 = c % 16
       const int r = c >> 4, c4 = (c & 15) * 4;
-      const int64_t m = m0 + wm * 64 + i * 16 + r;
+      const int64_t m = m0 + wm * (BM / 2) + i * 16 + r;
       const int64_t col = n0 + wn * 64 + c4;
-      if (m < a.M && col < a.N) {
+      if (m < a.M && col < a.N && !(a.dbg & 4)) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
         if (a.bias) v = gt_add4(v, *reinterpret_cast<const float4*>(a.bias + col));
         if (a.act == 1) v = gt_relu4(v);
@@ -237,8 +260,9 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
 // dX[M][K] = dZ[M][N] W[N][K]      (contraction over n)
 // MFMA rows = output columns k (A operand = W^T via transposed LDS read), MFMA cols = rows m.
 // ------------------------------------------------------------------------------------------------
-template <typename TY, typename TX, typename TC>
+template <typename TY, typename TX, typename TC, int BMT>
 __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
+  constexpr int BM = BMT, MI = BMT / 32;
   constexpr int BKc = Tile<TC>::BK;            // n-slots per stage
   constexpr int LDZ = Tile<TC>::LD;            // dZ tile [BM][BKc]
   constexpr int LDW = BN + Tile<TC>::PAD;      // W tile [BKc n][BN k]
@@ -254,42 +278,48 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
   const TY* dY = reinterpret_cast<const TY*>(a.a);
   const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
   const bool has_mask = Ym != nullptr;
-  f32x4 acc[4][4];  // [k tile j][m tile i]
+  f32x4 acc[4][MI];  // [k tile j][m tile i]
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   Loader<TY, TC, BM, BKc, LDZ, true> lz;
   Loader<float, TC, BKc, BN, LDW, false> lw;
-  lz.load(dY, a.N, m0, a.M, 0, a.N, Ym);
-  lw.load(a.w, a.K, 0, a.N, kk0, a.K, nullptr);
+  const TY* zo = dY + m0 * a.N;
+  const TY* mo = has_mask ? Ym + m0 * a.N : nullptr;
+  const float* wo = a.w + kk0;
+  lz.init(a.N);
+  lw.init(a.K);
+  lz.load(zo, a.M - m0, a.N, mo);
+  lw.load(wo, a.N, a.K - kk0, nullptr);
   for (int64_t c0 = 0; c0 < a.N; c0 += BKc) {
     __syncthreads();
     lz.store(sZ, has_mask, a.inv_keep);
     lw.store(sW, false, 1.f);
     __syncthreads();
     if (c0 + BKc < a.N) {
-      lz.load(dY, a.N, m0, a.M, c0 + BKc, a.N, Ym);
-      lw.load(a.w, a.K, c0 + BKc, a.N, kk0, a.K, nullptr);
+      const int64_t c1 = c0 + BKc;
+      lz.load(zo + c1, a.M - m0, a.N - c1, has_mask ? mo + c1 : nullptr);
+      lw.load(wo + c1 * a.K, a.N - c1, a.K - kk0, nullptr);
     }
 #pragma unroll
     for (int s = 0; s < BKc / 32; ++s) {
-      Frag<TC> fz[4], fw[4];
+      Frag<TC> fz[MI], fw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fz[i] = frag_load(sZ + (wm * 64 + i * 16 + n) * LDZ + s * 32 + g * 8);
+      for (int i = 0; i < MI; ++i) fz[i] = frag_load(sZ + (wm * (BM / 2) + i * 16 + n) * LDZ + s * 32 + g * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fw[j] = frag_load_tr(sW, LDW, s * 32, wk * 64 + j * 16, n, g);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mma(fw[j], fz[i], acc[j][i]);
+        for (int i = 0; i < MI; ++i) acc[j][i] = mma(fw[j], fz[i], acc[j][i]);
     }
   }
   __syncthreads();
   float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TX* dX = reinterpret_cast<TX*>(a.out);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + n * PATCH_LD + j * 16 + g * 4) =
@@ -300,7 +330,7 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int c = lane + q * 64;
       const int r = c >> 4, c4 = (c & 15) * 4;
-      const int64_t m = m0 + wm * 64 + i * 16 + r;
+      const int64_t m = m0 + wm * (BM / 2) + i * 16 + r;
       const int64_t col = kk0 + wk * 64 + c4;
       if (m < a.M && col < a.K) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
@@ -347,9 +377,11 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   float dbacc = 0.f;  // thread t < BN: column n0 + t
   Loader<TY, TC, BMc, BN, LDZ, true> lz;
   Loader<TX, TC, BMc, BN, LDX, false> lx;
+  lz.init(a.N);
+  lx.init(a.K);
   if (mb < me) {
-    lz.load(dY, a.N, mb, me, n0, a.N, Ym);
-    lx.load(X, a.K, mb, me, k0, a.K, nullptr);
+    lz.load(dY + mb * a.N + n0, me - mb, a.N - n0, has_mask ? Ym + mb * a.N + n0 : nullptr);
+    lx.load(X + mb * a.K + k0, me - mb, a.K - k0, nullptr);
   }
   for (int64_t m0 = mb; m0 < me; m0 += BMc) {
     __syncthreads();
@@ -357,8 +389,9 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     lx.store(sX, false, 1.f);
     __syncthreads();
     if (m0 + BMc < me) {
-      lz.load(dY, a.N, m0 + BMc, me, n0, a.N, Ym);
-      lx.load(X, a.K, m0 + BMc, me, k0, a.K, nullptr);
+      const int64_t m1 = m0 + BMc;
+      lz.load(dY + m1 * a.N + n0, me - m1, a.N - n0, has_mask ? Ym + m1 * a.N + n0 : nullptr);
+      lx.load(X + m1 * a.K + k0, me - m1, a.K - k0, nullptr);
     }
     if (blockIdx.y == 0 && threadIdx.x < BN) {
 #pragma unroll 8
@@ -463,6 +496,25 @@ int dw_splits(int64_t M, int64_t N, int64_t K, int compute) {
     else hipLaunchKernelGGL((KERNEL<gt_bf16, gt_bf16, gt_bf16>), grid, dim3(LT), 0, stream, args);                 \
   } while (0)
 
+#define GT_LIN_DISPATCH_BM(KERNEL, BMV, grid, args)                                                                \
+  do {                                                                                                             \
+    if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float, BMV>), grid, dim3(LT), 0, stream, args); \
+    else if (t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args);   \
+    else if (t0 == GT_F32 && t1 == GT_BF16) hipLaunchKernelGGL((KERNEL<float, gt_bf16, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args); \
+    else if (t0 == GT_BF16 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args); \
+    else hipLaunchKernelGGL((KERNEL<gt_bf16, gt_bf16, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args);            \
+  } while (0)
+
+int pick_bm(int64_t M) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("GT_LINEAR_BM");
+    env = e ? atoi(e) : 0;
+  }
+  if (env == 64 || env == 128) return env;
+  return M >= 4096 ? 64 : 128;
+}
+
 }  // namespace
 
 extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
@@ -479,10 +531,13 @@ extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* 
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.act = act;
+  { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
-  dim3 grid((unsigned)gt_cdiv(M, BM), (unsigned)gt_cdiv(N, BN));
+  const int bm = pick_bm(M);
+  dim3 grid((unsigned)gt_cdiv(M, bm), (unsigned)gt_cdiv(N, BN));
   const int t0 = x_dtype, t1 = y_dtype;
-  GT_LIN_DISPATCH(k_linear_fwd, grid, a);
+  if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_fwd, 64, grid, a);
+  else GT_LIN_DISPATCH_BM(k_linear_fwd, 128, grid, a);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
@@ -514,9 +569,11 @@ extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* 
   }
   if (dx) {
     a.out = dx;
-    dim3 grid((unsigned)gt_cdiv(M, BM), (unsigned)gt_cdiv(K, BN));
+    const int bm = pick_bm(M);
+    dim3 grid((unsigned)gt_cdiv(M, bm), (unsigned)gt_cdiv(K, BN));
     const int t0 = y_dtype, t1 = x_dtype;
-    GT_LIN_DISPATCH(k_linear_dx, grid, a);
+    if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_dx, 64, grid, a);
+    else GT_LIN_DISPATCH_BM(k_linear_dx, 128, grid, a);
   }
   if (dweight) {
     const int splits = dw_splits(M, N, K, compute);

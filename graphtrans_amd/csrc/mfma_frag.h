@@ -94,10 +94,10 @@ __device__ __forceinline__ Frag<T> frag_from_f32(const float* x);
 template <>
 __device__ __forceinline__ Frag<gt_bf16> frag_from_f32<gt_bf16>(const float* x) {
   Frag<gt_bf16> f;
-  f.v.x = (uint32_t)gt_f32_to_bf16(x[0]) | ((uint32_t)gt_f32_to_bf16(x[1]) << 16);
-  f.v.y = (uint32_t)gt_f32_to_bf16(x[2]) | ((uint32_t)gt_f32_to_bf16(x[3]) << 16);
-  f.v.z = (uint32_t)gt_f32_to_bf16(x[4]) | ((uint32_t)gt_f32_to_bf16(x[5]) << 16);
-  f.v.w = (uint32_t)gt_f32_to_bf16(x[6]) | ((uint32_t)gt_f32_to_bf16(x[7]) << 16);
+  f.v.x = gt_pack_bf16(x[0], x[1]);
+  f.v.y = gt_pack_bf16(x[2], x[3]);
+  f.v.z = gt_pack_bf16(x[4], x[5]);
+  f.v.w = gt_pack_bf16(x[6], x[7]);
   return f;
 }
 template <>

@@ -54,6 +54,7 @@ const char* gt_last_error(void);
  * starts recording, (0) stops; after a device synchronisation gt_profile_get returns the entry
  * point name, its elapsed milliseconds and the 6 size fields it was called with. */
 int gt_profile_enable(unsigned mask);
+int gt_profile_resume(unsigned mask); /* change the mask, keep the records (sampling) */
 int64_t gt_profile_count(void);
 int gt_profile_get(int64_t index, char* name_out, int64_t name_cap, float* ms, int64_t* dims6);
 
