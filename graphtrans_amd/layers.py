@@ -153,6 +153,7 @@ class _GcnLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h_in, vn, gs, spec, relu, residual, training, bn, *params):
+        ctx.set_materialize_grads(False)  # an unused output (x without consumers) must not cost a zero fill
         L = _bind()
         h_in = h_in.contiguous()
         N, D = h_in.shape
@@ -207,7 +208,9 @@ class _GcnLayer(torch.autograd.Function):
         params = ctx.saved_tensors[2:]
         desc = ctx.desc
         dev = x.device
-        gy = gy.contiguous() if gy is not None else torch.zeros_like(x)
+        if gy is None:  # only x had consumers: the layer itself contributes nothing
+            gy = torch.zeros_like(x)
+        gy = gy.contiguous()
         gx_c = gx.contiguous() if (gx is not None and ctx.has_vn) else None
         d_h = torch.empty_like(x)
         d_vn = torch.empty((desc.B, desc.D), dtype=torch.float32, device=dev) if ctx.has_vn else None

@@ -5,6 +5,10 @@ import torch.nn.functional as F
 
 def code2_loss(pred_list, y_arr):
     """dataset/code.py:39-45: mean over the max_seq_len heads of CrossEntropy(pred_i, y_arr[:, i])."""
+    stacked = getattr(pred_list, "stacked", None)
+    if stacked is not None:  # heads computed as one GEMM: equal-size means -> one cross-entropy over B*L rows
+        B, L, C = stacked.shape
+        return F.cross_entropy(stacked.to(torch.float32).reshape(B * L, C), y_arr[:, :L].reshape(B * L))
     loss = 0
     for i, pred in enumerate(pred_list):
         loss = loss + F.cross_entropy(pred.to(torch.float32), y_arr[:, i])

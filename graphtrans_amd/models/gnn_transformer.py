@@ -142,7 +142,13 @@ class GNNTransformer(BaseModel):
 
         if self.max_seq_len is None:
             return self.graph_pred_linear(h_graph)
-        return [self.graph_pred_linear_list[i](h_graph) for i in range(self.max_seq_len)]
+        # the max_seq_len heads (gnn_transformer.py:124-126) as ONE GEMM over the stacked weights; the
+        # returned list holds views of it (losses.code2_loss recognises them and runs one cross-entropy)
+        heads = self.graph_pred_linear_list
+        w = torch.cat([m.weight for m in heads], dim=0)
+        b = torch.cat([m.bias for m in heads], dim=0)
+        stacked = torch.nn.functional.linear(h_graph, w, b).view(h_graph.shape[0], self.max_seq_len, self.num_tasks)
+        return StackedHeads(stacked)
 
     def epoch_callback(self, epoch):
         if self.freeze_gnn is not None and epoch >= self.freeze_gnn:
@@ -158,6 +164,14 @@ class GNNTransformer(BaseModel):
                 module_index = new_key.index(module_name)
                 new_state_dict[".".join(new_key[module_index + 1:])] = v
         return new_state_dict
+
+
+class StackedHeads(list):
+    """list of the per-position logits (B, num_tasks), all views of `.stacked` (B, L, num_tasks)."""
+
+    def __init__(self, stacked):
+        super().__init__(stacked[:, i] for i in range(stacked.shape[1]))
+        self.stacked = stacked
 
 
 class PositionalEncoding(nn.Module):

@@ -201,6 +201,7 @@ def _scatter_raw(tokens, base, gs, lay, want_cls):
 class _SeqGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, cls, gs, lay, want_mask):
+        ctx.set_materialize_grads(False)
         h = _dev(h, "h")
         cls_c = None if cls is None else _dev(cls.reshape(-1).to(h.dtype), "cls")
         tokens, mask = _gather_raw(h, cls_c, gs, lay, want_mask)
