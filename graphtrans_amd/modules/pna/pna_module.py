@@ -1,0 +1,153 @@
+"""PNANodeEmbedding (modules/pna/pna_module.py:16-78) and the PNAConv it instantiates.
+
+The reference's conv is PyG 1.6.3's `PNAConv(towers=4, divide_input=True)` (third-party, not in the
+tree); its math is restated from the in-tree copy modules/pna_layer.py:131-167 and
+modules/pna/{aggregators,scalers}.py.  Parameter names / state_dict keys follow PyG:
+`pre_nns.{t}.0.{weight (F,2F),bias}`, `post_nns.{t}.0.{weight (F_out,(A*S+1)F),bias}`, `lin.{weight,bias}`,
+and `batch_norms.{i}.module.*` (PyG's BatchNorm wraps nn.BatchNorm1d as `.module`).
+
+Data path: the per-edge pre-Linear is split into per-node terms (U = x A^T + b for the target role,
+V = x B^T for the source role; two small batched GEMMs), the four aggregators run in ONE HIP pass
+over the CSR (gt_pna_aggregate_fwd/bwd), the degree scalers are per-node scalars applied while the
+post-Linear input is assembled.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ..gnn_module import batch_structure
+from ..norm import BatchNorm1d
+
+_AGG_SLOT = {"mean": 0, "max": 1, "min": 2, "std": 3}
+
+
+class PNAConv(nn.Module):
+    def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
+                 post_layers=1, divide_input=False):
+        super().__init__()
+        if edge_dim is not None or pre_layers != 1 or post_layers != 1:
+            raise NotImplementedError("the reference uses PNAConv without edge features and with single-layer pre/post nets")
+        if divide_input:
+            assert in_channels % towers == 0
+        assert out_channels % towers == 0
+        for a in aggregators:
+            if a not in _AGG_SLOT:
+                raise NotImplementedError(f"aggregator {a}")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aggregators, self.scalers = list(aggregators), list(scalers)
+        self.towers, self.divide_input = towers, divide_input
+        self.F_in = in_channels // towers if divide_input else in_channels
+        self.F_out = out_channels // towers
+        deg = torch.as_tensor(deg).to(torch.float)
+        # avg_deg over the degree HISTOGRAM tensor, exactly as PyG 1.6.3 / modules/pna_layer.py:92-97 do
+        self.avg_deg = {"lin": deg.mean().item(), "log": (deg + 1).log().mean().item(), "exp": deg.exp().mean().item()}
+        self.pre_nns = nn.ModuleList()
+        self.post_nns = nn.ModuleList()
+        for _ in range(towers):
+            self.pre_nns.append(nn.Sequential(nn.Linear(2 * self.F_in, self.F_in)))
+            self.post_nns.append(nn.Sequential(nn.Linear((len(aggregators) * len(scalers) + 1) * self.F_in, self.F_out)))
+        self.lin = nn.Linear(out_channels, out_channels)
+
+    def _scales(self, deg):
+        """per-node scaler factors (modules/pna/scalers.py:10-31), deg = in-degree (N,1,1)."""
+        out = []
+        for s in self.scalers:
+            if s == "identity":
+                out.append(None)
+            elif s == "amplification":
+                out.append(torch.log(deg + 1) / self.avg_deg["log"])
+            elif s == "attenuation":
+                sc = self.avg_deg["log"] / torch.log(deg + 1)
+                out.append(torch.where(deg == 0, torch.ones_like(sc), sc))
+            elif s == "linear":
+                out.append(deg / self.avg_deg["lin"])
+            elif s == "inverse_linear":
+                sc = self.avg_deg["lin"] / deg
+                out.append(torch.where(deg == 0, torch.ones_like(sc), sc))
+            else:
+                raise ValueError(s)
+        return out
+
+    def forward(self, x, edge_index, edge_attr=None, graph=None):
+        if edge_attr is not None:
+            raise NotImplementedError("PNAConv with edge features is not on the reference's path")
+        gs = graph
+        if gs is None:
+            from ...graph import GraphStructure
+            gs = GraphStructure.build(edge_index, torch.zeros(x.shape[0], dtype=torch.int64, device=x.device), num_graphs=1)
+        N, T, Fi = x.shape[0], self.towers, self.F_in
+        xt = x.view(N, T, Fi) if self.divide_input else x.view(N, 1, Fi).expand(N, T, Fi)
+        Wp = torch.stack([m[0].weight for m in self.pre_nns])  # (T, F, 2F): [A | B] on [x_i || x_j]
+        bp = torch.stack([m[0].bias for m in self.pre_nns])    # (T, F)
+        xb = xt.transpose(0, 1)                                # (T, N, F)
+        U = torch.baddbmm(bp.unsqueeze(1), xb, Wp[:, :, :Fi].transpose(1, 2)).transpose(0, 1).reshape(N, T * Fi)
+        V = torch.bmm(xb, Wp[:, :, Fi:].transpose(1, 2)).transpose(0, 1).reshape(N, T * Fi)
+        agg4 = ops.pna_aggregate(U, V, gs, T).view(N, T, 4, Fi)          # [mean | max | min | std]
+        agg = torch.cat([agg4[:, :, _AGG_SLOT[a]] for a in self.aggregators], dim=-1)  # (N, T, A*F)
+        deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(x.dtype).view(-1, 1, 1)
+        parts = [xt]
+        for sc in self._scales(deg):
+            parts.append(agg if sc is None else agg * sc)
+        out = torch.cat(parts, dim=-1)                                   # (N, T, (A*S+1) F)
+        Wq = torch.stack([m[0].weight for m in self.post_nns])           # (T, F_out, (A*S+1)F)
+        bq = torch.stack([m[0].bias for m in self.post_nns])
+        out = torch.baddbmm(bq.unsqueeze(1), out.transpose(0, 1), Wq.transpose(1, 2)).transpose(0, 1).reshape(N, -1)
+        return ops.linear_module(self.lin, out)
+
+
+class BatchNorm(nn.Module):
+    """PyG 1.6.3 `torch_geometric.nn.BatchNorm`: nn.BatchNorm1d held as `.module` (state_dict keys)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.module = BatchNorm1d(in_channels)
+
+    def forward(self, x, relu=False):
+        return self.module(x, relu=relu)
+
+
+class PNANodeEmbedding(nn.Module):
+    @staticmethod
+    def add_args(parser):
+        group = parser.add_argument_group("PNANet configs")
+        group.add_argument("--aggregators", type=str, nargs="+", default=["mean", "max", "min", "std"])
+        group.add_argument("--scalers", type=str, nargs="+", default=["identity", "amplification", "attenuation"])
+        group.add_argument("--post_layers", type=int, default=1)
+        group.add_argument("--add_edge", type=str, default="none")
+        group.set_defaults(gnn_residual=True)
+        group.set_defaults(gnn_dropout=0.3)
+        group.set_defaults(gnn_emb_dim=70)
+        group.set_defaults(gnn_num_layer=4)
+
+    def __init__(self, node_encoder, args):
+        super().__init__()
+        self.num_layer = args.gnn_num_layer
+        self.max_seq_len = args.max_seq_len
+        self.aggregators = args.aggregators
+        self.scalers = args.scalers
+        self.residual = args.gnn_residual
+        self.drop_ratio = args.gnn_dropout
+        self.graph_pooling = args.graph_pooling
+        self.node_encoder = node_encoder
+        self.layers = nn.ModuleList([
+            PNAConv(args.gnn_emb_dim, args.gnn_emb_dim, aggregators=self.aggregators, scalers=self.scalers, deg=args.deg,
+                    towers=4, divide_input=True) for _ in range(self.num_layer)])
+        self.batch_norms = nn.ModuleList([BatchNorm(args.gnn_emb_dim) for _ in range(self.num_layer)])
+
+    def forward(self, batched_data, perturb=None):
+        x, edge_index = batched_data.x, batched_data.edge_index
+        node_depth = batched_data.node_depth if hasattr(batched_data, "node_depth") else None
+        gs = batch_structure(batched_data)
+        encoded_node = self.node_encoder(x) if node_depth is None else self.node_encoder(x, node_depth.view(-1))
+        x = encoded_node + perturb if perturb is not None else encoded_node
+        for conv, batch_norm in zip(self.layers, self.batch_norms):
+            h = batch_norm(conv(x, edge_index, graph=gs), relu=True)  # F.relu(batch_norm(conv(x)))  (:73)
+            if self.residual:
+                x = h + x
+            else:  # the reference leaves x unchanged without the residual (h is dropped, :73-76)
+                x = x
+            x = F.dropout(x, self.drop_ratio, training=self.training)
+        return x

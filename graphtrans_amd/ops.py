@@ -481,3 +481,37 @@ def linear_module(mod, x, act=None, dropout_p=0.0, seed=0):
     if dropout_p > 0:
         y = torch.nn.functional.dropout(y, dropout_p, True)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# PNA multi-aggregator message passing
+# ------------------------------------------------------------------------------------------------
+class _PnaAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, V, gs, towers):
+        U, V = _dev(U.float(), "U"), _dev(V.float(), "V")
+        N, D = V.shape
+        out = torch.empty((N, towers, 4 * (D // towers)), dtype=torch.float32, device=V.device)
+        mean_v = torch.empty_like(V)
+        arg = torch.empty((N, 2, D), dtype=torch.int32, device=V.device)
+        _lib.launch("gt_pna_aggregate_fwd", _ptr(U), _ptr(V), N, D, towers, _ptr(gs.in_ptr), _ptr(gs.in_src),
+                    _ptr(gs.in_eid), _ptr(out), _ptr(mean_v), _ptr(arg), _stream())
+        ctx.save_for_backward(V, out, mean_v, arg)
+        ctx.gs, ctx.towers = gs, towers
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        V, out, mean_v, arg = ctx.saved_tensors
+        gs = ctx.gs
+        g = _dev(g.float(), "grad")
+        N, D = V.shape
+        dU, dV = torch.empty_like(V), torch.empty_like(V)
+        _lib.launch("gt_pna_aggregate_bwd", _ptr(V), _ptr(out), _ptr(mean_v), _ptr(arg), _ptr(g), N, D, ctx.towers,
+                    _ptr(gs.in_ptr), _ptr(gs.out_ptr), _ptr(gs.out_dst), _ptr(gs.out_eid), _ptr(dU), _ptr(dV), _stream())
+        return dU, dV, None, None
+
+
+def pna_aggregate(U, V, gs, towers):
+    """(N, towers, 4F): [U+mean V | U+max V | U+min V | std V] over the in-edges (gt_pna_aggregate_*)."""
+    return _PnaAggregate.apply(U, V, gs, towers)

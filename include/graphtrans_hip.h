@@ -120,6 +120,26 @@ int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* h, const vo
                      size_t workspace_bytes, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * PNA multi-aggregator message passing (mean | max | min | std over the in-edges in one pass).
+ * Replaces PyG PNAConv's per-edge Linear + 4 torch_scatter reductions (modules/pna/pna_module.py:73;
+ * math stated in-tree by modules/pna_layer.py:131-167, modules/pna/aggregators.py:11-34).  The
+ * per-edge message pre_nn_t([x_i || x_j]) is split into per-node terms m_k = U[i] + V[j_k]
+ * (U = x A_t^T + b, V = x B_t^T computed by the caller):
+ *   out[i][t][0F..1F) = U + mean_k V[j_k]   [1F..2F) = U + max_k V[j_k]   [2F..3F) = U + min_k V[j_k]
+ *   out[i][t][3F..4F) = sqrt(relu(E[V^2] - E[V]^2) + 1e-5);   empty neighbourhood: 0, 0, 0, sqrt(1e-5)
+ * with F = dim / towers (tower-major layout, the A-operand of the post Linear).  fp32.
+ * mean_v [N][dim] and arg [N][2][dim] (original edge ids of the first max / min) are saved for the
+ * backward, which returns dU and dV.  Deterministic (CSR / CSC traversal, no atomics).
+ */
+int gt_pna_aggregate_fwd(const float* U, const float* V, int64_t num_nodes, int64_t dim, int towers,
+                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, float* out,
+                         float* mean_v, int32_t* arg, gt_stream_t stream);
+int gt_pna_aggregate_bwd(const float* V, const float* out, const float* mean_v, const int32_t* arg,
+                         const float* grad_out, int64_t num_nodes, int64_t dim, int towers, const int32_t* in_ptr,
+                         const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* dU, float* dV,
+                         gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-graph segment ops on the sorted `batch` vector (virtual node + pooling).
  * gt_segment_bcast_add: out[n] = (x ? x[n] : 0) + seg[g(n)]      -- `h + vn[batch]`
  *   (modules/gnn_module.py:199); also the backward of global_add_pool.

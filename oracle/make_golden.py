@@ -351,6 +351,35 @@ def g8_model():
             run_and_dump(f"G8_{name}_{mode}", meta, inputs, m, lambda: m(b), float_inputs=("x",) if feat == "tud" else ())
 
 
+def g9_pna():
+    """In-tree PNA aggregators / scalers (modules/pna/aggregators.py, scalers.py) on hand-made
+    segments incl. empty ones; the only runnable pieces of the reference's PNA statement."""
+    spec = importlib.util.spec_from_file_location("ref_pna_aggr", os.path.join(REF, "modules/pna/aggregators.py"))
+    aggr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(aggr)
+    spec = importlib.util.spec_from_file_location("ref_pna_scal", os.path.join(REF, "modules/pna/scalers.py"))
+    scal = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scal)
+    g = torch.Generator().manual_seed(9)
+    n, e = 9, 40
+    index = torch.randint(0, n, (e,), generator=g)
+    index[index == 4] = 5  # segment 4 is empty; segment 8 possibly too
+    index[index == 8] = 0
+    src = torch.randn(e, 4, 6, generator=g)
+    d = {"meta": np.array(json.dumps(dict(kind="pna_aggr", n=n))), "in.src": src.numpy(), "in.index": index.numpy()}
+    for name in ("mean", "max", "min", "std", "var", "sum"):
+        d["out." + name] = aggr.AGGREGATORS[name](src, index, n).numpy()
+    deg = torch.bincount(index, minlength=n).float().view(-1, 1, 1)
+    avg = {"lin": 2.5, "log": 1.1, "exp": 20.0}
+    d["in.deg"] = deg.numpy()
+    x = torch.randn(n, 4, 6, generator=g)
+    d["in.x"] = x.numpy()
+    for name in ("identity", "amplification", "attenuation", "linear", "inverse_linear"):
+        d["out.scale_" + name] = scal.SCALERS[name](x.clone(), deg, avg).numpy()
+    np.savez_compressed(os.path.join(OUT, "G9_pna_aggr_scalers.npz"), **d)
+    print("G9_pna_aggr_scalers")
+
+
 def g10_struct():
     for name, b in (("tiny", synth.tiny_mixed(seed=3, sizes=(14, 1, 23, 12), feat="dense", num_features=4)),
                     ("code2", synth.code2_like(B=6, seed=1)), ("mol", synth.molpcba_like(B=12, seed=2))):
@@ -373,6 +402,7 @@ if __name__ == "__main__":
     g6_encoder()
     g7_masked()
     g8_model()
+    g9_pna()
     g10_struct()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total {total / 1024:.0f} KB in {len(os.listdir(OUT))} files")

@@ -476,3 +476,138 @@ def mol_loss(pred, y):
 def tud_loss(pred, y):
     """dataset/tud.py:25-27."""
     return F.cross_entropy(pred, y)
+
+
+# --------------------------------------------------------------------------------------------
+# a11: PNA  (PyG 1.6.3 PNAConv is third-party and absent: restated from the in-tree copy
+# modules/pna_layer.py:131-167 + modules/pna/aggregators.py:11-34 + modules/pna/scalers.py:10-31;
+# the aggregator / scaler functions are pinned by the G9 golden fixtures, the conv wiring is
+# PARITY-UNPINNED: no runnable reference implementation of it exists in this container)
+# --------------------------------------------------------------------------------------------
+
+
+def scatter_mean(src, index, n):
+    s = torch.zeros((n,) + src.shape[1:], dtype=src.dtype).index_add_(0, index, src)
+    c = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones(index.numel(), dtype=src.dtype))
+    return s / c.clamp(min=1).view((-1,) + (1,) * (src.dim() - 1))
+
+
+def scatter_minmax(src, index, n, reduce):
+    """torch-scatter semantics: empty segments -> 0.  Gradient goes to ONE winner (the first
+    extremum in edge order), like torch_scatter's arg-based backward."""
+    flat = src.reshape(src.shape[0], -1)
+    big = float("inf") if reduce == "min" else float("-inf")
+    out = torch.full((n, flat.shape[1]), big, dtype=src.dtype)
+    idx = index.view(-1, 1).expand_as(flat)
+    out = out.scatter_reduce(0, idx, flat.detach(), reduce="amin" if reduce == "min" else "amax", include_self=True)
+    # first position attaining the extremum, per (segment, column)
+    hit = flat.detach() == out[index]
+    pos = torch.arange(flat.shape[0]).view(-1, 1).expand_as(flat)
+    pos = torch.where(hit, pos, torch.full_like(pos, flat.shape[0]))
+    first = torch.full((n, flat.shape[1]), flat.shape[0], dtype=torch.long).scatter_reduce(0, idx, pos, reduce="amin")
+    has = first < flat.shape[0]
+    gathered = torch.gather(flat, 0, first.clamp(max=max(flat.shape[0] - 1, 0))) if flat.shape[0] else torch.zeros_like(out)
+    res = torch.where(has, gathered, torch.zeros_like(out))
+    return res.view((n,) + src.shape[1:])
+
+
+def pna_aggregators(src, index, n, names):
+    """modules/pna/aggregators.py:11-34."""
+    outs = []
+    for a in names:
+        if a == "mean":
+            outs.append(scatter_mean(src, index, n))
+        elif a in ("max", "min"):
+            outs.append(scatter_minmax(src, index, n, a))
+        elif a == "std":
+            mean = scatter_mean(src, index, n)
+            mean_sq = scatter_mean(src * src, index, n)
+            outs.append(torch.sqrt(torch.relu(mean_sq - mean * mean) + 1e-5))
+        elif a == "var":
+            mean = scatter_mean(src, index, n)
+            outs.append(scatter_mean(src * src, index, n) - mean * mean)
+        elif a == "sum":
+            outs.append(torch.zeros((n,) + src.shape[1:], dtype=src.dtype).index_add_(0, index, src))
+        else:
+            raise ValueError(a)
+    return torch.cat(outs, dim=-1)
+
+
+def pna_scalers(src, deg, avg_deg, names):
+    """modules/pna/scalers.py:10-31; deg shaped (N,1,1)."""
+    outs = []
+    for s in names:
+        if s == "identity":
+            outs.append(src)
+        elif s == "amplification":
+            outs.append(src * (torch.log(deg + 1) / avg_deg["log"]))
+        elif s == "attenuation":
+            scale = avg_deg["log"] / torch.log(deg + 1)
+            scale = torch.where(deg == 0, torch.ones_like(scale), scale)
+            outs.append(src * scale)
+        elif s == "linear":
+            outs.append(src * (deg / avg_deg["lin"]))
+        elif s == "inverse_linear":
+            scale = avg_deg["lin"] / deg
+            scale = torch.where(deg == 0, torch.ones_like(scale), scale)
+            outs.append(src * scale)
+        else:
+            raise ValueError(s)
+    return torch.cat(outs, dim=-1)
+
+
+def pna_avg_deg(deg_hist):
+    """modules/pna_layer.py:92-97: statistics of the degree HISTOGRAM tensor (a PyG 1.6.3 quirk)."""
+    d = torch.as_tensor(deg_hist).to(torch.float)
+    return {"lin": d.mean().item(), "log": (d + 1).log().mean().item(), "exp": d.exp().mean().item()}
+
+
+def pna_conv(sd, prefix, x, edge_index, aggregators, scalers, avg_deg, towers=4):
+    """PNAConv.forward/message/aggregate with divide_input=True, no edge features
+    (modules/pna_layer.py:131-167; modules/pna/pna_module.py:43-51)."""
+    n, D = x.shape
+    Fi = D // towers
+    xt = x.view(n, towers, Fi)
+    row, col = edge_index[0], edge_index[1]
+    h = torch.cat([xt[col], xt[row]], dim=-1)  # [x_i || x_j]: i = target (edge_index[1]), j = source
+    msgs = torch.stack([linear(h[:, t], sd, f"{prefix}.pre_nns.{t}.0") for t in range(towers)], dim=1)
+    out = pna_aggregators(msgs, col, n, aggregators)
+    deg = torch.zeros(n, dtype=x.dtype).index_add_(0, col, torch.ones(col.numel(), dtype=x.dtype)).view(-1, 1, 1)
+    out = pna_scalers(out, deg, avg_deg, scalers)
+    out = torch.cat([xt, out], dim=-1)
+    out = torch.cat([linear(out[:, t], sd, f"{prefix}.post_nns.{t}.0") for t in range(towers)], dim=1)
+    return linear(out, sd, prefix + ".lin")
+
+
+def pna_node_embedding(sd, prefix, args, data, perturb=None, training=True):
+    """PNANodeEmbedding.forward (modules/pna/pna_module.py:57-78)."""
+    s = _sub(sd, prefix)
+    x = node_encode(s, "node_encoder", data.x, getattr(data, "node_depth", None))
+    if perturb is not None:
+        x = x + perturb
+    avg = pna_avg_deg(args.deg)
+    for i in range(args.gnn_num_layer):
+        h = pna_conv(s, f"layers.{i}", x, data.edge_index, args.aggregators, args.scalers, avg)
+        h = torch.relu(batch_norm(h, s, f"batch_norms.{i}.module", training))
+        if args.gnn_residual:
+            x = h + x
+        x = dropout(x, args.gnn_dropout, training)
+    return x
+
+
+def pna_transformer(sd, args, data, perturb=None, training=True):
+    """PNATransformer.forward (models/pna_transformer.py:78-100); `mean` pooling divides by the
+    number of VALID positions here (:89), unlike GNNTransformer."""
+    h = pna_node_embedding(sd, "gnn_node", args, data, perturb, training)
+    h = linear(h, sd, "gnn2transformer")
+    padded, mask, _, _ = pad_batch(h, data.batch, int(args.max_input_len))
+    out, mask2 = transformer_node_encoder(sd, "transformer_encoder", args, padded, mask, training)
+    if args.graph_pooling in ("last", "cls"):
+        h_graph = out[-1]
+    elif args.graph_pooling == "mean":
+        h_graph = out.sum(0) / (~mask2).sum(-1, keepdim=True)
+    else:
+        raise NotImplementedError
+    if args.max_seq_len is None:
+        return linear(h_graph, sd, "graph_pred_linear")
+    return [linear(h_graph, sd, f"graph_pred_linear_list.{i}") for i in range(args.max_seq_len)]

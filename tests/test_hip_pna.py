@@ -1,0 +1,97 @@
+"""GPU parity of the PNA path (gt_pna_aggregate_fwd/bwd, PNAConv, PNANodeEmbedding, PNATransformer)
+against the CPU oracle's restatement of modules/pna_layer.py:131-167 (whose aggregators / scalers
+are pinned by the G9 fixtures; the conv wiring itself is parity-unpinned: PyG's PNAConv is absent).
+fp32, 1e-4 scale-relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(seed, n_graphs=6, with_dupes=True):
+    from graphtrans_amd import synth
+
+    b = synth.tiny_mixed(seed=seed, sizes=tuple(int(s) for s in np.random.default_rng(seed).integers(1, 30, n_graphs)),
+                         feat="code2")
+    if with_dupes:  # duplicate some edges: ties for max/min between identical sources
+        ei = b.edge_index
+        b.edge_index = torch.cat([ei, ei[:, ::3]], dim=1).contiguous()
+    return b
+
+
+@pytest.mark.parametrize("D,towers", [(272, 4), (64, 4), (16, 1), (520, 2)])
+def test_pna_aggregate_vs_oracle(D, towers):
+    from graphtrans_amd import ops
+    from graphtrans_amd.graph import GraphStructure
+    from oracle import reference_math as rm
+
+    torch.manual_seed(0)
+    b = _graph(3)
+    N = b.num_nodes
+    F = D // towers
+    U, V = torch.randn(N, D), torch.randn(N, D)
+    w = torch.randn(N, towers, 4 * F)
+    # oracle: m_k = U[dst] + V[src] per edge, then the in-tree aggregators
+    Ur, Vr = U.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    row, col = b.edge_index[0], b.edge_index[1]
+    m = (Ur[col] + Vr[row]).view(-1, towers, F)
+    ref = rm.pna_aggregators(m, col, N, ["mean", "max", "min", "std"])
+    (ref * w).sum().backward()
+    gs = GraphStructure.build(b.edge_index.to(DEV), b.batch.to(DEV), num_graphs=b.num_graphs)
+    Ud, Vd = U.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
+    out = ops.pna_aggregate(Ud, Vd, gs, towers)
+    (out * w.to(DEV)).sum().backward()
+    assert_close(out.cpu(), ref.detach(), what="agg")
+    assert_close(Ud.grad.cpu(), Ur.grad, what="dU")
+    assert_close(Vd.grad.cpu(), Vr.grad, what="dV")
+
+
+def _args(**kw):
+    from oracle.reference_math import default_args
+
+    return default_args(gnn_emb_dim=32, gnn_num_layer=2, gnn_residual=True, gnn_dropout=0.0, d_model=32, nhead=2,
+                        dim_feedforward=48, transformer_dropout=0.0, num_encoder_layers=2, transformer_norm_input=True,
+                        aggregators=["mean", "max", "min", "std"], scalers=["identity", "amplification", "attenuation"],
+                        deg=torch.tensor([0, 5, 9, 7, 3, 1, 0, 2]), **kw)
+
+
+def _randomize(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.2))
+            if n.endswith("module.weight") or "norm" in n and n.endswith("weight"):
+                p.add_(1.0)
+
+
+@pytest.mark.parametrize("pooling,max_seq_len,training", [("cls", 3, True), ("mean", None, True), ("cls", None, False)])
+def test_pna_transformer_vs_oracle(pooling, max_seq_len, training):
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.pna_transformer import PNATransformer
+    from oracle import reference_math as rm
+
+    torch.manual_seed(1)
+    args = _args(graph_pooling=pooling, max_seq_len=max_seq_len)
+    b = _graph(5, with_dupes=False)
+    model = PNATransformer(7, ASTNodeEncoder(32, 11, 13, 20), None, args)
+    _randomize(model, 11)
+    model.train(training)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    ref = rm.pna_transformer(sd, args, b, None, training)
+    ref = ref if isinstance(ref, list) else [ref]
+    g = torch.Generator().manual_seed(2)
+    ws = [torch.randn(r.shape, generator=g) for r in ref]
+    sum((r * w).sum() for r, w in zip(ref, ws)).backward()
+    model = model.to(DEV)
+    out = model(b.to(DEV))
+    out = out if isinstance(out, list) else [out]
+    sum((o * w.to(DEV)).sum() for o, w in zip(out, ws)).backward()
+    for i, (o, r) in enumerate(zip(out, ref)):
+        assert_close(o.detach().cpu(), r.detach(), what=f"out{i}")
+    for k, p in model.named_parameters():
+        if sd[k].grad is not None:
+            assert_close(p.grad.cpu(), sd[k].grad, what=f"grad {k}")

@@ -141,3 +141,17 @@ def test_degree_uses_source_index():
     """conv.py:57: deg = degree(row) + 1 where row = edge_index[0] (Appendix A)."""
     ei = torch.tensor([[0, 0, 0, 1], [1, 2, 3, 0]])
     assert rm.gcn_degree(ei, 4).tolist() == [4.0, 2.0, 1.0, 1.0]
+
+
+def test_pna_aggregators_scalers_golden():
+    """G9: the oracle's PNA aggregators / scalers vs the reference's in-tree functions
+    (modules/pna/aggregators.py:11-34, modules/pna/scalers.py:10-31), incl. empty segments."""
+    g = Golden("G9_pna_aggr_scalers")
+    src, index, n = g.inputs["src"], g.inputs["index"], g.meta["n"]
+    for name in ("mean", "max", "min", "std", "var", "sum"):
+        got = rm.pna_aggregators(src, index, n, [name])
+        assert_close(got, g.outs[name], what=name)
+    deg, x = g.inputs["deg"], g.inputs["x"]
+    avg = {"lin": 2.5, "log": 1.1, "exp": 20.0}
+    for name in ("identity", "amplification", "attenuation", "linear", "inverse_linear"):
+        assert_close(rm.pna_scalers(x, deg, avg, [name]), g.outs["scale_" + name], what=name)
