@@ -55,6 +55,10 @@ def model_args(workload, dtype):
     elif workload == "er":
         a.update(gnn_virtual_node=False, gnn_num_layer=4, gnn_emb_dim=256, gnn_JK="last", d_model=256,
                  dim_feedforward=1024, transformer_dropout=0.0, max_seq_len=None)
+    elif workload == "code2-pna":  # configs/code2/pna-transformer/pooling=cls+norm_input.yml:16-23
+        a.update(gnn_virtual_node=False, gnn_num_layer=4, gnn_emb_dim=272, gnn_JK="last", gnn_residual=True,
+                 gnn_dropout=0.0, aggregators=["mean", "max", "min", "std"],
+                 scalers=["identity", "amplification", "attenuation"], deg=torch.tensor([0, 4000, 2500, 900, 300, 90, 30, 9]))
     return SimpleNamespace(**a)
 
 
@@ -75,6 +79,12 @@ def build(workload, dtype, device, batch_graphs):
         gen = lambda seed: synth.molpcba_like(B=batch_graphs, seed=seed)
         loss = lambda out, b: losses.mol_loss(out, b.y)
         name = "OGBG-Molpcba-like synthetic, GraphTrans GIN-Virtual L5 D300 JK=cat cls norm_input"
+    elif workload == "code2-pna":
+        from graphtrans_amd.models.pna_transformer import PNATransformer
+        model = PNATransformer(5002, ASTNodeEncoder(D, 98, 10030, 20), None, args)
+        gen = lambda seed: synth.code2_like(B=batch_graphs, seed=seed)
+        loss = lambda out, b: losses.code2_loss(out, b.y_arr)
+        name = "OGBG-Code2-like synthetic, GraphTrans (PNA) L4 D272 towers 4, cls norm_input, 4 enc layers d128"
     elif workload == "nci1":
         def zero_cls(_):
             return lambda _x: 0
@@ -194,7 +204,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er"])
+    ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er", "code2-pna"])
     ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,7 +232,7 @@ def main():
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
     from graphtrans_amd import ops as gt_ops
     gt_ops.set_matmul_dtype(dtype)  # GNN linears: fp32 storage, MFMA compute type follows --dtype
-    per_gpu = opt.batch or (32 if opt.workload == "nci1" else 256)
+    per_gpu = opt.batch or {"nci1": 32, "code2-pna": 128}.get(opt.workload, 256)
     torch.manual_seed(1234)  # identical initial parameters on every rank
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()

@@ -57,15 +57,22 @@ __global__ void __launch_bounds__(PT) k_pna_fwd(PnaArgs a) {
   for (int j = 0; j < NCH; ++j) {
     const int col = (sl + j * 64) * 4;
     if (col >= D) continue;
-    float4 s1 = gt_zero4(), s2 = gt_zero4();
+    // Welford running mean / M2 per column: E[V^2] - E[V]^2 cancels catastrophically when the
+    // neighbours' values nearly agree (variance ~1e-6), exactly where the std gradient 1/std is largest
+    float4 mv = gt_zero4(), m2 = gt_zero4();
+    float cnt = 0.f;
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     int4 amx = make_int4(-1, -1, -1, -1), amn = make_int4(-1, -1, -1, -1);
     for (int p = beg; p < end; ++p) {
       const int src = a.nbr[p], e = a.eid[p];
       const float4 x = *reinterpret_cast<const float4*>(a.V + (int64_t)src * D + col);
-      s1 = gt_add4(s1, x);
-      s2 = make_float4(fmaf(x.x, x.x, s2.x), fmaf(x.y, x.y, s2.y), fmaf(x.z, x.z, s2.z), fmaf(x.w, x.w, s2.w));
+      cnt += 1.f;
+      const float ik = 1.0f / cnt;
+      const float4 dl = make_float4(x.x - mv.x, x.y - mv.y, x.z - mv.z, x.w - mv.w);
+      mv = gt_fma4(dl, ik, mv);
+      m2 = make_float4(fmaf(dl.x, x.x - mv.x, m2.x), fmaf(dl.y, x.y - mv.y, m2.y), fmaf(dl.z, x.z - mv.z, m2.z),
+                       fmaf(dl.w, x.w - mv.w, m2.w));
       if (x.x > mx.x) { mx.x = x.x; amx.x = e; }
       if (x.y > mx.y) { mx.y = x.y; amx.y = e; }
       if (x.z > mx.z) { mx.z = x.z; amx.z = e; }
@@ -76,17 +83,14 @@ __global__ void __launch_bounds__(PT) k_pna_fwd(PnaArgs a) {
       if (x.w < mn.w) { mn.w = x.w; amn.w = e; }
     }
     float4 mean = gt_zero4(), omax = gt_zero4(), omin = gt_zero4(), ostd;
-    float4 mv = gt_zero4();
     if (end > beg) {
       const float inv = 1.0f / deg;
       const float4 u = *reinterpret_cast<const float4*>(a.U + v * D + col);
-      mv = gt_scale4(s1, inv);
       mean = gt_add4(u, mv);
       omax = gt_add4(u, mx);
       omin = gt_add4(u, mn);
-      const float4 ms = gt_scale4(s2, inv);
-      ostd = make_float4(sqrtf(fmaxf(ms.x - mv.x * mv.x, 0.f) + 1e-5f), sqrtf(fmaxf(ms.y - mv.y * mv.y, 0.f) + 1e-5f),
-                         sqrtf(fmaxf(ms.z - mv.z * mv.z, 0.f) + 1e-5f), sqrtf(fmaxf(ms.w - mv.w * mv.w, 0.f) + 1e-5f));
+      ostd = make_float4(sqrtf(m2.x * inv + 1e-5f), sqrtf(m2.y * inv + 1e-5f), sqrtf(m2.z * inv + 1e-5f),
+                         sqrtf(m2.w * inv + 1e-5f));
     } else {
       const float e0 = sqrtf(1e-5f);
       ostd = make_float4(e0, e0, e0, e0);
