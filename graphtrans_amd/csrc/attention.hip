@@ -50,6 +50,11 @@ struct AttnArgs {
   void* out;          // fwd: ctx ; bwd: d_qkv
   const int32_t* desc;
   const int32_t* work;  // optional [num_work][2] = {sequence, 64-row tile}: 1-D grid over real tiles only
+  // optional dense masks of CausalSelfAttention (modules/masked_transformer_encoder.py:44-47): entries == 0 are
+  // FILLED with mask_fill (masked_fill semantics: finite value, no gradient through the score)
+  const float* dense_mask;  // [num_seqs][npos][npos]
+  const float* key_valid;   // [num_seqs][npos]
+  float mask_fill2;         // mask_value * log2(e)
   int64_t rows, d_model, row_stride;
   int nhead;
   float scale_log2;   // scale * log2(e)
@@ -60,6 +65,12 @@ struct AttnArgs {
 };
 
 // head dims 8 / 16 are zero-padded to one 32-deep MFMA step (HDP); LDS rows are HDP wide + 16 B pad
+__device__ __forceinline__ bool dense_masked(const AttnArgs& a, int seq, int qpos, int kp, int npos) {
+  if (a.key_valid && a.key_valid[(int64_t)seq * npos + kp] == 0.f) return true;
+  if (a.dense_mask && a.dense_mask[((int64_t)seq * npos + qpos) * npos + kp] == 0.f) return true;
+  return false;
+}
+
 template <int HD, typename T>
 struct Lds {
   static constexpr int HDP = HD < 32 ? 32 : HD;
@@ -134,6 +145,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
   for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
     __syncthreads();
     load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
@@ -155,6 +167,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int kp = k0 + g * 8 + i;
       s[i] = (kp >= kv_off && kp < kv_end) ? s[i] * a.scale_log2 : -INFINITY;
+      if (dense && qvalid && kp < npos && dense_masked(a, seq, qp, kp, npos)) s[i] = a.mask_fill2;
       mt = fmaxf(mt, s[i]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
@@ -246,6 +259,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   delta += __shfl_xor(delta, 32, 64);
   const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
+  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
   zero_pad_cols<T, HD>(sK);
   zero_pad_cols<T, HD>(sV);
 
@@ -274,13 +288,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         const int i = t * 4 + r;
         const int kp = k0 + g * 8 + i;
         const bool kvalid = kp >= kv_off && kp < kv_end;
-        const float p = kvalid ? exp2f(c[r] * a.scale_log2 - lse) : 0.f;
+        const bool filled = dense && qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
+        const float p = kvalid ? exp2f((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) : 0.f;
         float dpi = dp[r];
         if (a.drop_thr) {
           const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)kp);
           dpi = h >= a.drop_thr ? dpi * a.inv_keep : 0.f;
         }
-        ds[i] = p * (dpi - delta);
+        ds[i] = filled ? 0.f : p * (dpi - delta);  // masked_fill: no gradient through a filled score
       }
     }
     const Frag<T> bds = frag_from_f32<T>(ds);
@@ -340,6 +355,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
   for (int q0 = 0; any_valid && q0 < npos; q0 += TILE) {
@@ -370,7 +386,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         const int qi = g * 8 + i;  // query row inside the tile owned by this slot
         const int qpos = q0 + qi;
         const bool ok = kvalid && qpos < npos;
-        float p = ok ? exp2f(c[r] * a.scale_log2 - sLse[qi]) : 0.f;
+        const bool filled = dense && ok && dense_masked(a, seq, qpos, kp, npos);
+        float p = ok ? exp2f((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) : 0.f;
         float dpi = dp[r];
         float pdrop = p;
         if (a.drop_thr) {
@@ -380,7 +397,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
           pdrop = keep ? p * a.inv_keep : 0.f;
         }
         pd[i] = pdrop;
-        ds[i] = p * (dpi - sDelta[qi]);
+        ds[i] = filled ? 0.f : p * (dpi - sDelta[qi]);
       }
     }
     const Frag<T> bp = frag_from_f32<T>(pd);
@@ -418,8 +435,10 @@ int check_attn(const char* fn, int dtype, int64_t d_model, int nhead, int64_t nu
 
 AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* lse, float* delta, void* out,
                    int64_t rows, int64_t d_model, int nhead, const int32_t* desc, const int32_t* work,
-                   int64_t row_stride, float scale, float dropout_p, uint64_t seed) {
+                   int64_t row_stride, float scale, float dropout_p, uint64_t seed, const float* dense_mask,
+                   const float* key_valid, float mask_value) {
   AttnArgs a{};
+  a.dense_mask = dense_mask; a.key_valid = key_valid; a.mask_fill2 = mask_value * LOG2E;
   a.qkv = qkv; a.ctx = ctx; a.d_ctx = d_ctx; a.lse = lse; a.delta = delta; a.out = out; a.desc = desc; a.work = work;
   a.rows = rows; a.d_model = d_model; a.row_stride = row_stride; a.nhead = nhead;
   a.scale = scale; a.scale_log2 = scale * LOG2E;
@@ -434,8 +453,9 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
 
 extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
                            int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
-                           int64_t max_npos, const int32_t* work_items, int64_t num_work, float scale,
-                           float dropout_p, uint64_t seed, gt_stream_t stream_) {
+                           int64_t max_npos, const int32_t* work_items, int64_t num_work, const float* dense_mask,
+                           const float* key_valid, float mask_value, float scale, float dropout_p, uint64_t seed,
+                           gt_stream_t stream_) {
   int rc = check_attn("gt_attn_fwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
   if (rc) return rc;
   GT_CHECK_ARG(qkv && ctx && lse && seq_desc, "null buffer");
@@ -444,7 +464,7 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   hipStream_t stream = (hipStream_t)stream_;
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, work_items,
-                         row_stride, scale, dropout_p, seed);
+                         row_stride, scale, dropout_p, seed, dense_mask, key_valid, mask_value);
   dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
@@ -464,7 +484,8 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
 extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
                            float* delta, void* d_qkv, int64_t total_rows, int64_t d_model, int nhead,
                            const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
-                           const int32_t* work_items, int64_t num_work, float scale, float dropout_p, uint64_t seed,
+                           const int32_t* work_items, int64_t num_work, const float* dense_mask,
+                           const float* key_valid, float mask_value, float scale, float dropout_p, uint64_t seed,
                            gt_stream_t stream_) {
   int rc = check_attn("gt_attn_bwd", dtype, d_model, nhead, num_seqs, max_npos, dropout_p);
   if (rc) return rc;
@@ -474,7 +495,7 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   hipStream_t stream = (hipStream_t)stream_;
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, ctx, d_ctx, const_cast<float*>(lse), delta, d_qkv, total_rows, d_model, nhead, seq_desc,
-                         work_items, row_stride, scale, dropout_p, seed);
+                         work_items, row_stride, scale, dropout_p, seed, dense_mask, key_valid, mask_value);
   dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);

@@ -250,7 +250,7 @@ extern "C" int gt_encoder_layer_fwd(const gt_encoder_layer* L, const void* x, vo
   const float scale = 1.0f / sqrtf((float)(d / L->nhead));
   GT_TRY(gt_linear_fwd(t, t, c, x, L->in_w, L->in_b, s.qkv, R, 3 * d, d, 0, 0.f, 0, st));
   GT_TRY(gt_attn_fwd(t, s.qkv, s.ctx, s.lse, R, d, L->nhead, L->seq_desc, L->num_seqs, L->row_stride, L->max_npos,
-                     L->work_items, L->num_work, scale, p, L->seed, st));
+                     L->work_items, L->num_work, nullptr, nullptr, 0.f, scale, p, L->seed, st));
   GT_TRY(gt_linear_fwd(t, t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, 0, 0.f, 0, st));
   GT_TRY(gt_layernorm_fwd(t, s.a, x, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, s.x1, s.st1,
                           s.st1 + R, st));
@@ -290,7 +290,7 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_attn_bwd(t, s.qkv, s.ctx, w.d_ctx, s.lse, w.delta, w.d_qkv, R, d, L->nhead, L->seq_desc, L->num_seqs,
-                     L->row_stride, L->max_npos, L->work_items, L->num_work, scale, p, L->seed, st));
+                     L->row_stride, L->max_npos, L->work_items, L->num_work, nullptr, nullptr, 0.f, scale, p, L->seed, st));
   // qkv = x Win^T + bin ; dx += ...
   GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, g.in_w, g.in_b, R, 3 * d, d, 0.f, w.lin_ws,
                        w.lin_ws_bytes, st));

@@ -260,25 +260,27 @@ def seq_scatter(tokens, base, gs, lay):
 # ------------------------------------------------------------------------------------------------
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, lay, nhead, scale, dropout_p, seed):
+    def forward(ctx, qkv, lay, nhead, scale, dropout_p, seed, dense_mask=None, key_valid=None, mask_value=0.0):
         qkv = _dev(qkv, "qkv")
+        dense_mask = None if dense_mask is None else _dev(dense_mask.float(), "attn_mask")
+        key_valid = None if key_valid is None else _dev(key_valid.float(), "valid_input_mask")
         rows, d3 = qkv.shape
         d = d3 // 3
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
         meta = dict(lay=lay, d=d, nhead=nhead, elt=qkv.element_size())
         _lib.launch("gt_attn_fwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
-                    lay.B, lay.row_stride, lay.max_npos, _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), scale,
-                    dropout_p, seed, _stream(), meta=meta)
+                    lay.B, lay.row_stride, lay.max_npos, _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0),
+                    _ptr(dense_mask), _ptr(key_valid), float(mask_value), scale, dropout_p, seed, _stream(), meta=meta)
         ctx.meta = meta
-        ctx.save_for_backward(qkv, out, lse)
-        ctx.cfg = (lay, nhead, scale, dropout_p, seed)
+        ctx.save_for_backward(qkv, out, lse, dense_mask, key_valid)
+        ctx.cfg = (lay, nhead, scale, dropout_p, seed, mask_value)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, out, lse = ctx.saved_tensors
-        lay, nhead, scale, dropout_p, seed = ctx.cfg
+        qkv, out, lse, dense_mask, key_valid = ctx.saved_tensors
+        lay, nhead, scale, dropout_p, seed, mask_value = ctx.cfg
         g = _dev(g.to(qkv.dtype), "grad")
         rows, d3 = qkv.shape
         # rows that belong to no sequence position do not exist in either layout -> fully written
@@ -286,17 +288,19 @@ class _Attention(torch.autograd.Function):
         delta = torch.empty_like(lse)
         _lib.launch("gt_attn_bwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
                     _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos,
-                    _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), scale, dropout_p, seed, _stream(),
-                    meta=ctx.meta)
-        return dqkv, None, None, None, None, None
+                    _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), _ptr(dense_mask), _ptr(key_valid),
+                    float(mask_value), scale, dropout_p, seed, _stream(), meta=ctx.meta)
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def attention(qkv, lay, nhead, dropout_p=0.0, seed=0, scale=None):
-    """ctx rows = softmax(mask(scale q k^T)) v per (sequence, head); qkv (rows, 3*d_model)."""
+def attention(qkv, lay, nhead, dropout_p=0.0, seed=0, scale=None, dense_mask=None, key_valid=None, mask_value=-1e6):
+    """ctx rows = softmax(mask(scale q k^T)) v per (sequence, head); qkv (rows, 3*d_model).
+    dense_mask (B,T,T) / key_valid (B,T): CausalSelfAttention's masked_fill(mask == 0, mask_value)."""
     d = qkv.shape[1] // 3
     if scale is None:
         scale = float(d // nhead) ** -0.5
-    return _Attention.apply(qkv, lay, nhead, float(scale), float(dropout_p), int(seed))
+    return _Attention.apply(qkv, lay, nhead, float(scale), float(dropout_p), int(seed), dense_mask, key_valid,
+                            float(mask_value))
 
 
 # ------------------------------------------------------------------------------------------------

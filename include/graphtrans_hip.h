@@ -185,17 +185,22 @@ int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_
  *   work_items (optional) [num_work][2] int32 = {sequence, 64-position tile}: when given, the grid
  *   covers exactly these tiles (ragged graph sizes: most sequences need 2 of the max_npos/64 tiles);
  *   NULL -> dense grid (max tiles x heads x sequences, empty tiles exit).
+ *   dense_mask [num_seqs][npos][npos] / key_valid [num_seqs][npos] (optional, fp32; every sequence
+ *   must have npos == max_npos): the masks of CausalSelfAttention (modules/masked_transformer_encoder.py
+ *   :44-47) — scores whose mask entry is 0 are FILLED with the finite `mask_value` (masked_fill
+ *   semantics: a fully masked row becomes uniform, no gradient flows through a filled score).
  */
 int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model, int nhead,
                 const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
-                const int32_t* work_items, int64_t num_work, float scale, float dropout_p, uint64_t seed,
-                gt_stream_t stream);
+                const int32_t* work_items, int64_t num_work, const float* dense_mask, const float* key_valid,
+                float mask_value, float scale, float dropout_p, uint64_t seed, gt_stream_t stream);
 /* d_qkv [rows][3*d_model] is fully written for every row belonging to a sequence position.
  * delta [nhead][rows] fp32 workspace (rowsum(dO*O)). */
 int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse, float* delta,
                 void* d_qkv, int64_t total_rows, int64_t d_model, int nhead, const int32_t* seq_desc,
                 int64_t num_seqs, int64_t row_stride, int64_t max_npos, const int32_t* work_items, int64_t num_work,
-                float scale, float dropout_p, uint64_t seed, gt_stream_t stream);
+                const float* dense_mask, const float* key_valid, float mask_value, float scale, float dropout_p,
+                uint64_t seed, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d over the rows of an [rows][dim] matrix (channels = columns), optional fused ReLU.
