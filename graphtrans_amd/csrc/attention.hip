@@ -45,7 +45,7 @@ struct AttnArgs {
   const void* qkv;
   const void* ctx;    // fwd: output ; bwd: saved output
   const void* d_ctx;  // bwd
-  float* lse;         // [nhead][rows], log2 domain of the scaled scores
+  float* lse;         // [2][nhead][rows]: running max m and log2(sum exp2(s - m)), log2 domain of the scaled scores
   float* delta;       // [nhead][rows]
   void* out;          // fwd: ctx ; bwd: d_qkv
   const int32_t* desc;
@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     o[0] *= inv_l; o[1] *= inv_l; o[2] *= inv_l; o[3] *= inv_l;
     if (dt * 16 + g * 4 < HD) store4<T>(ctx + qrow * a.d_model + head * HD + dt * 16 + g * 4, o);
   }
-  if (g == 0) a.lse[(int64_t)head * a.rows + qrow] = m + log2f(lsum);
+  if (g == 0) {  // running max and log2(sum) kept apart: m may be -1.44e6 (masked_fill rows), where m + log2(l) loses l
+    a.lse[(int64_t)head * a.rows + qrow] = m;
+    a.lse[((int64_t)a.nhead + head) * a.rows + qrow] = log2f(lsum);
+  }
 }
 
 // =================================================================================================
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   delta += __shfl_xor(delta, 16, 64);
   delta += __shfl_xor(delta, 32, 64);
   const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
+  const float logl = qvalid ? a.lse[((int64_t)a.nhead + head) * a.rows + qrow] : 0.f;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
   const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
   zero_pad_cols<T, HD>(sK);
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         const int kp = k0 + g * 8 + i;
         const bool kvalid = kp >= kv_off && kp < kv_end;
         const bool filled = dense && qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
-        const float p = kvalid ? exp2f((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) : 0.f;
+        const float p = kvalid ? exp2f(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
         float dpi = dp[r];
         if (a.drop_thr) {
           const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)kp);
@@ -322,7 +326,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
-  __shared__ float sLse[TILE], sDelta[TILE];
+  __shared__ float sLse[TILE], sLogl[TILE], sDelta[TILE];
   const int head = blockIdx.y;
   const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -362,12 +366,13 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     __syncthreads();
     load_tile<T, HD>(sQ, qkv + head * HD, ld3, row0, a.row_stride, q0, 0, npos);
     load_tile<T, HD>(sDO, dctx + head * HD, a.d_model, row0, a.row_stride, q0, 0, npos);
-    if (threadIdx.x < 2 * TILE) {
+    if (threadIdx.x < 3 * TILE) {
       const int r = threadIdx.x & (TILE - 1);
+      const int which = threadIdx.x / TILE;  // 0: running max, 1: log2(sum), 2: delta
       const int pos = q0 + r;
-      const float* src = threadIdx.x < TILE ? a.lse : a.delta;
+      const float* src = which == 0 ? a.lse : (which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
       float v = pos < npos ? src[(int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride] : 0.f;
-      (threadIdx.x < TILE ? sLse : sDelta)[r] = v;
+      (which == 0 ? sLse : (which == 1 ? sLogl : sDelta))[r] = v;
     }
     __syncthreads();
     float pd[8], ds[8];
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         const int qpos = q0 + qi;
         const bool ok = kvalid && qpos < npos;
         const bool filled = dense && ok && dense_masked(a, seq, qpos, kp, npos);
-        float p = ok ? exp2f((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) : 0.f;
+        float p = ok ? exp2f(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) - sLogl[qi]) : 0.f;
         float dpi = dp[r];
         float pdrop = p;
         if (a.drop_thr) {

@@ -47,7 +47,7 @@ EncSaved enc_saved(const gt_encoder_layer* L, void* p) {
   s.x1 = b.take((size_t)L->rows * L->d_model * e);
   s.f1 = b.take((size_t)L->rows * L->ffn * e);
   s.f2 = b.take((size_t)L->rows * L->d_model * e);
-  s.lse = (float*)b.take((size_t)L->nhead * L->rows * 4);
+  s.lse = (float*)b.take((size_t)2 * L->nhead * L->rows * 4);
   s.st1 = (float*)b.take((size_t)2 * L->rows * 4);
   s.st2 = (float*)b.take((size_t)2 * L->rows * 4);
   s.bytes = b.off;

@@ -267,7 +267,7 @@ class _Attention(torch.autograd.Function):
         rows, d3 = qkv.shape
         d = d3 // 3
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((2, nhead, rows), dtype=torch.float32, device=qkv.device)
         meta = dict(lay=lay, d=d, nhead=nhead, elt=qkv.element_size())
         _lib.launch("gt_attn_fwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
                     lay.B, lay.row_stride, lay.max_npos, _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0),
@@ -285,7 +285,7 @@ class _Attention(torch.autograd.Function):
         rows, d3 = qkv.shape
         # rows that belong to no sequence position do not exist in either layout -> fully written
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty_like(lse)
+        delta = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
         _lib.launch("gt_attn_bwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
                     _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos,
                     _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0), _ptr(dense_mask), _ptr(key_valid),

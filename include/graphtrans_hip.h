@@ -177,7 +177,8 @@ int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_
  * the S x S scores).  Replaces F.multi_head_attention_forward's bmm / masked_fill(-inf) / softmax
  * / dropout / bmm (modules/transformer_encoder.py:59) between in_proj and out_proj.
  *   qkv [rows][3*d_model] (torch packed in_proj order q|k|v), ctx [rows][d_model],
- *   lse [nhead][rows] fp32 (saved for backward).  head_dim = d_model/nhead in {32, 64}.
+ *   lse [2][nhead][rows] fp32 (row max and log2 of the row sum, saved for backward).
+ *   head_dim = d_model/nhead in {8, 16, 32, 64}.
  *   Keys outside [kv_off, kv_off+kv_len) are masked (the key_padding_mask); every query position
  *   in [0, npos) is computed.  P = softmax(scale * q k^T); dropout(P, p) with a counter-based RNG
  *   keyed by (seed, seq, head, query, key) so backward replays it.
