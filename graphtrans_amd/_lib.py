@@ -41,6 +41,9 @@ SIGNATURES = {
                               C.POINTER(C.c_int32), _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_pna_aggregate_fwd": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
     "gt_pna_aggregate_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gt_embed_sum_fwd": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "gt_embed_sum_bwd_workspace_bytes": (_sz, [_i, _p, _i64]),
+    "gt_embed_sum_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
     "gt_segment_bcast_add": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_segment_sum": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),

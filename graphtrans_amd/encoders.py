@@ -5,6 +5,8 @@ modules with ogb's published layout: one nn.Embedding per categorical column, su
 """
 import torch
 
+from . import ops
+
 ATOM_FEATURE_DIMS = [119, 4, 12, 12, 10, 6, 6, 2, 2]
 BOND_FEATURE_DIMS = [5, 6, 2]
 
@@ -21,8 +23,9 @@ class ASTNodeEncoder(torch.nn.Module):
         self.depth_encoder = torch.nn.Embedding(self.max_depth + 1, emb_dim)
 
     def forward(self, x, depth):
-        depth = depth.clamp(max=self.max_depth)
-        return self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1]) + self.depth_encoder(depth)
+        return ops.embed_sum([x[:, 0], x[:, 1], depth.reshape(-1)],
+                             [self.type_encoder.weight, self.attribute_encoder.weight, self.depth_encoder.weight],
+                             clamps=[None, None, self.max_depth])
 
 
 class _SumEmbedding(torch.nn.Module):
@@ -37,10 +40,10 @@ class _SumEmbedding(torch.nn.Module):
 
     @staticmethod
     def _sum(embs, x):
-        out = 0
-        for i in range(x.shape[1]):
-            out = out + embs[i](x[:, i])
-        return out
+        cols = x.shape[1]
+        if cols > 16:
+            raise ValueError("at most 16 categorical columns")
+        return ops.embed_sum([x[:, i] for i in range(cols)], [embs[i].weight for i in range(cols)])
 
 
 class AtomEncoder(_SumEmbedding):

@@ -519,3 +519,56 @@ class _PnaAggregate(torch.autograd.Function):
 def pna_aggregate(U, V, gs, towers):
     """(N, towers, 4F): [U+mean V | U+max V | U+min V | std V] over the in-edges (gt_pna_aggregate_*)."""
     return _PnaAggregate.apply(U, V, gs, towers)
+
+
+class _EmbedSum(torch.autograd.Function):
+    """sum_t table_t[min(idx_t, clamp_t)] (gt_embed_sum_fwd / _bwd).  `cols` is a list of
+    (int64 tensor, element offset, element stride, clamp) column descriptors."""
+
+    @staticmethod
+    def forward(ctx, cols, *tables):
+        T = len(tables)
+        tables = [_dev(t, "table") for t in tables]
+        if any(t.dtype != torch.float32 for t in tables):
+            raise TypeError("embed_sum: fp32 tables only")
+        D = tables[0].shape[1]
+        N = cols[0][0].shape[0]
+        I64, P = C.c_int64 * T, C.c_void_p * T
+        idx = P(*[c[0].data_ptr() + 8 * c[1] for c in cols])
+        strides = I64(*[c[2] for c in cols])
+        clamp = I64(*[c[3] for c in cols])
+        tabs = P(*[t.data_ptr() for t in tables])
+        out = torch.empty((N, D), dtype=torch.float32, device=tables[0].device)
+        _lib.launch("gt_embed_sum_fwd", T, idx, strides, clamp, tabs, N, D, _ptr(out), _stream())
+        ctx.cols, ctx.meta = cols, (T, N, D, [t.shape[0] for t in tables], tables[0].device)
+        ctx.desc = (idx, strides, clamp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        T, N, D, rows, device = ctx.meta
+        idx, strides, clamp = ctx.desc
+        g = _dev(g.float(), "grad")
+        I64, P = C.c_int64 * T, C.c_void_p * T
+        rows_c = I64(*rows)
+        grads = [torch.empty((r, D), dtype=torch.float32, device=device) if ctx.needs_input_grad[1 + t] else None
+                 for t, r in enumerate(rows)]
+        dt = P(*[(x.data_ptr() if x is not None else None) for x in grads])
+        ws_bytes = _lib.lib().gt_embed_sum_bwd_workspace_bytes(T, rows_c, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        _lib.launch("gt_embed_sum_bwd", T, idx, strides, clamp, rows_c, _ptr(g), N, D, dt, _ptr(ws), ws_bytes, _stream())
+        return (None, *grads)
+
+
+def embed_sum(columns, tables, clamps=None):
+    """out[n] = sum_t tables[t][min(columns[t][n], clamps[t])].  `columns[t]` is an int64 device
+    tensor of shape (N,), possibly a strided view of an (N, C) matrix (no copy is made)."""
+    cols = []
+    for t, c in enumerate(columns):
+        if c.dtype != torch.int64 or c.dim() != 1:
+            raise TypeError("embed_sum: index columns must be 1-D int64")
+        if not c.is_cuda:
+            raise RuntimeError("index must be a GPU tensor: graphtrans_amd has no CPU fallback")
+        clamp = -1 if clamps is None or clamps[t] is None else int(clamps[t])
+        cols.append((c, 0, c.stride(0) if c.shape[0] > 1 else 1, clamp))
+    return _EmbedSum.apply(cols, *tables)

@@ -140,6 +140,23 @@ int gt_pna_aggregate_bwd(const float* V, const float* out, const float* mean_v, 
                          gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input node encoders: out[n] = sum_t table_t[min(idx_t[n * stride_t], clamp_t)]  (clamp_t < 0: none).
+ *   Code2: ASTNodeEncoder.forward dataset/utils.py:28-30 (type + attribute + clamped depth);
+ *   Molpcba: ogb AtomEncoder (dataset/mol.py:83), one table per categorical column.
+ * Up to 16 tables; the *_host arrays are HOST arrays of length num_tables (device pointers inside).
+ * Backward: d_table_t[r] = sum_{n: idx_t[n] = r} grad_out[n], deterministic (64-bit fixed-point
+ * integer atomics scaled by 2^30 / max|grad_out|, see csrc/embed.hip); d_tables_host[t] may be NULL.
+ */
+int gt_embed_sum_fwd(int num_tables, const int64_t* const* idx_ptrs_host, const int64_t* idx_strides_host,
+                     const int64_t* clamp_max_host, const float* const* tables_host, int64_t num_nodes, int64_t dim,
+                     float* out, gt_stream_t stream);
+size_t gt_embed_sum_bwd_workspace_bytes(int num_tables, const int64_t* table_rows_host, int64_t dim);
+int gt_embed_sum_bwd(int num_tables, const int64_t* const* idx_ptrs_host, const int64_t* idx_strides_host,
+                     const int64_t* clamp_max_host, const int64_t* table_rows_host, const float* grad_out,
+                     int64_t num_nodes, int64_t dim, float* const* d_tables_host, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-graph segment ops on the sorted `batch` vector (virtual node + pooling).
  * gt_segment_bcast_add: out[n] = (x ? x[n] : 0) + seg[g(n)]      -- `h + vn[batch]`
  *   (modules/gnn_module.py:199); also the backward of global_add_pool.

@@ -1,0 +1,77 @@
+"""Input encoders: gt_embed_sum_fwd / _bwd against torch.nn.Embedding sums
+(reference: ASTNodeEncoder.forward dataset/utils.py:28-30, ogb AtomEncoder dataset/mol.py:83)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(cols, tables, clamps):
+    out = 0
+    for c, t, k in zip(cols, tables, clamps):
+        if k is not None:
+            c = c.clamp(max=k)
+        out = out + t[c]
+    return out
+
+
+@pytest.mark.parametrize("N,D,rows,clamps", [
+    (1000, 128, [98, 1003, 21], [None, None, 20]),
+    (5000, 300, [98, 10030, 21], [None, None, 20]),
+    (777, 64, [119, 4, 12, 12, 10, 6, 6, 2, 2], [None] * 9),
+    (1, 32, [5], [None]),
+])
+def test_embed_sum_fwd_bwd(N, D, rows, clamps):
+    from graphtrans_amd import ops
+    g = torch.Generator().manual_seed(N + D)
+    x = torch.stack([torch.randint(0, r, (N,), generator=g) for r in rows], 1)
+    if clamps[-1] is not None:  # depth column may exceed max_depth before the clamp
+        x[:, -1] = torch.randint(0, 3 * rows[-1], (N,), generator=g)
+    x = x.cuda()
+    tables = [torch.randn(r, D, generator=g).cuda().requires_grad_() for r in rows]
+    cols = [x[:, i] for i in range(len(rows))]
+    out = ops.embed_sum(cols, tables, clamps)
+    ref = _ref(cols, [t.detach() for t in tables], clamps)
+    assert torch.equal(out, ref)  # same summation order -> bit-exact
+
+    gout = (torch.randn(N, D, generator=g) * torch.logspace(-3, 1, N).unsqueeze(1)).cuda()
+    out.backward(gout)
+    got = [t.grad.clone() for t in tables]
+    t64 = [t.detach().double().requires_grad_() for t in tables]
+    _ref(cols, t64, clamps).backward(gout.double())
+    scale = gout.abs().max().item()
+    for a, b, r in zip(got, t64, rows):
+        # fixed point: each addend is rounded to 2^-30 of max|g| (<= 2^-29 * max after the pow2 scale)
+        n_max = max(int(N), 1)
+        assert (a.double() - b.grad).abs().max().item() <= scale * 2.0 ** -29 * n_max + 1e-6 * b.grad.abs().max().item()
+    # deterministic: a second run is bit-identical
+    for t in tables:
+        t.grad = None
+    ops.embed_sum(cols, tables, clamps).backward(gout)
+    for a, t in zip(got, tables):
+        assert torch.equal(a, t.grad)
+
+
+def test_embed_sum_empty_and_zero_grad():
+    from graphtrans_amd import ops
+    tab = torch.randn(7, 16).cuda().requires_grad_()
+    idx = torch.zeros(0, dtype=torch.int64).cuda()
+    out = ops.embed_sum([idx], [tab])
+    assert out.shape == (0, 16)
+    idx = torch.arange(5).cuda()
+    out = ops.embed_sum([idx], [tab])
+    out.backward(torch.zeros_like(out))
+    assert torch.equal(tab.grad, torch.zeros_like(tab))
+
+
+def test_ast_node_encoder_matches_reference_formula():
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    torch.manual_seed(0)
+    enc = ASTNodeEncoder(64, 11, 13, 20).cuda()
+    x = torch.stack([torch.randint(0, 11, (300,)), torch.randint(0, 13, (300,))], 1).cuda()
+    depth = torch.randint(0, 50, (300, 1)).cuda()
+    out = enc(x, depth.view(-1))
+    d = depth.view(-1).clamp(max=20)
+    ref = enc.type_encoder.weight[x[:, 0]] + enc.attribute_encoder.weight[x[:, 1]] + enc.depth_encoder.weight[d]
+    assert torch.equal(out, ref)
+    assert depth.max().item() > 20  # caller's tensor is not clamped in place

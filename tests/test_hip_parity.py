@@ -139,7 +139,10 @@ def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     # ---- oracle (fp32 CPU)
     h_ref = h.clone().requires_grad_(True)
     sp_ref = self_param.clone().requires_grad_(True)
-    e_ref = enc(b.edge_attr) if enc is not None else None
+    if edge == "bond":  # the encoder module itself is GPU-only; restate ogb's BondEncoder sum for the oracle
+        e_ref = sum(emb(b.edge_attr[:, i]) for i, emb in enumerate(enc.bond_embedding_list))
+    else:
+        e_ref = enc(b.edge_attr) if enc is not None else None
     if conv_name == "gcn":
         out_ref = rm.gcn_aggregate(h_ref, e_ref, b.edge_index, sp_ref)
     else:
