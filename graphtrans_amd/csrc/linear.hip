@@ -38,11 +38,13 @@ struct LinArgs {
   void* out;          // fwd: Y; dx: dX; dw: partial [splits][N][K] fp32
   float* dbpart;      // dw: [splits][N]
   int64_t M, N, K;
+  int64_t ldy;        // row stride (elements) of Y / dY / ymask; >= N
   int act;            // 0 none, 1 relu
   float inv_keep;     // 1/(1-p)
   uint32_t thr, s0, s1;
   int splits;
   int64_t m_per_split;
+  int64_t n_per_split;  // dx: contraction range per blockIdx.z when splits > 1 (partials [splits][M][K] fp32 in `out`)
   int dbg;  // ablation bits (GT_LINEAR_DBG): 1 no W loads, 2 no X loads, 4 no stores, 8 no MFMA
 };
 
@@ -165,6 +167,16 @@ constexpr int PATCH_FLOATS = 16 * PATCH_LD;
 template <typename TO>
 __device__ __forceinline__ void store_chunk(TO* p, float4 v) { gt_store4<TO>(p, v); }
 
+// bias[col..col+3]; the last chunk of an N that is not a multiple of 4 must not read past the array
+__device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int64_t N) {
+  if (col + 4 <= N) return *reinterpret_cast<const float4*>(bias + col);
+  float4 b = gt_zero4();
+  if (col < N) b.x = bias[col];
+  if (col + 1 < N) b.y = bias[col + 1];
+  if (col + 2 < N) b.z = bias[col + 2];
+  return b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: Y = act(X W^T + b) [dropout]
 // MFMA rows = output columns n (W rows), MFMA cols = output rows m (X rows).
@@ -240,7 +252,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
       const int64_t col = n0 + wn * 64 + c4;
       if (m < a.M && col < a.N && !(a.dbg & 4)) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
-        if (a.bias) v = gt_add4(v, *reinterpret_cast<const float4*>(a.bias + col));
+        if (a.bias) v = gt_add4(v, bias_chunk(a.bias, col, a.N));
         if (a.act == 1) v = gt_relu4(v);
         if (a.thr) {
           float* vv = reinterpret_cast<float*>(&v);
@@ -248,7 +260,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
           for (int e = 0; e < 4; ++e)
             vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
         }
-        store_chunk<TY>(Y + m * a.N + col, v);
+        store_chunk<TY>(Y + m * a.ldy + col, v);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -285,22 +297,27 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   Loader<TY, TC, BM, BKc, LDZ, true> lz;
   Loader<float, TC, BKc, BN, LDW, false> lw;
-  const TY* zo = dY + m0 * a.N;
-  const TY* mo = has_mask ? Ym + m0 * a.N : nullptr;
+  const TY* zo = dY + m0 * a.ldy;
+  const TY* mo = has_mask ? Ym + m0 * a.ldy : nullptr;
   const float* wo = a.w + kk0;
-  lz.init(a.N);
+  // contraction range of this block (whole N unless the launch splits it over blockIdx.z)
+  const int64_t cb = a.splits > 1 ? (int64_t)blockIdx.z * a.n_per_split : 0;
+  const int64_t ce = a.splits > 1 ? (cb + a.n_per_split < a.N ? cb + a.n_per_split : a.N) : a.N;
+  lz.init(a.ldy);
   lw.init(a.K);
-  lz.load(zo, a.M - m0, a.N, mo);
-  lw.load(wo, a.N, a.K - kk0, nullptr);
-  for (int64_t c0 = 0; c0 < a.N; c0 += BKc) {
+  if (cb < ce) {
+    lz.load(zo + cb, a.M - m0, ce - cb, has_mask ? mo + cb : nullptr);
+    lw.load(wo + cb * a.K, ce - cb, a.K - kk0, nullptr);
+  }
+  for (int64_t c0 = cb; c0 < ce; c0 += BKc) {
     __syncthreads();
     lz.store(sZ, has_mask, a.inv_keep);
     lw.store(sW, false, 1.f);
     __syncthreads();
-    if (c0 + BKc < a.N) {
+    if (c0 + BKc < ce) {
       const int64_t c1 = c0 + BKc;
-      lz.load(zo + c1, a.M - m0, a.N - c1, has_mask ? mo + c1 : nullptr);
-      lw.load(wo + c1 * a.K, a.N - c1, a.K - kk0, nullptr);
+      lz.load(zo + c1, a.M - m0, ce - c1, has_mask ? mo + c1 : nullptr);
+      lw.load(wo + c1 * a.K, ce - c1, a.K - kk0, nullptr);
     }
 #pragma unroll
     for (int s = 0; s < BKc / 32; ++s) {
@@ -332,7 +349,10 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
       const int r = c >> 4, c4 = (c & 15) * 4;
       const int64_t m = m0 + wm * (BM / 2) + i * 16 + r;
       const int64_t col = kk0 + wk * 64 + c4;
-      if (m < a.M && col < a.K) {
+      if (m < a.M && col < a.K && a.splits > 1) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + ((int64_t)blockIdx.z * a.M + m) * a.K + col) =
+            *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
+      } else if (m < a.M && col < a.K) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
         if (a.add1) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add1) + m * a.K + col));
         if (a.add2) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add2) + m * a.K + col));
@@ -377,10 +397,10 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   float dbacc = 0.f;  // thread t < BN: column n0 + t
   Loader<TY, TC, BMc, BN, LDZ, true> lz;
   Loader<TX, TC, BMc, BN, LDX, false> lx;
-  lz.init(a.N);
+  lz.init(a.ldy);
   lx.init(a.K);
   if (mb < me) {
-    lz.load(dY + mb * a.N + n0, me - mb, a.N - n0, has_mask ? Ym + mb * a.N + n0 : nullptr);
+    lz.load(dY + mb * a.ldy + n0, me - mb, a.N - n0, has_mask ? Ym + mb * a.ldy + n0 : nullptr);
     lx.load(X + mb * a.K + k0, me - mb, a.K - k0, nullptr);
   }
   for (int64_t m0 = mb; m0 < me; m0 += BMc) {
@@ -390,7 +410,7 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     __syncthreads();
     if (m0 + BMc < me) {
       const int64_t m1 = m0 + BMc;
-      lz.load(dY + m1 * a.N + n0, me - m1, a.N - n0, has_mask ? Ym + m1 * a.N + n0 : nullptr);
+      lz.load(dY + m1 * a.ldy + n0, me - m1, a.N - n0, has_mask ? Ym + m1 * a.ldy + n0 : nullptr);
       lx.load(X + m1 * a.K + k0, me - m1, a.K - k0, nullptr);
     }
     if (blockIdx.y == 0 && threadIdx.x < BN) {
@@ -457,13 +477,14 @@ __global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ 
   }
 }
 
-int check_lin(const char* fn, int x_dtype, int y_dtype, int compute, int64_t M, int64_t N, int64_t K) {
+int check_lin(const char* fn, int x_dtype, int y_dtype, int compute, int64_t M, int64_t N, int64_t K, int64_t ldy) {
   if ((x_dtype != GT_F32 && x_dtype != GT_BF16) || (y_dtype != GT_F32 && y_dtype != GT_BF16) ||
       (compute != GT_F32 && compute != GT_BF16)) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
   if (compute == GT_F32 && (x_dtype != GT_F32 || y_dtype != GT_F32)) { gt_set_error("%s: fp32 compute needs fp32 storage", fn); return GT_ERR_UNSUPPORTED; }
   if (M < 0 || N <= 0 || K <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
-  if (N % 4 != 0 || K % 4 != 0) { gt_set_error("%s: N and K must be multiples of 4 (got %lld, %lld)", fn, (long long)N, (long long)K); return GT_ERR_UNSUPPORTED; }
-  if ((x_dtype == GT_BF16 && K % 8 != 0) || (y_dtype == GT_BF16 && N % 8 != 0)) { gt_set_error("%s: bf16 storage needs K (x) / N (y) to be multiples of 8", fn); return GT_ERR_UNSUPPORTED; }
+  if (ldy < N) { gt_set_error("%s: ldy (%lld) < N (%lld)", fn, (long long)ldy, (long long)N); return GT_ERR_INVALID_ARG; }
+  if (ldy % 4 != 0 || K % 4 != 0) { gt_set_error("%s: ldy (= N unless given) and K must be multiples of 4 (got %lld, %lld)", fn, (long long)ldy, (long long)K); return GT_ERR_UNSUPPORTED; }
+  if ((x_dtype == GT_BF16 && K % 8 != 0) || (y_dtype == GT_BF16 && ldy % 8 != 0)) { gt_set_error("%s: bf16 storage needs K (x) / ldy (y) to be multiples of 8", fn); return GT_ERR_UNSUPPORTED; }
   return GT_OK;
 }
 
@@ -484,6 +505,18 @@ int dw_splits(int64_t M, int64_t N, int64_t K, int compute) {
   if (s < 1) s = 1;
   if (s > 256) s = 256;
   return (int)s;
+}
+
+// dX with a long contraction (N >> M, K: the 5 x 5002-way prediction heads) has too few output tiles
+// to fill the chip: split N over blockIdx.z into fp32 partials, reduced in fixed order.
+int dx_splits(int64_t M, int64_t N, int64_t K, int bm) {
+  const int64_t tiles = gt_cdiv(M, bm) * gt_cdiv(K, BN);
+  if (tiles >= 128 || N < 2048) return 1;
+  int64_t s = 512 / tiles;
+  const int64_t maxs = N / 256;  // at least 4 stages of 64 per split
+  if (s > maxs) s = maxs;
+  if (s > 256) s = 256;
+  return s < 2 ? 1 : (int)s;
 }
 
 // dispatch over (storage of the M-sized operands, compute type)
@@ -520,7 +553,13 @@ int pick_bm(int64_t M) {
 extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                              const float* bias, void* y, int64_t M, int64_t N, int64_t K, int act, float dropout_p,
                              uint64_t seed, gt_stream_t stream_) {
-  int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K);
+  return gt_linear_fwd_ld(x_dtype, y_dtype, compute, x, weight, bias, y, M, N, K, N, act, dropout_p, seed, stream_);
+}
+
+extern "C" int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
+                                const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldy, int act,
+                                float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K, ldy);
   if (rc) return rc;
   GT_CHECK_ARG(x && weight && y, "null buffer");
   GT_CHECK_ARG(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
@@ -530,7 +569,7 @@ extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* 
   GtProfScope prof__(GT_PROF_LINEAR, "gt_linear_fwd", stream_, {M, N, K, x_dtype, y_dtype, compute});
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
-  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.act = act;
+  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.act = act;
   { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
   const int bm = pick_bm(M);
@@ -543,14 +582,25 @@ extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* 
 }
 
 extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K) {
-  return (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float) + 256;
+  const size_t dw = (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float);
+  const int dxs = dx_splits(M, N, K, pick_bm(M));
+  const size_t dx = dxs > 1 ? (size_t)dxs * M * K * sizeof(float) : 0;
+  return (dw > dx ? dw : dx) + 256;  // the dx partials are consumed before dw reuses the space
 }
 
 extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                              const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                              float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
                              size_t workspace_bytes, gt_stream_t stream_) {
-  int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K);
+  return gt_linear_bwd_ld(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
+                          N, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                                float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldy, float dropout_p,
+                                void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K, ldy);
   if (rc) return rc;
   GT_CHECK_ARG(weight && dy, "null buffer");
   GT_CHECK_ARG(dx || dweight, "nothing to compute");
@@ -560,24 +610,36 @@ extern "C" int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* 
   GtProfScope prof__(GT_PROF_LINEAR, dx ? (dweight ? "gt_linear_bwd" : "gt_linear_bwd_dx") : "gt_linear_bwd_dw", stream_,
                      {M, N, K, x_dtype, y_dtype, compute});
   LinArgs a{};
-  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.add1 = dx_add1; a.add2 = dx_add2;
+  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy;
+  a.add1 = dx_add1; a.add2 = dx_add2;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
   if (M == 0) {
     if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)N * K * sizeof(float), stream);
     if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream);
     return GT_OK;
   }
+  const size_t need = gt_linear_bwd_workspace_bytes(compute, M, N, K);
   if (dx) {
-    a.out = dx;
     const int bm = pick_bm(M);
-    dim3 grid((unsigned)gt_cdiv(M, bm), (unsigned)gt_cdiv(K, BN));
+    // split-N partials are plain fp32 sums: only for fp32 dX without fused addends
+    int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2) ? dx_splits(M, N, K, bm) : 1;
+    if (splits > 1 && (!workspace || workspace_bytes < need)) splits = 1;
+    a.splits = splits;
+    a.n_per_split = gt_cdiv(gt_cdiv(N, splits), 64) * 64;
+    a.out = splits > 1 ? workspace : dx;
+    dim3 grid((unsigned)gt_cdiv(M, bm), (unsigned)gt_cdiv(K, BN), (unsigned)splits);
     const int t0 = y_dtype, t1 = x_dtype;
     if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_dx, 64, grid, a);
     else GT_LIN_DISPATCH_BM(k_linear_dx, 128, grid, a);
+    if (splits > 1) {
+      const int64_t len = M * K;
+      const int rg = (int)(gt_cdiv(len, 256) < 2048 ? gt_cdiv(len, 256) : 2048);
+      hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len,
+                         reinterpret_cast<float*>(dx));
+    }
   }
   if (dweight) {
     const int splits = dw_splits(M, N, K, compute);
-    size_t need = gt_linear_bwd_workspace_bytes(compute, M, N, K);
     if (!workspace || workspace_bytes < need) {
       gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
       return GT_ERR_WORKSPACE;

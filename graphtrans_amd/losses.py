@@ -8,6 +8,9 @@ def code2_loss(pred_list, y_arr):
     stacked = getattr(pred_list, "stacked", None)
     if stacked is not None:  # heads computed as one GEMM: equal-size means -> one cross-entropy over B*L rows
         B, L, C = stacked.shape
+        if stacked.is_cuda and stacked.dtype == torch.float32 and stacked.stride(2) == 1 and stacked.stride(1) == C:
+            from . import ops
+            return ops.softmax_xent(stacked, y_arr)
         return F.cross_entropy(stacked.to(torch.float32).reshape(B * L, C), y_arr[:, :L].reshape(B * L))
     loss = 0
     for i, pred in enumerate(pred_list):

@@ -22,7 +22,7 @@ from ..modules.gnn_module import GNNNodeEmbedding, batch_structure
 from ..modules.masked_transformer_encoder import MaskedOnlyTransformerEncoder
 from ..modules.transformer_encoder import TransformerNodeEncoder
 from ..modules.utils import pad_batch
-from .base_model import BaseModel
+from .base_model import BaseModel, StackedHeads, stacked_heads  # noqa: F401
 
 
 class GNNTransformer(BaseModel):
@@ -141,14 +141,8 @@ class GNNTransformer(BaseModel):
                 raise NotImplementedError
 
         if self.max_seq_len is None:
-            return self.graph_pred_linear(h_graph)
-        # the max_seq_len heads (gnn_transformer.py:124-126) as ONE GEMM over the stacked weights; the
-        # returned list holds views of it (losses.code2_loss recognises them and runs one cross-entropy)
-        heads = self.graph_pred_linear_list
-        w = torch.cat([m.weight for m in heads], dim=0)
-        b = torch.cat([m.bias for m in heads], dim=0)
-        stacked = torch.nn.functional.linear(h_graph, w, b).view(h_graph.shape[0], self.max_seq_len, self.num_tasks)
-        return StackedHeads(stacked)
+            return ops.linear_module(self.graph_pred_linear, h_graph)
+        return stacked_heads(h_graph, self.graph_pred_linear_list, self.num_tasks)
 
     def epoch_callback(self, epoch):
         if self.freeze_gnn is not None and epoch >= self.freeze_gnn:
@@ -164,14 +158,6 @@ class GNNTransformer(BaseModel):
                 module_index = new_key.index(module_name)
                 new_state_dict[".".join(new_key[module_index + 1:])] = v
         return new_state_dict
-
-
-class StackedHeads(list):
-    """list of the per-position logits (B, num_tasks), all views of `.stacked` (B, L, num_tasks)."""
-
-    def __init__(self, stacked):
-        super().__init__(stacked[:, i] for i in range(stacked.shape[1]))
-        self.stacked = stacked
 
 
 class PositionalEncoding(nn.Module):

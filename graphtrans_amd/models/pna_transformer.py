@@ -8,7 +8,7 @@ from ..modules.gnn_module import batch_structure
 from ..modules.pna.pna_module import PNANodeEmbedding
 from ..modules.transformer_encoder import TransformerNodeEncoder
 from ..modules.utils import pad_batch
-from .base_model import BaseModel
+from .base_model import BaseModel, stacked_heads
 
 
 class PNATransformer(BaseModel):
@@ -87,8 +87,8 @@ class PNATransformer(BaseModel):
             else:
                 raise NotImplementedError
         if self.max_seq_len is None:
-            return self.graph_pred_linear(h_graph)
-        return [self.graph_pred_linear_list[i](h_graph) for i in range(self.max_seq_len)]
+            return ops.linear_module(self.graph_pred_linear, h_graph)
+        return stacked_heads(h_graph, self.graph_pred_linear_list, self.num_tasks)
 
     def epoch_callback(self, epoch):
         if self.freeze_gnn is not None and epoch >= self.freeze_gnn:

@@ -410,43 +410,63 @@ def get_matmul_dtype():
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, dropout_p, seed, compute, out_dtype):
+    def forward(ctx, x, weight, bias, act, dropout_p, seed, compute, out_dtype, ldy):
         x2 = _dev(x.reshape(-1, x.shape[-1]), "x")
         M, K = x2.shape
         N = weight.shape[0]
+        ldy = N if ldy is None else int(ldy)
         w32 = _f32(weight)
         b32 = _f32(bias)
-        y = torch.empty((M, N), dtype=out_dtype, device=x2.device)
-        _lib.launch("gt_linear_fwd", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
-                    M, N, K, act, float(dropout_p), int(seed), _stream())
+        y = torch.empty((M, ldy), dtype=out_dtype, device=x2.device)
+        _lib.launch("gt_linear_fwd_ld", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
+                    M, N, K, ldy, act, float(dropout_p), int(seed), _stream())
         fused = act == 1
         ctx.save_for_backward(x2, w32, y if fused else None)
-        ctx.cfg = (compute, dropout_p if fused else 0.0, x.shape, weight.dtype, None if bias is None else bias.dtype)
+        ctx.cfg = (compute, dropout_p if fused else 0.0, x.shape, weight.dtype, None if bias is None else bias.dtype, ldy)
+        if ldy != N:
+            return y[:, :N]  # (M, N) view with row stride ldy
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w32, ymask = ctx.saved_tensors
-        compute, dropout_p, xshape, wdt, bdt = ctx.cfg
+        compute, dropout_p, xshape, wdt, bdt, ldy = ctx.cfg
         M, K = x2.shape
         N = w32.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], bdt is not None and ctx.needs_input_grad[2]
         ydt = ymask.dtype if ymask is not None else (dy.dtype if dy.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         if compute == GT_F32:
             ydt = torch.float32
-        dy2 = _dev(dy.reshape(-1, N).to(ydt), "grad")
+        if ldy != N:
+            dy2 = _padded_rows(dy.reshape(M, N).to(ydt), ldy)
+        else:
+            dy2 = _dev(dy.reshape(-1, N).to(ydt), "grad")
         dev = x2.device
         dx = torch.empty_like(x2) if need_x else None
         dw = torch.empty((N, K), dtype=torch.float32, device=dev) if (need_w or need_b) else None
         db = torch.empty(N, dtype=torch.float32, device=dev) if need_b else None
         L = _lib.lib()
-        ws_bytes = L.gt_linear_bwd_workspace_bytes(compute, M, N, K) if dw is not None else 0
+        ws_bytes = L.gt_linear_bwd_workspace_bytes(compute, M, N, K)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        _lib.launch("gt_linear_bwd", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
-                    _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, float(dropout_p), _ptr(ws), ws_bytes,
-                    _stream())
+        _lib.launch("gt_linear_bwd_ld", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
+                    _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, ldy, float(dropout_p), _ptr(ws),
+                    ws_bytes, _stream())
         return (None if dx is None else dx.view(xshape), None if not need_w else dw.to(wdt),
-                None if db is None else db.to(bdt), None, None, None, None, None)
+                None if db is None else db.to(bdt), None, None, None, None, None, None)
+
+
+def _padded_rows(t, ld):
+    """(M, N) tensor -> an (M, ld) row-padded buffer holding it with ZERO pad columns.  A gradient that
+    already lives in such a buffer (the cross-entropy backward writes one) is used in place."""
+    M, N = t.shape
+    if (t.is_cuda and t.stride() == (ld, 1) and t.data_ptr() % 16 == 0
+            and (t.storage_offset() + M * ld) * t.element_size() <= t.untyped_storage().nbytes()):
+        full = t.as_strided((M, ld), (ld, 1))
+        full[:, N:].zero_()
+        return full
+    full = torch.zeros((M, ld), dtype=t.dtype, device=t.device)
+    full[:, :N].copy_(t)
+    return full
 
 
 def linear_supported(x, weight):
@@ -455,9 +475,11 @@ def linear_supported(x, weight):
             and weight.shape[1] % q == 0 and x.shape[-1] == weight.shape[1])
 
 
-def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None):
+def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None, ldy=None):
     """act in {None, 'relu'}; dropout_p > 0 only together with relu (mask recovered from y > 0).
-    bf16-stored x always computes in bf16; fp32-stored x computes in get_matmul_dtype()."""
+    bf16-stored x always computes in bf16; fp32-stored x computes in get_matmul_dtype().
+    ldy: row stride of the output buffer (multiple of 4 / 8 for fp32 / bf16) when N itself is not;
+    the result is then the (M, N) column slice of an (M, ldy) buffer."""
     if x.dtype == torch.bfloat16:
         compute = GT_BF16
     else:
@@ -471,14 +493,20 @@ def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None
         raise ValueError(act)
     if dropout_p > 0 and a == 0:
         raise ValueError("fused dropout needs act='relu'")
-    return _Linear.apply(x, weight, bias, a, float(dropout_p), int(seed), compute, out_dtype)
+    return _Linear.apply(x, weight, bias, a, float(dropout_p), int(seed), compute, out_dtype, ldy)
 
 
 def linear_module(mod, x, act=None, dropout_p=0.0, seed=0):
-    """Apply an nn.Linear through the HIP kernel when its shape is supported (N, K multiples of 4),
-    else through torch's GEMM (odd shapes: e.g. the 37-feature TU node encoder, the 5002-way heads)."""
+    """Apply an nn.Linear through the HIP kernel when its shape is supported (K a multiple of 4 / 8;
+    an odd N is written into row-padded storage), else through torch's GEMM (e.g. the 37-feature TU
+    node encoder)."""
     if linear_supported(x, mod.weight):
         return linear(x, mod.weight, mod.bias, act=act, dropout_p=dropout_p, seed=seed)
+    q = 8 if x.dtype == torch.bfloat16 else 4
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] == mod.weight.shape[1] \
+            and mod.weight.shape[1] % q == 0 and x.dim() == 2:
+        N = mod.weight.shape[0]
+        return linear(x, mod.weight, mod.bias, act=act, dropout_p=dropout_p, seed=seed, ldy=(N + q - 1) // q * q)
     y = torch.nn.functional.linear(x, mod.weight.to(x.dtype), None if mod.bias is None else mod.bias.to(x.dtype))
     if act == "relu":
         y = torch.relu(y)
@@ -572,3 +600,45 @@ def embed_sum(columns, tables, clamps=None):
         clamp = -1 if clamps is None or clamps[t] is None else int(clamps[t])
         cols.append((c, 0, c.stride(0) if c.shape[0] > 1 else 1, clamp))
     return _EmbedSum.apply(cols, *tables)
+
+
+# ------------------------------------------------------------------------------------------------
+# softmax cross-entropy over the stacked prediction heads
+# ------------------------------------------------------------------------------------------------
+class _Xent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stacked, target):
+        B, L, C = stacked.shape
+        if stacked.dtype != torch.float32 or stacked.stride(2) != 1 or stacked.stride(1) != C:
+            raise TypeError("softmax_xent: fp32 (B, L, C) logits with contiguous heads expected")
+        if not stacked.is_cuda:
+            raise RuntimeError("logits must be a GPU tensor: graphtrans_amd has no CPU fallback")
+        ld = stacked.stride(0) if B > 1 else L * C
+        target = target.contiguous()
+        dev = stacked.device
+        aux = torch.empty(2 * B * L + L + 1, dtype=torch.float32, device=dev)
+        lse, row_loss, head_scale, loss = aux[:B * L], aux[B * L:2 * B * L], aux[2 * B * L:2 * B * L + L], aux[2 * B * L + L:]
+        _lib.launch("gt_xent_fwd", _ptr(stacked), B, L, C, ld, _ptr(target), target.stride(0), _ptr(lse), _ptr(row_loss),
+                    _ptr(head_scale), _ptr(loss), _stream())
+        ctx.save_for_backward(stacked, target, lse, head_scale)
+        ctx.ld = ld
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        stacked, target, lse, head_scale = ctx.saved_tensors
+        B, L, C = stacked.shape
+        ld = ctx.ld
+        g = g.to(torch.float32).contiguous()
+        buf = torch.empty((B, ld), dtype=torch.float32, device=stacked.device)
+        _lib.launch("gt_xent_bwd", _ptr(stacked), _ptr(lse), _ptr(head_scale), _ptr(target), target.stride(0), _ptr(g),
+                    B, L, C, ld, _ptr(buf), _stream())
+        return buf[:, :L * C].view(B, L, C), None
+
+
+def softmax_xent(stacked, target):
+    """mean_l CrossEntropyLoss()(stacked[:, l], target[:, l]) for (B, L, C) fp32 logits whose batch rows
+    may be padded (stride(0) >= L*C); ignore_index -100 like torch's default (gt_xent_fwd / _bwd)."""
+    if target.dtype != torch.int64 or target.dim() != 2 or target.shape[1] < stacked.shape[1]:
+        raise TypeError("softmax_xent: int64 (B, >=L) targets expected")
+    return _Xent.apply(stacked, target)

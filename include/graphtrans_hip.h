@@ -273,15 +273,41 @@ int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy
  * pass).  x_dtype / y_dtype: storage of x (and dx) / y (and dy); compute: GT_BF16
  * (v_mfma_f32_16x16x32_bf16) or GT_F32 (v_mfma_f32_16x16x4_f32, needs fp32 storage).
  * N % 4 == 0 and K % 4 == 0.  Fused dropout requires act == relu.  Deterministic.
+ * dX of a long contraction with few output tiles (N >= 2048) is split over N into fp32 partials.
  */
 int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
                   void* y, int64_t M, int64_t N, int64_t K, int act, float dropout_p, uint64_t seed,
                   gt_stream_t stream);
+/* Same, with an explicit row stride ldy >= N for y / dy / y_for_mask (ldy % 4 == 0, N arbitrary): the
+ * stacked 5 x 5002-way prediction heads (models/gnn_transformer.py:124-126) write N = 25010 logits per
+ * graph into rows of 25012.  Columns N..ldy of y are unspecified after the forward; the backward reads
+ * them in dy (multiplied by zero weights), so they must hold finite values. */
+int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                     void* y, int64_t M, int64_t N, int64_t K, int64_t ldy, int act, float dropout_p, uint64_t seed,
+                     gt_stream_t stream);
 size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K);
 int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                   const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                   float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
                   size_t workspace_bytes, gt_stream_t stream);
+int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                     const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                     float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldy, float dropout_p, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Softmax cross-entropy over the stacked prediction heads (the Code2 loss, dataset/code.py:39-45:
+ * (1/L) sum_l CrossEntropyLoss()(pred_l, y_arr[:, l])).  logits[b * ld + l * C + c], fp32;
+ * target[b * target_stride + l] int64, ignore_index -100 as torch's default.
+ *   fwd: lse [B*L], row_loss [B*L], head_scale [L] = 1 / (L * #live rows of head l), loss [1]
+ *   bwd: dlogits [B][ld] = (softmax - onehot) * head_scale[l] * grad_loss[0]; columns L*C..ld zeroed
+ */
+int gt_xent_fwd(const float* logits, int64_t B, int64_t L, int64_t C, int64_t ld, const int64_t* target,
+                int64_t target_stride, float* lse, float* row_loss, float* head_scale, float* loss,
+                gt_stream_t stream);
+int gt_xent_bwd(const float* logits, const float* lse, const float* head_scale, const int64_t* target,
+                int64_t target_stride, const float* grad_loss, int64_t B, int64_t L, int64_t C, int64_t ld,
+                float* dlogits, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Composite layer entry points: ONE call enqueues every kernel of a layer's forward or backward

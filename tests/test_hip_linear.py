@@ -96,3 +96,39 @@ def test_linear_fused_dropout():
     assert_close(w.grad.cpu(), wr.grad, what="dW")
     y2 = ops.linear(x, w, b, act="relu", dropout_p=p, seed=7)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 25010, 128), (64, 5002, 128), (33, 10, 8), (300, 2050, 64)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16c_fp32s"])
+def test_linear_padded_rows_and_split_dx(M, N, K, mode):
+    """gt_linear_*_ld: an N that is not a multiple of 4 lands in row-padded storage (the 5 x 5002-way
+    stacked heads, models/gnn_transformer.py:124-126); the long-contraction dX is split over N."""
+    from graphtrans_amd import ops
+
+    torch.manual_seed(1)
+    x = torch.randn(M, K)
+    w = torch.randn(N, K) / K ** 0.5
+    b = torch.randn(N) * 0.1
+    g = torch.randn(M, N)
+    if mode != "fp32":
+        x, w_ref, g = x.bfloat16().float(), w.bfloat16().float(), g.bfloat16().float()
+    else:
+        w_ref = w
+    xr, wr, br = x.double().requires_grad_(True), w_ref.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    (yr * g.double()).sum().backward()
+    ops.set_matmul_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        ld = (N + 3) // 4 * 4
+        yd = ops.linear(xd, wd, bd, ldy=ld)
+        assert yd.shape == (M, N) and yd.stride() == (ld, 1)
+        (yd * g.to(DEV)).sum().backward()
+    finally:
+        ops.set_matmul_dtype(torch.float32)
+    tol = 1e-4 if mode == "fp32" else 3e-2
+    assert_close(yd.detach().cpu(), yr.detach(), atol=tol, rtol=tol, what="y")
+    assert_close(xd.grad.cpu(), xr.grad, atol=tol, rtol=tol, what="dx")
+    assert_close(wd.grad.cpu(), wr.grad, atol=tol, rtol=tol, what="dw")
+    assert_close(bd.grad.cpu(), br.grad, atol=tol, rtol=tol, what="db")

@@ -1,0 +1,67 @@
+"""gt_xent_fwd / _bwd (the Code2 loss over the stacked heads, dataset/code.py:39-45) against
+torch.nn.CrossEntropyLoss per head in float64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(stacked, y):
+    L = stacked.shape[1]
+    loss = 0
+    for l in range(L):
+        loss = loss + F.cross_entropy(stacked[:, l], y[:, l])
+    return loss / L
+
+
+@pytest.mark.parametrize("B,L,C,pad", [(256, 5, 5002, 2), (7, 3, 10, 2), (64, 1, 128, 0), (5, 5, 33, 3)])
+@pytest.mark.parametrize("ignore", [False, True])
+def test_xent_matches_per_head_cross_entropy(B, L, C, pad, ignore):
+    from graphtrans_amd import ops
+    torch.manual_seed(B + C)
+    ld = L * C + pad
+    buf = torch.randn(B, ld) * 3
+    buf[:, L * C:] = float("nan")  # pad columns must never be read
+    y = torch.randint(0, C, (B, L + 1))
+    if ignore:
+        y[::3, 0] = -100
+        y[1, L - 1] = -100
+    logits = buf[:, :L * C].reshape(B, L, C).double().requires_grad_(True)
+    ref = _ref(logits, y)
+    ref.backward()
+
+    bd = buf.to(DEV)
+    stacked = bd[:, :L * C].view(B, L, C).requires_grad_(True)
+    loss = ops.softmax_xent(stacked, y.to(DEV))
+    (loss * 2.5).backward()
+    assert_close(loss.detach().cpu().double(), ref.detach(), atol=1e-5, rtol=1e-5, what="loss")
+    assert_close(stacked.grad.cpu().double(), logits.grad * 2.5, atol=1e-6, rtol=1e-4, what="dlogits")
+    # deterministic
+    loss2 = ops.softmax_xent(stacked.detach(), y.to(DEV))
+    assert torch.equal(loss2, loss.detach())
+
+
+def test_code2_loss_uses_fused_path_and_matches_reference_formula():
+    from graphtrans_amd import losses
+    from graphtrans_amd.models.base_model import stacked_heads
+    torch.manual_seed(0)
+    heads = torch.nn.ModuleList([torch.nn.Linear(128, 5002) for _ in range(5)]).to(DEV)
+    h = torch.randn(256, 128, device=DEV, requires_grad=True)
+    y = torch.randint(0, 5002, (256, 5), device=DEV)
+    preds = stacked_heads(h, heads, 5002)
+    assert len(preds) == 5 and preds[0].shape == (256, 5002)
+    loss = losses.code2_loss(preds, y)
+    loss.backward()
+    hr = h.detach().double().cpu().requires_grad_(True)
+    ref = 0
+    for i, m in enumerate(heads):
+        ref = ref + F.cross_entropy(F.linear(hr, m.weight.detach().double().cpu(), m.bias.detach().double().cpu()), y[:, i].cpu())
+    ref = ref / 5
+    ref.backward()
+    assert_close(loss.detach().cpu().double(), ref.detach(), atol=1e-4, rtol=1e-4, what="loss")
+    assert_close(h.grad.cpu().double(), hr.grad, atol=1e-4, rtol=1e-4, what="dh")
+    assert all(m.weight.grad is not None and m.bias.grad is not None for m in heads)
