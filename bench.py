@@ -237,7 +237,8 @@ def main():
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()
     sync = GradSync(model.parameters(), world_size=world)
-    optim = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0, fused=True)
+    from graphtrans_amd.optim import FusedAdamW
+    optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams
     batches = [attach_sizes(gen(1000 * rank + i)).to(device) for i in range(4)]  # .to() keeps the host-side sizes
 

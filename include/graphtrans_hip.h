@@ -379,6 +379,28 @@ int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, v
 int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, void* d_x, void* d_vn,
                      float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * AdamW (decoupled weight decay, no amsgrad) over many fp32 tensors in one launch: the optimizer step
+ * of the training loop (optim.AdamW at main.py:178, optimizer.step() at trainers/base_trainer.py:36).
+ * table [T] (device) describes every tensor; chunk c (gt_adamw_chunk_elems() elements) belongs to
+ * tensor chunk_tensor[c] and is its chunk_local[c]-th chunk (both device, built once).  One call
+ * updates tensors [tensor_begin, tensor_begin + num_tensors) = chunks [chunk_begin, +num_chunks);
+ * grads_host[i] is the DEVICE pointer of tensor tensor_begin + i's gradient (HOST array; NULL skips
+ * the tensor, as torch skips parameters without a gradient).  step = 1, 2, ... (bias correction).
+ */
+#define GT_ADAMW_MAX_TENSORS 384
+typedef struct gt_adamw_tensor {
+  float* param;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} gt_adamw_tensor;
+int gt_adamw_chunk_elems(void);
+int gt_adamw_step(const gt_adamw_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_local,
+                  int64_t chunk_begin, int64_t num_chunks, int tensor_begin, int num_tensors,
+                  const float* const* grads_host, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, gt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,9 +22,11 @@ torch.manual_seed(1234)
 args, model, gen, loss_fn, _ = bench.build("code2", torch.bfloat16, device, B)
 model.train()
 sync = GradSync(model.parameters(), world_size=1)
-optim = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0, fused=True)
+from graphtrans_amd.optim import FusedAdamW
+optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
 batches = [bench.attach_sizes(gen(i)).to(device) for i in range(4)]
 acc = {}
+scratch = torch.empty(16, device=device)
 
 
 def lap(name, t):
@@ -48,6 +50,10 @@ for i in range(steps + 20):
     loss = loss_fn(out, b); t = lap("loss", t)
     loss.backward(); t = lap("backward", t)
     sync.finish(); t = lap("grad_sync", t)
+    if os.environ.get("GT_PROBE"):
+        gl = [p.grad for p in sync.params]; t = lap("probe_grad_access", t)
+        scratch.zero_(); t = lap("probe_tiny_launch", t)
+        scratch.zero_(); t = lap("probe_tiny_launch2", t)
     optim.step(); t = lap("adamw", t)
 total = time.perf_counter() - t_all
 torch.cuda.synchronize()
