@@ -78,7 +78,10 @@ SIGNATURES = {
     "gt_vn_update_workspace_bytes": (_sz, [_p]),
     "gt_vn_update_grad_elems": (_i64, [_p]),
     "gt_vn_update_fwd": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p]),
-    "gt_vn_update_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_vn_update_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_copy2d": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "gt_rows_gather": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
+    "gt_rows_scatter": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_attn_fwd": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _f, _f, _f, _u64, _p]),
     "gt_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _f, _f, _f,
                          _u64, _p]),

@@ -379,8 +379,9 @@ extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void
   return GT_OK;
 }
 
-extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, const void* saved, void* d_x, void* d_vn,
-                                float* grads, void* workspace, size_t workspace_bytes, gt_stream_t st) {
+extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, const void* saved, const void* d_x_add,
+                                void* d_x, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
+                                gt_stream_t st) {
   GT_CHECK_ARG(L && d_vn_out && saved && d_x && d_vn && grads && workspace, "null buffer");
   const VnWork w = vn_work(L, workspace);
   if (workspace_bytes < w.bytes) { gt_set_error("gt_vn_update_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
@@ -396,8 +397,8 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   // d_t0 = d_z1 W1 ; d_vn = d_t0 (+ d_vn_out through the residual branch)
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, g.w1, g.b1, B,
                        2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-  // d_x[n] = d_t0[graph(n)]
-  GT_TRY(gt_segment_bcast_add(GT_F32, nullptr, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
+  // d_x[n] = d_t0[graph(n)] (+ d_x_add[n]: gradient reaching x from its other consumers)
+  GT_TRY(gt_segment_bcast_add(GT_F32, d_x_add, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
   if (L->residual)
     GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
   else

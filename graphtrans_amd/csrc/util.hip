@@ -1,0 +1,95 @@
+// util.hip — small data-movement kernels of the fused model path (engine.py): column-slab copies
+// for the JK concatenation and row gathers / scatters for the sequence pooling.
+//
+// Reference (paths under /root/reference): torch.cat([h_list[0], h_list[-1]], dim=1) for JK = "cat"
+// (modules/gnn_module.py:104-105) and transformer_out[-1] for the "cls" / "last" pooling
+// (models/gnn_transformer.py:113-114).  Pure HBM copies, 16-byte vectorised.
+#include "gt_common.h"
+
+namespace {
+
+constexpr int UT = 256;
+
+// dst[r][0..width) = src[r][0..width), byte pitches; width, pitches and bases multiples of 16
+__global__ void __launch_bounds__(UT) k_copy2d(char* __restrict__ dst, int64_t dst_pitch, const char* __restrict__ src,
+                                               int64_t src_pitch, int64_t width16, int64_t rows) {
+  const int64_t total = rows * width16;
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
+    const int64_t r = i / width16, c = i % width16;
+    *reinterpret_cast<uint4*>(dst + r * dst_pitch + c * 16) = *reinterpret_cast<const uint4*>(src + r * src_pitch + c * 16);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(UT) k_rows_gather(const T* __restrict__ x, const int64_t* __restrict__ idx, int64_t n,
+                                                    int64_t dim, float* __restrict__ out) {
+  const int64_t C = dim / 4, total = n * C;
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
+    const int64_t r = i / C, c = (i % C) * 4;
+    *reinterpret_cast<float4*>(out + r * dim + c) = gt_load4<T>(x + idx[r] * dim + c);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(UT) k_rows_scatter(const float* __restrict__ g, const int64_t* __restrict__ idx, int64_t n,
+                                                     int64_t dim, T* __restrict__ out) {
+  const int64_t C = dim / 4, total = n * C;
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
+    const int64_t r = i / C, c = (i % C) * 4;
+    gt_store4<T>(out + idx[r] * dim + c, *reinterpret_cast<const float4*>(g + r * dim + c));
+  }
+}
+
+int grid_for(int64_t items) {
+  int64_t g = gt_cdiv(items, UT);
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes, int64_t width_bytes,
+                         int64_t rows, gt_stream_t stream_) {
+  GT_CHECK_ARG(rows >= 0 && width_bytes >= 0, "bad sizes");
+  if (rows == 0 || width_bytes == 0) return GT_OK;
+  GT_CHECK_ARG(dst && src, "null buffer");
+  GT_CHECK_ARG(((uintptr_t)dst | (uintptr_t)src | (uintptr_t)dst_pitch_bytes | (uintptr_t)src_pitch_bytes |
+                (uintptr_t)width_bytes) % 16 == 0, "pointers, pitches and width must be multiples of 16 bytes");
+  hipLaunchKernelGGL(k_copy2d, dim3(grid_for(rows * (width_bytes / 16))), dim3(UT), 0, (hipStream_t)stream_, (char*)dst,
+                     dst_pitch_bytes, (const char*)src, src_pitch_bytes, width_bytes / 16, rows);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_rows_gather(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, float* out,
+                              gt_stream_t stream_) {
+  GT_CHECK_ARG(dtype == GT_F32 || dtype == GT_BF16, "bad dtype");
+  GT_CHECK_ARG(n >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
+  if (n == 0) return GT_OK;
+  GT_CHECK_ARG(x && idx && out, "null buffer");
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_rows_gather<float>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, (hipStream_t)stream_, (const float*)x, idx,
+                       n, dim, out);
+  else
+    hipLaunchKernelGGL(k_rows_gather<gt_bf16>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, (hipStream_t)stream_,
+                       (const gt_bf16*)x, idx, n, dim, out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim,
+                               void* out, gt_stream_t stream_) {
+  GT_CHECK_ARG(dtype == GT_F32 || dtype == GT_BF16, "bad dtype");
+  GT_CHECK_ARG(n >= 0 && total_rows >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
+  if (total_rows == 0) return GT_OK;
+  GT_CHECK_ARG(out && (n == 0 || (grad && idx)), "null buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipMemsetAsync(out, 0, (size_t)total_rows * dim * (dtype == GT_F32 ? 4 : 2), stream);
+  if (n == 0) return GT_OK;
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_rows_scatter<float>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, stream, grad, idx, n, dim, (float*)out);
+  else
+    hipLaunchKernelGGL(k_rows_scatter<gt_bf16>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, stream, grad, idx, n, dim,
+                       (gt_bf16*)out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -1,0 +1,563 @@
+"""Fused model path: the whole GNNTransformer forward (and its backward) as ONE autograd node.
+
+The module-by-module path (modules/, layers.py) costs ~3.5 ms of host time per Code2 step in Python
+autograd bookkeeping alone (tools/host_phases.py): ~80 autograd Functions, each saving a dozen
+parameter tensors and returning a dozen gradients.  Here the same C-ABI entry points are called back
+to back on buffers carved out of one arena, parameter gradients are written straight into one flat
+buffer whose slices become `p.grad`, and autograd sees a single node.
+
+Covered configuration (everything else keeps using the module path, see `eligible`):
+  GNN_node / GNN_node_Virtualnode with GCNConv layers, Linear(<=4, D) or "zero" edge encoders,
+  gnn_dropout 0 (or eval), JK in {last, cat}, ASTNodeEncoder / AtomEncoder inputs, no perturb;
+  packed token layout (cls / last pooling, no positional encoder, no masked layers), ReLU post-norm
+  encoder layers; stacked max_seq_len heads or a single head.
+Reference call path: models/gnn_transformer.py:88-127 -> modules/gnn_module.py:181-224 ->
+modules/transformer_encoder.py:42-61.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, layers
+from ._lib import GT_BF16, GT_EDGE_LINEAR, GT_EDGE_NONE, GT_F32
+from .graph import _stream
+
+
+def _c4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Bump:
+    """Byte offsets inside one arena (256-byte aligned)."""
+
+    def __init__(self):
+        self.off = 0
+
+    def take(self, nbytes):
+        o = self.off
+        self.off = (o + int(nbytes) + 255) // 256 * 256
+        return o
+
+
+# ---------------------------------------------------------------------------------------------------
+# plan: parameter order, gradient layout, persistent descriptors (built once per model)
+# ---------------------------------------------------------------------------------------------------
+class _Plan:
+    def __init__(self, model):
+        from .modules.gnn_module import GNN_node_Virtualnode
+        gnn, enc = model.gnn_node, model.transformer_encoder
+        self.L, self.has_vn = gnn.num_layer, isinstance(gnn, GNN_node_Virtualnode)
+        self.D = gnn.convs[0].emb_dim
+        self.d = enc.d_model
+        self.jk_cat = gnn.JK == "cat"
+        self.dev = next(model.parameters()).device
+        self.total = 0
+        self.params = []   # (param, offset)
+        self._cache = {}   # per batch size: small index arrays
+
+        def seg(p):
+            off = self.total
+            self.params.append((p, off))
+            self.total += _c4(p.numel())
+            return off
+
+        ne = gnn.node_encoder
+        if hasattr(ne, "type_encoder"):  # ASTNodeEncoder
+            self.embed = [ne.type_encoder.weight, ne.attribute_encoder.weight, ne.depth_encoder.weight]
+            self.embed_clamp = [-1, -1, int(ne.max_depth)]
+            self.embed_kind = "ast"
+        else:
+            self.embed = [e.weight for e in ne.atom_embedding_list]
+            self.embed_clamp = [-1] * len(self.embed)
+            self.embed_kind = "atom"
+        self.embed_off = [seg(t) for t in self.embed]
+        self.vn_emb = gnn.virtualnode_embedding.weight if self.has_vn else None
+        self.vn_emb_off = seg(self.vn_emb) if self.has_vn else None
+        # GCN layers: gradient block order of gt_gcn_layer_bwd = lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b
+        self.gcn, self.gcn_off, self.gcn_edge = [], [], []
+        for conv, bn in zip(gnn.convs, gnn.batch_norms):
+            ee = conv.edge_encoder
+            edge = [ee.weight, ee.bias] if isinstance(ee, torch.nn.Module) else []
+            self.gcn_edge.append(len(edge) > 0)
+            self.gcn.append((conv, bn))
+            off = None
+            for p in [conv.linear.weight, conv.linear.bias, conv.root_emb.weight, *edge, bn.weight, bn.bias]:
+                o = seg(p)
+                off = o if off is None else off
+            self.gcn_off.append(off)
+        self.vn, self.vn_off = [], []
+        if self.has_vn:
+            for seq in gnn.mlp_virtualnode_list:
+                m = list(seq)
+                off = None
+                for p in [m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias]:
+                    o = seg(p)
+                    off = o if off is None else off
+                self.vn.append(m)
+                self.vn_off.append(off)
+        g2t = model.gnn2transformer
+        self.g2t = g2t
+        self.g2t_off = (seg(g2t.weight), seg(g2t.bias))
+        self.cls = enc.cls_embedding
+        self.cls_off = seg(self.cls) if self.cls is not None else None
+        self.norm_in = enc.norm_input
+        self.norm_in_off = (seg(enc.norm_input.weight), seg(enc.norm_input.bias)) if enc.norm_input is not None else None
+        self.enc_layers, self.enc_off = list(enc.transformer.layers), []
+        for mod in self.enc_layers:
+            off = None
+            for p in layers.encoder_layer_params(mod):
+                o = seg(p)
+                off = o if off is None else off
+            self.enc_off.append(off)
+        self.norm_out = enc.transformer.norm
+        self.norm_out_off = (seg(self.norm_out.weight), seg(self.norm_out.bias)) if self.norm_out is not None else None
+        if model.max_seq_len is None:
+            self.heads = [model.graph_pred_linear]
+        else:
+            self.heads = list(model.graph_pred_linear_list)
+        self.num_tasks = model.num_tasks
+        self.Nh = sum(h.weight.shape[0] for h in self.heads)
+        self.ldy = _c4(self.Nh)
+        # head gradients: one [Nh][d] block and one [Nh] block; the per-head grads are slices of them
+        self.headw_off = self.total
+        for h in self.heads:
+            self.params.append((h.weight, self.total))
+            self.total += h.weight.numel()
+        self.total = _c4(self.total)
+        self.headb_off = self.total
+        for h in self.heads:
+            self.params.append((h.bias, self.total))
+            self.total += h.bias.numel()
+        self.total = _c4(self.total)
+        # persistent flat gradient buffer and its per-parameter views
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in self.params]
+        self.plist = [p for p, _ in self.params]
+        self.param_ptrs = tuple(p.data_ptr() for p in self.plist)
+        # persistent descriptors (batch-dependent fields are refreshed every step)
+        self.gcn_desc = [layers.GcnLayerDesc() for _ in self.gcn]
+        self.vn_desc = [layers.VnUpdateDesc() for _ in self.vn]
+        self.enc_desc = [layers.EncoderLayerDesc() for _ in self.enc_layers]
+        self._fill_static()
+
+    def _fill_static(self):
+        D = self.D
+        for (conv, bn), desc, has_edge in zip(self.gcn, self.gcn_desc, self.gcn_edge):
+            desc.D = D
+            desc.lin_w, desc.lin_b, desc.root = conv.linear.weight.data_ptr(), conv.linear.bias.data_ptr(), conv.root_emb.weight.data_ptr()
+            if has_edge:
+                desc.edge_mode = GT_EDGE_LINEAR
+                desc.edge_cols = conv.edge_encoder.weight.shape[1]
+                desc.edge_w, desc.edge_b = conv.edge_encoder.weight.data_ptr(), conv.edge_encoder.bias.data_ptr()
+            else:
+                desc.edge_mode = GT_EDGE_NONE
+            desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
+            desc.bn_rm, desc.bn_rv, desc.bn_nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+            desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+        for m, desc in zip(self.vn, self.vn_desc):
+            desc.D = D
+            for name, p in zip(("w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn2_w", "bn2_b"),
+                               (m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias)):
+                setattr(desc, name, p.data_ptr())
+            desc.bn1_rm, desc.bn1_rv, desc.bn1_nbt = m[1].running_mean.data_ptr(), m[1].running_var.data_ptr(), m[1].num_batches_tracked.data_ptr()
+            desc.bn2_rm, desc.bn2_rv, desc.bn2_nbt = m[4].running_mean.data_ptr(), m[4].running_var.data_ptr(), m[4].num_batches_tracked.data_ptr()
+            desc.bn_momentum, desc.bn_eps = float(m[1].momentum), float(m[1].eps)
+        for mod, desc in zip(self.enc_layers, self.enc_desc):
+            desc.d_model, desc.ffn = self.d, mod.linear1.weight.shape[0]
+            for name, p in zip(("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w",
+                                "n2_b"), layers.encoder_layer_params(mod)):
+                setattr(desc, name, p.data_ptr())
+            desc.ln_eps = float(mod.norm1.eps)
+
+    def small(self, B):
+        c = self._cache.get(B)
+        if c is None:
+            c = dict(zeros=torch.zeros(B, dtype=torch.int32, device=self.dev),
+                     ident=torch.arange(B, dtype=torch.int32, device=self.dev),
+                     ptr01=torch.tensor([0, B], dtype=torch.int32, device=self.dev))
+            self._cache[B] = c
+        return c
+
+
+def _plan(model):
+    plan = model.__dict__.get("_gt_plan")
+    if plan is None or plan.param_ptrs != tuple(p.data_ptr() for p in plan.plist):
+        plan = _Plan(model)
+        model.__dict__["_gt_plan"] = plan
+    return plan
+
+
+def eligible(model, batched_data, perturb):
+    """True when the fused path covers this model / call (cached per model and mode)."""
+    if perturb is not None or not getattr(model, "fused", True):
+        return False
+    key = (model.training, torch.is_grad_enabled())
+    cache = model.__dict__.setdefault("_gt_eligible", {})
+    ok = cache.get(key)
+    if ok is None:
+        ok = cache[key] = _eligible_static(model)
+    if not ok:
+        return False
+    x = batched_data.x
+    return x.is_cuda and x.dtype == torch.int64 and x.dim() == 2
+
+
+def _eligible_static(model):
+    from . import ops
+    from .modules.conv import GCNConv
+    from .modules.norm import BatchNorm1d
+    gnn, enc = model.gnn_node, model.transformer_encoder
+    try:
+        if not model._use_packed() or gnn.JK not in ("last", "cat"):
+            return False
+        if gnn.drop_ratio != 0 and model.training:
+            return False
+        ne = gnn.node_encoder
+        if not (hasattr(ne, "type_encoder") or hasattr(ne, "atom_embedding_list")):
+            return False
+        if hasattr(ne, "atom_embedding_list") and len(ne.atom_embedding_list) > 16:
+            return False
+        D = gnn.convs[0].emb_dim
+        if D % 4:
+            return False
+        for conv, bn in zip(gnn.convs, gnn.batch_norms):
+            if not isinstance(conv, GCNConv) or not isinstance(bn, BatchNorm1d):
+                return False
+            if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+                return False
+            ee = conv.edge_encoder
+            if isinstance(ee, torch.nn.Module):
+                if not (isinstance(ee, torch.nn.Linear) and ee.in_features <= 4 and ee.bias is not None):
+                    return False
+            else:
+                e = ee(None)
+                if not (isinstance(e, (int, float)) and e == 0):
+                    return False
+        if hasattr(gnn, "mlp_virtualnode_list"):
+            for seq in gnn.mlp_virtualnode_list:
+                m = list(seq)
+                if not (len(m) == 6 and isinstance(m[0], torch.nn.Linear) and isinstance(m[1], BatchNorm1d)
+                        and isinstance(m[3], torch.nn.Linear) and isinstance(m[4], BatchNorm1d)):
+                    return False
+        if enc.activation != "relu" or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if enc.compute_dtype == torch.bfloat16 and ops.get_matmul_dtype() != torch.bfloat16:
+            return False
+        for mod in enc.transformer.layers:
+            if mod.linear1.weight.shape[0] % 8:
+                return False
+        if model.gnn2transformer.weight.shape[1] % 4:
+            return False
+        for p in model.parameters():
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad):
+                return False
+    except Exception:
+        return False
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------
+# the autograd node
+# ---------------------------------------------------------------------------------------------------
+def _call(name, *args):
+    _lib.check(getattr(_lib.lib(), name)(*args), name)
+
+
+class _FusedModel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, trigger, model, batched_data, gs, lay):
+        from . import ops
+        plan = _plan(model)
+        L, D, d, dev = plan.L, plan.D, plan.d, plan.dev
+        N, E, B, rows = gs.N, gs.E, gs.B, lay.rows
+        st = _stream()
+        lib = _lib.lib()
+        training = 1 if model.training else 0
+        compute = GT_BF16 if ops.get_matmul_dtype() == torch.bfloat16 else GT_F32
+        enc = model.transformer_encoder
+        tdt = GT_BF16 if enc.compute_dtype == torch.bfloat16 else GT_F32
+        tsz = 2 if tdt == GT_BF16 else 4
+        sm = plan.small(B)
+        nenc = len(plan.enc_layers)
+
+        # ---- refresh the batch-dependent descriptor fields
+        ea = batched_data.edge_attr
+        ea_f = None
+        if any(plan.gcn_edge):
+            ea_f = ea if (ea.dtype == torch.float32 and ea.is_contiguous()) else ea.float().contiguous()
+        for l, desc in enumerate(plan.gcn_desc):
+            desc.N, desc.E, desc.B = N, E, B
+            desc.has_vn = 1 if plan.has_vn else 0
+            desc.relu = 1 if l != L - 1 else 0
+            desc.residual = 1 if model.gnn_node.residual else 0
+            desc.training, desc.compute = training, compute
+            layers._fill_graph(desc, gs)
+            if plan.gcn_edge[l]:
+                desc.edge_attr = ea_f.data_ptr()
+        for desc in plan.vn_desc:
+            desc.N, desc.B = N, B
+            desc.residual = 1 if model.gnn_node.residual else 0
+            desc.training, desc.compute = training, compute
+            desc.graph_ptr, desc.node_graph, desc.identity_graph = gs.graph_ptr.data_ptr(), gs.node_graph.data_ptr(), sm["ident"].data_ptr()
+        p_drop = float(enc.dropout_p) if model.training else 0.0
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if (model.training and enc.dropout_p > 0) else 0
+        for i, desc in enumerate(plan.enc_desc):
+            desc.rows, desc.nhead = rows, enc.nhead
+            desc.dtype, desc.compute, desc.training = tdt, compute, training
+            desc.seq_desc, desc.num_seqs, desc.row_stride, desc.max_npos = lay.desc.data_ptr(), lay.B, lay.row_stride, lay.max_npos
+            work = getattr(lay, "work", None)
+            desc.work_items, desc.num_work = (work.data_ptr() if work is not None else None), getattr(lay, "num_work", 0)
+            desc.dropout_p = p_drop
+            desc.seed = (seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF
+
+        # ---- arena layout
+        b = _Bump()
+        ND4 = N * D * 4
+        o = dict(h=[b.take(ND4) for _ in range(L + 1)])
+        if plan.has_vn:
+            o["x"] = [b.take(ND4) for _ in range(L)]
+            o["vn"] = [b.take(B * D * 4) for _ in range(L)]
+            vn_saved_bytes = [lib.gt_vn_update_saved_bytes(C.byref(dsc)) for dsc in plan.vn_desc]
+            o["vn_saved"] = [b.take(n) for n in vn_saved_bytes]
+        gcn_saved_bytes = [lib.gt_gcn_layer_saved_bytes(C.byref(dsc)) for dsc in plan.gcn_desc]
+        o["gcn_saved"] = [b.take(n) for n in gcn_saved_bytes]
+        Kc = 2 * D if plan.jk_cat else D
+        if plan.jk_cat:
+            o["cat"] = b.take(N * Kc * 4)
+        o["hn"] = b.take(N * d * tsz)
+        o["tok"] = b.take(rows * d * tsz)
+        if plan.norm_in is not None:
+            o["x0"] = b.take(rows * d * tsz)
+            o["st0"] = b.take(2 * rows * 4)
+        o["xe"] = [b.take(rows * d * tsz) for _ in range(nenc)]
+        enc_saved_bytes = [lib.gt_encoder_layer_saved_bytes(C.byref(dsc)) for dsc in plan.enc_desc]
+        o["enc_saved"] = [b.take(n) for n in enc_saved_bytes]
+        if plan.norm_out is not None:
+            o["xo"] = b.take(rows * d * tsz)
+            o["sto"] = b.take(2 * rows * 4)
+        o["hg"] = b.take(B * d * 4)
+        o["wcat"] = b.take(plan.Nh * d * 4)
+        o["bcat"] = b.take(plan.Nh * 4)
+        ws_bytes = max([lib.gt_gcn_layer_workspace_bytes(C.byref(dsc)) for dsc in plan.gcn_desc]
+                       + [lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
+        o["ws"] = b.take(ws_bytes)
+        arena = torch.empty(b.off, dtype=torch.uint8, device=dev)
+        base = arena.data_ptr()
+
+        def P(key, i=None):
+            return base + (o[key] if i is None else o[key][i])
+
+        # ---- input encoder: h0 = sum of embedding rows   (dataset/utils.py:28-30 / ogb AtomEncoder)
+        x = batched_data.x
+        T = len(plan.embed)
+        if plan.embed_kind == "ast":
+            depth = batched_data.node_depth.reshape(-1)
+            cols = [(x.data_ptr(), x.stride(0)), (x.data_ptr() + 8 * x.stride(1), x.stride(0)), (depth.data_ptr(), depth.stride(0) if N > 1 else 1)]
+        else:
+            cols = [(x.data_ptr() + 8 * i * x.stride(1), x.stride(0)) for i in range(T)]
+        I64, PT = C.c_int64 * T, C.c_void_p * T
+        e_idx, e_str = PT(*[c[0] for c in cols]), I64(*[c[1] for c in cols])
+        e_clamp = I64(*plan.embed_clamp)
+        e_tabs = PT(*[t.data_ptr() for t in plan.embed])
+        _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
+
+        # ---- message passing   (modules/gnn_module.py:181-224)
+        if plan.has_vn:
+            _call("gt_segment_bcast_add", GT_F32, None, plan.vn_emb.data_ptr(), sm["zeros"].data_ptr(), B, 1, D, P("vn", 0), st)
+        for l in range(L):
+            dsc = plan.gcn_desc[l]
+            if plan.has_vn:
+                _call("gt_gcn_layer_fwd", C.byref(dsc), P("h", l), P("vn", l), P("x", l), P("h", l + 1), P("gcn_saved", l),
+                      P("ws"), ws_bytes, st)
+                if l < L - 1:
+                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
+                          P("ws"), ws_bytes, st)
+            else:
+                _call("gt_gcn_layer_fwd", C.byref(dsc), P("h", l), None, None, P("h", l + 1), P("gcn_saved", l), P("ws"),
+                      ws_bytes, st)
+        first = P("x", 0) if plan.has_vn else P("h", 0)   # h_list[0] after the in-place virtual-node add
+        if plan.jk_cat:   # torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
+            _call("gt_copy2d", P("cat"), Kc * 4, first, D * 4, D * 4, N, st)
+            _call("gt_copy2d", P("cat") + D * 4, Kc * 4, P("h", L), D * 4, D * 4, N, st)
+            node_rep = P("cat")
+        else:
+            node_rep = P("h", L)
+
+        # ---- gnn2transformer + token rows + encoder   (models/gnn_transformer.py:92-114)
+        g2t = plan.g2t
+        _call("gt_linear_fwd", GT_F32, tdt, compute, node_rep, g2t.weight.data_ptr(), g2t.bias.data_ptr(), P("hn"), N, d, Kc,
+              0, 0.0, 0, st)
+        cls_t = None
+        if plan.cls is not None:
+            cls_t = plan.cls.detach().reshape(-1)
+            if tdt == GT_BF16:
+                cls_t = cls_t.to(torch.bfloat16)
+        _call("gt_seq_gather", tdt, P("hn"), None if cls_t is None else cls_t.data_ptr(), gs.graph_ptr.data_ptr(),
+              lay.desc.data_ptr(), lay.B, lay.row_stride, lay.max_npos, 1 if lay.with_cls else 0, d, P("tok"), None, st)
+        cur = P("tok")
+        if plan.norm_in is not None:
+            ln = plan.norm_in
+            _call("gt_layernorm_fwd", tdt, cur, None, ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps), 0.0, 0, rows, d,
+                  P("x0"), P("st0"), P("st0") + rows * 4, st)
+            cur = P("x0")
+        enc_in = []
+        for i, dsc in enumerate(plan.enc_desc):
+            enc_in.append(cur)
+            _call("gt_encoder_layer_fwd", C.byref(dsc), cur, P("xe", i), P("enc_saved", i), st)
+            cur = P("xe", i)
+        pre_out = cur
+        if plan.norm_out is not None:
+            ln = plan.norm_out
+            _call("gt_layernorm_fwd", tdt, cur, None, ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps), 0.0, 0, rows, d,
+                  P("xo"), P("sto"), P("sto") + rows * 4, st)
+            cur = P("xo")
+        _call("gt_rows_gather", tdt, cur, lay.last_rows.data_ptr(), B, d, P("hg"), st)
+
+        # ---- prediction heads as one GEMM over the stacked weights   (gnn_transformer.py:120-126)
+        if len(plan.heads) == 1:
+            wcat, bcat = plan.heads[0].weight.data_ptr(), plan.heads[0].bias.data_ptr()
+        else:
+            ww = arena[o["wcat"]:o["wcat"] + plan.Nh * d * 4].view(torch.float32).view(plan.Nh, d)
+            wb = arena[o["bcat"]:o["bcat"] + plan.Nh * 4].view(torch.float32)
+            torch.cat([h.weight.detach() for h in plan.heads], out=ww)
+            torch.cat([h.bias.detach() for h in plan.heads], out=wb)
+            wcat, bcat = P("wcat"), P("bcat")
+        logits = torch.empty((B, plan.ldy), dtype=torch.float32, device=dev)
+        _call("gt_linear_fwd_ld", GT_F32, GT_F32, compute, P("hg"), wcat, bcat, logits.data_ptr(), B, plan.Nh, d, plan.ldy, 0,
+              0.0, 0, st)
+
+        ctx.state = dict(plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
+                         ws_bytes=ws_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
+                         embed=(T, e_idx, e_str, e_clamp, cols), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
+                         dims=(N, E, B, rows))
+        ctx.set_materialize_grads(False)
+        out = logits[:, :plan.Nh] if plan.ldy != plan.Nh else logits
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        s = ctx.state
+        plan, o, base, gs, lay, sm = s["plan"], s["o"], s["base"], s["gs"], s["lay"], s["sm"]
+        compute, tdt, tsz = s["compute"], s["tdt"], s["tsz"]
+        N, E, B, rows = s["dims"]
+        L, D, d, dev, Kc = plan.L, plan.D, plan.d, plan.dev, s["Kc"]
+        st = _stream()
+        lib = _lib.lib()
+        from . import ops
+        if dlogits is None:
+            return None, None, None, None, None
+        dl = ops._padded_rows(dlogits.reshape(B, plan.Nh).to(torch.float32), plan.ldy) if plan.ldy != plan.Nh \
+            else dlogits.reshape(B, plan.Nh).to(torch.float32).contiguous()
+
+        def P(key, i=None):
+            return base + (o[key] if i is None else o[key][i])
+
+        # gradients: straight into the persistent flat buffer when nothing has to be accumulated
+        direct = all(p.grad is None for p in plan.plist)
+        flat = plan.flat if direct else torch.empty_like(plan.flat)
+        G = flat.data_ptr()
+
+        # ---- backward arena
+        nenc = len(plan.enc_desc)
+        b = _Bump()
+        q = dict(d_hg=b.take(B * d * 4), dtok=[b.take(rows * d * tsz) for _ in range(2)], d_hn=b.take(N * d * tsz),
+                 d_cls=b.take(B * d * tsz), d_rep=b.take(N * Kc * 4), dA=b.take(N * D * 4), dB=b.take(N * D * 4),
+                 dC=b.take(N * D * 4), dJ=b.take(N * D * 4 if plan.jk_cat else 0), dvn=[b.take(B * D * 4) for _ in range(4)])
+        enc_ws = max([lib.gt_encoder_layer_workspace_bytes(C.byref(dsc)) for dsc in plan.enc_desc] + [256])
+        ln_ws = lib.gt_layernorm_bwd_workspace_bytes(rows, d)
+        lin_ws = max(lib.gt_linear_bwd_workspace_bytes(compute, B, plan.Nh, d), lib.gt_linear_bwd_workspace_bytes(compute, N, d, Kc))
+        emb_rows = (C.c_int64 * len(plan.embed))(*[t.shape[0] for t in plan.embed])
+        emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
+        ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
+        q["ws"] = b.take(ws_bytes)
+        barena = torch.empty(b.off, dtype=torch.uint8, device=dev)
+        bb = barena.data_ptr()
+
+        def Q(key, i=None):
+            return bb + (q[key] if i is None else q[key][i])
+
+        # ---- heads
+        _call("gt_linear_bwd_ld", GT_F32, GT_F32, compute, P("hg"), s["wcat"], dl.data_ptr(), None, None, None, Q("d_hg"),
+              G + plan.headw_off * 4, G + plan.headb_off * 4, B, plan.Nh, d, plan.ldy, 0.0, Q("ws"), ws_bytes, st)
+        # ---- pooled rows -> token rows
+        dcur, dnext = Q("dtok", 0), Q("dtok", 1)
+        _call("gt_rows_scatter", tdt, Q("d_hg"), lay.last_rows.data_ptr(), B, rows, d, dcur, st)
+        if plan.norm_out is not None:
+            ln = plan.norm_out
+            _call("gt_layernorm_bwd", tdt, s["pre_out"], None, dcur, ln.weight.data_ptr(), P("sto"), P("sto") + rows * 4, 0.0, 0,
+                  rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, Q("ws"), ws_bytes, st)
+            dcur, dnext = dnext, dcur
+        for i in range(nenc - 1, -1, -1):
+            _call("gt_encoder_layer_bwd", C.byref(plan.enc_desc[i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
+                  G + plan.enc_off[i] * 4, Q("ws"), ws_bytes, st)
+            dcur, dnext = dnext, dcur
+        if plan.norm_in is not None:
+            ln = plan.norm_in
+            _call("gt_layernorm_bwd", tdt, P("tok"), None, dcur, ln.weight.data_ptr(), P("st0"), P("st0") + rows * 4, 0.0, 0,
+                  rows, d, dnext, None, G + plan.norm_in_off[0] * 4, G + plan.norm_in_off[1] * 4, Q("ws"), ws_bytes, st)
+            dcur, dnext = dnext, dcur
+        # ---- token rows -> node rows (+ the CLS gradient)
+        _call("gt_seq_scatter", tdt, dcur, None, gs.graph_ptr.data_ptr(), gs.node_graph.data_ptr(), lay.desc.data_ptr(), lay.B,
+              lay.row_stride, 1 if lay.with_cls else 0, N, d, Q("d_hn"), Q("d_cls") if plan.cls is not None else None, st)
+        if plan.cls is not None:
+            dc = barena[q["d_cls"]:q["d_cls"] + B * d * tsz].view(torch.bfloat16 if tdt == GT_BF16 else torch.float32).view(B, d)
+            torch.sum(dc, dim=0, dtype=torch.float32, out=flat[plan.cls_off:plan.cls_off + d])
+        g2t = plan.g2t
+        _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
+              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, Q("ws"), ws_bytes, st)
+        # ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l (=
+        # h_list[l] after the virtual-node add) from its consumers other than conv_l: the JK slab (l = 0)
+        # and the virtual-node update's pooling (l < L-1).
+        if plan.jk_cat:
+            _call("gt_copy2d", Q("dA"), D * 4, Q("d_rep") + D * 4, Kc * 4, D * 4, N, st)   # d h_list[-1]
+            _call("gt_copy2d", Q("dJ"), D * 4, Q("d_rep"), Kc * 4, D * 4, N, st)           # d h_list[0]
+            dy = Q("dA")
+        else:
+            dy = Q("d_rep")
+        d_vn_next = None   # total gradient of vn_{l+1}
+        for l in range(L - 1, -1, -1):
+            extra = Q("dJ") if (l == 0 and plan.jk_cat) else None
+            upd = plan.has_vn and l < L - 1
+            if upd:   # vn_{l+1} = update(x_l, vn_l): d x_l = pooled gradient (+ the JK slab at l = 0)
+                _call("gt_vn_update_bwd", C.byref(plan.vn_desc[l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
+                      G + plan.vn_off[l] * 4, Q("ws"), ws_bytes, st)
+                extra = Q("dC")
+            out = Q("dB") if dy == Q("dA") else Q("dA")
+            xin = P("x", l) if plan.has_vn else P("h", l)
+            _call("gt_gcn_layer_bwd", C.byref(plan.gcn_desc[l]), xin, dy, extra, P("gcn_saved", l), out,
+                  Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
+            if plan.has_vn:   # d vn_l = (layer l's broadcast add) + (update l's pooled + residual inputs)
+                tgt = Q("dvn", l % 2)
+                if upd:
+                    _call("gt_segment_bcast_add", GT_F32, Q("dvn", 3), Q("dvn", 2), sm["ident"].data_ptr(), B, B, D, tgt, st)
+                else:
+                    _call("gt_copy2d", tgt, D * 4, Q("dvn", 3), D * 4, D * 4, B, st)
+                d_vn_next = tgt
+            dy = out
+        d_h0 = dy
+        if plan.has_vn:
+            _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, st)
+        # ---- input encoder tables
+        T, e_idx, e_str, e_clamp, _cols = s["embed"]
+        d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
+        _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
+
+        # ---- hand the gradients to the parameters
+        if direct:
+            for p, v in zip(plan.plist, plan.views):
+                p.grad = v
+        else:
+            off_views = [flat[o_:o_ + p.numel()].view(p.shape) for p, o_ in plan.params]
+            for p, v in zip(plan.plist, off_views):
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    p.grad = p.grad + v
+        ctx.state = None
+        return None, None, None, None, None
+
+
+def forward(model, batched_data, gs, lay):
+    """logits (B, Nh) [row-padded storage] of the fused path; `model` must be `eligible`."""
+    plan = _plan(model)
+    return _FusedModel.apply(plan.plist[0], model, batched_data, gs, lay)

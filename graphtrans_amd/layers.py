@@ -308,7 +308,7 @@ class _VnUpdate(torch.autograd.Function):
         grads = torch.empty(L.gt_vn_update_grad_elems(C.byref(desc)), dtype=torch.float32, device=dev)
         ws_bytes = L.gt_vn_update_workspace_bytes(C.byref(desc))
         ws = _bytes(ws_bytes, dev)
-        _lib.check(L.gt_vn_update_bwd(C.byref(desc), _ptr(g), _ptr(saved), _ptr(d_x), _ptr(d_vn), _ptr(grads), _ptr(ws),
+        _lib.check(L.gt_vn_update_bwd(C.byref(desc), _ptr(g), _ptr(saved), None, _ptr(d_x), _ptr(d_vn), _ptr(grads), _ptr(ws),
                                       ws_bytes, _stream()), "gt_vn_update_bwd")
         return (d_x, d_vn, None, None, None, None, None, *_split(grads, params))
 

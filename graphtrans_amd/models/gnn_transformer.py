@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import engine, ops
 from ..modules.gnn_module import GNNNodeEmbedding, batch_structure
 from ..modules.masked_transformer_encoder import MaskedOnlyTransformerEncoder
 from ..modules.transformer_encoder import TransformerNodeEncoder
@@ -103,11 +103,18 @@ class GNNTransformer(BaseModel):
             raise ValueError("empty batch")
         if perturb is not None and perturb.shape[0] != batched_data.batch.numel():
             raise ValueError("perturb must have one row per node")
+        enc = self.transformer_encoder
+        max_len = int(enc.max_input_len)
+        if engine.eligible(self, batched_data, perturb):  # whole model as one autograd node (engine.py)
+            gs = batch_structure(batched_data)
+            lay = gs.layout("packed", max_len, enc.cls_embedding is not None)
+            out = engine.forward(self, batched_data, gs, lay)
+            if self.max_seq_len is None:
+                return out
+            return StackedHeads(out.view(out.shape[0], self.max_seq_len, self.num_tasks))
         h_node = self.gnn_node(batched_data, perturb)
         h_node = ops.linear_module(self.gnn2transformer, h_node)
         gs = batch_structure(batched_data)
-        enc = self.transformer_encoder
-        max_len = int(enc.max_input_len)
 
         if self._use_packed():
             with_cls = enc.cls_embedding is not None

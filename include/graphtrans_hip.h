@@ -375,9 +375,24 @@ size_t gt_vn_update_workspace_bytes(const gt_vn_update* layer);
 int64_t gt_vn_update_grad_elems(const gt_vn_update* layer);
 int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, void* vn_out, void* saved,
                      void* workspace, size_t workspace_bytes, gt_stream_t stream);
-/* d_x [N][D] = d(pooled)[graph(n)], d_vn [B][D]. */
-int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, void* d_x, void* d_vn,
-                     float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* d_x [N][D] = d(pooled)[graph(n)] (+ d_x_add [N][D] when not NULL), d_vn [B][D]. */
+int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, const void* d_x_add, void* d_x,
+                     void* d_vn, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data movement of the fused model path (graphtrans_amd/engine.py).
+ * gt_copy2d: dst[r][0..width) = src[r][0..width) with byte pitches (all multiples of 16): the two
+ *   column slabs of JK = "cat" (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105)
+ *   and their split in the backward.
+ * gt_rows_gather: out[i] (fp32) = x[idx[i]] -- transformer_out[-1] of every sequence for the cls / last
+ *   pooling (models/gnn_transformer.py:113-114); gt_rows_scatter: its adjoint into a zeroed
+ *   [total_rows][dim] buffer of the given dtype (idx must not repeat).
+ */
+int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes, int64_t width_bytes,
+              int64_t rows, gt_stream_t stream);
+int gt_rows_gather(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, float* out, gt_stream_t stream);
+int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim,
+                    void* out, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * AdamW (decoupled weight decay, no amsgrad) over many fp32 tensors in one launch: the optimizer step

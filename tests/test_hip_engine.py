@@ -1,0 +1,111 @@
+"""Fused model path (graphtrans_amd/engine.py: one autograd node for the whole GNNTransformer) against
+the module-by-module path on the same parameters, batch and dropout seeds."""
+import copy
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _args(**kw):
+    a = dict(gnn_virtual_node=True, gnn_num_layer=3, gnn_emb_dim=64, gnn_JK="cat", gnn_dropout=0.0, gnn_residual=False,
+             gnn_type="gcn", pretrained_gnn=None, freeze_gnn=None, d_model=32, nhead=4, dim_feedforward=64,
+             transformer_dropout=0.2, transformer_activation="relu", num_encoder_layers=2, max_input_len=1000,
+             transformer_norm_input=True, graph_pooling="cls", num_encoder_layers_masked=0, transformer_prenorm=False,
+             pos_encoder=False, max_seq_len=3, compute_dtype=torch.float32, token_layout="auto")
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def _run(model, batch, y, fused, seed):
+    from graphtrans_amd import losses
+    model.fused = fused
+    for p in model.parameters():
+        p.grad = None
+    torch.manual_seed(seed)
+    out = model(batch)
+    loss = losses.code2_loss(out, y) if model.max_seq_len is not None else out.float().square().mean()
+    loss.backward()
+    return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}, \
+        {n: b.detach().clone() for n, b in model.named_buffers()}
+
+
+CASES = [dict(), dict(gnn_JK="last"), dict(gnn_virtual_node=False), dict(gnn_residual=True),
+         dict(graph_pooling="last", transformer_norm_input=False), dict(max_seq_len=None), dict(gnn_virtual_node=False, gnn_JK="last"),
+         dict(compute_dtype=torch.bfloat16)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in CASES])
+def test_fused_model_matches_module_path(kw):
+    from graphtrans_amd import engine, ops, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    args = _args(**kw)
+    bf16 = args.compute_dtype == torch.bfloat16
+    ops.set_matmul_dtype(torch.bfloat16 if bf16 else torch.float32)
+    try:
+        torch.manual_seed(0)
+        model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV)
+        with torch.no_grad():  # non-trivial virtual-node embedding and BN statistics
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+            if args.gnn_virtual_node:
+                model.gnn_node.virtualnode_embedding.weight.normal_(0, 0.3)
+        model.train()
+        b = synth.code2_like(B=12, seed=5, num_nodeattributes=300).to(DEV)
+        y = torch.randint(0, 50, (12, 5), device=DEV)
+        assert engine.eligible(model, b, None)
+        ref_model = copy.deepcopy(model)
+        l0, g0, b0 = _run(ref_model, b, y, False, 7)
+        l1, g1, b1 = _run(model, b, y, True, 7)
+        tol = dict(rtol=2e-2, atol=2e-3) if bf16 else dict(rtol=1e-4, atol=1e-6)
+        assert torch.allclose(l0, l1, **tol), (l0, l1)
+        for n in g0:
+            scale = max(1.0, float(g0[n].abs().max()))
+            assert torch.allclose(g0[n] / scale, g1[n] / scale, **tol), (n, (g0[n] - g1[n]).abs().max())
+        for n in b0:  # BatchNorm running statistics advance identically
+            assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-4, atol=1e-6), n
+        # second backward with gradients still in place accumulates
+        model.fused = True
+        torch.manual_seed(7)
+        out = model(b)
+        from graphtrans_amd import losses
+        loss = losses.code2_loss(out, y) if model.max_seq_len is not None else out.float().square().mean()
+        loss.backward()
+        n0 = next(iter(g1))
+        p0 = dict(model.named_parameters())[n0]
+        assert torch.allclose(p0.grad, 2 * g1[n0], rtol=1e-3, atol=1e-6)
+    finally:
+        ops.set_matmul_dtype(torch.float32)
+
+
+def test_fused_model_eval_matches_module_path():
+    from graphtrans_amd import synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    torch.manual_seed(0)
+    model = GNNTransformer(50, ASTNodeEncoder(64, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), _args()).to(DEV).eval()
+    b = synth.code2_like(B=9, seed=2).to(DEV)
+    with torch.no_grad():
+        model.fused = True
+        a = [t.clone() for t in model(b)]
+        model.fused = False
+        c = model(b)
+    for u, v in zip(a, c):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)
+
+
+def test_not_eligible_configurations_fall_back():
+    from graphtrans_amd import engine, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    b = synth.code2_like(B=4, seed=2).to(DEV)
+    for kw in (dict(gnn_type="gin"), dict(gnn_dropout=0.5), dict(graph_pooling="mean"), dict(pos_encoder=True)):
+        model = GNNTransformer(50, ASTNodeEncoder(64, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
+        assert not engine.eligible(model, b, None), kw
+        out = model(b)  # module path still runs
+        assert len(out) == 3
