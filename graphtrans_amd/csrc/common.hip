@@ -93,3 +93,24 @@ extern "C" int gt_profile_get(int64_t i, char* name_out, int64_t name_cap, float
   for (int k = 0; k < 6; ++k) dims6[k] = r.dims[k];
   return GT_OK;
 }
+
+
+// ---- events for cross-stream dependencies between entry points -------------------------------------
+extern "C" void* gt_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return ev;
+}
+extern "C" void gt_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int gt_event_record(void* event, gt_stream_t stream) {
+  GT_CHECK_ARG(event, "null event");
+  if (hipEventRecord((hipEvent_t)event, (hipStream_t)stream) != hipSuccess) { gt_set_error("gt_event_record failed"); return GT_ERR_LAUNCH; }
+  return GT_OK;
+}
+extern "C" int gt_stream_wait_event(gt_stream_t stream, void* event) {
+  GT_CHECK_ARG(event, "null event");
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) != hipSuccess) { gt_set_error("gt_stream_wait_event failed"); return GT_ERR_LAUNCH; }
+  return GT_OK;
+}

@@ -318,6 +318,7 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
   if (L->has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
     GT_TRY(gt_segment_bcast_add(GT_F32, h_in, vn, L->node_graph, L->N, L->B, L->D, x_out, st));
     x = x_out;
+    if (L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));
   }
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_b, s.lin, L->N, L->D, L->D, 0, 0.f, 0, st));
   GT_TRY(gt_aggregate_fwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, L->N, L->E, L->D, L->in_ptr, L->in_src, L->in_eid, L->deg,
@@ -346,6 +347,7 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
                           L->out_eid, L->deg, L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off,
                           L->table_rows, nullptr, w.d_lin, g.root, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
   // d_x = d_lin W (+ grads reaching x from its other consumers) (+ dy through the residual branch)
+  if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, x, L->lin_w, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr, d_h_in,
                        g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   if (L->has_vn) GT_TRY(gt_segment_sum(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, st));

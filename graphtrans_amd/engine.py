@@ -15,12 +15,16 @@ Reference call path: models/gnn_transformer.py:88-127 -> modules/gnn_module.py:1
 modules/transformer_encoder.py:42-61.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib, layers
 from ._lib import GT_BF16, GT_EDGE_LINEAR, GT_EDGE_NONE, GT_F32
 from .graph import _stream
+
+
+OVERLAP_VN = os.environ.get("GT_OVERLAP_VN", "1") != "0"
 
 
 def _c4(n):
@@ -139,6 +143,23 @@ class _Plan:
         self.vn_desc = [layers.VnUpdateDesc() for _ in self.vn]
         self.enc_desc = [layers.EncoderLayerDesc() for _ in self.enc_layers]
         self._fill_static()
+        # the virtual-node update of layer l only feeds layer l+1: it runs on a second stream beside layer
+        # l's conv (forward) / beside layer l's BatchNorm + aggregate backward (backward)
+        self.side = torch.cuda.Stream(device=self.dev) if (self.has_vn and OVERLAP_VN) else None
+        lib = _lib.lib()
+        nev = len(self.vn) if self.side is not None else 0
+        self.ev_x = [lib.gt_event_create() for _ in range(nev)]      # x_l ready (main -> side)
+        self.ev_vn = [lib.gt_event_create() for _ in range(nev)]     # vn_{l+1} ready (side -> main)
+        self.ev_dvn = [lib.gt_event_create() for _ in range(nev)]    # d vn_{l+1} complete (main -> side)
+        self.ev_extra = [lib.gt_event_create() for _ in range(nev)]  # d x_l extra complete (side -> main)
+
+    def __del__(self):
+        try:
+            lib = _lib.lib()
+            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra:
+                lib.gt_event_destroy(ev)
+        except Exception:
+            pass
 
     def _fill_static(self):
         D = self.D
@@ -294,6 +315,9 @@ class _FusedModel(torch.autograd.Function):
             layers._fill_graph(desc, gs)
             if plan.gcn_edge[l]:
                 desc.edge_attr = ea_f.data_ptr()
+            ov = plan.side is not None and l < L - 1
+            desc.ev_x_ready = plan.ev_x[l] if ov else None
+            desc.ev_dx_wait = plan.ev_extra[l] if ov else None
         for desc in plan.vn_desc:
             desc.N, desc.B = N, B
             desc.residual = 1 if model.gnn_node.residual else 0
@@ -341,8 +365,11 @@ class _FusedModel(torch.autograd.Function):
         ws_bytes = max([lib.gt_gcn_layer_workspace_bytes(C.byref(dsc)) for dsc in plan.gcn_desc]
                        + [lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
         o["ws"] = b.take(ws_bytes)
+        ws2_bytes = max([lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
+        o["ws2"] = b.take(ws2_bytes)   # the side stream's workspace
         arena = torch.empty(b.off, dtype=torch.uint8, device=dev)
         base = arena.data_ptr()
+        side = plan.side.cuda_stream if plan.side is not None else None
 
         def P(key, i=None):
             return base + (o[key] if i is None else o[key][i])
@@ -367,9 +394,16 @@ class _FusedModel(torch.autograd.Function):
         for l in range(L):
             dsc = plan.gcn_desc[l]
             if plan.has_vn:
+                if l > 0 and side is not None:   # vn_l comes from the side stream
+                    _call("gt_stream_wait_event", st, plan.ev_vn[l - 1])
                 _call("gt_gcn_layer_fwd", C.byref(dsc), P("h", l), P("vn", l), P("x", l), P("h", l + 1), P("gcn_saved", l),
                       P("ws"), ws_bytes, st)
-                if l < L - 1:
+                if l < L - 1 and side is not None:
+                    _call("gt_stream_wait_event", side, plan.ev_x[l])
+                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
+                          P("ws2"), ws2_bytes, side)
+                    _call("gt_event_record", plan.ev_vn[l], side)
+                elif l < L - 1:
                     _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
                           P("ws"), ws_bytes, st)
             else:
@@ -426,8 +460,10 @@ class _FusedModel(torch.autograd.Function):
         _call("gt_linear_fwd_ld", GT_F32, GT_F32, compute, P("hg"), wcat, bcat, logits.data_ptr(), B, plan.Nh, d, plan.ldy, 0,
               0.0, 0, st)
 
-        ctx.state = dict(plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
-                         ws_bytes=ws_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
+        # the plan's descriptors are rewritten by the next forward: the backward gets its own copies
+        snap = lambda ds: [type(x_).from_buffer_copy(x_) for x_ in ds]
+        ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
+                         ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
                          dims=(N, E, B, rows))
         ctx.set_materialize_grads(False)
@@ -458,20 +494,22 @@ class _FusedModel(torch.autograd.Function):
         G = flat.data_ptr()
 
         # ---- backward arena
-        nenc = len(plan.enc_desc)
+        nenc = len(s["enc_desc"])
         b = _Bump()
         q = dict(d_hg=b.take(B * d * 4), dtok=[b.take(rows * d * tsz) for _ in range(2)], d_hn=b.take(N * d * tsz),
                  d_cls=b.take(B * d * tsz), d_rep=b.take(N * Kc * 4), dA=b.take(N * D * 4), dB=b.take(N * D * 4),
                  dC=b.take(N * D * 4), dJ=b.take(N * D * 4 if plan.jk_cat else 0), dvn=[b.take(B * D * 4) for _ in range(4)])
-        enc_ws = max([lib.gt_encoder_layer_workspace_bytes(C.byref(dsc)) for dsc in plan.enc_desc] + [256])
+        enc_ws = max([lib.gt_encoder_layer_workspace_bytes(C.byref(dsc)) for dsc in s["enc_desc"]] + [256])
         ln_ws = lib.gt_layernorm_bwd_workspace_bytes(rows, d)
         lin_ws = max(lib.gt_linear_bwd_workspace_bytes(compute, B, plan.Nh, d), lib.gt_linear_bwd_workspace_bytes(compute, N, d, Kc))
         emb_rows = (C.c_int64 * len(plan.embed))(*[t.shape[0] for t in plan.embed])
         emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
         q["ws"] = b.take(ws_bytes)
+        q["ws2"] = b.take(s["ws2_bytes"])
         barena = torch.empty(b.off, dtype=torch.uint8, device=dev)
         bb = barena.data_ptr()
+        side = plan.side.cuda_stream if plan.side is not None else None
 
         def Q(key, i=None):
             return bb + (q[key] if i is None else q[key][i])
@@ -488,7 +526,7 @@ class _FusedModel(torch.autograd.Function):
                   rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, Q("ws"), ws_bytes, st)
             dcur, dnext = dnext, dcur
         for i in range(nenc - 1, -1, -1):
-            _call("gt_encoder_layer_bwd", C.byref(plan.enc_desc[i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
+            _call("gt_encoder_layer_bwd", C.byref(s["enc_desc"][i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
                   G + plan.enc_off[i] * 4, Q("ws"), ws_bytes, st)
             dcur, dnext = dnext, dcur
         if plan.norm_in is not None:
@@ -519,12 +557,19 @@ class _FusedModel(torch.autograd.Function):
             extra = Q("dJ") if (l == 0 and plan.jk_cat) else None
             upd = plan.has_vn and l < L - 1
             if upd:   # vn_{l+1} = update(x_l, vn_l): d x_l = pooled gradient (+ the JK slab at l = 0)
-                _call("gt_vn_update_bwd", C.byref(plan.vn_desc[l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
-                      G + plan.vn_off[l] * 4, Q("ws"), ws_bytes, st)
+                if side is not None:   # beside layer l's BatchNorm / aggregate backward; joined before its dX GEMM
+                    _call("gt_event_record", plan.ev_dvn[l], st)
+                    _call("gt_stream_wait_event", side, plan.ev_dvn[l])
+                    _call("gt_vn_update_bwd", C.byref(s["vn_desc"][l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
+                          G + plan.vn_off[l] * 4, Q("ws2"), s["ws2_bytes"], side)
+                    _call("gt_event_record", plan.ev_extra[l], side)
+                else:
+                    _call("gt_vn_update_bwd", C.byref(s["vn_desc"][l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
+                          G + plan.vn_off[l] * 4, Q("ws"), ws_bytes, st)
                 extra = Q("dC")
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = P("x", l) if plan.has_vn else P("h", l)
-            _call("gt_gcn_layer_bwd", C.byref(plan.gcn_desc[l]), xin, dy, extra, P("gcn_saved", l), out,
+            _call("gt_gcn_layer_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
                   Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
             if plan.has_vn:   # d vn_l = (layer l's broadcast add) + (update l's pooled + residual inputs)
                 tgt = Q("dvn", l % 2)

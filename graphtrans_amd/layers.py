@@ -32,7 +32,7 @@ class GcnLayerDesc(C.Structure):
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
                [(n, _fp) for n in ("graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid",
                                    "deg", "dis", "edge_attr", "lin_w", "lin_b", "root", "edge_w", "edge_b", "bn_w", "bn_b",
-                                   "bn_rm", "bn_rv", "bn_nbt")]
+                                   "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")]
 
 
 class VnUpdateDesc(C.Structure):

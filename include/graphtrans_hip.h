@@ -49,6 +49,13 @@ enum gt_edge_mode {
 int gt_version(void);
 const char* gt_last_error(void);
 
+/* Events for cross-stream dependencies between entry points (thin wrappers over hipEvent, timing
+ * disabled): gt_event_record marks a point on `stream`, gt_stream_wait_event makes `stream` wait for it. */
+void* gt_event_create(void);
+void gt_event_destroy(void* event);
+int gt_event_record(void* event, gt_stream_t stream);
+int gt_stream_wait_event(gt_stream_t stream, void* event);
+
 /* Opt-in launch profiler: HIP events on the launch stream around the selected entry points
  * (mask: 1 aggregate, 2 attention, 4 linear).  gt_profile_enable(mask != 0) clears old records and
  * starts recording, (0) stops; after a device synchronisation gt_profile_get returns the entry
@@ -348,6 +355,10 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
   const float *lin_w, *lin_b, *root, *edge_w, *edge_b, *bn_w, *bn_b; /* gradient order: these 7 */
   float *bn_rm, *bn_rv;
   int64_t* bn_nbt;
+  /* optional gt_event handles for running the virtual-node update on a second stream beside the conv:
+   * the forward records ev_x_ready once x_out is written; the backward waits for ev_dx_wait (dx_extra
+   * complete) right before the dX GEMM.  NULL = no cross-stream dependency. */
+  void *ev_x_ready, *ev_dx_wait;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
