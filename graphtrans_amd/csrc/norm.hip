@@ -66,13 +66,22 @@ __global__ void __launch_bounds__(NT) k_bn_stats_partial(const T* __restrict__ x
     float4 acc[2] = {gt_zero4(), gt_zero4()};
     if (m.tr < m.R && cact) {
       const float4 piv = gt_load4<T>(x + (int64_t)c * 4);  // row 0
-      for (int64_t r = r0 + m.tr; r < r1; r += m.R) {
-        float4 v = gt_load4<T>(x + r * D + (int64_t)c * 4);
+      auto add_row = [&](float4 v) {
         v = make_float4(v.x - piv.x, v.y - piv.y, v.z - piv.z, v.w - piv.w);
         acc[0] = gt_add4(acc[0], v);
         acc[1] = make_float4(fmaf(v.x, v.x, acc[1].x), fmaf(v.y, v.y, acc[1].y), fmaf(v.z, v.z, acc[1].z),
                              fmaf(v.w, v.w, acc[1].w));
+      };
+      // 8 independent row loads in flight per thread (one load per trip is a chain of memory round trips)
+      int64_t r = r0 + m.tr;
+      for (; r + 7 * m.R < r1; r += 8 * m.R) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gt_load4<T>(x + (r + (int64_t)u * m.R) * D + (int64_t)c * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) add_row(v[u]);
       }
+      for (; r < r1; r += m.R) add_row(gt_load4<T>(x + r * D + (int64_t)c * 4));
     }
     block_rowlane_reduce<2>(acc, m, sm4);
     if (m.tr == 0 && cact) {
@@ -191,14 +200,27 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
     if (m.tr < m.R && cact) {
       const float4 mu = *reinterpret_cast<const float4*>(mean + c * 4), rs = *reinterpret_cast<const float4*>(rstd + c * 4);
       const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(b + c * 4);
-      for (int64_t r = r0 + m.tr; r < r1; r += m.R) {
-        const int64_t o = r * D + (int64_t)c * 4;
-        float4 g = gt_load4<T>(dy + o);
-        const float4 v = gt_load4<T>(x + o);
+      auto add_row = [&](float4 g, const float4 v) {
         if (relu) g = bn_gate(g, v, mu, rs, ww, bb);
         acc[0] = gt_add4(acc[0], g);
         acc[1] = make_float4(fmaf(g.x, (v.x - mu.x) * rs.x, acc[1].x), fmaf(g.y, (v.y - mu.y) * rs.y, acc[1].y),
                              fmaf(g.z, (v.z - mu.z) * rs.z, acc[1].z), fmaf(g.w, (v.w - mu.w) * rs.w, acc[1].w));
+      };
+      int64_t r = r0 + m.tr;
+      for (; r + 3 * m.R < r1; r += 4 * m.R) {  // 8 independent loads in flight per thread
+        float4 g[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t o = (r + (int64_t)u * m.R) * D + (int64_t)c * 4;
+          g[u] = gt_load4<T>(dy + o);
+          v[u] = gt_load4<T>(x + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(g[u], v[u]);
+      }
+      for (; r < r1; r += m.R) {
+        const int64_t o = r * D + (int64_t)c * 4;
+        add_row(gt_load4<T>(dy + o), gt_load4<T>(x + o));
       }
     }
     block_rowlane_reduce<2>(acc, m, sm4);
