@@ -462,18 +462,23 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     a.dbpart[(int64_t)split * a.N + n0 + threadIdx.x] = dbacc;
 }
 
-// out[i] = sum_s part[s][i]  (fixed order, 8 loads in flight); used for dW (len N*K) and db (len N)
+// out[i] = sum_s part[s][i]  (fixed order, 8 loads in flight).  One launch reduces two partial arrays:
+// dW (len N*K -> out) and, when len2 > 0, db (len2 = N -> out2).
 __global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ part, int splits, int64_t len,
-                                                      float* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+                                                      float* __restrict__ out, const float* __restrict__ part2, int64_t len2,
+                                                      float* __restrict__ out2) {
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < len + len2; i0 += (int64_t)gridDim.x * 256) {
+    const bool second = i0 >= len;
+    const float* p = second ? part2 : part;
+    const int64_t n = second ? len2 : len, i = second ? i0 - len : i0;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int s = 0;
     for (; s + 8 <= splits; s += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += part[(int64_t)(s + u) * len + i];
+      for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(s + u) * n + i];
     }
-    for (; s < splits; ++s) acc[0] += part[(int64_t)s * len + i];
-    out[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; s < splits; ++s) acc[0] += p[(int64_t)s * n + i];
+    (second ? out2 : out)[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
 }
 
@@ -498,8 +503,10 @@ void fill_drop(LinArgs& a, float dropout_p, uint64_t seed) {
 
 int dw_splits(int64_t M, int64_t N, int64_t K, int compute) {
   const int64_t bmc = compute == GT_BF16 ? 64 : 32;
+  static int target = -1;  // blocks per launch (GT_DW_BLOCKS): partial traffic grows with it, parallelism too
+  if (target < 0) { const char* e = getenv("GT_DW_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
   int64_t tiles = gt_cdiv(N, BN) * gt_cdiv(K, BN);
-  int64_t s = 1024 / tiles;
+  int64_t s = target / tiles;
   int64_t maxs = gt_cdiv(M, bmc * 4);  // at least 4 stages per split
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
@@ -635,7 +642,7 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
       const int64_t len = M * K;
       const int rg = (int)(gt_cdiv(len, 256) < 2048 ? gt_cdiv(len, 256) : 2048);
       hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len,
-                         reinterpret_cast<float*>(dx));
+                         reinterpret_cast<float*>(dx), (const float*)nullptr, (int64_t)0, (float*)nullptr);
     }
   }
   if (dweight) {
@@ -652,11 +659,10 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
     dim3 grid((unsigned)gt_cdiv(N, BN), (unsigned)gt_cdiv(K, BN), (unsigned)splits);
     const int t0 = y_dtype, t1 = x_dtype;
     GT_LIN_DISPATCH(k_linear_dw, grid, a);
-    int64_t len = N * K;
-    int rg = (int)(gt_cdiv(len, 256) < 2048 ? gt_cdiv(len, 256) : 2048);
-    hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight);
-    if (dbias)
-      hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)gt_cdiv(N, 256)), dim3(256), 0, stream, a.dbpart, splits, N, dbias);
+    const int64_t len = N * K, len2 = dbias ? N : 0;
+    int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+    hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
+                       (const float*)a.dbpart, len2, dbias);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;
