@@ -236,7 +236,7 @@ def main():
     torch.manual_seed(1234)  # identical initial parameters on every rank
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()
-    sync = GradSync(model.parameters(), world_size=world)
+    sync = GradSync(model.parameters(), world_size=world).attach(model)
     from graphtrans_amd.optim import FusedAdamW
     optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams

@@ -10,6 +10,10 @@ collective on the path is the gradient all-reduce.  Parameters (9.05 M for the C
     RCCL's own stream while the next bucket is being packed,
   * xGMI is a point-to-point mesh: few, large messages (default 16 MB buckets) keep every link busy.
 BatchNorm statistics stay per rank (what torch DDP does); see DESIGN.md for the consequences.
+
+Fused model path (engine.py): all gradients already live in ONE flat buffer, so no packing is needed
+and the reduction is issued from inside the backward: the transformer + heads half of the buffer goes
+on the wire while the message-passing backward is still running (`attach` / `reduce_flat`).
 """
 import torch
 import torch.distributed as dist
@@ -26,8 +30,10 @@ class GradSync:
     is on the wire), averaged, and `.grad` is re-pointed at the reduced bucket views.
     """
 
-    def __init__(self, params, world_size=None, bucket_bytes=16 << 20, group=None):
+    def __init__(self, params, world_size=None, bucket_bytes=16 << 20, group=None, always_reduce=False):
         self.group = group
+        self.always_reduce = always_reduce   # issue the collective even for one rank (tests)
+        self._pending, self._flat_used = [], False
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []  # dict(flat, params, views)
@@ -51,12 +57,33 @@ class GradSync:
             off += p.numel()
         self.buckets.append(dict(flat=flat, params=ps, views=views))
 
+    def attach(self, model):
+        """Let the fused model path (engine.py) hand its flat gradient buffer to this reducer."""
+        model.__dict__["_gt_sync"] = self
+        return self
+
+    def reduce_flat(self, flat, lo, hi):
+        """Average flat[lo:hi] over the ranks, asynchronously (called from the fused backward as soon as
+        the kernels producing that range are enqueued).  finish() waits for it."""
+        if self.world == 1 and not self.always_reduce:
+            return
+        seg = flat[lo:hi]
+        if self.world > 1:
+            seg.div_(self.world)
+        self._pending.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._flat_used = True
+
     def zero(self):
         """Replaces optimizer.zero_grad(set_to_none=True)."""
         for p in self.params:
             p.grad = None
 
     def finish(self):
+        if self._flat_used:   # the fused backward already issued the reductions on its flat buffer
+            for h in self._pending:
+                h.wait()
+            self._pending, self._flat_used = [], False
+            return
         if self.world == 1:
             return
         handles = []

@@ -465,7 +465,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
-                         dims=(N, E, B, rows))
+                         dims=(N, E, B, rows), sync=model.__dict__.get("_gt_sync"))
         ctx.set_materialize_grads(False)
         out = logits[:, :plan.Nh] if plan.ldy != plan.Nh else logits
         return out
@@ -490,6 +490,7 @@ class _FusedModel(torch.autograd.Function):
 
         # gradients: straight into the persistent flat buffer when nothing has to be accumulated
         direct = all(p.grad is None for p in plan.plist)
+        model_sync = s["sync"]
         flat = plan.flat if direct else torch.empty_like(plan.flat)
         G = flat.data_ptr()
 
@@ -543,6 +544,10 @@ class _FusedModel(torch.autograd.Function):
         g2t = plan.g2t
         _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
               Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, Q("ws"), ws_bytes, st)
+        # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
+        sync = model_sync if direct else None
+        if sync is not None:
+            sync.reduce_flat(flat, plan.g2t_off[0], plan.total)
         # ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l (=
         # h_list[l] after the virtual-node add) from its consumers other than conv_l: the JK slab (l = 0)
         # and the virtual-node update's pooling (l < L-1).
@@ -587,6 +592,8 @@ class _FusedModel(torch.autograd.Function):
         d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
         _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
 
+        if sync is not None:
+            sync.reduce_flat(flat, 0, plan.g2t_off[0])
         # ---- hand the gradients to the parameters
         if direct:
             for p, v in zip(plan.plist, plan.views):

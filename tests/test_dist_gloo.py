@@ -75,3 +75,50 @@ def test_gradsync_single_process_views():
     assert all(p.grad is not None for p in m.body.parameters()) and all(p.grad is None for p in m.unused.parameters())
     sync.zero()
     assert all(p.grad is None for p in m.parameters())
+
+
+def _flat_worker(rank, world, port, out):
+    """The fused model path's protocol: gradients are views of one flat buffer, reduce_flat() is called
+    per finished range from inside the backward, finish() waits."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _model()
+    params = list(m.body.parameters())
+    sync = GradSync(params)
+    x, y = _data()
+    xs, ys = x[rank::world], y[rank::world]
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total)
+    sync.zero()
+    grads = torch.autograd.grad(((m(xs) - ys) ** 2).mean(), params)
+    off, views = 0, []
+    for p, g in zip(params, grads):
+        v = flat[off:off + p.numel()].view_as(p)
+        v.copy_(g)
+        p.grad = v
+        views.append(v)
+        off += p.numel()
+    half = total // 2
+    sync.reduce_flat(flat, half, total)
+    sync.reduce_flat(flat, 0, half)
+    sync.finish()
+    assert not sync._pending and not sync._flat_used
+    out[rank] = [p.grad.clone() for p in params]
+    dist.destroy_process_group()
+
+
+def test_gradsync_flat_buffer_protocol_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+    m = _model()
+    x, y = _data()
+    ((m(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in m.body.parameters()]
+    for r in (0, 1):
+        for a, b in zip(out[r], ref):
+            assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()

@@ -109,3 +109,38 @@ def test_not_eligible_configurations_fall_back():
         assert not engine.eligible(model, b, None), kw
         out = model(b)  # module path still runs
         assert len(out) == 3
+
+
+def test_fused_backward_issues_the_gradient_allreduce():
+    """dist.GradSync.attach: the fused backward hands ranges of its flat gradient buffer to RCCL
+    (one-rank nccl group here: exercises the stream hand-over, the values must not change)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from graphtrans_amd import losses, synth
+    from graphtrans_amd.dist import GradSync
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), _args()).to(DEV).train()
+        b = synth.code2_like(B=12, seed=5, num_nodeattributes=300).to(DEV)
+        y = torch.randint(0, 50, (12, 5), device=DEV)
+        _, g0, _ = _run(copy.deepcopy(model), b, y, True, 3)
+        sync = GradSync(model.parameters(), world_size=1, always_reduce=True).attach(model)
+        sync.zero()
+        torch.manual_seed(3)
+        losses.code2_loss(model(b), y).backward()
+        assert sync._flat_used and len(sync._pending) == 2
+        sync.finish()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, g0[n]), n
+    finally:
+        dist.destroy_process_group()
