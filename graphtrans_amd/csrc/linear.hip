@@ -545,6 +545,14 @@ int dx_splits(int64_t M, int64_t N, int64_t K, int bm) {
     else hipLaunchKernelGGL((KERNEL<gt_bf16, gt_bf16, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args);            \
   } while (0)
 
+// ---- optional overlap of the weight-gradient GEMMs (gt_overlap_dw_*): per host thread ------------
+struct DwOverlap {
+  bool active = false;
+  hipStream_t main = nullptr, side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+thread_local DwOverlap g_dw;
+
 int pick_bm(int64_t M) {
   static int env = -1;
   if (env < 0) {
@@ -651,6 +659,13 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
       gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
       return GT_ERR_WORKSPACE;
     }
+    // dW is off the critical path of the backward (only the optimizer reads it): inside a
+    // gt_overlap_dw_begin/_end section it runs on the side stream beside dX and whatever follows.
+    if (g_dw.active && stream == g_dw.main && dx && a.splits <= 1) {
+      (void)hipEventRecord(g_dw.ev_fork, stream);
+      (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+      stream = g_dw.side;
+    }
     const int64_t bmc = compute == GT_BF16 ? 64 : 32;
     a.splits = splits;
     a.m_per_split = gt_cdiv(gt_cdiv(M, splits), bmc) * bmc;
@@ -666,4 +681,31 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
   }
   GT_CHECK_LAUNCH();
   return GT_OK;
+}
+
+// ---- overlap section -------------------------------------------------------------------------------
+extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
+  GT_CHECK_ARG(side_ && main_ != side_, "need a distinct side stream");
+  if (!g_dw.ev_fork) {
+    if (hipEventCreateWithFlags(&g_dw.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_dw.ev_join, hipEventDisableTiming) != hipSuccess) {
+      gt_set_error("gt_overlap_dw_begin: event creation failed");
+      return GT_ERR_LAUNCH;
+    }
+  }
+  g_dw.main = (hipStream_t)main_;
+  g_dw.side = (hipStream_t)side_;
+  g_dw.active = true;
+  return GT_OK;
+}
+extern "C" int gt_overlap_dw_sync(void) {
+  if (!g_dw.active) return GT_OK;
+  (void)hipEventRecord(g_dw.ev_join, g_dw.side);
+  (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
+  return GT_OK;
+}
+extern "C" int gt_overlap_dw_end(void) {
+  const int rc = gt_overlap_dw_sync();
+  g_dw.active = false;
+  return rc;
 }

@@ -25,6 +25,7 @@ from .graph import _stream
 
 
 OVERLAP_VN = os.environ.get("GT_OVERLAP_VN", "1") != "0"
+OVERLAP_DW = os.environ.get("GT_OVERLAP_DW", "1") != "0"
 
 
 def _c4(n):
@@ -146,6 +147,8 @@ class _Plan:
         # the virtual-node update of layer l only feeds layer l+1: it runs on a second stream beside layer
         # l's conv (forward) / beside layer l's BatchNorm + aggregate backward (backward)
         self.side = torch.cuda.Stream(device=self.dev) if (self.has_vn and OVERLAP_VN) else None
+        # weight-gradient GEMMs run on a third stream beside the dX chain (gt_overlap_dw_*)
+        self.side_dw = torch.cuda.Stream(device=self.dev) if OVERLAP_DW else None
         lib = _lib.lib()
         nev = len(self.vn) if self.side is not None else 0
         self.ev_x = [lib.gt_event_create() for _ in range(nev)]      # x_l ready (main -> side)
@@ -515,21 +518,43 @@ class _FusedModel(torch.autograd.Function):
         def Q(key, i=None):
             return bb + (q[key] if i is None else q[key][i])
 
+        ov = plan.side_dw is not None
+        dw_sync = (lambda: _call("gt_overlap_dw_sync")) if ov else (lambda: None)
+        if ov:
+            _call("gt_overlap_dw_begin", st, plan.side_dw.cuda_stream)
+        try:
+            return _FusedModel._backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena,
+                                              emb_rows, st)
+        finally:
+            if ov:
+                _lib.lib().gt_overlap_dw_end()
+
+    @staticmethod
+    def _backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena, emb_rows, st):
+        gs, lay, sm = s["gs"], s["lay"], s["sm"]
+        compute, tdt, tsz = s["compute"], s["tdt"], s["tsz"]
+        N, E, B, rows = s["dims"]
+        L, D, d, dev, Kc = plan.L, plan.D, plan.d, plan.dev, s["Kc"]
+        nenc = len(s["enc_desc"])
+        side = plan.side.cuda_stream if plan.side is not None else None
         # ---- heads
         _call("gt_linear_bwd_ld", GT_F32, GT_F32, compute, P("hg"), s["wcat"], dl.data_ptr(), None, None, None, Q("d_hg"),
               G + plan.headw_off * 4, G + plan.headb_off * 4, B, plan.Nh, d, plan.ldy, 0.0, Q("ws"), ws_bytes, st)
         # ---- pooled rows -> token rows
         dcur, dnext = Q("dtok", 0), Q("dtok", 1)
         _call("gt_rows_scatter", tdt, Q("d_hg"), lay.last_rows.data_ptr(), B, rows, d, dcur, st)
+        dw_sync()   # the heads' dW (side stream) shares the workspace with what follows
         if plan.norm_out is not None:
             ln = plan.norm_out
             _call("gt_layernorm_bwd", tdt, s["pre_out"], None, dcur, ln.weight.data_ptr(), P("sto"), P("sto") + rows * 4, 0.0, 0,
                   rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, Q("ws"), ws_bytes, st)
             dcur, dnext = dnext, dcur
         for i in range(nenc - 1, -1, -1):
+            dw_sync()   # the previous layer's dW GEMMs still read its workspace
             _call("gt_encoder_layer_bwd", C.byref(s["enc_desc"][i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
                   G + plan.enc_off[i] * 4, Q("ws"), ws_bytes, st)
             dcur, dnext = dnext, dcur
+        dw_sync()
         if plan.norm_in is not None:
             ln = plan.norm_in
             _call("gt_layernorm_bwd", tdt, P("tok"), None, dcur, ln.weight.data_ptr(), P("st0"), P("st0") + rows * 4, 0.0, 0,
@@ -547,6 +572,7 @@ class _FusedModel(torch.autograd.Function):
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
         sync = model_sync if direct else None
         if sync is not None:
+            dw_sync()
             sync.reduce_flat(flat, plan.g2t_off[0], plan.total)
         # ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l (=
         # h_list[l] after the virtual-node add) from its consumers other than conv_l: the JK slab (l = 0)
@@ -574,6 +600,7 @@ class _FusedModel(torch.autograd.Function):
                 extra = Q("dC")
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = P("x", l) if plan.has_vn else P("h", l)
+            dw_sync()
             _call("gt_gcn_layer_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
                   Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
             if plan.has_vn:   # d vn_l = (layer l's broadcast add) + (update l's pooled + residual inputs)
@@ -585,6 +612,7 @@ class _FusedModel(torch.autograd.Function):
                 d_vn_next = tgt
             dy = out
         d_h0 = dy
+        dw_sync()
         if plan.has_vn:
             _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, st)
         # ---- input encoder tables

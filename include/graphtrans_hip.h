@@ -302,6 +302,16 @@ int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const
                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldy, float dropout_p, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
 
+/* Weight gradients are off the critical path of a backward pass (only the optimizer reads them).
+ * Between gt_overlap_dw_begin(main, side) and gt_overlap_dw_end() on the same host thread, every
+ * gt_linear_bwd[_ld] issued on `main` that computes both dX and dW launches the dW part (and its
+ * partial reduce) on `side`, ordered after everything already queued on `main`.  The caller must call
+ * gt_overlap_dw_sync() (main waits for the side stream) before it overwrites a dy / x / workspace
+ * buffer that such a call was given, and before it reads the weight gradients; _end syncs too. */
+int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
+int gt_overlap_dw_sync(void);
+int gt_overlap_dw_end(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy over the stacked prediction heads (the Code2 loss, dataset/code.py:39-45:
  * (1/L) sum_l CrossEntropyLoss()(pred_l, y_arr[:, l])).  logits[b * ld + l * C + c], fp32;
