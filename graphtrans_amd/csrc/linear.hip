@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t lin_hash(uint32_t s0, uint32_t s1, uint32_t 
 
 template <typename TC>
 struct Tile {
-  static constexpr int BK = sizeof(TC) == 2 ? 64 : 32;  // contraction elements per LDS stage (128 B rows)
+  static constexpr int BK = 32;
   static constexpr int PAD = sizeof(TC) == 2 ? 8 : 4;   // 16 B row pad
   static constexpr int LD = BK + PAD;
 };
@@ -185,8 +185,9 @@ template <typename TX, typename TY, typename TC, int BMT>
 __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   constexpr int BK = Tile<TC>::BK, LD = Tile<TC>::LD;
   constexpr int BM = BMT, MI = BMT / 32;  // rows per block, m16-tiles per wave
-  constexpr int LDS_ELEMS = (BM + BN) * LD;
-  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  constexpr int TILE_ELEMS = (BM + BN) * LD;
+  constexpr int PATCH_ELEMS = (int)(4 * PATCH_FLOATS * sizeof(float) / sizeof(TC));
+  constexpr int LDS_ELEMS = TILE_ELEMS > PATCH_ELEMS ? TILE_ELEMS : PATCH_ELEMS;  // the epilogue patches reuse the tiles
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
   TC* sX = smem;
   TC* sW = smem + BM * LD;
@@ -278,8 +279,9 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
   constexpr int BKc = Tile<TC>::BK;            // n-slots per stage
   constexpr int LDZ = Tile<TC>::LD;            // dZ tile [BM][BKc]
   constexpr int LDW = BN + Tile<TC>::PAD;      // W tile [BKc n][BN k]
-  constexpr int LDS_ELEMS = BM * LDZ + BKc * LDW;
-  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  constexpr int TILE_ELEMS = BM * LDZ + BKc * LDW;
+  constexpr int PATCH_ELEMS = (int)(4 * PATCH_FLOATS * sizeof(float) / sizeof(TC));
+  constexpr int LDS_ELEMS = TILE_ELEMS > PATCH_ELEMS ? TILE_ELEMS : PATCH_ELEMS;
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
   TC* sZ = smem;
   TC* sW = smem + BM * LDZ;
@@ -373,8 +375,9 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   constexpr int BMc = Tile<TC>::BK;            // m-slots per stage
   constexpr int LDZ = BN + Tile<TC>::PAD;      // dZ tile [BMc m][BN n]
   constexpr int LDX = BN + Tile<TC>::PAD;      // X tile  [BMc m][BN k]
-  constexpr int LDS_ELEMS = BMc * (LDZ + LDX);
-  static_assert(LDS_ELEMS * sizeof(TC) >= 4 * PATCH_FLOATS * sizeof(float), "epilogue patches must fit");
+  constexpr int TILE_ELEMS = BMc * (LDZ + LDX);
+  constexpr int PATCH_ELEMS = (int)(4 * PATCH_FLOATS * sizeof(float) / sizeof(TC));
+  constexpr int LDS_ELEMS = TILE_ELEMS > PATCH_ELEMS ? TILE_ELEMS : PATCH_ELEMS;
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
   TC* sZ = smem;
   TC* sX = smem + BMc * LDZ;
