@@ -140,6 +140,12 @@ __device__ __forceinline__ void edge_attr_load(const AggArgs& a, int eid, float*
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// One wave-tile walks FWD_CHUNK consecutive destination nodes.  A node is three dependent memory round
+// trips (ptr -> in-edge indices -> neighbour rows); with ~3 in-edges there is nothing inside one node
+// to hide them behind, so the walk is software pipelined across nodes: while node i's rows are gathered,
+// the indices of node i+1 and the ptr pair of node i+2 are already in flight.
+constexpr int FWD_CHUNK = 8;
+
 template <typename T, int LPN, int NCH, int EDGE>
 __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   constexpr int NPW = 64 / LPN;
@@ -147,65 +153,109 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * AGG_WAVES + (threadIdx.x >> 6);
   LaneMap<LPN, NCH> m(lane, a.D);
-  const int64_t v = wave * NPW + m.sub;
-  if (v >= a.N) return;
+  const int64_t v_lo = wave * (FWD_CHUNK * NPW) + m.sub;   // this sub-group's nodes: v_lo, v_lo + NPW, ...
+  if (v_lo >= a.N) return;
   EdgeState<EDGE, NCH> es;
   edge_state_init<EDGE, NCH, LPN>(es, a, m);
   const T* h = reinterpret_cast<const T*>(a.h);
+  T* out = reinterpret_cast<T*>(a.out);
   const bool gcn = a.conv == GT_CONV_GCN;
-  const int beg = a.ptr[v], end = a.ptr[v + 1];
-  float4 acc[NCH];
+  const float one_eps = gcn ? 0.f : 1.0f + a.self_param[0];
+  float4 root[NCH];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) acc[j] = gt_zero4();
+  for (int j = 0; j < NCH; ++j)
+    root[j] = (gcn && m.act[j]) ? *reinterpret_cast<const float4*>(a.self_param + m.col[j]) : gt_zero4();
 
-  for (int p = beg; p < end; p += U) {
-    int src[U], eid[U];
-    float wgt[U];
+  auto load_ptr = [&](int64_t v, int& b, int& e) {
+    const bool ok = v < a.N;
+    b = ok ? a.ptr[v] : 0;
+    e = ok ? a.ptr[v + 1] : 0;
+  };
+  auto load_idx = [&](int b, int e, int (&src)[U], int (&eid)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int q = p + u < end ? p + u : end - 1;
-      src[u] = a.nbr[q];
-      eid[u] = a.eid[q];
+      const int q = b + u < e ? b + u : (e > b ? e - 1 : -1);
+      src[u] = q >= 0 ? a.nbr[q] : 0;
+      eid[u] = q >= 0 ? a.eid[q] : 0;
     }
-    float4 row[U][NCH];
-    float av[U][MAX_K];
-    int ti[U][MAX_K];
+  };
+
+  int beg0, end0, beg1, end1;
+  int src0[U], eid0[U];
+  load_ptr(v_lo, beg0, end0);
+  load_ptr(v_lo + NPW, beg1, end1);
+  load_idx(beg0, end0, src0, eid0);
+
+#pragma unroll 1
+  for (int it = 0; it < FWD_CHUNK; ++it) {
+    const int64_t v = v_lo + (int64_t)it * NPW;
+    if (v >= a.N) break;
+    // ---- prefetch: indices of the next node, ptr pair of the one after
+    int src1[U], eid1[U], beg2, end2;
+    load_idx(beg1, end1, src1, eid1);
+    load_ptr(it + 2 < FWD_CHUNK ? v + 2 * NPW : a.N, beg2, end2);
+    // ---- current node
+    const float dv = gcn ? a.dis[v] : 1.0f;
+    const float degv = gcn ? a.deg[v] : 1.0f;
+    float4 hv[NCH], acc[NCH];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) row[u][j] = gt_load4<T>(h + (int64_t)src[u] * a.D + m.col[j]);
-      wgt[u] = gcn ? a.dis[src[u]] : 1.0f;
-      if (p + u >= end) wgt[u] = 0.f;
-      edge_attr_load<EDGE>(a, eid[u], av[u], ti[u]);
+    for (int j = 0; j < NCH; ++j) {
+      hv[j] = m.act[j] ? gt_load4<T>(h + v * a.D + m.col[j]) : gt_zero4();
+      acc[j] = gt_zero4();
     }
+    for (int p = beg0; p < end0; p += U) {
+      int src[U], eid[U];
+      if (p == beg0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u) { src[u] = src0[u]; eid[u] = eid0[u]; }
+      } else {
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid[u], av[u], ti[u]);
-        acc[j] = gt_fma4(gt_relu4(gt_add4(row[u][j], e)), wgt[u], acc[j]);
+        for (int u = 0; u < U; ++u) {
+          const int q = p + u < end0 ? p + u : end0 - 1;
+          src[u] = a.nbr[q];
+          eid[u] = a.eid[q];
+        }
+      }
+      float wgt[U];
+      float4 row[U][NCH];
+      float av[U][MAX_K];
+      int ti[U][MAX_K];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) row[u][j] = gt_load4<T>(h + (int64_t)src[u] * a.D + m.col[j]);
+        wgt[u] = gcn ? a.dis[src[u]] : 1.0f;
+        if (p + u >= end0) wgt[u] = 0.f;
+        edge_attr_load<EDGE>(a, eid[u], av[u], ti[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid[u], av[u], ti[u]);
+          acc[j] = gt_fma4(gt_relu4(gt_add4(row[u][j], e)), wgt[u], acc[j]);
+        }
       }
     }
-  }
-  T* out = reinterpret_cast<T*>(a.out);
-  const float dv = gcn ? a.dis[v] : 1.0f;
-  const float inv_deg = gcn ? 1.0f / a.deg[v] : 0.f;
-  const float one_eps = gcn ? 0.f : 1.0f + a.self_param[0];
+    const float inv_deg = gcn ? 1.0f / degv : 0.f;
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    if (!m.act[j]) continue;
-    float4 hv = gt_load4<T>(h + v * a.D + m.col[j]);
-    float4 r;
-    if (gcn) {
-      float4 root = *reinterpret_cast<const float4*>(a.self_param + m.col[j]);
-      // relu(x + root) * 1.0 / deg   (conv.py:63-65)
-      float4 s = gt_relu4(gt_add4(hv, root));
-      r = make_float4(acc[j].x * dv + s.x * inv_deg, acc[j].y * dv + s.y * inv_deg, acc[j].z * dv + s.z * inv_deg,
-                      acc[j].w * dv + s.w * inv_deg);
-    } else {
-      r = gt_fma4(hv, one_eps, acc[j]);
+    for (int j = 0; j < NCH; ++j) {
+      if (!m.act[j]) continue;
+      float4 r;
+      if (gcn) {
+        // relu(x + root) * 1.0 / deg   (conv.py:63-65)
+        float4 s = gt_relu4(gt_add4(hv[j], root[j]));
+        r = make_float4(acc[j].x * dv + s.x * inv_deg, acc[j].y * dv + s.y * inv_deg, acc[j].z * dv + s.z * inv_deg,
+                        acc[j].w * dv + s.w * inv_deg);
+      } else {
+        r = gt_fma4(hv[j], one_eps, acc[j]);
+      }
+      gt_store4<T>(out + v * a.D + m.col[j], r);
     }
-    gt_store4<T>(out + v * a.D + m.col[j], r);
+    // ---- rotate the pipeline registers
+    beg0 = beg1; end0 = end1; beg1 = beg2; end1 = end2;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { src0[u] = src1[u]; eid0[u] = eid1[u]; }
   }
 }
 
@@ -226,6 +276,7 @@ template <typename T, int LPN, int NCH, int EDGE>
 __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   constexpr int NPW = 64 / LPN;
   constexpr int NREG = reg_slots<EDGE>();
+  constexpr int UB = NCH >= 3 ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -267,15 +318,37 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
       acc[j] = gt_zero4();
     }
     const float du = gcn ? a.dis[u] : 1.0f;
-    for (int p = beg; p < end; ++p) {
-      const int dst = a.nbr[p], eid = a.eid[p];
-      float av[MAX_K];
-      int ti[MAX_K];
-      edge_attr_load<EDGE>(a, eid, av, ti);
-      const float wk = gcn ? du * a.dis[dst] : 1.0f;
+    const float degu = gcn ? a.deg[u] : 1.0f;
+    // out-edges UB at a time: the indices of UB edges, then every gradient row / attribute of the group,
+    // then the arithmetic in edge order (one edge per trip is a chain of 2 dependent round trips per edge)
+    for (int p0 = beg; p0 < end; p0 += UB) {
+      int dsts[UB], eids[UB];
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub) {
+        const int qq = p0 + ub < end ? p0 + ub : end - 1;
+        dsts[ub] = a.nbr[qq];
+        eids[ub] = a.eid[qq];
+      }
+      float4 gds[UB][NCH];
+      float avs[UB][MAX_K], wks[UB];
+      int tis[UB][MAX_K];
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub) {
+        edge_attr_load<EDGE>(a, eids[ub], avs[ub], tis[ub]);
+        wks[ub] = gcn ? du * a.dis[dsts[ub]] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) gds[ub][j] = gt_load4<T>(g + (int64_t)dsts[ub] * D + m.col[j]);
+      }
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub) {
+      if (p0 + ub >= end) break;
+      const int eid = eids[ub];
+      const float* av = avs[ub];
+      const int* ti = tis[ub];
+      const float wk = wks[ub];
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        float4 gd = gt_load4<T>(g + (int64_t)dst * D + m.col[j]);
+        const float4 gd = gds[ub][j];
         float4 e = edge_embed<T, EDGE, NCH, LPN>(es, a, m, j, eid, av, ti);
         float4 t = gate4(gt_add4(hu[j], e), gt_scale4(gd, wk));
         acc[j] = gt_add4(acc[j], t);
@@ -310,13 +383,14 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
           if (m.act[j]) gt_store4<T>(reinterpret_cast<T*>(a.d_dense) + (int64_t)eid * D + m.col[j], t);
         }
       }
+      }
     }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       float4 r;
       if (gcn) {
         float4 root = *reinterpret_cast<const float4*>(a.self_param + m.col[j]);
-        float4 s = gate4(gt_add4(hu[j], root), gt_scale4(gu[j], 1.0f / a.deg[u]));
+        float4 s = gate4(gt_add4(hu[j], root), gt_scale4(gu[j], 1.0f / degu));
         racc[0][j] = gt_add4(racc[0][j], s);
         r = gt_add4(acc[j], s);
       } else {
@@ -458,7 +532,7 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
       hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(grid_bwd), dim3(AGG_THREADS), lds_bytes,      \
                          stream, a);                                                                         \
     } else {                                                                                                 \
-      int64_t waves = gt_cdiv(a.N, NPW);                                                                     \
+      int64_t waves = gt_cdiv(a.N, NPW * FWD_CHUNK);                                                         \
       hipLaunchKernelGGL((k_agg_fwd<T, LPN, NCH, EDGE>), dim3((unsigned)gt_cdiv(waves, AGG_WAVES)),         \
                          dim3(AGG_THREADS), 0, stream, a);                                                   \
     }                                                                                                        \
