@@ -304,12 +304,39 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
     for (int64_t i = lane; i < (int64_t)a.table_rows * D; i += 64) wl[i] = 0.f;
   }
 
+  // persistent grid: every wave-tile walks its own contiguous run of source nodes, software pipelined
+  // like the forward (indices of node i+1 and the ptr pair of node i+2 in flight while node i's
+  // gradient rows are gathered).  The runs depend on (N, grid) only: partial sums stay reproducible.
   const int64_t total_waves = (int64_t)gridDim.x * AGG_WAVES;
   const int64_t wave0 = (int64_t)blockIdx.x * AGG_WAVES + wid;
-  for (int64_t base = wave0 * NPW; base < a.N; base += total_waves * NPW) {
-    const int64_t u = base + m.sub;
-    if (u >= a.N) continue;
-    const int beg = a.ptr[u], end = a.ptr[u + 1];
+  const int64_t cpw = (a.N + total_waves * NPW - 1) / (total_waves * NPW);   // nodes per sub-group
+  const int64_t u_lo = wave0 * cpw * NPW + m.sub;
+  auto load_ptr = [&](int64_t v, int& b, int& e) {
+    const bool ok = v < a.N;
+    b = ok ? a.ptr[v] : 0;
+    e = ok ? a.ptr[v + 1] : 0;
+  };
+  auto load_idx = [&](int b, int e, int (&dst)[UB], int (&eid)[UB]) {
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+      const int q = b + ub < e ? b + ub : (e > b ? e - 1 : -1);
+      dst[ub] = q >= 0 ? a.nbr[q] : 0;
+      eid[ub] = q >= 0 ? a.eid[q] : 0;
+    }
+  };
+  int beg0, end0, beg1, end1;
+  int dst0[UB], eid0[UB];
+  load_ptr(u_lo, beg0, end0);
+  load_ptr(u_lo + NPW, beg1, end1);
+  load_idx(beg0, end0, dst0, eid0);
+#pragma unroll 1
+  for (int64_t it = 0; it < cpw; ++it) {
+    const int64_t u = u_lo + it * NPW;
+    if (u >= a.N) break;
+    int dst1[UB], eid1[UB], beg2, end2;
+    load_idx(beg1, end1, dst1, eid1);
+    load_ptr(it + 2 < cpw ? u + 2 * NPW : a.N, beg2, end2);
+    const int beg = beg0, end = end0;
     float4 hu[NCH], gu[NCH], acc[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -323,11 +350,16 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
     // then the arithmetic in edge order (one edge per trip is a chain of 2 dependent round trips per edge)
     for (int p0 = beg; p0 < end; p0 += UB) {
       int dsts[UB], eids[UB];
+      if (p0 == beg) {
 #pragma unroll
-      for (int ub = 0; ub < UB; ++ub) {
-        const int qq = p0 + ub < end ? p0 + ub : end - 1;
-        dsts[ub] = a.nbr[qq];
-        eids[ub] = a.eid[qq];
+        for (int ub = 0; ub < UB; ++ub) { dsts[ub] = dst0[ub]; eids[ub] = eid0[ub]; }
+      } else {
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {
+          const int qq = p0 + ub < end ? p0 + ub : end - 1;
+          dsts[ub] = a.nbr[qq];
+          eids[ub] = a.eid[qq];
+        }
       }
       float4 gds[UB][NCH];
       float avs[UB][MAX_K], wks[UB];
@@ -400,6 +432,9 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
       }
       if (m.act[j]) gt_store4<T>(dh + u * D + m.col[j], r);
     }
+    beg0 = beg1; end0 = end1; beg1 = beg2; end1 = end2;
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) { dst0[ub] = dst1[ub]; eid0[ub] = eid1[ub]; }
   }
 
   // ---- block reduction of the register accumulators: sub-groups (shuffle) -> waves (LDS) -> partial
