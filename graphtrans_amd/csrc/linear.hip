@@ -664,7 +664,8 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
     }
     // dW is off the critical path of the backward (only the optimizer reads it): inside a
     // gt_overlap_dw_begin/_end section it runs on the side stream beside dX and whatever follows.
-    if (g_dw.active && stream == g_dw.main && dx && a.splits <= 1) {
+    // (not while the launch profiler brackets this call: its events sit on the caller's stream only)
+    if (g_dw.active && stream == g_dw.main && dx && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
       stream = g_dw.side;

@@ -403,13 +403,57 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
   for (int j = 0; j < NCH; ++j) aw[j] = ab[j] = gt_zero4();
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const int64_t total_waves = (int64_t)gridDim.x * (NT / 64);
-  for (int64_t base = ((int64_t)blockIdx.x * (NT / 64) + wid) * NPW; base < a.rows; base += total_waves * NPW) {
+  // the next row's operands are in flight while this row is reduced (a row is only 3 short loads per
+  // lane followed by two cross-lane reductions: without the prefetch every trip exposes a round trip)
+  struct Raw {
+    float4 x[NCH], r[NCH], d[NCH];
+    float mu, rs;
+  };
+  const T* xin = reinterpret_cast<const T*>(a.x);
+  const T* rin = reinterpret_cast<const T*>(a.resid);
+  auto load_raw = [&](int64_t row, Raw& q) {
+    if (row >= a.rows) return;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int col = (sl + j * 64) * 4;
+      if (col >= a.D) continue;
+      q.x[j] = gt_load4<T>(xin + row * a.D + col);
+      q.r[j] = rin ? gt_load4<T>(rin + row * a.D + col) : gt_zero4();
+      q.d[j] = gt_load4<T>(dy + row * a.D + col);
+    }
+    q.mu = a.mean[row];
+    q.rs = a.rstd[row];
+  };
+  Raw cur, nxt;
+  const int64_t base0 = ((int64_t)blockIdx.x * (NT / 64) + wid) * NPW;
+  load_raw(base0 + sub, cur);
+  for (int64_t base = base0; base < a.rows; base += total_waves * NPW) {
     const int64_t row = base + sub;
-    if (row >= a.rows) continue;
+    load_raw(row + total_waves * NPW, nxt);
+    if (row < a.rows) {
     float4 z[NCH];
     bool keep[NCH][4];
-    ln_load_z<T, LPN, NCH>(a, row, sl, z, keep);
-    const float mu = a.mean[row], rs = a.rstd[row];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int col = (sl + j * 64) * 4;
+      keep[j][0] = keep[j][1] = keep[j][2] = keep[j][3] = true;
+      if (col >= a.D) {
+        z[j] = gt_zero4();
+        continue;
+      }
+      float4 v = cur.x[j];
+      if (a.thr) {
+        float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          keep[j][e] = ln_hash(a.s0, a.s1, (uint32_t)row, (uint32_t)(col + e)) >= a.thr;
+          vv[e] = keep[j][e] ? vv[e] * a.inv_keep : 0.f;
+        }
+      }
+      if (rin) v = gt_add4(v, cur.r[j]);
+      z[j] = v;
+    }
+    const float mu = cur.mu, rs = cur.rs;
     float4 g[NCH], xh[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -419,7 +463,7 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
         g[j] = xh[j] = gt_zero4();
         continue;
       }
-      const float4 d = gt_load4<T>(dy + row * a.D + col);
+      const float4 d = cur.d[j];
       const float4 w = *reinterpret_cast<const float4*>(a.w + col);
       xh[j] = make_float4((z[j].x - mu) * rs, (z[j].y - mu) * rs, (z[j].z - mu) * rs, (z[j].w - mu) * rs);
       ab[j] = gt_add4(ab[j], d);
@@ -447,6 +491,8 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
         gt_store4<T>(reinterpret_cast<T*>(a.dx) + row * a.D + col, dz);
       }
     }
+    }
+    cur = nxt;
   }
   // reduce (sub-groups -> waves -> block partial)
   float* part = a.part + (int64_t)blockIdx.x * 2 * a.D;
