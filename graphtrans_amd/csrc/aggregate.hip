@@ -597,19 +597,18 @@ int launch_edge(int edge_mode, const AggArgs& a, size_t lds_bytes, int grid_bwd,
 
 int check_common(const char* fn, int conv, int edge_mode, int dtype, int64_t N, int64_t E, int64_t D, int64_t K,
                  const void* attr, const float* w, const float* b, const int32_t* tab_off, const void* dense) {
-  (void)E;
   if (conv != GT_CONV_GCN && conv != GT_CONV_GIN) { gt_set_error("%s: bad conv %d", fn, conv); return GT_ERR_INVALID_ARG; }
   if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype %d", fn, dtype); return GT_ERR_INVALID_ARG; }
   if (N < 0 || D <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
   if (D % 4 != 0 || D > 1024) { gt_set_error("%s: dim %lld unsupported (need dim %% 4 == 0 and dim <= 1024)", fn, (long long)D); return GT_ERR_UNSUPPORTED; }
   if (edge_mode == GT_EDGE_LINEAR) {
     if (K < 1 || K > MAX_K) { gt_set_error("%s: Linear edge encoder needs 1 <= K <= %d (got %lld)", fn, MAX_K, (long long)K); return GT_ERR_UNSUPPORTED; }
-    if (!attr || !w || !b) { gt_set_error("%s: null Linear edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
+    if ((!attr && E > 0) || !w || !b) { gt_set_error("%s: null Linear edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
   } else if (edge_mode == GT_EDGE_TABLES) {
     if (K < 1 || K > MAX_K) { gt_set_error("%s: table edge encoder needs 1 <= K <= %d", fn, MAX_K); return GT_ERR_UNSUPPORTED; }
-    if (!attr || !w || !tab_off) { gt_set_error("%s: null table edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
+    if ((!attr && E > 0) || !w || !tab_off) { gt_set_error("%s: null table edge-encoder buffer", fn); return GT_ERR_INVALID_ARG; }
   } else if (edge_mode == GT_EDGE_DENSE) {
-    if (!dense) { gt_set_error("%s: null dense edge embedding", fn); return GT_ERR_INVALID_ARG; }
+    if (!dense && E > 0) { gt_set_error("%s: null dense edge embedding", fn); return GT_ERR_INVALID_ARG; }
   } else if (edge_mode != GT_EDGE_NONE) {
     gt_set_error("%s: bad edge_mode %d", fn, edge_mode);
     return GT_ERR_INVALID_ARG;

@@ -144,3 +144,32 @@ def test_fused_backward_issues_the_gradient_allreduce():
             assert torch.equal(p.grad, g0[n]), n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["truncate", "no_edges", "one_graph"])
+def test_fused_model_edge_cases(case):
+    """max_input_len truncation (only the LAST kept_b nodes of a graph reach the encoder,
+    modules/utils.py:16-21), graphs without any edge, and a single-graph batch."""
+    from graphtrans_amd import engine, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    kw = dict(max_input_len=20) if case == "truncate" else {}
+    if case == "one_graph":  # BatchNorm over a 1-row virtual-node batch raises in training mode, as torch does
+        kw = dict(gnn_virtual_node=False)
+    torch.manual_seed(0)
+    model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
+    B = 1 if case == "one_graph" else 6
+    b = synth.code2_like(B=B, seed=11, num_nodeattributes=300)
+    if case == "no_edges":
+        b.edge_index = b.edge_index[:, :0]
+        b.edge_attr = b.edge_attr[:0]
+    b = b.to(DEV)
+    y = torch.randint(0, 50, (B, 5), device=DEV)
+    assert engine.eligible(model, b, None)
+    ref = copy.deepcopy(model)
+    l0, g0, _ = _run(ref, b, y, False, 5)
+    l1, g1, _ = _run(model, b, y, True, 5)
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
+    for n in g0:
+        scale = max(1.0, float(g0[n].abs().max()))
+        assert torch.allclose(g0[n] / scale, g1[n] / scale, rtol=1e-4, atol=1e-6), n
