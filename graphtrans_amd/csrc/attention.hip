@@ -31,6 +31,11 @@ constexpr int TILE = 32;    // keys (fwd, dQ) or queries (dK/dV) per inner step
 constexpr int BLOCK_N = 64; // queries (fwd, dQ) or keys (dK/dV) per block: 4 waves x 16
 constexpr float LOG2E = 1.4426950408889634f;
 
+// v_exp_f32 directly: the arguments here are <= 0 (scores minus the running max), where the library
+// exp2f's denormal-range rescaling (compare, select, two multiplies per call) buys nothing; results
+// below 2^-126 flush to zero, which is what a softmax weight that small contributes anyway.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ---- dropout RNG: counter-based hash of (seed, seq*nhead+head, query pos, key pos) ---------------
 __device__ __forceinline__ uint32_t rng_hash(uint32_t s0, uint32_t s1, uint32_t bh, uint32_t q, uint32_t k) {
   uint32_t x = (q * 0x9E3779B1u) ^ (k * 0x85EBCA77u + s0);
@@ -173,12 +178,12 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m, mt);  // finite: every tile in range holds >= 1 valid key
-    const float alpha = exp2f(m - m_new);
+    const float alpha = fast_exp2(m - m_new);
     m = m_new;
     float p[8], psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      p[i] = exp2f(s[i] - m_new);
+      p[i] = fast_exp2(s[i] - m_new);
       psum += p[i];
     }
     lsum = lsum * alpha + psum;
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         const int kp = k0 + g * 8 + i;
         const bool kvalid = kp >= kv_off && kp < kv_end;
         const bool filled = dense && qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
-        const float p = kvalid ? exp2f(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
+        const float p = kvalid ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
         float dpi = dp[r];
         if (a.drop_thr) {
           const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)kp);
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         const int qpos = q0 + qi;
         const bool ok = kvalid && qpos < npos;
         const bool filled = dense && ok && dense_masked(a, seq, qpos, kp, npos);
-        float p = ok ? exp2f(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) - sLogl[qi]) : 0.f;
+        float p = ok ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) - sLogl[qi]) : 0.f;
         float dpi = dp[r];
         float pdrop = p;
         if (a.drop_thr) {
