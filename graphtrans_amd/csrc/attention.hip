@@ -55,6 +55,7 @@ struct AttnArgs {
   void* out;          // fwd: ctx ; bwd: d_qkv
   const int32_t* desc;
   const int32_t* work;  // optional [num_work][2] = {sequence, 64-row tile}: 1-D grid over real tiles only
+  int num_work, work_per_xcd;  // work-list launches: see block_item
   // optional dense masks of CausalSelfAttention (modules/masked_transformer_encoder.py:44-47): entries == 0 are
   // FILLED with mask_fill (masked_fill semantics: finite value, no gradient through the score)
   const float* dense_mask;  // [num_seqs][npos][npos]
@@ -74,6 +75,27 @@ __device__ __forceinline__ bool dense_masked(const AttnArgs& a, int seq, int qpo
   if (a.key_valid && a.key_valid[(int64_t)seq * npos + kp] == 0.f) return true;
   if (a.dense_mask && a.dense_mask[((int64_t)seq * npos + qpos) * npos + kp] == 0.f) return true;
   return false;
+}
+
+// (sequence, 64-row tile, head) of this block.  Work-list launches are 1-D and XCD-aware: workgroup b
+// runs on XCD b % 8 (own L2); XCD x takes the x-th contiguous eighth of the (sequence-sorted) work list
+// and walks it head-fastest, so every tile and head of a sequence -- which all read that sequence's K
+// and V rows -- hit the same L2 (PMC before: 95 MB fetched per forward launch for 24.5 MB of qkv).
+__device__ __forceinline__ bool block_item(const AttnArgs& a, int& seq, int& tile, int& head) {
+  if (a.work) {
+    const int b = blockIdx.x;
+    const int slot = b / 8;
+    const int w = (b % 8) * a.work_per_xcd + slot / a.nhead;
+    if (slot / a.nhead >= a.work_per_xcd || w >= a.num_work) return false;
+    head = slot % a.nhead;
+    seq = a.work[w * 2];
+    tile = a.work[w * 2 + 1];
+  } else {
+    head = blockIdx.y;
+    seq = blockIdx.z;
+    tile = blockIdx.x;
+  }
+  return true;
 }
 
 template <int HD, typename T>
@@ -122,11 +144,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
-  const int head = blockIdx.y;
-  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
+  int seq, tile_, head;
+  if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int q_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
+  const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -229,11 +251,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
-  const int head = blockIdx.y;
-  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
+  int seq, tile_, head;
+  if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int q_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
+  const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -332,11 +354,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
   __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
   __shared__ float sLse[TILE], sLogl[TILE], sDelta[TILE];
-  const int head = blockIdx.y;
-  const int seq = a.work ? a.work[blockIdx.x * 2] : blockIdx.z;
+  int seq, tile_, head;
+  if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
-  const int k_base = (a.work ? a.work[blockIdx.x * 2 + 1] : blockIdx.x) * BLOCK_N;
+  const int k_base = tile_ * BLOCK_N;
   if (k_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -475,7 +497,9 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, nullptr, nullptr, lse, nullptr, ctx, total_rows, d_model, nhead, seq_desc, work_items,
                          row_stride, scale, dropout_p, seed, dense_mask, key_valid, mask_value);
-  dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
+  a.num_work = (int)num_work;
+  a.work_per_xcd = (int)gt_cdiv(num_work, 8);
+  dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
 #define GT_LAUNCH(T, HD) hipLaunchKernelGGL((k_attn_fwd<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a)
@@ -506,7 +530,9 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   if (work_items && num_work == 0) return GT_OK;
   AttnArgs a = make_args(qkv, ctx, d_ctx, const_cast<float*>(lse), delta, d_qkv, total_rows, d_model, nhead, seq_desc,
                          work_items, row_stride, scale, dropout_p, seed, dense_mask, key_valid, mask_value);
-  dim3 grid = work_items ? dim3((unsigned)num_work, (unsigned)nhead, 1)
+  a.num_work = (int)num_work;
+  a.work_per_xcd = (int)gt_cdiv(num_work, 8);
+  dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
 #define GT_LAUNCH(T, HD)                                                                        \

@@ -43,7 +43,8 @@ struct LinArgs {
   float inv_keep;     // 1/(1-p)
   uint32_t thr, s0, s1;
   int splits;
-  int ntiles;           // fwd / dx: column tiles per row tile (see tile_of_block)
+  int ntiles;           // fwd / dx: column tiles per row tile; dw: output tiles per M-split (see tile_of_block)
+  int ntx;              // dw: tiles along N
   int64_t m_per_split;
   int64_t n_per_split;  // dx: contraction range per blockIdx.z when splits > 1 (partials [splits][M][K] fp32 in `out`)
   int dbg;  // ablation bits (GT_LINEAR_DBG): 1 no W loads, 2 no X loads, 4 no stores, 8 no MFMA
@@ -406,8 +407,14 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int wn = wid & 1, wk = wid >> 1;
-  const int64_t n0 = (int64_t)blockIdx.x * BN, k0 = (int64_t)blockIdx.y * BN;
-  const int split = blockIdx.z;
+  // XCD-aware: the tiles of one M-split read the same dZ / X rows -> same XCD (see tile_of_block)
+  int64_t split_;
+  int tile_;
+  tile_of_block(a.ntiles, split_, tile_);
+  if (split_ >= a.splits) return;
+  const int split = (int)split_;
+  const int tx = tile_ % a.ntx, ty = tile_ / a.ntx;
+  const int64_t n0 = (int64_t)tx * BN, k0 = (int64_t)ty * BN;
   const int64_t mb = (int64_t)split * a.m_per_split;
   const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
   const TY* dY = reinterpret_cast<const TY*>(a.a);
@@ -438,7 +445,7 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
       lz.load(dY + m1 * a.ldy + n0, me - m1, a.N - n0, has_mask ? Ym + m1 * a.ldy + n0 : nullptr);
       lx.load(X + m1 * a.K + k0, me - m1, a.K - k0, nullptr);
     }
-    if (blockIdx.y == 0 && threadIdx.x < BN) {
+    if (ty == 0 && threadIdx.x < BN) {
 #pragma unroll 8
       for (int r = 0; r < BMc; ++r) {
         const TC v = sZ[r * LDZ + threadIdx.x];
@@ -483,7 +490,7 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (blockIdx.y == 0 && threadIdx.x < BN && n0 + threadIdx.x < a.N && a.dbpart)
+  if (ty == 0 && threadIdx.x < BN && n0 + threadIdx.x < a.N && a.dbpart)
     a.dbpart[(int64_t)split * a.N + n0 + threadIdx.x] = dbacc;
 }
 
@@ -699,7 +706,9 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
     a.m_per_split = gt_cdiv(gt_cdiv(M, splits), bmc) * bmc;
     a.out = workspace;
     a.dbpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)splits * N * K : nullptr;
-    dim3 grid((unsigned)gt_cdiv(N, BN), (unsigned)gt_cdiv(K, BN), (unsigned)splits);
+    a.ntx = (int)gt_cdiv(N, BN);
+    a.ntiles = a.ntx * (int)gt_cdiv(K, BN);
+    dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * a.ntiles));
     const int t0 = y_dtype, t1 = x_dtype;
     GT_LIN_DISPATCH(k_linear_dw, grid, a);
     const int64_t len = N * K, len2 = dbias ? N : 0;
