@@ -151,7 +151,11 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   constexpr int NPW = 64 / LPN;
   constexpr int U = NCH >= 3 ? 2 : 4;
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * AGG_WAVES + (threadIdx.x >> 6);
+  // XCD-aware block order (grid is a multiple of 8): workgroup b runs on XCD b % 8; XCD x walks the x-th
+  // contiguous eighth of the nodes, so the re-gathers of a row (self + ~3 neighbours of the same graph)
+  // hit one L2 instead of crossing the fabric from several XCDs.
+  const int64_t blk = (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  const int64_t wave = blk * AGG_WAVES + (threadIdx.x >> 6);
   LaneMap<LPN, NCH> m(lane, a.D);
   const int64_t v_lo = wave * (FWD_CHUNK * NPW) + m.sub;   // this sub-group's nodes: v_lo, v_lo + NPW, ...
   if (v_lo >= a.N) return;
@@ -308,7 +312,8 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   // like the forward (indices of node i+1 and the ptr pair of node i+2 in flight while node i's
   // gradient rows are gathered).  The runs depend on (N, grid) only: partial sums stay reproducible.
   const int64_t total_waves = (int64_t)gridDim.x * AGG_WAVES;
-  const int64_t wave0 = (int64_t)blockIdx.x * AGG_WAVES + wid;
+  const int64_t blk = gridDim.x % 8 == 0 ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  const int64_t wave0 = blk * AGG_WAVES + wid;   // XCD-aware like the forward: contiguous node runs per XCD
   const int64_t cpw = (a.N + total_waves * NPW - 1) / (total_waves * NPW);   // nodes per sub-group
   const int64_t u_lo = wave0 * cpw * NPW + m.sub;
   auto load_ptr = [&](int64_t v, int& b, int& e) {
@@ -568,7 +573,7 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
                          stream, a);                                                                         \
     } else {                                                                                                 \
       int64_t waves = gt_cdiv(a.N, NPW * FWD_CHUNK);                                                         \
-      hipLaunchKernelGGL((k_agg_fwd<T, LPN, NCH, EDGE>), dim3((unsigned)gt_cdiv(waves, AGG_WAVES)),         \
+      hipLaunchKernelGGL((k_agg_fwd<T, LPN, NCH, EDGE>), dim3((unsigned)(gt_cdiv(gt_cdiv(waves, AGG_WAVES), 8) * 8)), \
                          dim3(AGG_THREADS), 0, stream, a);                                                   \
     }                                                                                                        \
   } while (0)
