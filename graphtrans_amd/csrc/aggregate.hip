@@ -280,7 +280,7 @@ template <typename T, int LPN, int NCH, int EDGE>
 __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   constexpr int NPW = 64 / LPN;
   constexpr int NREG = reg_slots<EDGE>();
-  constexpr int UB = NCH >= 3 ? 2 : 4;
+  constexpr int UB = NCH >= 2 ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
