@@ -59,6 +59,8 @@ def model_args(workload, dtype):
         a.update(gnn_virtual_node=False, gnn_num_layer=4, gnn_emb_dim=272, gnn_JK="last", gnn_residual=True,
                  gnn_dropout=0.0, aggregators=["mean", "max", "min", "std"],
                  scalers=["identity", "amplification", "attenuation"], deg=torch.tensor([0, 4000, 2500, 900, 300, 90, 30, 9]))
+    if os.environ.get("GT_BENCH_TDROP") is not None:  # ablation only: transformer dropout rate
+        a["transformer_dropout"] = float(os.environ["GT_BENCH_TDROP"])
     return SimpleNamespace(**a)
 
 

@@ -392,8 +392,10 @@ __global__ void __launch_bounds__(NT) k_ln_fwd(LnArgs a) {
 }
 
 // backward: persistent grid; per-lane column accumulators for dw/db, block partials, fixed-order finish
-template <typename T, int LPN, int NCH>
-__global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
+// NTB threads per block: the column partials are reduced per block, so big blocks (1024 threads) put 6-8
+// waves on every SIMD without multiplying the partial rows the finish kernel has to sum.
+template <typename T, int LPN, int NCH, int NTB>
+__global__ void __launch_bounds__(NTB) k_ln_bwd(LnArgs a) {
   constexpr int NPW = 64 / LPN;
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -402,7 +404,7 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
 #pragma unroll
   for (int j = 0; j < NCH; ++j) aw[j] = ab[j] = gt_zero4();
   const T* dy = reinterpret_cast<const T*>(a.dy);
-  const int64_t total_waves = (int64_t)gridDim.x * (NT / 64);
+  const int64_t total_waves = (int64_t)gridDim.x * (NTB / 64);
   // the next row's operands are in flight while this row is reduced (a row is only 3 short loads per
   // lane followed by two cross-lane reductions: without the prefetch every trip exposes a round trip)
   struct Raw {
@@ -425,7 +427,7 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
     q.rs = a.rstd[row];
   };
   Raw cur, nxt;
-  const int64_t base0 = ((int64_t)blockIdx.x * (NT / 64) + wid) * NPW;
+  const int64_t base0 = ((int64_t)blockIdx.x * (NTB / 64) + wid) * NPW;
   load_raw(base0 + sub, cur);
   for (int64_t base = base0; base < a.rows; base += total_waves * NPW) {
     const int64_t row = base + sub;
@@ -511,10 +513,10 @@ __global__ void __launch_bounds__(NT) k_ln_bwd(LnArgs a) {
     }
   }
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < 2 * a.D; i += NT) {
+  for (int64_t i = threadIdx.x; i < 2 * a.D; i += NTB) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) t += lds[(int64_t)w * 2 * a.D + i];
+    for (int w = 0; w < NTB / 64; ++w) t += lds[(int64_t)w * 2 * a.D + i];
     part[i] = t;  // [0][D] = dweight partial, [1][D] = dbias partial
   }
 }
@@ -538,8 +540,12 @@ void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
 #define GT_LN(LPN, NCH)                                                                                      \
   do {                                                                                                       \
     if constexpr (BWD) {                                                                                     \
-      hipLaunchKernelGGL((k_ln_bwd<T, LPN, NCH>), dim3(grid_bwd), dim3(NT), (size_t)(NT / 64) * 2 * D * 4,   \
-                         stream, a);                                                                         \
+      if (D <= 256)                                                                                        \
+        hipLaunchKernelGGL((k_ln_bwd<T, LPN, NCH, 1024>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * D * 4, \
+                           stream, a);                                                                       \
+      else                                                                                                   \
+        hipLaunchKernelGGL((k_ln_bwd<T, LPN, NCH, NT>), dim3(grid_bwd), dim3(NT), (size_t)(NT / 64) * 2 * D * 4, \
+                           stream, a);                                                                       \
     } else {                                                                                                 \
       int64_t waves = gt_cdiv(a.rows, 64 / (LPN));                                                           \
       hipLaunchKernelGGL((k_ln_fwd<T, LPN, NCH>), dim3((unsigned)gt_cdiv(waves, NT / 64)), dim3(NT), 0,      \
@@ -694,7 +700,8 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   a.rstd = const_cast<float*>(save_rstd); a.rows = rows; a.D = dim; a.part = (float*)workspace;
   fill_drop(a, dropout_p, seed);
   const int64_t npw = dim <= 64 ? 4 : (dim <= 128 ? 2 : 1);
-  int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), NT / 64);
+  const int bwd_waves = dim <= 256 ? 16 : NT / 64;   // waves per block of the launch below
+  int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), bwd_waves);
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
