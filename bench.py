@@ -128,6 +128,20 @@ def _unused_attn_flops(meta, bwd):
     return f * (2.5 if bwd else 1.0)
 
 
+def pmc_traffic(workload, dtype, per_gpu):
+    best = {}
+    pdir = os.path.join(REPO, "profiles")
+    try:
+        for fn in sorted(os.listdir(pdir)):
+            if fn.endswith("_pmc_traffic.json"):
+                d = json.load(open(os.path.join(pdir, fn)))
+                if d.get("workload") == workload and d.get("dtype") == dtype and d.get("graphs_per_gpu") == per_gpu:
+                    best = d.get("traffic", {})  # the latest round's file wins (sorted names)
+    except OSError:
+        pass
+    return best
+
+
 def kernel_report(records, attn_flops_fwd, dtype):
     """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the launch stream,
     recorded inside the timed region).  -> per entry point roofline dicts."""
@@ -316,6 +330,13 @@ def main():
                 n = np.minimum(np.asarray(b._sizes, dtype=np.float64), max_len) + (1 if args.graph_pooling == "cls" else 0)
                 fl.append(float((4.0 * n * n * d_model).sum()))
             rep = kernel_report(records, float(np.mean(fl)), dtype)
+            # "traffic": HBM-side bytes per call from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, collected
+            # offline in separate rocprofv3 --pmc passes over this very command, committed under profiles/);
+            # null for configurations that were not measured
+            tr = pmc_traffic(opt.workload, opt.dtype, per_gpu)
+            for k in rep:
+                if k in tr:
+                    rep[k]["traffic"] = tr[k]
             if rep:
                 dom = max(rep, key=lambda k: rep[k]["total_ms"])
                 r = dict(rep[dom])
