@@ -326,7 +326,7 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
   // h = batch_norm(h) [relu] [+ h_list[layer]]   (gnn_module.py:204-212; dropout p = 0 or eval here)
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.agg, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr,
                           L->bn_momentum, L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->N, L->D, y, s.stats,
-                          s.stats + L->D, w.bn_ws, w.bn_ws_bytes, st));
+                          s.stats + L->D, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   return GT_OK;
 }
 
@@ -342,7 +342,7 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
   const GcnSaved s = gcn_saved(L, const_cast<void*>(saved));
   const GcnGrads g = gcn_grads(L, grads);
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.agg, dy, L->bn_w, L->bn_b, s.stats, s.stats + L->D, L->training, L->relu, L->N, L->D,
-                          w.d_agg, g.bn_w, g.bn_b, w.bn_ws, w.bn_ws_bytes, st));
+                          w.d_agg, g.bn_w, g.bn_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_aggregate_bwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, w.d_agg, L->N, L->E, L->D, L->out_ptr, L->out_dst,
                           L->out_eid, L->deg, L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off,
                           L->table_rows, nullptr, w.d_lin, g.root, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
@@ -372,12 +372,12 @@ extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void
   // mlp_virtualnode_list[layer]: Linear(D,2D) BN ReLU Linear(2D,D) BN ReLU   (gnn_module.py:161-170)
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, L->b1, s.z1, B, 2 * D, D, 0, 0.f, 0, st));
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
-                          L->bn_momentum, L->bn_eps, L->training, 1, nullptr, B, 2 * D, s.a1, s.st1, s.st1 + 2 * D, w.bn_ws,
-                          w.bn_ws_bytes, st));
+                          L->bn_momentum, L->bn_eps, L->training, 1, nullptr, B, 2 * D, s.a1, s.st1, s.st1 + 2 * D, 0.f, 0,
+                          w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, L->b2, s.z2, B, D, 2 * D, 0, 0.f, 0, st));
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.z2, L->bn2_w, L->bn2_b, L->bn2_rm, L->bn2_rv, L->training ? L->bn2_nbt : nullptr,
                           L->bn_momentum, L->bn_eps, L->training, 1, L->residual ? vn : nullptr, B, D, vn_out, s.st2,
-                          s.st2 + D, w.bn_ws, w.bn_ws_bytes, st));
+                          s.st2 + D, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));  // vn (+)= drop(mlp(t))   (:222)
   return GT_OK;
 }
 
@@ -391,11 +391,11 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   const VnGrads g = vn_grads(L, grads);
   const int64_t B = L->B, D = L->D;
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, d_vn_out, L->bn2_w, L->bn2_b, s.st2, s.st2 + D, L->training, 1, B, D, w.d_z2, g.bn2_w,
-                          g.bn2_b, w.bn_ws, w.bn_ws_bytes, st));
+                          g.bn2_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, B, D,
                        2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, B, 2 * D, w.d_z1,
-                          g.bn1_w, g.bn1_b, w.bn_ws, w.bn_ws_bytes, st));
+                          g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
   // d_t0 = d_z1 W1 ; d_vn = d_t0 (+ d_vn_out through the residual branch)
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, g.w1, g.b1, B,
                        2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));

@@ -156,12 +156,32 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
   rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-// pass 3: y = (x - mean) * rstd * w + b  [relu]
+// dropout fused behind BatchNorm(+ReLU): F.dropout(h, drop_ratio) of the GNN layers
+// (modules/gnn_module.py:88-90,209-212,222).  Counter hash of (seed, row, column), replayed by the backward.
+struct BnDrop {
+  uint32_t thr, s0, s1;  // keep iff hash >= thr ; thr == 0: no dropout
+  float inv_keep;
+};
+__device__ __forceinline__ uint32_t bn_hash(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col) {
+  uint32_t x = (row * 0x9E3779B1u + s0) ^ (col * 0x85EBCA77u + s1);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float4 bn_drop4(float4 v, const BnDrop& d, uint32_t row, uint32_t col) {
+  return make_float4(bn_hash(d.s0, d.s1, row, col) >= d.thr ? v.x * d.inv_keep : 0.f,
+                     bn_hash(d.s0, d.s1, row, col + 1) >= d.thr ? v.y * d.inv_keep : 0.f,
+                     bn_hash(d.s0, d.s1, row, col + 2) >= d.thr ? v.z * d.inv_keep : 0.f,
+                     bn_hash(d.s0, d.s1, row, col + 3) >= d.thr ? v.w * d.inv_keep : 0.f);
+}
+
+// pass 3: y = drop((x - mean) * rstd * w + b  [relu]) [+ resid]
 template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ w,
                                                  const float* __restrict__ b, const T* __restrict__ resid, int relu,
-                                                 int64_t N, int64_t D, T* __restrict__ y) {
+                                                 BnDrop drop, int64_t N, int64_t D, T* __restrict__ y) {
   const int64_t C = D / 4, total = N * C;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t c = (i % C) * 4;
@@ -171,6 +191,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const 
     v = make_float4((v.x - mu.x) * rs.x * ww.x + bb.x, (v.y - mu.y) * rs.y * ww.y + bb.y,
                     (v.z - mu.z) * rs.z * ww.z + bb.z, (v.w - mu.w) * rs.w * ww.w + bb.w);
     if (relu) v = gt_relu4(v);
+    if (drop.thr) v = bn_drop4(v, drop, (uint32_t)(i / C), (uint32_t)c);
     if (resid) v = gt_add4(v, gt_load4<T>(resid + i * 4));
     gt_store4<T>(y + i * 4, v);
   }
@@ -187,7 +208,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, const T* __restrict__ dy,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       int relu, int64_t N, int64_t D, float* __restrict__ part) {
+                                                       int relu, BnDrop drop, int64_t N, int64_t D, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float4 sm4[];
   ColMap m(D);
   const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
@@ -200,7 +221,8 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
     if (m.tr < m.R && cact) {
       const float4 mu = *reinterpret_cast<const float4*>(mean + c * 4), rs = *reinterpret_cast<const float4*>(rstd + c * 4);
       const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(b + c * 4);
-      auto add_row = [&](float4 g, const float4 v) {
+      auto add_row = [&](float4 g, const float4 v, int64_t r) {
+        if (drop.thr) g = bn_drop4(g, drop, (uint32_t)r, (uint32_t)(c * 4));
         if (relu) g = bn_gate(g, v, mu, rs, ww, bb);
         acc[0] = gt_add4(acc[0], g);
         acc[1] = make_float4(fmaf(g.x, (v.x - mu.x) * rs.x, acc[1].x), fmaf(g.y, (v.y - mu.y) * rs.y, acc[1].y),
@@ -216,11 +238,11 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
           v[u] = gt_load4<T>(x + o);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) add_row(g[u], v[u]);
+        for (int u = 0; u < 4; ++u) add_row(g[u], v[u], r + (int64_t)u * m.R);
       }
       for (; r < r1; r += m.R) {
         const int64_t o = r * D + (int64_t)c * 4;
-        add_row(gt_load4<T>(dy + o), gt_load4<T>(x + o));
+        add_row(gt_load4<T>(dy + o), gt_load4<T>(x + o), r);
       }
     }
     block_rowlane_reduce<2>(acc, m, sm4);
@@ -249,7 +271,8 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ dbias, const float* __restrict__ dweight,
-                                                     int relu, int training, int64_t N, int64_t D, T* __restrict__ dx) {
+                                                     int relu, int training, BnDrop drop, int64_t N, int64_t D,
+                                                     T* __restrict__ dx) {
   const int64_t C = D / 4, total = N * C;
   const float inv_n = training ? 1.0f / (float)N : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
@@ -258,6 +281,7 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
     const float4 v = gt_load4<T>(x + i * 4);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
     const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    if (drop.thr) g = bn_drop4(g, drop, (uint32_t)(i / C), (uint32_t)c);
     if (relu) g = bn_gate(g, v, mu, rs, ww, *reinterpret_cast<const float4*>(b + c));
     const float4 db = *reinterpret_cast<const float4*>(dbias + c), dw = *reinterpret_cast<const float4*>(dweight + c);
     float4 r;
@@ -572,6 +596,16 @@ void fill_drop(LnArgs& a, float dropout_p, uint64_t seed) {
 }  // namespace
 
 // ---- C ABI -----------------------------------------------------------------------------------------
+static BnDrop make_bn_drop(float dropout_p, uint64_t seed) {
+  BnDrop d{};
+  d.inv_keep = 1.0f / (1.0f - dropout_p);
+  double thr = (double)dropout_p * 4294967296.0;
+  d.thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
+  d.s0 = (uint32_t)seed;
+  d.s1 = (uint32_t)(seed >> 32);
+  return d;
+}
+
 extern "C" size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim) {
   return (size_t)part_blocks(rows) * 2 * dim * sizeof(float) + 256;
 }
@@ -579,10 +613,12 @@ extern "C" size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim) {
 extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float momentum, float eps, int training, int relu, const void* resid, int64_t rows,
-                                int64_t dim, void* y, float* save_mean, float* save_rstd, void* workspace,
-                                size_t workspace_bytes, gt_stream_t stream_) {
+                                int64_t dim, void* y, float* save_mean, float* save_rstd, float dropout_p,
+                                uint64_t seed, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_norm("gt_batchnorm_fwd", dtype, rows, dim);
   if (rc) return rc;
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  const BnDrop drop = make_bn_drop(training ? dropout_p : 0.f, seed);
   GT_CHECK_ARG(x && weight && bias && y && save_mean && save_rstd, "null buffer");
   GT_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
   if (rows == 0) return GT_OK;
@@ -613,20 +649,22 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
   const int g = flat_blocks(rows * (dim / 4));
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, save_mean, save_rstd, weight,
-                       bias, (const float*)resid, relu, rows, dim, (float*)y);
+                       bias, (const float*)resid, relu, drop, rows, dim, (float*)y);
   else
     hipLaunchKernelGGL(k_bn_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, save_mean, save_rstd, weight,
-                       bias, (const gt_bf16*)resid, relu, rows, dim, (gt_bf16*)y);
+                       bias, (const gt_bf16*)resid, relu, drop, rows, dim, (gt_bf16*)y);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
 
 extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
                                 const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
-                                int64_t dim, void* dx, float* dweight, float* dbias, void* workspace,
-                                size_t workspace_bytes, gt_stream_t stream_) {
+                                int64_t dim, void* dx, float* dweight, float* dbias, float dropout_p, uint64_t seed,
+                                void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_norm("gt_batchnorm_bwd", dtype, rows, dim);
   if (rc) return rc;
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  const BnDrop drop = make_bn_drop(training ? dropout_p : 0.f, seed);
   GT_CHECK_ARG(x && dy && weight && bias && save_mean && save_rstd && dx && dweight && dbias, "null buffer");
   if (rows == 0) return GT_OK;
   if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
@@ -641,16 +679,16 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const int g = flat_blocks(rows * (dim / 4));
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
-                       weight, bias, save_mean, save_rstd, relu, rows, dim, part);
+                       weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, rows, dim, (float*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (float*)dx);
   } else {
     hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       weight, bias, save_mean, save_rstd, relu, rows, dim, part);
+                       weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, rows, dim, (gt_bf16*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (gt_bf16*)dx);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;

@@ -8,7 +8,7 @@ buffer whose slices become `p.grad`, and autograd sees a single node.
 
 Covered configuration (everything else keeps using the module path, see `eligible`):
   GNN_node / GNN_node_Virtualnode with GCNConv layers, Linear(<=4, D) or "zero" edge encoders,
-  gnn_dropout 0 (or eval), JK in {last, cat}, ASTNodeEncoder / AtomEncoder inputs, no perturb;
+  any gnn_dropout, JK in {last, cat}, ASTNodeEncoder / AtomEncoder inputs, no perturb;
   packed token layout (cls / last pooling, no positional encoder, no masked layers), ReLU post-norm
   encoder layers; stacked max_seq_len heads or a single head.
 Reference call path: models/gnn_transformer.py:88-127 -> modules/gnn_module.py:181-224 ->
@@ -234,8 +234,6 @@ def _eligible_static(model):
     try:
         if not model._use_packed() or gnn.JK not in ("last", "cat"):
             return False
-        if gnn.drop_ratio != 0 and model.training:
-            return False
         ne = gnn.node_encoder
         if not (hasattr(ne, "type_encoder") or hasattr(ne, "atom_embedding_list")):
             return False
@@ -304,6 +302,10 @@ class _FusedModel(torch.autograd.Function):
         sm = plan.small(B)
         nenc = len(plan.enc_layers)
 
+        # dropout seeds: drawn in the module path's order (GNN first, then the encoder)
+        from .modules.gnn_module import _gnn_seed, layer_seed, vn_seed
+        gnn_base = _gnn_seed(model.gnn_node)
+        gnn_p = float(model.gnn_node.drop_ratio) if model.training else 0.0
         # ---- refresh the batch-dependent descriptor fields
         ea = batched_data.edge_attr
         ea_f = None
@@ -315,13 +317,15 @@ class _FusedModel(torch.autograd.Function):
             desc.relu = 1 if l != L - 1 else 0
             desc.residual = 1 if model.gnn_node.residual else 0
             desc.training, desc.compute = training, compute
+            desc.dropout_p, desc.seed = gnn_p, layer_seed(gnn_base, l)
             layers._fill_graph(desc, gs)
             if plan.gcn_edge[l]:
                 desc.edge_attr = ea_f.data_ptr()
             ov = plan.side is not None and l < L - 1
             desc.ev_x_ready = plan.ev_x[l] if ov else None
             desc.ev_dx_wait = plan.ev_extra[l] if ov else None
-        for desc in plan.vn_desc:
+        for l, desc in enumerate(plan.vn_desc):
+            desc.dropout_p, desc.seed = gnn_p, vn_seed(gnn_base, l)
             desc.N, desc.B = N, B
             desc.residual = 1 if model.gnn_node.residual else 0
             desc.training, desc.compute = training, compute

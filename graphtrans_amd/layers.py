@@ -32,7 +32,8 @@ class GcnLayerDesc(C.Structure):
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
                [(n, _fp) for n in ("graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid",
                                    "deg", "dis", "edge_attr", "lin_w", "lin_b", "root", "edge_w", "edge_b", "bn_w", "bn_b",
-                                   "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")]
+                                   "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")] + \
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
 
 
 class VnUpdateDesc(C.Structure):
@@ -40,7 +41,8 @@ class VnUpdateDesc(C.Structure):
                 ("residual", C.c_int32), ("training", C.c_int32), ("compute", C.c_int32), ("pad_", C.c_int32),
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
                [(n, _fp) for n in ("graph_ptr", "node_graph", "identity_graph", "w1", "b1", "bn1_w", "bn1_b", "w2", "b2",
-                                   "bn2_w", "bn2_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv", "bn1_nbt", "bn2_nbt")]
+                                   "bn2_w", "bn2_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv", "bn1_nbt", "bn2_nbt")] + \
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
 
 
 def _bind():
@@ -152,7 +154,7 @@ class _GcnLayer(torch.autograd.Function):
     y = BN(GCNConv(x)) [relu] [+ x]."""
 
     @staticmethod
-    def forward(ctx, h_in, vn, gs, spec, relu, residual, training, bn, *params):
+    def forward(ctx, h_in, vn, gs, spec, relu, residual, training, bn, dropout_p, seed, *params):
         ctx.set_materialize_grads(False)  # an unused output (x without consumers) must not cost a zero fill
         L = _bind()
         h_in = h_in.contiguous()
@@ -163,6 +165,7 @@ class _GcnLayer(torch.autograd.Function):
         desc.relu, desc.residual, desc.training = int(relu), int(residual), int(training)
         desc.compute = _compute_code()
         desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+        desc.dropout_p, desc.seed = (float(dropout_p) if training else 0.0), int(seed)
         _fill_graph(desc, gs)
         lin_w, lin_b, root, bn_w, bn_b = params[:5]
         edge_params = params[5:]
@@ -238,17 +241,17 @@ class _GcnLayer(torch.autograd.Function):
             for t in edge_params:
                 g_edge.append(take(t.numel(), t.shape))
         g_bn_w, g_bn_b = take(D, bn_w.shape), take(D, bn_b.shape)
-        return (d_h, d_vn, None, None, None, None, None, None, g_lin_w, g_lin_b, g_root, g_bn_w, g_bn_b, *g_edge)
+        return (d_h, d_vn, None, None, None, None, None, None, None, None, g_lin_w, g_lin_b, g_root, g_bn_w, g_bn_b, *g_edge)
 
 
 def gcn_layer_eligible(conv, bn, h, spec, drop_ratio, training):
     from .modules.conv import GCNConv
     return (isinstance(conv, GCNConv) and h.is_cuda and h.dtype == torch.float32 and h.shape[1] % 4 == 0
-            and spec.kind in ("linear", "tables", "none") and (drop_ratio == 0 or not training)
+            and spec.kind in ("linear", "tables", "none")
             and bn.affine and bn.track_running_stats and bn.momentum is not None)
 
 
-def gcn_layer(h_in, vn, gs, conv, bn, spec, relu, residual, training):
+def gcn_layer(h_in, vn, gs, conv, bn, spec, relu, residual, training, dropout_p=0.0, seed=0):
     """-> (x, y); x is h_in when vn is None."""
     if spec.kind == "linear":
         edge_params = [spec.weight, spec.bias]
@@ -256,7 +259,7 @@ def gcn_layer(h_in, vn, gs, conv, bn, spec, relu, residual, training):
         edge_params = list(spec.table_list)
     else:
         edge_params = []
-    x, y = _GcnLayer.apply(h_in, vn, gs, spec, relu, residual, training, bn, conv.linear.weight, conv.linear.bias,
+    x, y = _GcnLayer.apply(h_in, vn, gs, spec, relu, residual, training, bn, dropout_p, seed, conv.linear.weight, conv.linear.bias,
                            conv.root_emb.weight, bn.weight, bn.bias, *edge_params)
     return (x if vn is not None else h_in), y
 
@@ -266,7 +269,7 @@ def gcn_layer(h_in, vn, gs, conv, bn, spec, relu, residual, training):
 # ------------------------------------------------------------------------------------------------
 class _VnUpdate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, vn, gs, residual, training, bn1, bn2, *params):
+    def forward(ctx, x, vn, gs, residual, training, bn1, bn2, dropout_p, seed, *params):
         L = _bind()
         x, vn = x.contiguous(), vn.contiguous()
         N, D = x.shape
@@ -274,6 +277,7 @@ class _VnUpdate(torch.autograd.Function):
         desc.N, desc.B, desc.D = N, gs.B, D
         desc.residual, desc.training, desc.compute = int(residual), int(training), _compute_code()
         desc.bn_momentum, desc.bn_eps = float(bn1.momentum), float(bn1.eps)
+        desc.dropout_p, desc.seed = (float(dropout_p) if training else 0.0), int(seed)
         ident = getattr(gs, "_identity", None)
         desc.graph_ptr, desc.node_graph = _ptr(gs.graph_ptr), _ptr(gs.node_graph)
         if residual:
@@ -310,7 +314,7 @@ class _VnUpdate(torch.autograd.Function):
         ws = _bytes(ws_bytes, dev)
         _lib.check(L.gt_vn_update_bwd(C.byref(desc), _ptr(g), _ptr(saved), None, _ptr(d_x), _ptr(d_vn), _ptr(grads), _ptr(ws),
                                       ws_bytes, _stream()), "gt_vn_update_bwd")
-        return (d_x, d_vn, None, None, None, None, None, *_split(grads, params))
+        return (d_x, d_vn, None, None, None, None, None, None, None, *_split(grads, params))
 
 
 def vn_update_eligible(seq, x, drop_ratio, training):
@@ -318,10 +322,10 @@ def vn_update_eligible(seq, x, drop_ratio, training):
     mods = list(seq)
     return (len(mods) == 6 and isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], BatchNorm1d)
             and isinstance(mods[3], torch.nn.Linear) and isinstance(mods[4], BatchNorm1d) and x.is_cuda
-            and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and (drop_ratio == 0 or not training))
+            and x.dtype == torch.float32 and x.shape[1] % 4 == 0)
 
 
-def vn_update(x, vn, gs, seq, residual, training):
+def vn_update(x, vn, gs, seq, residual, training, dropout_p=0.0, seed=0):
     m = list(seq)
-    return _VnUpdate.apply(x, vn, gs, residual, training, m[1], m[4], m[0].weight, m[0].bias, m[1].weight, m[1].bias,
+    return _VnUpdate.apply(x, vn, gs, residual, training, m[1], m[4], dropout_p, seed, m[0].weight, m[0].bias, m[1].weight, m[1].bias,
                            m[3].weight, m[3].bias, m[4].weight, m[4].bias)

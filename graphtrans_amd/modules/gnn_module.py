@@ -49,21 +49,41 @@ def _make_convs(self, num_layer, emb_dim, edge_encoder_cls, gnn_type):
         self.batch_norms.append(BatchNorm1d(emb_dim))
 
 
-def _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr):
+_SEED_STEP = 0x9E3779B97F4A7C15
+_SEED_MASK = 0xFFFFFFFFFFFFFFFF
+
+
+def _gnn_seed(self):
+    """Base seed of this forward's GNN dropout masks (one draw from torch's CPU generator)."""
+    if self.training and self.drop_ratio > 0:
+        return int(torch.empty((), dtype=torch.int64).random_().item())
+    return 0
+
+
+def layer_seed(base, layer):
+    return (base + _SEED_STEP * (2 * layer + 1)) & _SEED_MASK
+
+
+def vn_seed(base, layer):
+    return (base + _SEED_STEP * (2 * layer + 2)) & _SEED_MASK
+
+
+def _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr, base_seed=0):
     """One message-passing layer: [x = h + vn[batch]] -> conv -> BN (+ReLU except on the last layer)
     -> dropout -> [+ x].  Returns (x, h).  GCN layers in the covered configuration run as ONE
     composite op (layers.gcn_layer); everything else through the fine-grained ops."""
     conv, bn = self.convs[layer], self.batch_norms[layer]
     relu = layer != self.num_layer - 1
     h_in = h_list[layer]
+    p = self.drop_ratio if self.training else 0.0
+    seed = layer_seed(base_seed, layer)
     if isinstance(conv, GCNConv):
         spec = edge_spec(conv.edge_encoder, edge_attr, conv.emb_dim)
         if layers.gcn_layer_eligible(conv, bn, h_in, spec, self.drop_ratio, self.training):
-            return layers.gcn_layer(h_in, vn, gs, conv, bn, spec, relu, self.residual, self.training)
+            return layers.gcn_layer(h_in, vn, gs, conv, bn, spec, relu, self.residual, self.training, p, seed)
     x = ops.segment_bcast_add(h_in, vn, gs) if vn is not None else h_in  # + vn[batch]   (:199)
     h = conv(x, edge_index, edge_attr, graph=gs)
-    h = bn(h, relu=relu)
-    h = F.dropout(h, self.drop_ratio, training=self.training)
+    h = bn(h, relu=relu, dropout_p=p, seed=seed)  # F.dropout(h, drop_ratio) fused behind the BatchNorm (:88-90,209-212)
     if self.residual:
         h = h + x
     return x, h
@@ -101,8 +121,9 @@ class GNN_node(torch.nn.Module):
         edge_index, edge_attr = batched_data.edge_index, batched_data.edge_attr
         encoded = _encode_nodes(self.node_encoder, batched_data)
         h_list = [encoded + perturb if perturb is not None else encoded]
+        base = _gnn_seed(self)
         for layer in range(self.num_layer):
-            h_list.append(_conv_bn_layer(self, layer, h_list, None, gs, edge_index, edge_attr)[1])
+            h_list.append(_conv_bn_layer(self, layer, h_list, None, gs, edge_index, edge_attr, base)[1])
         return _jk(self.JK, h_list, self.num_layer)
 
 
@@ -134,16 +155,18 @@ class GNN_node_Virtualnode(torch.nn.Module):
         h_list = [encoded + perturb if perturb is not None else encoded]
         # one zero-initialised embedding row per graph (gnn_module.py:195), without the .item() sync
         vn = self.virtualnode_embedding.weight.expand(gs.B, -1)
+        base = _gnn_seed(self)
+        p = self.drop_ratio if self.training else 0.0
         for layer in range(self.num_layer):
-            h_list[layer], h = _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr)
+            h_list[layer], h = _conv_bn_layer(self, layer, h_list, vn, gs, edge_index, edge_attr, base)
             h_list.append(h)
             if layer < self.num_layer - 1:
                 seq = self.mlp_virtualnode_list[layer]
                 if layers.vn_update_eligible(seq, h_list[layer], self.drop_ratio, self.training):
-                    vn = layers.vn_update(h_list[layer], vn, gs, seq, self.residual, self.training)
+                    vn = layers.vn_update(h_list[layer], vn, gs, seq, self.residual, self.training, p, vn_seed(base, layer))
                 else:
                     t = ops.segment_sum(h_list[layer], gs, add=vn)  # global_add_pool + vn   (:219)
-                    t = F.dropout(mlp_bn_relu(seq, t), self.drop_ratio, training=self.training)
+                    t = mlp_bn_relu(seq, t, dropout_p=p, seed=vn_seed(base, layer))  # F.dropout fused (:222)
                     vn = vn + t if self.residual else t
         return _jk(self.JK, h_list, self.num_layer)
 

@@ -308,7 +308,7 @@ def attention(qkv, lay, nhead, dropout_p=0.0, seed=0, scale=None, dense_mask=Non
 # ------------------------------------------------------------------------------------------------
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, training, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, training, relu, dropout_p, seed):
         x = _dev(x, "x")
         rows, D = x.shape
         dev = x.device
@@ -320,15 +320,16 @@ class _BatchNorm(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.launch("gt_batchnorm_fwd", _dtype_code(x), _ptr(x), _ptr(w32), _ptr(b32), _ptr(running_mean),
                     _ptr(running_var), _ptr(nbt), float(momentum), float(eps), 1 if training else 0, 1 if relu else 0,
-                    None, rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws_bytes, _stream())
+                    None, rows, D, _ptr(y), _ptr(stats[0]), _ptr(stats[1]), float(dropout_p), int(seed), _ptr(ws), ws_bytes,
+                    _stream())
         ctx.save_for_backward(x, b32, w32, stats)
-        ctx.cfg = (training, relu, weight.dtype, bias.dtype)
+        ctx.cfg = (training, relu, weight.dtype, bias.dtype, float(dropout_p), int(seed))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, b32, w32, stats = ctx.saved_tensors
-        training, relu, wdt, bdt = ctx.cfg
+        training, relu, wdt, bdt, dropout_p, seed = ctx.cfg
         dy = _dev(dy.to(x.dtype), "grad")
         rows, D = x.shape
         dx = torch.empty_like(x)
@@ -338,13 +339,15 @@ class _BatchNorm(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(w32), _ptr(b32), _ptr(stats[0]),
                     _ptr(stats[1]), 1 if training else 0, 1 if relu else 0, rows, D, _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]),
-                    _ptr(ws), ws_bytes, _stream())
-        return dx, dwb[0].to(wdt), dwb[1].to(bdt), None, None, None, None, None, None, None
+                    dropout_p, seed, _ptr(ws), ws_bytes, _stream())
+        return dx, dwb[0].to(wdt), dwb[1].to(bdt), None, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu=False):
-    """BatchNorm1d over rows of (rows, dim) with optional fused ReLU (gt_batchnorm_fwd/bwd)."""
-    return _BatchNorm.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu)
+def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu=False,
+               dropout_p=0.0, seed=0):
+    """BatchNorm1d over rows of (rows, dim) with optional fused ReLU and (training) dropout (gt_batchnorm_fwd/bwd)."""
+    return _BatchNorm.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu,
+                            dropout_p if training else 0.0, seed)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -234,19 +234,22 @@ int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, 
  * batch mean / biased variance, running stats updated with `momentum` (unbiased variance) and
  * num_batches_tracked += 1; eval -> running stats.  weight/bias/stat buffers are fp32.
  * save_mean/save_rstd [dim] are written for backward.  Deterministic (fixed reduction order).
+ * dropout_p > 0 (training only) fuses the F.dropout that follows the layer BatchNorm in the GNN
+ * (gnn_module.py:88-90,209-212,222): y = drop(bn(x)[relu]) [+ resid]; the mask is a counter hash of
+ * (seed, row, column) replayed by the backward (pass the same dropout_p and seed).
  */
 size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim);
 int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
                      int relu, const void* resid /* optional: y = bn(x)[relu] + resid */, int64_t rows, int64_t dim,
-                     void* y, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                     gt_stream_t stream);
+                     void* y, float* save_mean, float* save_rstd, float dropout_p, uint64_t seed, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
 /* dx w.r.t. the BN input (the residual branch's gradient is dy itself).  The ReLU gate is recomputed
  * from x, the saved statistics, weight and bias: the forward output is not needed. */
 int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
                      const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
-                     int64_t dim, void* dx, float* dweight, float* dbias, void* workspace, size_t workspace_bytes,
-                     gt_stream_t stream);
+                     int64_t dim, void* dx, float* dweight, float* dbias, float dropout_p, uint64_t seed, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(resid + dropout(x)) over the last dim of [rows][dim] token rows (dim <= 1024).
@@ -369,6 +372,10 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
    * the forward records ev_x_ready once x_out is written; the backward waits for ev_dx_wait (dx_extra
    * complete) right before the dX GEMM.  NULL = no cross-stream dependency. */
   void *ev_x_ready, *ev_dx_wait;
+  /* F.dropout(h, drop_ratio) after the layer BatchNorm[+ReLU] (gnn_module.py:88-90,209-212), training only */
+  uint64_t seed;
+  float dropout_p;
+  int32_t pad2_;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
@@ -382,7 +389,7 @@ int gt_gcn_layer_bwd(const gt_gcn_layer* layer, const void* x, const void* dy, c
                      void* d_h_in, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
                      gt_stream_t stream);
 
-typedef struct gt_vn_update {  /* vn_out = ReLU(BN(W2 ReLU(BN(W1 (pool(x) + vn))))) [+ vn]; fp32 */
+typedef struct gt_vn_update {  /* vn_out = drop(ReLU(BN(W2 ReLU(BN(W1 (pool(x) + vn)))))) [+ vn]; fp32 */
   int64_t N, B, D;
   int32_t residual, training, compute, pad_;
   float bn_momentum, bn_eps;
@@ -390,6 +397,9 @@ typedef struct gt_vn_update {  /* vn_out = ReLU(BN(W2 ReLU(BN(W1 (pool(x) + vn))
   const float *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn2_w, *bn2_b; /* gradient order: these 8 */
   float *bn1_rm, *bn1_rv, *bn2_rm, *bn2_rv;
   int64_t *bn1_nbt, *bn2_nbt;
+  uint64_t seed;     /* F.dropout on the MLP output (gnn_module.py:222), training only */
+  float dropout_p;
+  int32_t pad2_;
 } gt_vn_update;
 size_t gt_vn_update_saved_bytes(const gt_vn_update* layer);
 size_t gt_vn_update_workspace_bytes(const gt_vn_update* layer);

@@ -35,7 +35,7 @@ def _run(model, batch, y, fused, seed):
 
 CASES = [dict(), dict(gnn_JK="last"), dict(gnn_virtual_node=False), dict(gnn_residual=True),
          dict(graph_pooling="last", transformer_norm_input=False), dict(max_seq_len=None), dict(gnn_virtual_node=False, gnn_JK="last"),
-         dict(compute_dtype=torch.bfloat16)]
+         dict(compute_dtype=torch.bfloat16), dict(gnn_dropout=0.25), dict(gnn_dropout=0.25, gnn_residual=True, gnn_JK="last")]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in CASES])
@@ -104,7 +104,7 @@ def test_not_eligible_configurations_fall_back():
     from graphtrans_amd.encoders import ASTNodeEncoder
     from graphtrans_amd.models.gnn_transformer import GNNTransformer
     b = synth.code2_like(B=4, seed=2).to(DEV)
-    for kw in (dict(gnn_type="gin"), dict(gnn_dropout=0.5), dict(graph_pooling="mean"), dict(pos_encoder=True)):
+    for kw in (dict(gnn_type="gin"), dict(graph_pooling="mean"), dict(pos_encoder=True)):
         model = GNNTransformer(50, ASTNodeEncoder(64, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
         assert not engine.eligible(model, b, None), kw
         out = model(b)  # module path still runs

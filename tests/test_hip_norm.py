@@ -114,3 +114,48 @@ def test_layernorm_dropout_replay():
     y2 = ops.layer_norm(xd.detach(), g, b, 1e-5, resid=rd.detach(), dropout_p=p, seed=seed)
     y3 = ops.layer_norm(xd.detach(), g, b, 1e-5, resid=rd.detach(), dropout_p=p, seed=seed + 1)
     assert torch.equal(y2, y.detach()) and not torch.equal(y3, y.detach())
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("rows,D", [(1000, 300), (257, 64)])
+def test_batchnorm_fused_dropout(rows, D, relu):
+    """F.dropout behind the layer BatchNorm (gnn_module.py:88-90,209-212) fused into gt_batchnorm_*: the
+    kept set is replayed by the backward; values are bn(x)[relu] / (1 - p) or 0."""
+    from graphtrans_amd import ops
+    torch.manual_seed(3)
+    p = 0.3
+    x = torch.randn(rows, D, device=DEV).requires_grad_(True)
+    w = (torch.rand(D, device=DEV) + 0.5).requires_grad_(True)
+    b = torch.randn(D, device=DEV).mul_(0.2).requires_grad_(True)
+    rm, rv, nbt = torch.zeros(D, device=DEV), torch.ones(D, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    y = ops.batch_norm(x, w, b, rm, rv, nbt, 0.1, 1e-5, True, relu, dropout_p=p, seed=1234567)
+    y0 = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm.clone(), rv.clone(), nbt.clone(), 0.1, 1e-5, True, relu)
+    live = y0 != 0
+    kept = (y != 0) & live
+    rate = 1.0 - kept.sum().item() / live.sum().item()
+    assert abs(rate - p) < 0.01, rate
+    assert torch.allclose(y[kept], y0[kept] / (1 - p), rtol=1e-6, atol=1e-7)
+    assert (y[~kept] == 0).all()
+    # same seed -> same mask; another seed -> another mask
+    y_again = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm.clone(), rv.clone(), nbt.clone(), 0.1, 1e-5, True, relu,
+                             dropout_p=p, seed=1234567)
+    assert torch.equal(y_again, y.detach())
+    y_other = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm.clone(), rv.clone(), nbt.clone(), 0.1, 1e-5, True, relu,
+                             dropout_p=p, seed=7654321)
+    assert not torch.equal(y_other, y.detach())
+    # backward: autograd of the same function with the recovered mask, in float64
+    g = torch.randn(rows, D, device=DEV)
+    y.backward(g)
+    xr, wr, br = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    mu, var = xr.mean(0), xr.var(0, unbiased=False)
+    yr = (xr - mu) / torch.sqrt(var + 1e-5) * wr + br
+    if relu:
+        yr = torch.relu(yr)
+    (yr * kept.double() / (1 - p) * g.double()).sum().backward()
+    assert_close(x.grad.double().cpu(), xr.grad.cpu(), atol=1e-4, rtol=1e-4, what="dx")
+    assert_close(w.grad.double().cpu(), wr.grad.cpu(), atol=1e-4, rtol=1e-4, what="dw")
+    assert_close(b.grad.double().cpu(), br.grad.cpu(), atol=1e-4, rtol=1e-4, what="db")
+    # eval mode: dropout is off
+    ye = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm, rv, None, 0.1, 1e-5, False, relu, dropout_p=p, seed=1)
+    ye0 = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm, rv, None, 0.1, 1e-5, False, relu)
+    assert torch.equal(ye, ye0)
