@@ -86,6 +86,12 @@ SIGNATURES = {
     "gt_event_destroy": (None, [_p]),
     "gt_event_record": (_i, [_p, _p]),
     "gt_stream_wait_event": (_i, [_p, _p]),
+    "gt_gin_layer_saved_bytes": (_sz, [_p]),
+    "gt_gin_layer_workspace_bytes": (_sz, [_p]),
+    "gt_gin_layer_grad_elems": (_i64, [_p]),
+    "gt_gin_layer_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_gin_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_add3": (_i, [_p, _p, _p, _i64, _p, _p]),
     "gt_copy2d": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "gt_rows_gather": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
     "gt_rows_scatter": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),

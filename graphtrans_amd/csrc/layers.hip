@@ -297,6 +297,79 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   return GT_OK;
 }
 
+// ---------------------------------------------------------------- GIN layer
+struct GinSaved {
+  void *agg, *z1, *a1, *z2;
+  float *st1, *st;
+  size_t bytes;
+};
+GinSaved gin_saved(const gt_gin_layer* L, void* p) {
+  Bump b(p);
+  GinSaved s;
+  s.agg = b.take((size_t)L->N * L->D * 4);
+  s.z1 = b.take((size_t)L->N * 2 * L->D * 4);
+  s.a1 = b.take((size_t)L->N * 2 * L->D * 4);
+  s.z2 = b.take((size_t)L->N * L->D * 4);
+  s.st1 = (float*)b.take((size_t)2 * 2 * L->D * 4);
+  s.st = (float*)b.take((size_t)2 * L->D * 4);
+  s.bytes = b.off;
+  return s;
+}
+int64_t gin_edge_w_elems(const gt_gin_layer* L) {
+  if (L->edge_mode == GT_EDGE_LINEAR) return L->D * L->edge_cols;
+  if (L->edge_mode == GT_EDGE_TABLES) return L->table_rows * L->D;
+  return 0;
+}
+constexpr int64_t GIN_EPS_SLOT = 20;  // d_eps + the aggregate backward's column-tile scratch (1 + ceil(1024/64))
+struct GinGrads {
+  float *eps, *edge_w, *edge_b, *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn_w, *bn_b;
+};
+GinGrads gin_grads(const gt_gin_layer* L, float* g) {
+  const int64_t D = L->D;
+  GinGrads r;
+  r.eps = g; g += GIN_EPS_SLOT;
+  r.edge_w = g; g += gin_edge_w_elems(L);
+  r.edge_b = g; g += (L->edge_mode == GT_EDGE_LINEAR ? D : 0);
+  r.w1 = g; g += 2 * D * D;
+  r.b1 = g; g += 2 * D;
+  r.bn1_w = g; g += 2 * D;
+  r.bn1_b = g; g += 2 * D;
+  r.w2 = g; g += 2 * D * D;
+  r.b2 = g; g += D;
+  r.bn_w = g; g += D;
+  r.bn_b = g; g += D;
+  return r;
+}
+struct GinWork {
+  void *d_z2, *d_a1, *d_z1, *d_agg, *d_x, *bn_ws, *agg_ws, *lin_ws;
+  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, bytes;
+};
+GinWork gin_work(const gt_gin_layer* L, void* p) {
+  Bump b(p);
+  GinWork w;
+  const int64_t N = L->N, D = L->D;
+  w.d_z2 = b.take((size_t)N * D * 4);
+  w.d_a1 = b.take((size_t)N * 2 * D * 4);
+  w.d_z1 = b.take((size_t)N * 2 * D * 4);
+  w.d_agg = b.take((size_t)N * D * 4);
+  w.d_x = b.take((size_t)N * D * 4);
+  w.bn_ws_bytes = gt_batchnorm_workspace_bytes(N, 2 * D);
+  w.bn_ws = b.take(w.bn_ws_bytes);
+  w.agg_ws_bytes = gt_aggregate_bwd_workspace_bytes(GT_CONV_GIN, L->edge_mode, D, L->edge_cols, L->table_rows);
+  w.agg_ws = b.take(w.agg_ws_bytes);
+  size_t a = gt_linear_bwd_workspace_bytes(L->compute, N, 2 * D, D), c = gt_linear_bwd_workspace_bytes(L->compute, N, D, 2 * D);
+  w.lin_ws_bytes = a > c ? a : c;
+  w.lin_ws = b.take(w.lin_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+int gin_check(const char* fn, const gt_gin_layer* L) {
+  if (!L) { gt_set_error("%s: null descriptor", fn); return GT_ERR_INVALID_ARG; }
+  if (L->N < 0 || L->D <= 0 || L->D % 4 || L->D > 1024) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
+  if (L->edge_mode == GT_EDGE_DENSE) { gt_set_error("%s: dense edge embeddings use the un-fused ops", fn); return GT_ERR_UNSUPPORTED; }
+  return GT_OK;
+}
+
 // =================================================================================================
 extern "C" size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* L) { return L ? gcn_saved(L, nullptr).bytes : 0; }
 extern "C" size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* L) { return L ? gcn_work(L, nullptr).bytes : 0; }
@@ -405,5 +478,81 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
     GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
   else
     (void)hipMemcpyAsync(d_vn, w.d_t0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
+  return GT_OK;
+}
+
+// =================================================================================================
+extern "C" size_t gt_gin_layer_saved_bytes(const gt_gin_layer* L) { return L ? gin_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_gin_layer_workspace_bytes(const gt_gin_layer* L) { return L ? gin_work(L, nullptr).bytes : 0; }
+extern "C" int64_t gt_gin_layer_grad_elems(const gt_gin_layer* L) {
+  if (!L) return 0;
+  const int64_t D = L->D;
+  return GIN_EPS_SLOT + gin_edge_w_elems(L) + (L->edge_mode == GT_EDGE_LINEAR ? D : 0) + 4 * D * D + 9 * D;
+}
+
+extern "C" int gt_gin_layer_fwd(const gt_gin_layer* L, const void* h_in, const void* vn, void* x_out, void* y, void* saved,
+                                void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(gin_check("gt_gin_layer_fwd", L));
+  GT_CHECK_ARG(h_in && y && saved && workspace, "null buffer");
+  GT_CHECK_ARG(!L->has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
+  const GinWork w = gin_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_gin_layer_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const GinSaved s = gin_saved(L, saved);
+  const int64_t N = L->N, D = L->D;
+  const void* x = h_in;
+  if (L->has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
+    GT_TRY(gt_segment_bcast_add(GT_F32, h_in, vn, L->node_graph, N, L->B, D, x_out, st));
+    x = x_out;
+    if (L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));
+  }
+  // GINConv: mlp((1 + eps) x + sum_k relu(x_j + e_k))   (conv.py:26-36)
+  GT_TRY(gt_aggregate_fwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, N, L->E, D, L->in_ptr, L->in_src, L->in_eid, nullptr, nullptr,
+                          L->eps, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, nullptr, s.agg, st));
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.agg, L->w1, L->b1, s.z1, N, 2 * D, D, 0, 0.f, 0, st));
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
+                          L->bn_momentum, L->bn_eps, L->training, 1, nullptr, N, 2 * D, s.a1, s.st1, s.st1 + 2 * D, 0.f, 0,
+                          w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, L->b2, s.z2, N, D, 2 * D, 0, 0.f, 0, st));
+  // h = drop(batch_norm(h) [relu]) [+ h_list[layer]]   (gnn_module.py:204-212)
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z2, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr, L->bn_momentum,
+                          L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, N, D, y, s.st, s.st + D, L->dropout_p,
+                          L->seed, w.bn_ws, w.bn_ws_bytes, st));
+  return GT_OK;
+}
+
+extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void* dy, const void* dx_extra,
+                                const void* saved, void* d_h_in, void* d_vn, float* grads, void* workspace,
+                                size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(gin_check("gt_gin_layer_bwd", L));
+  GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
+  GT_CHECK_ARG(!L->has_vn || d_vn, "virtual-node layer needs d_vn");
+  const GinWork w = gin_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_gin_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const GinSaved s = gin_saved(L, const_cast<void*>(saved));
+  const GinGrads g = gin_grads(L, grads);
+  const int64_t N = L->N, D = L->D;
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, dy, L->bn_w, L->bn_b, s.st, s.st + D, L->training, L->relu, N, D, w.d_z2, g.bn_w, g.bn_b,
+                          L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, N, D,
+                       2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, N, 2 * D, w.d_z1,
+                          g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.agg, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_agg, g.w1, g.b1, N,
+                       2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  const bool adds = dx_extra || L->residual;
+  void* dx_conv = adds ? w.d_x : d_h_in;
+  GT_TRY(gt_aggregate_bwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, w.d_agg, N, L->E, D, L->out_ptr, L->out_dst, L->out_eid, nullptr,
+                          nullptr, L->eps, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr,
+                          dx_conv, g.eps, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
+  // d_x = conv gradient (+ grads reaching x from its other consumers) (+ dy through the residual branch)
+  if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
+  if (adds) {
+    const float* e1 = dx_extra ? (const float*)dx_extra : (const float*)dy;
+    const float* e2 = (dx_extra && L->residual) ? (const float*)dy : nullptr;
+    GT_TRY(gt_add3((const float*)w.d_x, e1, e2, N * D, (float*)d_h_in, st));
+  }
+  if (L->has_vn) GT_TRY(gt_segment_sum(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, st));
   return GT_OK;
 }

@@ -40,6 +40,16 @@ __global__ void __launch_bounds__(UT) k_rows_scatter(const float* __restrict__ g
   }
 }
 
+// out = a + b (+ c), fp32, n4 float4 chunks
+__global__ void __launch_bounds__(UT) k_add3(const float* __restrict__ a, const float* __restrict__ b,
+                                             const float* __restrict__ c, int64_t n4, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * UT) {
+    float4 v = gt_add4(*reinterpret_cast<const float4*>(a + i * 4), *reinterpret_cast<const float4*>(b + i * 4));
+    if (c) v = gt_add4(v, *reinterpret_cast<const float4*>(c + i * 4));
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+  }
+}
+
 int grid_for(int64_t items) {
   int64_t g = gt_cdiv(items, UT);
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -90,6 +100,15 @@ extern "C" int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx,
   else
     hipLaunchKernelGGL(k_rows_scatter<gt_bf16>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, stream, grad, idx, n, dim,
                        (gt_bf16*)out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_add3(const float* a, const float* b, const float* c, int64_t n, float* out, gt_stream_t stream_) {
+  GT_CHECK_ARG(n >= 0 && n % 4 == 0, "element count must be a multiple of 4");
+  if (n == 0) return GT_OK;
+  GT_CHECK_ARG(a && b && out, "null buffer");
+  hipLaunchKernelGGL(k_add3, dim3(grid_for(n / 4)), dim3(UT), 0, (hipStream_t)stream_, a, b, c, n / 4, out);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -7,7 +7,8 @@ to back on buffers carved out of one arena, parameter gradients are written stra
 buffer whose slices become `p.grad`, and autograd sees a single node.
 
 Covered configuration (everything else keeps using the module path, see `eligible`):
-  GNN_node / GNN_node_Virtualnode with GCNConv layers, Linear(<=4, D) or "zero" edge encoders,
+  GNN_node / GNN_node_Virtualnode with GCNConv or GINConv layers, Linear(<=4, D), BondEncoder-style
+  embedding tables or "zero" edge encoders,
   any gnn_dropout, JK in {last, cat}, ASTNodeEncoder / AtomEncoder inputs, no perturb;
   packed token layout (cls / last pooling, no positional encoder, no masked layers), ReLU post-norm
   encoder layers; stacked max_seq_len heads or a single head.
@@ -20,7 +21,7 @@ import os
 import torch
 
 from . import _lib, layers
-from ._lib import GT_BF16, GT_EDGE_LINEAR, GT_EDGE_NONE, GT_F32
+from ._lib import GT_BF16, GT_EDGE_LINEAR, GT_EDGE_NONE, GT_EDGE_TABLES, GT_F32
 from .graph import _stream
 
 
@@ -78,17 +79,45 @@ class _Plan:
         self.embed_off = [seg(t) for t in self.embed]
         self.vn_emb = gnn.virtualnode_embedding.weight if self.has_vn else None
         self.vn_emb_off = seg(self.vn_emb) if self.has_vn else None
-        # GCN layers: gradient block order of gt_gcn_layer_bwd = lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b
-        self.gcn, self.gcn_off, self.gcn_edge = [], [], []
+        # conv layers.  Gradient block order of gt_gcn_layer_bwd: lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b;
+        # of gt_gin_layer_bwd: eps (20-float slot), edge tables | edge_w, edge_b, w1, b1, bn1_w, bn1_b, w2, b2, bn_w, bn_b
+        from .modules.conv import GINConv
+        self.kind = "gin" if isinstance(gnn.convs[0], GINConv) else "gcn"
+        self.gcn, self.gcn_off, self.gcn_edge = [], [], []   # gcn_edge: "linear" | "tables" | None
+        self.tables, self.tab_off, self.table_rows = [], [], []
         for conv, bn in zip(gnn.convs, gnn.batch_norms):
             ee = conv.edge_encoder
-            edge = [ee.weight, ee.bias] if isinstance(ee, torch.nn.Module) else []
-            self.gcn_edge.append(len(edge) > 0)
+            tabs = getattr(ee, "bond_embedding_list", None)
+            if tabs is not None:
+                edge, mode = [t.weight for t in tabs], "tables"
+                offs, acc = [], 0
+                for t in tabs:
+                    offs.append(acc)
+                    acc += int(t.weight.shape[0])
+                self.tab_off.append(offs)
+                self.table_rows.append(acc)
+            elif isinstance(ee, torch.nn.Module):
+                edge, mode = [ee.weight, ee.bias], "linear"
+                self.tab_off.append([])
+                self.table_rows.append(0)
+            else:
+                edge, mode = [], None
+                self.tab_off.append([])
+                self.table_rows.append(0)
+            self.tables.append(edge if mode == "tables" else [])
+            self.gcn_edge.append(mode)
             self.gcn.append((conv, bn))
+            if self.kind == "gcn":
+                plist = [conv.linear.weight, conv.linear.bias, conv.root_emb.weight, *edge, bn.weight, bn.bias]
+            else:
+                m = list(conv.mlp)
+                plist = [conv.eps, *edge, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, bn.weight, bn.bias]
             off = None
-            for p in [conv.linear.weight, conv.linear.bias, conv.root_emb.weight, *edge, bn.weight, bn.bias]:
+            for p in plist:
                 o = seg(p)
                 off = o if off is None else off
+                if self.kind == "gin" and p is conv.eps:
+                    self.total = o + 20   # d_eps + the aggregate backward's scratch (GIN_EPS_SLOT in layers.hip)
             self.gcn_off.append(off)
         self.vn, self.vn_off = [], []
         if self.has_vn:
@@ -140,7 +169,8 @@ class _Plan:
         self.plist = [p for p, _ in self.params]
         self.param_ptrs = tuple(p.data_ptr() for p in self.plist)
         # persistent descriptors (batch-dependent fields are refreshed every step)
-        self.gcn_desc = [layers.GcnLayerDesc() for _ in self.gcn]
+        self.gcn_desc = [(layers.GinLayerDesc() if self.kind == "gin" else layers.GcnLayerDesc()) for _ in self.gcn]
+        self.conv_api = "gt_gin_layer" if self.kind == "gin" else "gt_gcn_layer"
         self.vn_desc = [layers.VnUpdateDesc() for _ in self.vn]
         self.enc_desc = [layers.EncoderLayerDesc() for _ in self.enc_layers]
         self._fill_static()
@@ -166,13 +196,25 @@ class _Plan:
 
     def _fill_static(self):
         D = self.D
-        for (conv, bn), desc, has_edge in zip(self.gcn, self.gcn_desc, self.gcn_edge):
+        for l, ((conv, bn), desc, mode) in enumerate(zip(self.gcn, self.gcn_desc, self.gcn_edge)):
             desc.D = D
-            desc.lin_w, desc.lin_b, desc.root = conv.linear.weight.data_ptr(), conv.linear.bias.data_ptr(), conv.root_emb.weight.data_ptr()
-            if has_edge:
+            if self.kind == "gcn":
+                desc.lin_w, desc.lin_b, desc.root = conv.linear.weight.data_ptr(), conv.linear.bias.data_ptr(), conv.root_emb.weight.data_ptr()
+            else:
+                m = list(conv.mlp)
+                desc.eps = conv.eps.data_ptr()
+                desc.w1, desc.b1, desc.bn1_w, desc.bn1_b = m[0].weight.data_ptr(), m[0].bias.data_ptr(), m[1].weight.data_ptr(), m[1].bias.data_ptr()
+                desc.w2, desc.b2 = m[3].weight.data_ptr(), m[3].bias.data_ptr()
+                desc.bn1_rm, desc.bn1_rv, desc.bn1_nbt = m[1].running_mean.data_ptr(), m[1].running_var.data_ptr(), m[1].num_batches_tracked.data_ptr()
+            if mode == "linear":
                 desc.edge_mode = GT_EDGE_LINEAR
                 desc.edge_cols = conv.edge_encoder.weight.shape[1]
                 desc.edge_w, desc.edge_b = conv.edge_encoder.weight.data_ptr(), conv.edge_encoder.bias.data_ptr()
+            elif mode == "tables":
+                desc.edge_mode = GT_EDGE_TABLES
+                desc.edge_cols, desc.table_rows = len(self.tables[l]), self.table_rows[l]
+                for i, o in enumerate(self.tab_off[l]):
+                    desc.tab_off[i] = o
             else:
                 desc.edge_mode = GT_EDGE_NONE
             desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -242,13 +284,28 @@ def _eligible_static(model):
         D = gnn.convs[0].emb_dim
         if D % 4:
             return False
+        from .modules.conv import GINConv, _LDS_TABLE_BUDGET
+        kinds = {type(conv) for conv in gnn.convs}
+        if len(kinds) != 1 or not (kinds <= {GCNConv, GINConv}):
+            return False
         for conv, bn in zip(gnn.convs, gnn.batch_norms):
-            if not isinstance(conv, GCNConv) or not isinstance(bn, BatchNorm1d):
+            if not isinstance(bn, BatchNorm1d):
                 return False
             if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
                 return False
+            if isinstance(conv, GINConv):
+                m = list(conv.mlp)
+                if not (len(m) == 4 and isinstance(m[0], torch.nn.Linear) and isinstance(m[1], BatchNorm1d)
+                        and isinstance(m[3], torch.nn.Linear) and m[1].affine and m[1].track_running_stats
+                        and m[1].momentum is not None):
+                    return False
             ee = conv.edge_encoder
-            if isinstance(ee, torch.nn.Module):
+            tabs = getattr(ee, "bond_embedding_list", None)
+            if tabs is not None:
+                rows = sum(int(t.weight.shape[0]) for t in tabs)
+                if len(tabs) > 4 or (rows + 1) * D * 4 * 4 > _LDS_TABLE_BUDGET:
+                    return False
+            elif isinstance(ee, torch.nn.Module):
                 if not (isinstance(ee, torch.nn.Linear) and ee.in_features <= 4 and ee.bias is not None):
                     return False
             else:
@@ -309,8 +366,12 @@ class _FusedModel(torch.autograd.Function):
         # ---- refresh the batch-dependent descriptor fields
         ea = batched_data.edge_attr
         ea_f = None
-        if any(plan.gcn_edge):
+        if "linear" in plan.gcn_edge:
             ea_f = ea if (ea.dtype == torch.float32 and ea.is_contiguous()) else ea.float().contiguous()
+        elif "tables" in plan.gcn_edge:
+            if ea.dtype != torch.int64:
+                raise TypeError("embedding-table edge encoders need int64 edge_attr")
+            ea_f = ea.contiguous()
         for l, desc in enumerate(plan.gcn_desc):
             desc.N, desc.E, desc.B = N, E, B
             desc.has_vn = 1 if plan.has_vn else 0
@@ -319,7 +380,7 @@ class _FusedModel(torch.autograd.Function):
             desc.training, desc.compute = training, compute
             desc.dropout_p, desc.seed = gnn_p, layer_seed(gnn_base, l)
             layers._fill_graph(desc, gs)
-            if plan.gcn_edge[l]:
+            if plan.gcn_edge[l] and E > 0:
                 desc.edge_attr = ea_f.data_ptr()
             ov = plan.side is not None and l < L - 1
             desc.ev_x_ready = plan.ev_x[l] if ov else None
@@ -350,7 +411,7 @@ class _FusedModel(torch.autograd.Function):
             o["vn"] = [b.take(B * D * 4) for _ in range(L)]
             vn_saved_bytes = [lib.gt_vn_update_saved_bytes(C.byref(dsc)) for dsc in plan.vn_desc]
             o["vn_saved"] = [b.take(n) for n in vn_saved_bytes]
-        gcn_saved_bytes = [lib.gt_gcn_layer_saved_bytes(C.byref(dsc)) for dsc in plan.gcn_desc]
+        gcn_saved_bytes = [getattr(lib, plan.conv_api + "_saved_bytes")(C.byref(dsc)) for dsc in plan.gcn_desc]
         o["gcn_saved"] = [b.take(n) for n in gcn_saved_bytes]
         Kc = 2 * D if plan.jk_cat else D
         if plan.jk_cat:
@@ -366,10 +427,12 @@ class _FusedModel(torch.autograd.Function):
         if plan.norm_out is not None:
             o["xo"] = b.take(rows * d * tsz)
             o["sto"] = b.take(2 * rows * 4)
+        tab_rows_total = sum(plan.table_rows)
+        o["etab"] = b.take(tab_rows_total * D * 4)
         o["hg"] = b.take(B * d * 4)
         o["wcat"] = b.take(plan.Nh * d * 4)
         o["bcat"] = b.take(plan.Nh * 4)
-        ws_bytes = max([lib.gt_gcn_layer_workspace_bytes(C.byref(dsc)) for dsc in plan.gcn_desc]
+        ws_bytes = max([getattr(lib, plan.conv_api + "_workspace_bytes")(C.byref(dsc)) for dsc in plan.gcn_desc]
                        + [lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
         o["ws"] = b.take(ws_bytes)
         ws2_bytes = max([lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
@@ -381,6 +444,14 @@ class _FusedModel(torch.autograd.Function):
         def P(key, i=None):
             return base + (o[key] if i is None else o[key][i])
 
+        if tab_rows_total:   # every layer's bond tables stacked by one copy: layer l reads its [rows_l][D] slice
+            tv = arena[o["etab"]:o["etab"] + tab_rows_total * D * 4].view(torch.float32).view(tab_rows_total, D)
+            torch.cat([t.detach() for tl in plan.tables for t in tl], out=tv)
+            roff = 0
+            for l, dsc in enumerate(plan.gcn_desc):
+                if plan.gcn_edge[l] == "tables":
+                    dsc.edge_w = P("etab") + roff * D * 4
+                    roff += plan.table_rows[l]
         # ---- input encoder: h0 = sum of embedding rows   (dataset/utils.py:28-30 / ogb AtomEncoder)
         x = batched_data.x
         T = len(plan.embed)
@@ -403,7 +474,7 @@ class _FusedModel(torch.autograd.Function):
             if plan.has_vn:
                 if l > 0 and side is not None:   # vn_l comes from the side stream
                     _call("gt_stream_wait_event", st, plan.ev_vn[l - 1])
-                _call("gt_gcn_layer_fwd", C.byref(dsc), P("h", l), P("vn", l), P("x", l), P("h", l + 1), P("gcn_saved", l),
+                _call(plan.conv_api + "_fwd", C.byref(dsc), P("h", l), P("vn", l), P("x", l), P("h", l + 1), P("gcn_saved", l),
                       P("ws"), ws_bytes, st)
                 if l < L - 1 and side is not None:
                     _call("gt_stream_wait_event", side, plan.ev_x[l])
@@ -414,7 +485,7 @@ class _FusedModel(torch.autograd.Function):
                     _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
                           P("ws"), ws_bytes, st)
             else:
-                _call("gt_gcn_layer_fwd", C.byref(dsc), P("h", l), None, None, P("h", l + 1), P("gcn_saved", l), P("ws"),
+                _call(plan.conv_api + "_fwd", C.byref(dsc), P("h", l), None, None, P("h", l + 1), P("gcn_saved", l), P("ws"),
                       ws_bytes, st)
         first = P("x", 0) if plan.has_vn else P("h", 0)   # h_list[0] after the in-place virtual-node add
         if plan.jk_cat:   # torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
@@ -605,7 +676,7 @@ class _FusedModel(torch.autograd.Function):
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = P("x", l) if plan.has_vn else P("h", l)
             dw_sync()
-            _call("gt_gcn_layer_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
+            _call(plan.conv_api + "_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
                   Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
             if plan.has_vn:   # d vn_l = (layer l's broadcast add) + (update l's pooled + residual inputs)
                 tgt = Q("dvn", l % 2)

@@ -36,6 +36,19 @@ class GcnLayerDesc(C.Structure):
                [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
 
 
+class GinLayerDesc(C.Structure):
+    _fields_ = [("N", C.c_int64), ("E", C.c_int64), ("B", C.c_int64), ("D", C.c_int64),
+                ("edge_mode", C.c_int32), ("has_vn", C.c_int32), ("relu", C.c_int32), ("residual", C.c_int32),
+                ("training", C.c_int32), ("compute", C.c_int32),
+                ("edge_cols", C.c_int64), ("table_rows", C.c_int64), ("tab_off", C.c_int32 * 4),
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
+               [(n, _fp) for n in ("graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid",
+                                   "edge_attr", "eps", "edge_w", "edge_b", "w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn_w",
+                                   "bn_b", "bn1_rm", "bn1_rv", "bn_rm", "bn_rv", "bn1_nbt", "bn_nbt", "ev_x_ready",
+                                   "ev_dx_wait")] + \
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
+
+
 class VnUpdateDesc(C.Structure):
     _fields_ = [("N", C.c_int64), ("B", C.c_int64), ("D", C.c_int64),
                 ("residual", C.c_int32), ("training", C.c_int32), ("compute", C.c_int32), ("pad_", C.c_int32),

@@ -389,6 +389,33 @@ int gt_gcn_layer_bwd(const gt_gcn_layer* layer, const void* x, const void* dy, c
                      void* d_h_in, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
                      gt_stream_t stream);
 
+typedef struct gt_gin_layer {  /* x = h_in [+ vn[batch]]; y = drop(BN(GINConv(x)) [relu]) [+ x]; fp32 rows.
+                                * GINConv(x) = W2 ReLU(BN1(W1 ((1 + eps) x + sum_k relu(x_j + e_k))))  (conv.py:18-36) */
+  int64_t N, E, B, D;
+  int32_t edge_mode /* NONE | LINEAR | TABLES */, has_vn, relu, residual, training, compute;
+  int64_t edge_cols, table_rows;
+  int32_t tab_off[4];
+  float bn_momentum, bn_eps;
+  const int32_t *graph_ptr, *node_graph, *in_ptr, *in_src, *in_eid, *out_ptr, *out_dst, *out_eid;
+  const void* edge_attr;
+  /* gradient order: eps [20 floats: d_eps + scratch], edge_w, edge_b (LINEAR only), w1, b1, bn1_w, bn1_b, w2, b2, bn_w, bn_b */
+  const float *eps, *edge_w, *edge_b, *w1, *b1, *bn1_w, *bn1_b, *w2, *b2, *bn_w, *bn_b;
+  float *bn1_rm, *bn1_rv, *bn_rm, *bn_rv;
+  int64_t *bn1_nbt, *bn_nbt;
+  void *ev_x_ready, *ev_dx_wait; /* as in gt_gcn_layer (the backward waits right before its last add) */
+  uint64_t seed;
+  float dropout_p;
+  int32_t pad2_;
+} gt_gin_layer;
+size_t gt_gin_layer_saved_bytes(const gt_gin_layer* layer);
+size_t gt_gin_layer_workspace_bytes(const gt_gin_layer* layer);
+int64_t gt_gin_layer_grad_elems(const gt_gin_layer* layer);
+int gt_gin_layer_fwd(const gt_gin_layer* layer, const void* h_in, const void* vn, void* x_out, void* y, void* saved,
+                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
+int gt_gin_layer_bwd(const gt_gin_layer* layer, const void* x, const void* dy, const void* dx_extra, const void* saved,
+                     void* d_h_in, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
+                     gt_stream_t stream);
+
 typedef struct gt_vn_update {  /* vn_out = drop(ReLU(BN(W2 ReLU(BN(W1 (pool(x) + vn)))))) [+ vn]; fp32 */
   int64_t N, B, D;
   int32_t residual, training, compute, pad_;
@@ -421,6 +448,7 @@ int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void
  */
 int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes, int64_t width_bytes,
               int64_t rows, gt_stream_t stream);
+int gt_add3(const float* a, const float* b, const float* c /* or NULL */, int64_t n, float* out, gt_stream_t stream);
 int gt_rows_gather(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, float* out, gt_stream_t stream);
 int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim,
                     void* out, gt_stream_t stream);

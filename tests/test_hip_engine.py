@@ -104,7 +104,7 @@ def test_not_eligible_configurations_fall_back():
     from graphtrans_amd.encoders import ASTNodeEncoder
     from graphtrans_amd.models.gnn_transformer import GNNTransformer
     b = synth.code2_like(B=4, seed=2).to(DEV)
-    for kw in (dict(gnn_type="gin"), dict(graph_pooling="mean"), dict(pos_encoder=True)):
+    for kw in (dict(graph_pooling="mean"), dict(pos_encoder=True), dict(transformer_activation="gelu")):
         model = GNNTransformer(50, ASTNodeEncoder(64, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
         assert not engine.eligible(model, b, None), kw
         out = model(b)  # module path still runs
@@ -173,3 +173,65 @@ def test_fused_model_edge_cases(case):
     for n in g0:
         scale = max(1.0, float(g0[n].abs().max()))
         assert torch.allclose(g0[n] / scale, g1[n] / scale, rtol=1e-4, atol=1e-6), n
+
+
+GIN_CASES = [dict(feat="mol"), dict(feat="mol", gnn_dropout=0.3, gnn_JK="last"), dict(feat="mol", gnn_virtual_node=False, gnn_residual=True),
+             dict(feat="ast"), dict(feat="ast", gnn_residual=True, gnn_dropout=0.2), dict(feat="mol", compute_dtype=torch.bfloat16)]
+
+
+@pytest.mark.parametrize("kw", GIN_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in GIN_CASES])
+def test_fused_gin_model_matches_module_path(kw):
+    """GIN convs (conv.py:18-36) through gt_gin_layer_*: Molpcba-style inputs (AtomEncoder nodes, BondEncoder
+    edge tables, single 128-way head, dataset/mol.py:24-31 loss) and Code2-style inputs (Linear edge encoder)."""
+    from graphtrans_amd import engine, losses, ops, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder, AtomEncoder, BondEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    kw = dict(kw)
+    feat = kw.pop("feat")
+    args = _args(gnn_type="gin", **kw)
+    bf16 = args.compute_dtype == torch.bfloat16
+    ops.set_matmul_dtype(torch.bfloat16 if bf16 else torch.float32)
+    try:
+        torch.manual_seed(0)
+        if feat == "mol":
+            args.max_seq_len = None
+            model = GNNTransformer(16, AtomEncoder(64), lambda d: BondEncoder(d), args).to(DEV)
+            b = synth.molpcba_like(B=24, seed=4).to(DEV)
+            y = (torch.rand(24, 16, device=DEV) > 0.5).float()
+            y[torch.rand(24, 16, device=DEV) < 0.2] = float("nan")
+            loss_fn = lambda out: losses.mol_loss(out, y)
+        else:
+            model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV)
+            b = synth.code2_like(B=12, seed=5, num_nodeattributes=300).to(DEV)
+            yy = torch.randint(0, 50, (12, 5), device=DEV)
+            loss_fn = lambda out: losses.code2_loss(out, yy)
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+            if args.gnn_virtual_node:
+                model.gnn_node.virtualnode_embedding.weight.normal_(0, 0.3)
+        model.train()
+        assert engine.eligible(model, b, None)
+
+        def run(m, fused):
+            m.fused = fused
+            for p in m.parameters():
+                p.grad = None
+            torch.manual_seed(9)
+            loss = loss_fn(m(b))
+            loss.backward()
+            return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, \
+                {n: t.detach().clone() for n, t in m.named_buffers()}
+
+        l0, g0, b0 = run(copy.deepcopy(model), False)
+        l1, g1, b1 = run(model, True)
+        tol = dict(rtol=2e-2, atol=2e-3) if bf16 else dict(rtol=1e-4, atol=1e-6)
+        assert torch.allclose(l0, l1, **tol), (l0, l1)
+        for n in g0:
+            scale = max(1.0, float(g0[n].abs().max()))
+            assert torch.allclose(g0[n] / scale, g1[n] / scale, **tol), (n, (g0[n] - g1[n]).abs().max())
+        for n in b0:
+            assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-4, atol=1e-6), n
+    finally:
+        ops.set_matmul_dtype(torch.float32)
