@@ -35,7 +35,7 @@ SIGNATURES = {
     "gt_graph_prep_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gt_graph_prep": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_aggregate_fwd": (_i, [_i, _i, _i, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
-                              C.POINTER(C.c_int32), _p, _p, _p]),
+                              C.POINTER(C.c_int32), _i64, _p, _p, _p]),
     "gt_aggregate_bwd_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
     "gt_aggregate_bwd": (_i, [_i, _i, _i, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
                               C.POINTER(C.c_int32), _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

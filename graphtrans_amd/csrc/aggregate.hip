@@ -50,6 +50,7 @@ struct AggArgs {
   const float* b;  // Linear bias [D]
   int tab_off[MAX_K];
   int table_rows;
+  int chunk;      // fwd: consecutive nodes per wave-tile (<= FWD_CHUNK)
   const void* dense;
   void* out;      // fwd: out ; bwd: grad_h
   void* d_dense;  // bwd
@@ -144,12 +145,23 @@ __device__ __forceinline__ void edge_attr_load(const AggArgs& a, int eid, float*
 // trips (ptr -> in-edge indices -> neighbour rows); with ~3 in-edges there is nothing inside one node
 // to hide them behind, so the walk is software pipelined across nodes: while node i's rows are gathered,
 // the indices of node i+1 and the ptr pair of node i+2 are already in flight.
-constexpr int FWD_CHUNK = 8;
+constexpr int FWD_CHUNK = 8;   // at most; small batches use shorter walks so that the chip still fills (a.chunk)
 
 template <typename T, int LPN, int NCH, int EDGE>
 __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   constexpr int NPW = 64 / LPN;
   constexpr int U = NCH >= 3 ? 2 : 4;
+  if constexpr (EDGE == GT_EDGE_TABLES) {
+    // Bond-style embedding tables are a dozen rows: every edge sums K of them, so the block reads them
+    // from LDS instead of issuing K dependent global row loads per edge (a.table_rows > 0 = staged)
+    extern __shared__ __attribute__((aligned(16))) float tab_lds[];
+    if (a.table_rows > 0) {
+      for (int64_t i = threadIdx.x * 4; i < (int64_t)a.table_rows * a.D; i += AGG_THREADS * 4)
+        *reinterpret_cast<float4*>(tab_lds + i) = *reinterpret_cast<const float4*>(a.w + i);
+      __syncthreads();
+      a.w = tab_lds;
+    }
+  }
   const int lane = threadIdx.x & 63;
   // XCD-aware block order (grid is a multiple of 8): workgroup b runs on XCD b % 8; XCD x walks the x-th
   // contiguous eighth of the nodes, so the re-gathers of a row (self + ~3 neighbours of the same graph)
@@ -157,7 +169,8 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   const int64_t blk = (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
   const int64_t wave = blk * AGG_WAVES + (threadIdx.x >> 6);
   LaneMap<LPN, NCH> m(lane, a.D);
-  const int64_t v_lo = wave * (FWD_CHUNK * NPW) + m.sub;   // this sub-group's nodes: v_lo, v_lo + NPW, ...
+  const int chunk = a.chunk;
+  const int64_t v_lo = wave * (chunk * NPW) + m.sub;   // this sub-group's nodes: v_lo, v_lo + NPW, ...
   if (v_lo >= a.N) return;
   EdgeState<EDGE, NCH> es;
   edge_state_init<EDGE, NCH, LPN>(es, a, m);
@@ -191,13 +204,13 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_fwd(AggArgs a) {
   load_idx(beg0, end0, src0, eid0);
 
 #pragma unroll 1
-  for (int it = 0; it < FWD_CHUNK; ++it) {
+  for (int it = 0; it < chunk; ++it) {
     const int64_t v = v_lo + (int64_t)it * NPW;
     if (v >= a.N) break;
     // ---- prefetch: indices of the next node, ptr pair of the one after
     int src1[U], eid1[U], beg2, end2;
     load_idx(beg1, end1, src1, eid1);
-    load_ptr(it + 2 < FWD_CHUNK ? v + 2 * NPW : a.N, beg2, end2);
+    load_ptr(it + 2 < chunk ? v + 2 * NPW : a.N, beg2, end2);
     // ---- current node
     const float dv = gcn ? a.dis[v] : 1.0f;
     const float degv = gcn ? a.deg[v] : 1.0f;
@@ -572,9 +585,9 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
       hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(grid_bwd), dim3(AGG_THREADS), lds_bytes,      \
                          stream, a);                                                                         \
     } else {                                                                                                 \
-      int64_t waves = gt_cdiv(a.N, NPW * FWD_CHUNK);                                                         \
+      int64_t waves = gt_cdiv(a.N, NPW * a.chunk);                                                           \
       hipLaunchKernelGGL((k_agg_fwd<T, LPN, NCH, EDGE>), dim3((unsigned)(gt_cdiv(gt_cdiv(waves, AGG_WAVES), 8) * 8)), \
-                         dim3(AGG_THREADS), 0, stream, a);                                                   \
+                         dim3(AGG_THREADS), lds_bytes, stream, a);                                           \
     }                                                                                                        \
   } while (0)
   if (D <= 64) GT_AGG_LAUNCH(16, 1);
@@ -639,7 +652,7 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
                                 const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const float* deg,
                                 const float* dis, const float* self_param, const void* edge_attr, int64_t K,
                                 const float* edge_w, const float* edge_b, const int32_t* tab_off_host,
-                                const void* edge_dense, void* out, gt_stream_t stream_) {
+                                int64_t table_rows, const void* edge_dense, void* out, gt_stream_t stream_) {
   int rc = check_common("gt_aggregate_fwd", conv, edge_mode, dtype, N, E, D, K, edge_attr, edge_w, edge_b,
                         tab_off_host, edge_dense);
   if (rc != GT_OK) return rc;
@@ -656,8 +669,19 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
   if (edge_mode == GT_EDGE_TABLES)
     for (int k = 0; k < K; ++k) a.tab_off[k] = tab_off_host[k];
   hipStream_t stream = (hipStream_t)stream_;
-  rc = dtype == GT_F32 ? launch_edge<float, false>(edge_mode, a, 0, 0, stream)
-                       : launch_edge<gt_bf16, false>(edge_mode, a, 0, 0, stream);
+  {  // nodes per wave-tile: 8 when that still gives >= 4096 wave-tiles, fewer for small batches
+    const int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
+    int64_t c = N / (4096 * npw);
+    a.chunk = (int)(c < 1 ? 1 : (c > FWD_CHUNK ? FWD_CHUNK : c));
+  }
+  // embedding-table edge encoders: the (few) table rows are parked in LDS per block when they fit
+  size_t fwd_lds = 0;
+  if (edge_mode == GT_EDGE_TABLES && table_rows > 0 && (size_t)table_rows * D * 4 <= 48 * 1024) {
+    a.table_rows = (int)table_rows;
+    fwd_lds = (size_t)table_rows * D * 4;
+  }
+  rc = dtype == GT_F32 ? launch_edge<float, false>(edge_mode, a, fwd_lds, 0, stream)
+                       : launch_edge<gt_bf16, false>(edge_mode, a, fwd_lds, 0, stream);
   if (rc != GT_OK) return rc;
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -702,7 +726,10 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   const int nslots = bwd_slots(edge_mode, K, table_rows);
   // persistent grid: enough wave-tiles to cover N, capped at BWD_BLOCKS
   int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
-  int64_t want = gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw), AGG_WAVES);
+  // (the table mode pays a fixed cost per block -- zeroing and flushing the per-wave LDS table rows -- so
+  // its wave-tiles take at least 8 nodes each)
+  const int64_t min_nodes = edge_mode == GT_EDGE_TABLES ? 8 : 1;
+  int64_t want = gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw * min_nodes), AGG_WAVES);
   int grid = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
   AggArgs a{};
   a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.g = grad_out; a.ptr = out_ptr; a.nbr = out_dst;

@@ -395,7 +395,7 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
   }
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_b, s.lin, L->N, L->D, L->D, 0, 0.f, 0, st));
   GT_TRY(gt_aggregate_fwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, L->N, L->E, L->D, L->in_ptr, L->in_src, L->in_eid, L->deg,
-                          L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, nullptr, s.agg, st));
+                          L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr, s.agg, st));
   // h = batch_norm(h) [relu] [+ h_list[layer]]   (gnn_module.py:204-212; dropout p = 0 or eval here)
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.agg, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr,
                           L->bn_momentum, L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->N, L->D, y, s.stats,
@@ -508,7 +508,7 @@ extern "C" int gt_gin_layer_fwd(const gt_gin_layer* L, const void* h_in, const v
   }
   // GINConv: mlp((1 + eps) x + sum_k relu(x_j + e_k))   (conv.py:26-36)
   GT_TRY(gt_aggregate_fwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, N, L->E, D, L->in_ptr, L->in_src, L->in_eid, nullptr, nullptr,
-                          L->eps, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, nullptr, s.agg, st));
+                          L->eps, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr, s.agg, st));
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.agg, L->w1, L->b1, s.z1, N, 2 * D, D, 0, 0.f, 0, st));
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
                           L->bn_momentum, L->bn_eps, L->training, 1, nullptr, N, 2 * D, s.a1, s.st1, s.st1 + 2 * D, 0.f, 0,

@@ -19,9 +19,15 @@ def code2_loss(pred_list, y_arr):
 
 
 def mol_loss(pred, y):
-    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries only."""
+    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries only.  Written without
+    boolean indexing (`pred[is_labeled]` is a device->host sync on the number of kept entries): the
+    mean over the labelled entries is sum(mask * bce) / sum(mask)."""
+    pred = pred.to(torch.float32)
     is_labeled = y == y
-    return F.binary_cross_entropy_with_logits(pred.to(torch.float32)[is_labeled], y.to(torch.float32)[is_labeled])
+    target = torch.where(is_labeled, y.to(torch.float32), torch.zeros((), dtype=torch.float32, device=y.device))
+    per = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
+    m = is_labeled.to(torch.float32)
+    return (per * m).sum() / m.sum()
 
 
 def tud_loss(pred, y):

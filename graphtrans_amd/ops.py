@@ -67,7 +67,8 @@ class _Aggregate(torch.autograd.Function):
                     attr_bytes=0 if attr_c is None else attr_c.shape[1] * attr_c.element_size())
         _lib.launch("gt_aggregate_fwd", conv, mode, _dtype_code(h), _ptr(h), N, gs.E, D, _ptr(gs.in_ptr),
                     _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(sp), _ptr(attr_c), K,
-                    _ptr(ew32), _ptr(eb32), toff, _ptr(dense_c), _ptr(out), _stream(), meta=meta)
+                    _ptr(ew32), _ptr(eb32), toff, (int(ew32.shape[0]) if (tab_off and ew32 is not None) else 0), _ptr(dense_c),
+                    _ptr(out), _stream(), meta=meta)
         ctx.meta = meta
         ctx.save_for_backward(h, sp, ew32, eb32, dense_c, attr_c)
         ctx.gs, ctx.conv, ctx.mode, ctx.tab_off, ctx.K = gs, conv, mode, tab_off, K

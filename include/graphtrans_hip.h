@@ -103,7 +103,8 @@ int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* h, int64_t 
                      int64_t dim, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
                      const float* deg, const float* dis, const float* self_param, const void* edge_attr,
                      int64_t edge_attr_cols, const float* edge_w, const float* edge_b,
-                     const int32_t* tab_off_host, const void* edge_dense, void* out, gt_stream_t stream);
+                     const int32_t* tab_off_host, int64_t table_rows /* total rows of the tables, 0 = unknown */,
+                     const void* edge_dense, void* out, gt_stream_t stream);
 
 /* Backward of gt_aggregate_fwd (autograd of the ops above in the reference).
  *   t_k   = w_k * 1[h[row_k] + e_k > 0] * g[col_k]            (w_k = dis[row_k] dis[col_k] | 1)
