@@ -85,10 +85,11 @@ __device__ __forceinline__ float emb_scale(const unsigned* absmax) {
 // so every table marked `small` is accumulated in an LDS copy of its slab first (ds_add_u64) and
 // flushed with one global atomic per (row, column) per block; large tables (attribute: 10 k rows)
 // go straight to global atomics where collisions are rare.
-constexpr int SC_COLS = 32, SC_LANES = ET / SC_COLS, SC_NODES = 512;
+constexpr int SC_COLS = 32, SC_LANES = ET / SC_COLS;
+// nodes per block: 512 for big batches (fewer slab flushes), 128 for small ones (more blocks in flight)
 constexpr int SC_LDS_ROWS = 256;  // sum of rows over the small tables must fit: 256 * 32 * 8 B = 64 KB
 
-__global__ void __launch_bounds__(ET) k_embed_scatter(EmbArgs a, unsigned small_mask, int lds_rows) {
+__global__ void __launch_bounds__(ET) k_embed_scatter(EmbArgs a, unsigned small_mask, int lds_rows, int SC_NODES) {
   extern __shared__ unsigned long long slab[];  // [lds_rows][SC_COLS]
   const int cl = threadIdx.x % SC_COLS, nl = threadIdx.x / SC_COLS;
   const int64_t c = (int64_t)blockIdx.y * SC_COLS + cl;
@@ -213,8 +214,9 @@ extern "C" int gt_embed_sum_bwd(int num_tables, const int64_t* const* idx_ptrs_h
       small_mask |= 1u << best;
       lds_rows += (int)a.rows[best];
     }
-    hipLaunchKernelGGL(k_embed_scatter, dim3((unsigned)gt_cdiv(N, SC_NODES), (unsigned)gt_cdiv(D, SC_COLS)), dim3(ET),
-                       (size_t)lds_rows * SC_COLS * sizeof(unsigned long long), stream, a, small_mask, lds_rows);
+    const int sc_nodes = N >= 16384 ? 512 : 128;
+    hipLaunchKernelGGL(k_embed_scatter, dim3((unsigned)gt_cdiv(N, sc_nodes), (unsigned)gt_cdiv(D, SC_COLS)), dim3(ET),
+                       (size_t)lds_rows * SC_COLS * sizeof(unsigned long long), stream, a, small_mask, lds_rows, sc_nodes);
   }
   hipLaunchKernelGGL(k_embed_convert, dim3(grid_for(off * D)), dim3(ET), 0, stream, a);
   GT_CHECK_LAUNCH();
