@@ -39,6 +39,7 @@ struct LinArgs {
   float* dbpart;      // dw: [splits][N]
   int64_t M, N, K;
   int64_t ldy;        // row stride (elements) of Y / dY / ymask; >= N
+  int64_t ldx;        // row stride (elements) of X / dX / the dX addends; >= K
   int act;            // 0 none, 1 relu
   float inv_keep;     // 1/(1-p)
   uint32_t thr, s0, s1;
@@ -223,9 +224,9 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   Loader<TX, TC, BM, BK, LD, false> lx;
   Loader<float, TC, BN, BK, LD, false> lw;
   const int64_t Mx = (a.dbg & 2) ? 0 : a.M - m0, Nw = (a.dbg & 1) ? 0 : a.N - n0;
-  const TX* xo = X + m0 * a.K;
+  const TX* xo = X + m0 * a.ldx;
   const float* wo = a.w + n0 * a.K;
-  lx.init(a.K);
+  lx.init(a.ldx);
   lw.init(a.K);
   lx.load(xo, Mx, a.K, nullptr);
   lw.load(wo, Nw, a.K, nullptr);
@@ -379,9 +380,9 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
             *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
       } else if (m < a.M && col < a.K) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
-        if (a.add1) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add1) + m * a.K + col));
-        if (a.add2) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add2) + m * a.K + col));
-        store_chunk<TX>(dX + m * a.K + col, v);
+        if (a.add1) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add1) + m * a.ldx + col));
+        if (a.add2) v = gt_add4(v, gt_load4<TX>(reinterpret_cast<const TX*>(a.add2) + m * a.ldx + col));
+        store_chunk<TX>(dX + m * a.ldx + col, v);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -430,10 +431,10 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   Loader<TY, TC, BMc, BN, LDZ, true> lz;
   Loader<TX, TC, BMc, BN, LDX, false> lx;
   lz.init(a.ldy);
-  lx.init(a.K);
+  lx.init(a.ldx);
   if (mb < me) {
     lz.load(dY + mb * a.ldy + n0, me - mb, a.N - n0, has_mask ? Ym + mb * a.ldy + n0 : nullptr);
-    lx.load(X + mb * a.K + k0, me - mb, a.K - k0, nullptr);
+    lx.load(X + mb * a.ldx + k0, me - mb, a.K - k0, nullptr);
   }
   for (int64_t m0 = mb; m0 < me; m0 += BMc) {
     __syncthreads();
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     if (m0 + BMc < me) {
       const int64_t m1 = m0 + BMc;
       lz.load(dY + m1 * a.ldy + n0, me - m1, a.N - n0, has_mask ? Ym + m1 * a.ldy + n0 : nullptr);
-      lx.load(X + m1 * a.K + k0, me - m1, a.K - k0, nullptr);
+      lx.load(X + m1 * a.ldx + k0, me - m1, a.K - k0, nullptr);
     }
     if (ty == 0 && threadIdx.x < BN) {
 #pragma unroll 8
@@ -606,7 +607,17 @@ extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* 
 extern "C" int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                                 const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldy, int act,
                                 float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  return gt_linear_fwd_ld2(x_dtype, y_dtype, compute, x, weight, bias, y, M, N, K, K, ldy, act, dropout_p, seed, stream_);
+}
+
+extern "C" int gt_linear_fwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
+                                 const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
+                                 int act, float dropout_p, uint64_t seed, gt_stream_t stream_) {
   int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K, ldy);
+  if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
+    gt_set_error("gt_linear_fwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
+    rc = GT_ERR_UNSUPPORTED;
+  }
   if (rc) return rc;
   GT_CHECK_ARG(x && weight && y, "null buffer");
   GT_CHECK_ARG(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
@@ -616,7 +627,7 @@ extern "C" int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const voi
   GtProfScope prof__(GT_PROF_LINEAR, "gt_linear_fwd", stream_, {M, N, K, x_dtype, y_dtype, compute});
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
-  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.act = act;
+  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act;
   { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
   const int bm = pick_bm(M);
@@ -648,7 +659,19 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
                                 const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                                 float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldy, float dropout_p,
                                 void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  return gt_linear_bwd_ld2(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
+                           K, ldy, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                 const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                                 float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
+                                 void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K, ldy);
+  if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
+    gt_set_error("gt_linear_bwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
+    rc = GT_ERR_UNSUPPORTED;
+  }
   if (rc) return rc;
   GT_CHECK_ARG(weight && dy, "null buffer");
   GT_CHECK_ARG(dx || dweight, "nothing to compute");
@@ -658,7 +681,7 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
   GtProfScope prof__(GT_PROF_LINEAR, dx ? (dweight ? "gt_linear_bwd" : "gt_linear_bwd_dx") : "gt_linear_bwd_dw", stream_,
                      {M, N, K, x_dtype, y_dtype, compute});
   LinArgs a{};
-  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy;
+  a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx;
   a.add1 = dx_add1; a.add2 = dx_add2;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
   if (M == 0) {
@@ -670,7 +693,7 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
   if (dx) {
     const int bm = pick_bm(M);
     // split-N partials are plain fp32 sums: only for fp32 dX without fused addends
-    int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2) ? dx_splits(M, N, K, bm) : 1;
+    int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2 && ldx == K) ? dx_splits(M, N, K, bm) : 1;
     if (splits > 1 && (!workspace || workspace_bytes < need)) splits = 1;
     a.splits = splits;
     a.n_per_split = gt_cdiv(gt_cdiv(N, splits), 64) * 64;

@@ -71,6 +71,31 @@ class PNAConv(nn.Module):
                 raise ValueError(s)
         return out
 
+    def _post_maps(self, device):
+        """Gather maps that restack post_nns[t].weight (F_out, (A*S+1)F) into (S*F_out, 5F): block s holds the
+        columns of scaler s over the kernel's [mean|max|min|std] slots (zeros for unused aggregators) and, for s = 0
+        only, the x_i columns.  Then  post(cat[x, agg*s_0, agg*s_1, ...]) = sum_s scale_s (x) Y[:, s]."""
+        key = str(device)
+        if getattr(self, "_maps_key", None) == key:
+            return self._wmap, self._bmap
+        Fi, Fo, A, S = self.F_in, self.F_out, len(self.aggregators), len(self.scalers)
+        cols = (A * S + 1) * Fi
+        zero_w = Fo * cols   # index of the appended zero
+        wmap = torch.full((S * Fo, 5 * Fi), zero_w, dtype=torch.int64)
+        o = torch.arange(Fo).view(Fo, 1)
+        f = torch.arange(Fi).view(1, Fi)
+        for s in range(S):
+            rows = slice(s * Fo, (s + 1) * Fo)
+            if s == 0:
+                wmap[rows, 0:Fi] = o * cols + f
+            for ai, a in enumerate(self.aggregators):
+                slot = _AGG_SLOT[a]
+                wmap[rows, Fi + slot * Fi:Fi + (slot + 1) * Fi] = o * cols + Fi + s * A * Fi + ai * Fi + f
+        bmap = torch.full((S * Fo,), Fo, dtype=torch.int64)
+        bmap[:Fo] = torch.arange(Fo)
+        self._wmap, self._bmap, self._maps_key = wmap.reshape(-1).to(device), bmap.to(device), key
+        return self._wmap, self._bmap
+
     def forward(self, x, edge_index, edge_attr=None, graph=None):
         if edge_attr is not None:
             raise NotImplementedError("PNAConv with edge features is not on the reference's path")
@@ -78,24 +103,29 @@ class PNAConv(nn.Module):
         if gs is None:
             from ...graph import GraphStructure
             gs = GraphStructure.build(edge_index, torch.zeros(x.shape[0], dtype=torch.int64, device=x.device), num_graphs=1)
-        N, T, Fi = x.shape[0], self.towers, self.F_in
-        xt = x.view(N, T, Fi) if self.divide_input else x.view(N, 1, Fi).expand(N, T, Fi)
+        N, T, Fi, Fo = x.shape[0], self.towers, self.F_in, self.F_out
+        S = len(self.scalers)
+        xt = (x.view(N, T, Fi) if self.divide_input else x.view(N, 1, Fi).expand(N, T, Fi)).contiguous()
         Wp = torch.stack([m[0].weight for m in self.pre_nns])  # (T, F, 2F): [A | B] on [x_i || x_j]
         bp = torch.stack([m[0].bias for m in self.pre_nns])    # (T, F)
-        xb = xt.transpose(0, 1)                                # (T, N, F)
-        U = torch.baddbmm(bp.unsqueeze(1), xb, Wp[:, :, :Fi].transpose(1, 2)).transpose(0, 1).reshape(N, T * Fi)
-        V = torch.bmm(xb, Wp[:, :, Fi:].transpose(1, 2)).transpose(0, 1).reshape(N, T * Fi)
-        agg4 = ops.pna_aggregate(U, V, gs, T).view(N, T, 4, Fi)          # [mean | max | min | std]
-        agg = torch.cat([agg4[:, :, _AGG_SLOT[a]] for a in self.aggregators], dim=-1)  # (N, T, A*F)
-        deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(x.dtype).view(-1, 1, 1)
-        parts = [xt]
-        for sc in self._scales(deg):
-            parts.append(agg if sc is None else agg * sc)
-        out = torch.cat(parts, dim=-1)                                   # (N, T, (A*S+1) F)
+        # the per-edge pre-Linear splits into per-node terms: U = x A^T + b (target role), V = x B^T (source role)
+        U = ops.tower_linear(xt, Wp[:, :, :Fi].contiguous(), bp).view(N, T * Fi)
+        V = ops.tower_linear(xt, Wp[:, :, Fi:].contiguous(), None).view(N, T * Fi)
+        agg4 = ops.pna_aggregate(U, V, gs, T).view(N, T, 4 * Fi)         # [mean | max | min | std]
+        # post-Linear without materialising the (A*S+1)F-wide scaled copies: one GEMM on [x | agg] per tower,
+        # the degree scalers (per-node scalars) are applied to its S output blocks
+        wmap, bmap = self._post_maps(x.device)
         Wq = torch.stack([m[0].weight for m in self.post_nns])           # (T, F_out, (A*S+1)F)
-        bq = torch.stack([m[0].bias for m in self.post_nns])
-        out = torch.baddbmm(bq.unsqueeze(1), out.transpose(0, 1), Wq.transpose(1, 2)).transpose(0, 1).reshape(N, -1)
-        return ops.linear_module(self.lin, out)
+        bq = torch.stack([m[0].bias for m in self.post_nns])             # (T, F_out)
+        Wst = torch.cat([Wq.reshape(T, -1), Wq.new_zeros(T, 1)], 1).index_select(1, wmap).view(T, S * Fo, 5 * Fi)
+        bst = torch.cat([bq, bq.new_zeros(T, 1)], 1).index_select(1, bmap)
+        Y = ops.tower_linear(torch.cat([xt, agg4], dim=-1), Wst, bst).view(N, T, S, Fo)
+        deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(x.dtype).view(-1, 1, 1)
+        out = None
+        for s, sc in enumerate(self._scales(deg)):
+            term = Y[:, :, s] if sc is None else Y[:, :, s] * sc
+            out = term if out is None else out + term
+        return ops.linear_module(self.lin, out.reshape(N, T * Fo))
 
 
 class BatchNorm(nn.Module):

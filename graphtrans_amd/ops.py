@@ -646,3 +646,56 @@ def softmax_xent(stacked, target):
     if target.dtype != torch.int64 or target.dim() != 2 or target.shape[1] < stacked.shape[1]:
         raise TypeError("softmax_xent: int64 (B, >=L) targets expected")
     return _Xent.apply(stacked, target)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-tower linears (PNAConv's pre_nns / post_nns): column slices in, column slices out
+# ------------------------------------------------------------------------------------------------
+class _TowerLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, compute):
+        x = _dev(x, "x")                      # (M, T, K) contiguous: tower t is the column slice [t*K, (t+1)*K)
+        M, T, K = x.shape
+        Nout = weight.shape[1]
+        w32 = _f32(weight)                    # (T, Nout, K)
+        b32 = _f32(bias)                      # (T, Nout) or None
+        y = torch.empty((M, T, Nout), dtype=x.dtype, device=x.device)
+        es = x.element_size()
+        for t in range(T):
+            _lib.launch("gt_linear_fwd_ld2", _dtype_code(x), _dtype_code(y), compute, x.data_ptr() + t * K * es,
+                        w32.data_ptr() + t * Nout * K * 4, None if b32 is None else b32.data_ptr() + t * Nout * 4,
+                        y.data_ptr() + t * Nout * es, M, Nout, K, T * K, T * Nout, 0, 0.0, 0, _stream())
+        ctx.save_for_backward(x, w32)
+        ctx.cfg = (compute, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32 = ctx.saved_tensors
+        compute, wdt, bdt = ctx.cfg
+        M, T, K = x.shape
+        Nout = w32.shape[1]
+        dy = _dev(dy.to(x.dtype), "grad")
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2])
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty((T, Nout, K), dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty((T, Nout), dtype=torch.float32, device=x.device) if (need_w and bdt is not None) else None
+        ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(compute, M, Nout, K)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        es = x.element_size()
+        for t in range(T):
+            _lib.launch("gt_linear_bwd_ld2", _dtype_code(x), _dtype_code(dy), compute, x.data_ptr() + t * K * es,
+                        w32.data_ptr() + t * Nout * K * 4, dy.data_ptr() + t * Nout * es, None, None, None,
+                        None if dx is None else dx.data_ptr() + t * K * es, None if dw is None else dw.data_ptr() + t * Nout * K * 4,
+                        None if db is None else db.data_ptr() + t * Nout * 4, M, Nout, K, T * K, T * Nout, 0.0, _ptr(ws), ws_bytes,
+                        _stream())
+        return dx, (None if dw is None else dw.to(wdt)), (None if db is None else db.to(bdt)), None
+
+
+def tower_linear(x, weight, bias=None):
+    """y[:, t] = x[:, t] @ weight[t].T + bias[t] for (M, T, K) x, (T, Nout, K) weight -> (M, T, Nout): T launches of
+    gt_linear_*_ld2 on column slices (no transposes, no per-tower copies).  K and Nout multiples of 4 (8 for bf16)."""
+    if x.dim() != 3 or weight.dim() != 3 or x.shape[1] != weight.shape[0] or x.shape[2] != weight.shape[2]:
+        raise ValueError("tower_linear: x (M, T, K), weight (T, Nout, K)")
+    compute = GT_BF16 if (x.dtype == torch.bfloat16 or _MATMUL_DTYPE == torch.bfloat16) else GT_F32
+    return _TowerLinear.apply(x, weight, bias, compute)

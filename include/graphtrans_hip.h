@@ -296,6 +296,11 @@ int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const fl
 int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
                      void* y, int64_t M, int64_t N, int64_t K, int64_t ldy, int act, float dropout_p, uint64_t seed,
                      gt_stream_t stream);
+/* ... and with an explicit row stride ldx >= K for x / dx / the dx addends as well: column slices of a wider
+ * matrix in, column slices out (the per-tower linears of PNAConv, modules/pna/pna_module.py:33-41). */
+int gt_linear_fwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                      void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int act, float dropout_p,
+                      uint64_t seed, gt_stream_t stream);
 size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K);
 int gt_linear_bwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                   const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
@@ -315,6 +320,11 @@ int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const
 int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
 int gt_overlap_dw_sync(void);
 int gt_overlap_dw_end(void);
+
+int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                      const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
+                      void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy over the stacked prediction heads (the Code2 loss, dataset/code.py:39-45:
