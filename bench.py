@@ -189,19 +189,28 @@ def cpu_baseline(workload, model, args, sample_graphs=64, iters=2, threads=16, b
     from graphtrans_amd import synth
     from oracle import reference_math as rm
 
-    if workload != "code2":
+    if workload == "code2":
+        b = synth.code2_like(B=sample_graphs, seed=0)
+        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like"
+    elif workload == "molpcba":
+        sample_graphs = 256
+        b = synth.molpcba_like(B=sample_graphs, seed=0)
+        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.mol_loss(out, b.y)), "Molpcba-like"
+    elif workload == "code2-pna":
+        b = synth.code2_like(B=sample_graphs, seed=0)
+        fwd, loss_of, what = rm.pna_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like (PNA)"
+    else:
         return None
     threads = min(threads, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
-    b = synth.code2_like(B=sample_graphs, seed=0)
     times, t_start = [], time.perf_counter()
     for it in range(iters + 1):
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
-        out = rm.gnn_transformer(sd, args, b, None, True)
-        rm.code2_loss(out, b.y_arr).backward()
+        out = fwd(sd, args, b, None, True)
+        loss_of(out).backward()
         dt = time.perf_counter() - t0
         if it > 0 or dt > budget_s / 2:  # a slow box: keep the warm-up iteration as the sample
             times.append(dt)
@@ -210,7 +219,7 @@ def cpu_baseline(workload, model, args, sample_graphs=64, iters=2, threads=16, b
     t = float(np.median(times))
     return dict(value=round(sample_graphs / t, 2), unit="graphs/s", cores=threads, kind="port",
                 sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on a {sample_graphs}-graph "
-                       f"seed-0 Code2-like batch, median of {len(times)} timed iteration(s); padded layout like the "
+                       f"seed-0 {what} batch, median of {len(times)} timed iteration(s); padded layout like the "
                        f"reference (S = max nodes of the sample); host has {os.cpu_count()} logical cores",
                 s_per_step=round(t, 3))
 
