@@ -551,6 +551,9 @@ class _FusedModel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         s = ctx.state
+        if s is None:
+            raise RuntimeError("graphtrans_amd fused model: backward through the graph a second time "
+                               "(the saved activations are freed after the first backward)")
         plan, o, base, gs, lay, sm = s["plan"], s["o"], s["base"], s["gs"], s["lay"], s["sm"]
         compute, tdt, tsz = s["compute"], s["tdt"], s["tsz"]
         N, E, B, rows = s["dims"]

@@ -176,7 +176,8 @@ def test_fused_model_edge_cases(case):
 
 
 GIN_CASES = [dict(feat="mol"), dict(feat="mol", gnn_dropout=0.3, gnn_JK="last"), dict(feat="mol", gnn_virtual_node=False, gnn_residual=True),
-             dict(feat="ast"), dict(feat="ast", gnn_residual=True, gnn_dropout=0.2), dict(feat="mol", compute_dtype=torch.bfloat16)]
+             dict(feat="ast"), dict(feat="ast", gnn_residual=True, gnn_dropout=0.2), dict(feat="mol", compute_dtype=torch.bfloat16),
+             dict(feat="mol", gnn_type="gcn", gnn_dropout=0.1)]
 
 
 @pytest.mark.parametrize("kw", GIN_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in GIN_CASES])
@@ -188,7 +189,8 @@ def test_fused_gin_model_matches_module_path(kw):
     from graphtrans_amd.models.gnn_transformer import GNNTransformer
     kw = dict(kw)
     feat = kw.pop("feat")
-    args = _args(gnn_type="gin", **kw)
+    kw.setdefault("gnn_type", "gin")
+    args = _args(**kw)
     bf16 = args.compute_dtype == torch.bfloat16
     ops.set_matmul_dtype(torch.bfloat16 if bf16 else torch.float32)
     try:
