@@ -693,13 +693,18 @@ class _FusedModel(torch.autograd.Function):
         dw_sync()
         if plan.has_vn:
             _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, st)
+        # the message-passing gradients (everything between the embedding tables and gnn2transformer) are final:
+        # on the wire while the embedding backward runs; the tables themselves follow right after it
+        gnn_lo = plan.vn_emb_off if plan.has_vn else plan.gcn_off[0]
+        if sync is not None:
+            sync.reduce_flat(flat, gnn_lo, plan.g2t_off[0])
         # ---- input encoder tables
         T, e_idx, e_str, e_clamp, _cols = s["embed"]
         d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
         _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
 
         if sync is not None:
-            sync.reduce_flat(flat, 0, plan.g2t_off[0])
+            sync.reduce_flat(flat, 0, gnn_lo)
         # ---- hand the gradients to the parameters
         if direct:
             for p, v in zip(plan.plist, plan.views):

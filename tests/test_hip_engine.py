@@ -137,7 +137,7 @@ def test_fused_backward_issues_the_gradient_allreduce():
         sync.zero()
         torch.manual_seed(3)
         losses.code2_loss(model(b), y).backward()
-        assert sync._flat_used and len(sync._pending) == 2
+        assert sync._flat_used and len(sync._pending) == 3
         sync.finish()
         torch.cuda.synchronize()
         for n, p in model.named_parameters():
