@@ -37,13 +37,21 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- dropout RNG: counter-based hash of (seed, seq*nhead+head, query pos, key pos) ---------------
-__device__ __forceinline__ uint32_t rng_hash(uint32_t s0, uint32_t s1, uint32_t bh, uint32_t q, uint32_t k) {
-  uint32_t x = (q * 0x9E3779B1u) ^ (k * 0x85EBCA77u + s0);
-  x ^= bh * 0xC2B2AE3Du + s1;
+// The pre-mix is an XOR of a query/head part and a key part, so a lane that walks keys for one query (fwd, dQ)
+// or queries for one key (dK/dV) hoists its fixed part and advances the other by one add (no per-pair multiply
+// before the finalizer; 32-bit integer multiplies are quarter rate).
+constexpr uint32_t RNG_CQ = 0x9E3779B1u, RNG_CK = 0x85EBCA77u, RNG_CH = 0xC2B2AE3Du;
+__device__ __forceinline__ uint32_t rng_qpart(uint32_t s1, uint32_t bh, uint32_t q) { return (q * RNG_CQ) ^ (bh * RNG_CH + s1); }
+__device__ __forceinline__ uint32_t rng_kpart(uint32_t s0, uint32_t k) { return k * RNG_CK + s0; }
+__device__ __forceinline__ uint32_t rng_mix(uint32_t qpart, uint32_t kpart) {
+  uint32_t x = qpart ^ kpart;
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= x >> 15; x *= 0x846ca68bu;
   x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t rng_hash(uint32_t s0, uint32_t s1, uint32_t bh, uint32_t q, uint32_t k) {
+  return rng_mix(rng_qpart(s1, bh, q), rng_kpart(s0, k));
 }
 
 struct AttnArgs {
@@ -137,7 +145,7 @@ __device__ __forceinline__ void load_tile(T* lds, const T* src, int64_t src_ld, 
 // =================================================================================================
 // forward
 // =================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool DENSE>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;  // 32-deep steps over head_dim
@@ -172,7 +180,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
-  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
+  const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
+  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
     __syncthreads();
     load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
@@ -190,12 +199,24 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
       for (int r = 0; r < 4; ++r) s[t * 4 + r] = c[r];
     }
     float mt = -INFINITY;
+    bool full_tile = false;
+    if constexpr (!DENSE) full_tile = k0 >= kv_off && k0 + TILE <= kv_end;  // block-uniform: every key valid
+    if (full_tile) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int kp = k0 + g * 8 + i;
-      s[i] = (kp >= kv_off && kp < kv_end) ? s[i] * a.scale_log2 : -INFINITY;
-      if (dense && qvalid && kp < npos && dense_masked(a, seq, qp, kp, npos)) s[i] = a.mask_fill2;
-      mt = fmaxf(mt, s[i]);
+      for (int i = 0; i < 8; ++i) {
+        s[i] *= a.scale_log2;
+        mt = fmaxf(mt, s[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kp = k0 + g * 8 + i;
+        s[i] = (kp >= kv_off && kp < kv_end) ? s[i] * a.scale_log2 : -INFINITY;
+        if constexpr (DENSE) {
+          if (qvalid && kp < npos && dense_masked(a, seq, qp, kp, npos)) s[i] = a.mask_fill2;
+        }
+        mt = fmaxf(mt, s[i]);
+      }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -210,9 +231,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     }
     lsum = lsum * alpha + psum;
     if (a.drop_thr) {
+      const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)(k0 + g * 8 + i));
+        const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)i * RNG_CK);
         p[i] = h >= a.drop_thr ? p[i] * a.inv_keep : 0.f;
       }
     }
@@ -244,7 +266,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 // =================================================================================================
 // backward, pass 1: delta = rowsum(dO * O) and dQ      (block = 64 queries, loop over key tiles)
 // =================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool DENSE>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;
@@ -290,7 +312,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
   const float logl = qvalid ? a.lse[((int64_t)a.nhead + head) * a.rows + qrow] : 0.f;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
-  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
+  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   zero_pad_cols<T, HD>(sK);
   zero_pad_cols<T, HD>(sV);
 
@@ -299,12 +321,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
+  const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
   for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
     __syncthreads();
     load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
     load_tile<T, HD>(sV, qkv + 2 * a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
     __syncthreads();
     float ds[8];
+    const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -323,7 +347,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         const float p = kvalid ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
         float dpi = dp[r];
         if (a.drop_thr) {
-          const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qp, (uint32_t)kp);
+          const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)i * RNG_CK);
           dpi = h >= a.drop_thr ? dpi * a.inv_keep : 0.f;
         }
         ds[i] = filled ? 0.f : p * (dpi - delta);  // masked_fill: no gradient through a filled score
@@ -346,7 +370,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
 // =================================================================================================
 // backward, pass 2: dK, dV                              (block = 64 keys, loop over query tiles)
 // =================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool DENSE>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;
@@ -386,7 +410,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
-  const bool dense = a.dense_mask != nullptr || a.key_valid != nullptr;
+  const uint32_t kpart = rng_kpart(a.seed0, (uint32_t)kp);
+  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
   for (int q0 = 0; any_valid && q0 < npos; q0 += TILE) {
@@ -423,7 +448,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         float dpi = dp[r];
         float pdrop = p;
         if (a.drop_thr) {
-          const uint32_t h = rng_hash(a.seed0, a.seed1, bh, (uint32_t)qpos, (uint32_t)kp);
+          const uint32_t h = rng_mix(rng_qpart(a.seed1, bh, (uint32_t)qpos), kpart);
           const bool keep = h >= a.drop_thr;
           dpi = keep ? dpi * a.inv_keep : 0.f;
           pdrop = keep ? p * a.inv_keep : 0.f;
@@ -502,7 +527,12 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
-#define GT_LAUNCH(T, HD) hipLaunchKernelGGL((k_attn_fwd<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a)
+  const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
+#define GT_LAUNCH(T, HD)                                                                                     \
+  do {                                                                                                       \
+    if (dense_launch) hipLaunchKernelGGL((k_attn_fwd<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a);  \
+    else hipLaunchKernelGGL((k_attn_fwd<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);              \
+  } while (0)
   if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
     else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
@@ -535,10 +565,16 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
+  const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
 #define GT_LAUNCH(T, HD)                                                                        \
   do {                                                                                          \
-    hipLaunchKernelGGL((k_attn_bwd_dq<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);          \
-    hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD>), grid, dim3(ATT_THREADS), 0, stream, a);         \
+    if (dense_launch) {                                                                         \
+      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a);  \
+      hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a); \
+    } else {                                                                                    \
+      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a); \
+      hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);\
+    }                                                                                           \
   } while (0)
   if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
