@@ -411,6 +411,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   }
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t kpart = rng_kpart(a.seed0, (uint32_t)kp);
+  const uint32_t hb = bh * RNG_CH + a.seed1;
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
@@ -428,6 +429,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     }
     __syncthreads();
     float pd[8], ds[8];
+    const uint32_t qmul0 = (uint32_t)(q0 + g * 8) * RNG_CQ;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         float dpi = dp[r];
         float pdrop = p;
         if (a.drop_thr) {
-          const uint32_t h = rng_mix(rng_qpart(a.seed1, bh, (uint32_t)qpos), kpart);
+          const uint32_t h = rng_mix((qmul0 + (uint32_t)i * RNG_CQ) ^ hb, kpart);  // == rng_qpart(seed1, bh, qpos)
           const bool keep = h >= a.drop_thr;
           dpi = keep ? dpi * a.inv_keep : 0.f;
           pdrop = keep ? p * a.inv_keep : 0.f;
