@@ -24,7 +24,7 @@ namespace {
 
 constexpr int AGG_THREADS = 256;
 constexpr int AGG_WAVES = AGG_THREADS / GT_WAVE;
-constexpr int BWD_BLOCKS = 1024;
+constexpr int BWD_BLOCKS = 2048;  // upper bound (sizes the partial workspace); the launch takes ~16 nodes per wave-tile
 constexpr int MAX_K = 4;
 // internal edge mode: Linear edge encoder with K <= 2 (the Code2 case, dataset/code.py:117): half the
 // weight registers / accumulators of the generic K <= 4 variant -> higher occupancy
@@ -726,9 +726,11 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   const int nslots = bwd_slots(edge_mode, K, table_rows);
   // persistent grid: enough wave-tiles to cover N, capped at BWD_BLOCKS
   int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
-  // (the table mode pays a fixed cost per block -- zeroing and flushing the per-wave LDS table rows -- so
-  // its wave-tiles take at least 8 nodes each)
-  const int64_t min_nodes = edge_mode == GT_EDGE_TABLES ? 8 : 1;
+  // ~16 source nodes per wave-tile: measured best on both the Code2 batch (31.6 k nodes: 512 blocks, 105 -> 97 us)
+  // and the 131 k-node stress batch (2048 blocks); fewer, longer walks lose parallelism, more blocks only add
+  // partial rows to reduce.
+  int64_t min_nodes = N / (2048 * npw);   // small batches: shorter walks, so that ~2048 wave-tiles still exist
+  min_nodes = min_nodes < 2 ? 2 : (min_nodes > 32 ? 32 : min_nodes);
   int64_t want = gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw * min_nodes), AGG_WAVES);
   int grid = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
   AggArgs a{};
