@@ -99,20 +99,39 @@ __global__ void __launch_bounds__(ET) k_embed_scatter(EmbArgs a, unsigned small_
   __syncthreads();
   const float scale = emb_scale(a.absmax);
   if (c < a.D) {
-    for (int64_t n = n0 + nl; n < n1; n += SC_LANES) {
-      const long long q = __float2ll_rn(a.g[n * a.D + c] * scale);
-      if (q == 0) continue;
-      int lrow = 0;
-      for (int t = 0; t < a.T; ++t) {
-        if (!a.dtable[t]) continue;
-        const int64_t r = emb_index(a, t, n);
-        if (small_mask >> t & 1) {
-          atomicAdd(&slab[(lrow + r) * SC_COLS + cl], (unsigned long long)q);
+    // small tables: LDS slab
+    if (small_mask) {
+      for (int64_t n = n0 + nl; n < n1; n += SC_LANES) {
+        const long long q = __float2ll_rn(a.g[n * a.D + c] * scale);
+        if (q == 0) continue;
+        int lrow = 0;
+        for (int t = 0; t < a.T; ++t) {
+          if (!a.dtable[t] || !(small_mask >> t & 1)) continue;
+          atomicAdd(&slab[(lrow + emb_index(a, t, n)) * SC_COLS + cl], (unsigned long long)q);
           lrow += (int)a.rows[t];
-        } else {
-          atomicAdd(reinterpret_cast<unsigned long long*>(a.acc + (a.row_off[t] + r) * a.D + c), (unsigned long long)q);
         }
       }
+    }
+    // large tables: straight to global atomics, but consecutive nodes of a thread that hit the SAME row are
+    // summed in a register first (attribute vocabularies are skewed: one hot row would otherwise serialise
+    // thousands of atomics on 300 addresses; uniform data pays nothing for the run-length check)
+    for (int t = 0; t < a.T; ++t) {
+      if (!a.dtable[t] || (small_mask >> t & 1)) continue;
+      int64_t cur_row = -1;
+      long long cur_sum = 0;
+      for (int64_t n = n0 + nl; n < n1; n += SC_LANES) {
+        const long long q = __float2ll_rn(a.g[n * a.D + c] * scale);
+        const int64_t r = emb_index(a, t, n);
+        if (r != cur_row) {
+          if (cur_sum) atomicAdd(reinterpret_cast<unsigned long long*>(a.acc + (a.row_off[t] + cur_row) * a.D + c),
+                                 (unsigned long long)cur_sum);
+          cur_row = r;
+          cur_sum = 0;
+        }
+        cur_sum += q;
+      }
+      if (cur_sum) atomicAdd(reinterpret_cast<unsigned long long*>(a.acc + (a.row_off[t] + cur_row) * a.D + c),
+                             (unsigned long long)cur_sum);
     }
   }
   __syncthreads();

@@ -75,3 +75,21 @@ def test_ast_node_encoder_matches_reference_formula():
     ref = enc.type_encoder.weight[x[:, 0]] + enc.attribute_encoder.weight[x[:, 1]] + enc.depth_encoder.weight[d]
     assert torch.equal(out, ref)
     assert depth.max().item() > 20  # caller's tensor is not clamped in place
+
+
+def test_embed_sum_bwd_hot_row():
+    """A skewed index column (most nodes share one row of a large table): same result, and the
+    register run-length aggregation keeps it from serialising on that row."""
+    from graphtrans_amd import ops
+    g = torch.Generator().manual_seed(1)
+    N, D, R = 20000, 128, 5000
+    idx = torch.randint(0, R, (N,), generator=g)
+    idx[torch.rand(N, generator=g) < 0.8] = 17
+    idx = idx.cuda()
+    tab = torch.randn(R, D, generator=g).cuda().requires_grad_()
+    out = ops.embed_sum([idx], [tab])
+    gout = torch.randn(N, D, generator=g).cuda()
+    out.backward(gout)
+    ref = torch.zeros(R, D, dtype=torch.float64, device="cuda").index_add_(0, idx, gout.double())
+    scale = gout.abs().max().item()
+    assert (tab.grad.double() - ref).abs().max().item() <= scale * 2.0 ** -29 * N + 1e-6 * ref.abs().max().item()
