@@ -32,6 +32,9 @@ SIGNATURES = {
     "gt_profile_resume": (_i, [C.c_uint]),
     "gt_profile_count": (_i64, []),
     "gt_profile_get": (_i, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    "gt_attr_rank": (_i, [_p, _i64, _p, _p]),
+    "gt_collate_workspace_bytes": (_sz, [_i64]),
+    "gt_collate": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gt_graph_prep_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gt_graph_prep": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_aggregate_fwd": (_i, [_i, _i, _i, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,

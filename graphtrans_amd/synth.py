@@ -31,11 +31,13 @@ def _finish(xs, eis, eas, sizes, extra):
     return b
 
 
-def code2_like(B=256, seed=0, mean_nodes=105.0, sigma=0.6, min_nodes=11, max_nodes=2000,
-               num_nodetypes=98, num_nodeattributes=10030, num_vocab=5002, max_seq_len=5):
+def _code2_graphs(B, seed, mean_nodes, sigma, min_nodes, max_nodes, num_nodetypes, num_nodeattributes, num_vocab,
+                  max_seq_len):
+    """Raw per-graph arrays as the OGB dataset stores them BEFORE the reference's per-sample transform
+    (dataset/code.py:97-101): AST edges only, `node_is_attributed`, DFS-ordered nodes."""
     rng = np.random.default_rng(seed)
     sizes = np.clip(np.round(rng.lognormal(np.log(mean_nodes), sigma, B)), min_nodes, max_nodes).astype(np.int64)
-    xs, eis, eas, depths = [], [], [], []
+    graphs = []
     for n in sizes:
         n = int(n)
         # random rooted tree, parent < child, parent among the 8 most recent nodes (AST-like)
@@ -46,15 +48,39 @@ def code2_like(B=256, seed=0, mean_nodes=105.0, sigma=0.6, min_nodes=11, max_nod
         for c, p in zip(child, parent):
             depth[c] = depth[p] + 1
         ast = np.stack([parent, child])
-        attributed = np.nonzero(rng.random(n) < 0.4)[0]
+        is_attr = rng.random(n) < 0.4
+        x = np.stack([rng.integers(0, num_nodetypes, n), rng.integers(0, num_nodeattributes, n)], 1).astype(np.int64)
+        graphs.append(dict(x=x, edge_index=ast.astype(np.int64), node_depth=depth.reshape(-1, 1),
+                           node_is_attributed=is_attr.astype(np.int64).reshape(-1, 1)))
+    y_arr = rng.integers(0, num_vocab, (B, max_seq_len)).astype(np.int64)
+    for g, y in zip(graphs, y_arr):
+        g["y_arr"] = y.reshape(1, -1)
+    return sizes, graphs
+
+
+def code2_raw(B=256, seed=0, mean_nodes=105.0, sigma=0.6, min_nodes=11, max_nodes=2000,
+              num_nodetypes=98, num_nodeattributes=10030, num_vocab=5002, max_seq_len=5):
+    """List of raw graphs (numpy dicts) for data.GraphStore; collating graphs 0..B-1 of it on the device
+    reproduces code2_like(B, seed) exactly."""
+    return _code2_graphs(B, seed, mean_nodes, sigma, min_nodes, max_nodes, num_nodetypes, num_nodeattributes,
+                         num_vocab, max_seq_len)[1]
+
+
+def code2_like(B=256, seed=0, mean_nodes=105.0, sigma=0.6, min_nodes=11, max_nodes=2000,
+               num_nodetypes=98, num_nodeattributes=10030, num_vocab=5002, max_seq_len=5):
+    sizes, graphs = _code2_graphs(B, seed, mean_nodes, sigma, min_nodes, max_nodes, num_nodetypes,
+                                  num_nodeattributes, num_vocab, max_seq_len)
+    xs, eis, eas, depths = [], [], [], []
+    for g in graphs:
+        ast = g["edge_index"]
+        attributed = np.nonzero(g["node_is_attributed"].reshape(-1))[0]
         nt = np.stack([attributed[:-1], attributed[1:]]) if attributed.size > 1 else np.zeros((2, 0), np.int64)
         ei = np.concatenate([ast, ast[::-1], nt, nt[::-1]], axis=1)
         ea = np.concatenate([
             np.zeros((ast.shape[1], 2)), np.stack([np.zeros(ast.shape[1]), np.ones(ast.shape[1])], 1),
             np.stack([np.ones(nt.shape[1]), np.zeros(nt.shape[1])], 1), np.ones((nt.shape[1], 2))], 0).astype(np.float32)
-        x = np.stack([rng.integers(0, num_nodetypes, n), rng.integers(0, num_nodeattributes, n)], 1).astype(np.int64)
-        xs.append(x); eis.append(ei); eas.append(ea); depths.append(depth)
-    y_arr = rng.integers(0, num_vocab, (B, max_seq_len)).astype(np.int64)
+        xs.append(g["x"]); eis.append(ei); eas.append(ea); depths.append(g["node_depth"].reshape(-1))
+    y_arr = np.concatenate([g["y_arr"] for g in graphs], 0)
     return _finish(xs, eis, eas, sizes, dict(
         node_depth=torch.from_numpy(np.concatenate(depths).reshape(-1, 1)), y_arr=torch.from_numpy(y_arr)))
 
@@ -79,20 +105,34 @@ def _random_undirected(rng, n, m):
     return np.concatenate([e, e[::-1]], axis=1)
 
 
-def molpcba_like(B=256, seed=0, num_tasks=128):
+def _molpcba_graphs(B, seed, num_tasks):
     rng = np.random.default_rng(seed)
     sizes = np.clip(np.round(rng.normal(26, 6, B)), 2, 332).astype(np.int64)
-    xs, eis, eas = [], [], []
+    graphs = []
     for n in sizes:
         n = int(n)
         ei = _random_undirected(rng, n, int(round(1.08 * n)))
         half = ei.shape[1] // 2
         ea_half = np.stack([rng.integers(0, d, half) for d in BOND_DIMS], 1).astype(np.int64)
-        xs.append(np.stack([rng.integers(0, d, n) for d in ATOM_DIMS], 1).astype(np.int64))
-        eis.append(ei); eas.append(np.concatenate([ea_half, ea_half], 0))
+        x = np.stack([rng.integers(0, d, n) for d in ATOM_DIMS], 1).astype(np.int64)
+        graphs.append(dict(x=x, edge_index=ei, edge_attr=np.concatenate([ea_half, ea_half], 0)))
     y = rng.integers(0, 2, (B, num_tasks)).astype(np.float32)
     y[rng.random((B, num_tasks)) < 0.6] = np.nan
-    return _finish(xs, eis, eas, sizes, dict(y=torch.from_numpy(y)))
+    for g, row in zip(graphs, y):
+        g["y"] = row.reshape(1, -1)
+    return sizes, graphs
+
+
+def molpcba_raw(B=256, seed=0, num_tasks=128):
+    """Raw graphs for data.GraphStore (no per-sample transform for Molpcba, dataset/mol.py)."""
+    return _molpcba_graphs(B, seed, num_tasks)[1]
+
+
+def molpcba_like(B=256, seed=0, num_tasks=128):
+    sizes, graphs = _molpcba_graphs(B, seed, num_tasks)
+    y = np.concatenate([g["y"] for g in graphs], 0)
+    return _finish([g["x"] for g in graphs], [g["edge_index"] for g in graphs], [g["edge_attr"] for g in graphs],
+                   sizes, dict(y=torch.from_numpy(y)))
 
 
 def nci1_like(B=32, seed=0, num_features=37):

@@ -66,6 +66,58 @@ int64_t gt_profile_count(void);
 int gt_profile_get(int64_t index, char* name_out, int64_t name_cap, float* ms, int64_t* dims6);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mini-batch assembly from an HBM-resident graph store.
+ * Replaces: the per-sample `augment_edge` transform (dataset/utils.py:89-141, installed at
+ * dataset/code.py:97-101) and PyG `Batch.from_data_list` behind the DataLoader (main.py:149-152).
+ *
+ * Store = per-graph slices of concatenated int64 arrays: node_ptr/edge_ptr [G+1]; x [Ns][x_cols];
+ * node_depth [Ns] (optional); edge_src/edge_dst [Es] with node ids LOCAL to their graph; edge_attr
+ * [Es][ea_cols] (optional); y [G][y_row_bytes] raw label rows (optional).  attr_rank [Ns+1] (optional) is
+ * the exclusive prefix sum of (node_is_attributed == 1) over all store nodes, built once by
+ * gt_attr_rank; when present the batch is AUGMENTED: per graph the output edges are
+ * [ast, ast^-1, next-token, next-token^-1] and edge_attr_f32 [E][2] = (is next-token, is inverse),
+ * exactly the reference's edge order and values; stored edge_attr is then ignored.
+ *
+ * gt_collate: graph_ids [B] (device) -> x [N][x_cols], node_depth [N], batch [N], ptr [B+1] (optional),
+ * edge_index [2][E] (global ids), edge_attr_f32 or edge_attr_i64 [E][ea_cols], y [B][y_row_bytes].
+ * N and E are the totals over the selected graphs (the caller owns the allocations and knows the
+ * per-graph sizes: E_i = e_i, or 2 e_i + 2 max(a_i - 1, 0) when augmenting); graphs that would not
+ * fit the stated N / E are skipped rather than written out of bounds.  Integer-exact.
+ */
+typedef struct gt_graph_store {
+  const int64_t* node_ptr;
+  const int64_t* edge_ptr;
+  const int64_t* x;
+  const int64_t* node_depth;
+  const int64_t* edge_src;
+  const int64_t* edge_dst;
+  const int64_t* edge_attr;
+  const int64_t* attr_rank;
+  const void* y;
+  int64_t y_row_bytes;
+  int64_t num_graphs;
+  int32_t x_cols;
+  int32_t ea_cols;
+} gt_graph_store;
+
+typedef struct gt_collate_out {
+  int64_t* x;
+  int64_t* node_depth;   /* optional */
+  int64_t* batch;
+  int64_t* ptr;          /* optional */
+  int64_t* edge_index;
+  float* edge_attr_f32;  /* augmenting stores */
+  int64_t* edge_attr_i64; /* optional, plain stores */
+  void* y;               /* optional */
+} gt_collate_out;
+
+int gt_attr_rank(const int64_t* node_is_attributed, int64_t num_nodes, int64_t* rank, gt_stream_t stream);
+size_t gt_collate_workspace_bytes(int64_t num_graphs);
+int gt_collate(const gt_graph_store* store, const int64_t* graph_ids, int64_t num_graphs, int64_t num_nodes,
+               int64_t num_edges, const gt_collate_out* out, void* workspace, size_t workspace_bytes,
+               gt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph structure, built once per collated batch.
  * Replaces: the per-layer `degree(row, N)` (modules/conv.py:57, PyG degree -> scatter_add) and the
  * unsorted atomic scatter of torch-scatter (conv.py:28,63 via MessagePassing.aggregate) with a

@@ -394,8 +394,71 @@ def g10_struct():
         print(f"G10_struct_{name}")
 
 
+def pack_store(graphs):
+    """Flatten raw graphs into the store layout data.GraphStore uses (node_ptr/edge_ptr + concatenated arrays)."""
+    d = {"node_ptr": np.concatenate([[0], np.cumsum([g["x"].shape[0] for g in graphs])]).astype(np.int64),
+         "edge_ptr": np.concatenate([[0], np.cumsum([g["edge_index"].shape[1] for g in graphs])]).astype(np.int64),
+         "x": np.concatenate([g["x"] for g in graphs], 0),
+         "edge_index": np.concatenate([g["edge_index"] for g in graphs], 1)}
+    for k in ("node_depth", "node_is_attributed", "edge_attr", "y", "y_arr"):
+        if k in graphs[0]:
+            d[k] = np.concatenate([g[k] for g in graphs], 0)
+    return d
+
+
+def g11_collate():
+    """augment_edge (dataset/utils.py:89-141) run by the reference itself, per graph; the batch is then
+    assembled by the PyG collation rule restated in oracle/collate.py (PyG is not importable here)."""
+    from oracle import collate as oc
+
+    class Data:  # augment_edge only touches attributes
+        pass
+
+    rng = np.random.default_rng(11)
+    graphs = synth.code2_raw(B=5, seed=4, mean_nodes=20.0, max_nodes=60)
+    one = dict(x=np.array([[3, 7]], np.int64), edge_index=np.zeros((2, 0), np.int64), node_depth=np.zeros((1, 1), np.int64),
+               node_is_attributed=np.ones((1, 1), np.int64), y_arr=rng.integers(0, 50, (1, 5)))
+    none_attr = {k: v.copy() for k, v in graphs[1].items()}
+    none_attr["node_is_attributed"][:] = 0
+    single_attr = {k: v.copy() for k, v in graphs[2].items()}
+    single_attr["node_is_attributed"][:] = 0
+    single_attr["node_is_attributed"][4] = 1
+    graphs = graphs + [one, none_attr, single_attr]
+    ids = np.array([3, 0, 6, 7, 5, 2, 1, 4], np.int64)
+    aug = []
+    for g in graphs:
+        d = Data()
+        d.edge_index = torch.from_numpy(g["edge_index"])
+        d.node_is_attributed = torch.from_numpy(g["node_is_attributed"])
+        d = _du.augment_edge(d)
+        ei, ea = d.edge_index.numpy(), d.edge_attr.numpy()
+        ei2, ea2 = oc.augment_edge(g["edge_index"], g["node_is_attributed"])
+        assert ei.dtype == np.int64 and ea.dtype == np.float32
+        assert np.array_equal(ei, ei2) and np.array_equal(ea, ea2), "oracle/collate.py disagrees with the reference"
+        aug.append(dict(g, edge_index=ei, edge_attr=ea))
+    out = oc.collate([aug[i] for i in ids])
+    d = {"meta": np.array(json.dumps(dict(kind="collate", augment=True))), "in.ids": ids}
+    d.update({"store." + k: v for k, v in pack_store(graphs).items()})
+    d.update({"out." + k: v for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "G11_collate_code2.npz"), **d)
+    print("G11_collate_code2")
+
+    graphs = synth.molpcba_raw(B=9, seed=5)
+    ids = np.array([8, 2, 2, 0, 5], np.int64)
+    out = oc.collate([graphs[i] for i in ids])
+    d = {"meta": np.array(json.dumps(dict(kind="collate", augment=False))), "in.ids": ids}
+    d.update({"store." + k: v for k, v in pack_store(graphs).items()})
+    d.update({"out." + k: v for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "G11_collate_mol.npz"), **d)
+    print("G11_collate_mol")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:   # regenerate selected groups only, e.g. `make_golden.py g11_collate`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_g2_convs()
     g3_g4_gnn()
     g5_pad()
