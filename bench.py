@@ -104,6 +104,45 @@ def build(workload, dtype, device, batch_graphs):
     return args, model.to(device), gen, loss, name
 
 
+RAW_GEN = {"code2": "code2_raw", "code2-pna": "code2_raw", "molpcba": "molpcba_raw"}   # synth generators
+
+
+def make_store(workload, num_graphs, seed):
+    from graphtrans_amd.data import GraphStore
+    if workload not in RAW_GEN:
+        raise SystemExit("--from-store: no raw graph store for workload %r" % workload)
+    from graphtrans_amd import synth
+    return GraphStore(getattr(synth, RAW_GEN[workload])(B=num_graphs, seed=seed))
+
+
+def collate_report(workload, per_gpu, with_cpu):
+    """Batch assembly beside the step (collation is reported separately): device = gt_collate from the
+    HBM store (sample -> augment_edge -> concatenate), cpu = the numpy restatement of the reference's per-sample
+    transform + PyG collation (oracle/collate.py) on the same graphs, one thread."""
+    from graphtrans_amd import synth
+    from graphtrans_amd.data import GraphStore
+    raw = getattr(synth, RAW_GEN[workload])(B=2 * per_gpu, seed=77)
+    store = GraphStore(raw)
+    rng = np.random.default_rng(0)
+    ids = [rng.permutation(len(raw))[:per_gpu] for _ in range(20)]
+    for i in ids[:3]:
+        store.collate(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in ids:
+        store.collate(i)
+    torch.cuda.synchronize()
+    rep = {"device_us_per_batch": round((time.perf_counter() - t0) / len(ids) * 1e6, 1), "graphs": per_gpu,
+           "store_mb": round(store.nbytes() / 1e6, 1)}
+    if with_cpu:
+        from oracle import collate as oc
+        t0 = time.perf_counter()
+        for i in ids[:3]:
+            oc.collate([raw[j] for j in i], augment=store.augment)
+        rep["cpu_us_per_batch"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
+    return rep
+
+
 def attach_sizes(b):
     b._sizes = torch.bincount(b.batch, minlength=b.num_graphs).numpy()
     return b
@@ -235,6 +274,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--from-store", action="store_true",
+                    help="assemble every batch on the device from an HBM graph store inside the timed step "
+                         "(gt_collate: sampling + augment_edge + collation; code2 / molpcba / code2-pna)")
     opt = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,10 +308,17 @@ def main():
     optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams
     batches = [attach_sizes(gen(1000 * rank + i)).to(device) for i in range(4)]  # .to() keeps the host-side sizes
+    store = None
+    if opt.from_store:
+        store = make_store(opt.workload, 4 * per_gpu, 1000 * rank)
+        sampler = np.random.default_rng(rank)
 
     def step(i):
-        b = batches[i % len(batches)]
-        b.__dict__.pop("_gt_structure", None)  # graph_prep is part of the step
+        if store is not None:
+            b = store.collate(sampler.permutation(len(store))[:per_gpu])
+        else:
+            b = batches[i % len(batches)]
+            b.__dict__.pop("_gt_structure", None)  # graph_prep is part of the step
         sync.zero()
         out = model(b)
         loss = loss_fn(out, b)
@@ -327,7 +376,7 @@ def main():
             "config": {"workload": wl_name, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
-                       "step": "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
+                       "step": ("collate+" if store is not None else "") + "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
                        "gnn_dtype": "fp32 storage, %s MFMA linears" % opt.dtype, "transformer_dtype": opt.dtype,
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
@@ -352,6 +401,8 @@ def main():
                 r["kernel"] = dom
                 res["roofline"] = r
                 res["kernels"] = rep
+        if opt.workload in RAW_GEN:
+            res["collate"] = collate_report(opt.workload, per_gpu, with_cpu=(world == 1 and not opt.no_cpu_baseline))
         if world == 1 and not opt.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opt.workload, model, args)
         print(json.dumps(res))
