@@ -98,6 +98,7 @@ SIGNATURES = {
     "gt_gin_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_add3": (_i, [_p, _p, _p, _i64, _p, _p]),
     "gt_copy2d": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "gt_repitch": (_i, [_p, _i64, _p, _i64, _i64, _i, _p]),
     "gt_rows_gather": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
     "gt_rows_scatter": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_attn_fwd": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _f, _f, _f, _u64, _p]),

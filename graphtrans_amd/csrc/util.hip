@@ -50,6 +50,17 @@ __global__ void __launch_bounds__(UT) k_add3(const float* __restrict__ a, const 
   }
 }
 
+// dst[r][c] = c < src_cols ? src[r][c] : 0, contiguous rows of dst_cols / src_cols elements (any counts)
+template <typename U>
+__global__ void __launch_bounds__(UT) k_repitch(U* __restrict__ dst, int64_t dst_cols, const U* __restrict__ src,
+                                                int64_t src_cols, int64_t rows) {
+  const int64_t total = rows * dst_cols;
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
+    const int64_t r = i / dst_cols, c = i % dst_cols;
+    dst[i] = c < src_cols ? src[r * src_cols + c] : (U)0;
+  }
+}
+
 int grid_for(int64_t items) {
   int64_t g = gt_cdiv(items, UT);
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -66,6 +77,22 @@ extern "C" int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, in
                 (uintptr_t)width_bytes) % 16 == 0, "pointers, pitches and width must be multiples of 16 bytes");
   hipLaunchKernelGGL(k_copy2d, dim3(grid_for(rows * (width_bytes / 16))), dim3(UT), 0, (hipStream_t)stream_, (char*)dst,
                      dst_pitch_bytes, (const char*)src, src_pitch_bytes, width_bytes / 16, rows);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_repitch(void* dst, int64_t dst_cols, const void* src, int64_t src_cols, int64_t rows, int elt_bytes,
+                          gt_stream_t stream_) {
+  GT_CHECK_ARG(rows >= 0 && dst_cols >= 0 && src_cols >= 0, "bad sizes");
+  GT_CHECK_ARG(elt_bytes == 2 || elt_bytes == 4, "elt_bytes must be 2 or 4");
+  if (rows == 0 || dst_cols == 0) return GT_OK;
+  GT_CHECK_ARG(dst && (src || src_cols == 0), "null buffer");
+  if (elt_bytes == 4)
+    hipLaunchKernelGGL(k_repitch<uint32_t>, dim3(grid_for(rows * dst_cols)), dim3(UT), 0, (hipStream_t)stream_, (uint32_t*)dst,
+                       dst_cols, (const uint32_t*)src, src_cols, rows);
+  else
+    hipLaunchKernelGGL(k_repitch<uint16_t>, dim3(grid_for(rows * dst_cols)), dim3(UT), 0, (hipStream_t)stream_, (uint16_t*)dst,
+                       dst_cols, (const uint16_t*)src, src_cols, rows);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -72,11 +72,18 @@ class _Plan:
             self.embed = [ne.type_encoder.weight, ne.attribute_encoder.weight, ne.depth_encoder.weight]
             self.embed_clamp = [-1, -1, int(ne.max_depth)]
             self.embed_kind = "ast"
+        elif type(ne) is torch.nn.Linear:   # TU datasets / the ER stress: dense float features (dataset/tud.py:65)
+            self.embed, self.embed_clamp, self.embed_kind = [], [], "linear"
+            self.ne_lin = ne
+            self.ne_K = int(ne.in_features)
+            self.ne_Kp = _c4(self.ne_K)
         else:
             self.embed = [e.weight for e in ne.atom_embedding_list]
             self.embed_clamp = [-1] * len(self.embed)
             self.embed_kind = "atom"
         self.embed_off = [seg(t) for t in self.embed]
+        if self.embed_kind == "linear":
+            self.ne_off = [seg(ne.weight), seg(ne.bias)]
         self.vn_emb = gnn.virtualnode_embedding.weight if self.has_vn else None
         self.vn_emb_off = seg(self.vn_emb) if self.has_vn else None
         # conv layers.  Gradient block order of gt_gcn_layer_bwd: lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b;
@@ -265,6 +272,11 @@ def eligible(model, batched_data, perturb):
     if not ok:
         return False
     x = batched_data.x
+    ne = model.gnn_node.node_encoder
+    if type(ne) is torch.nn.Linear:
+        # (features that require a gradient go through the module path: the fused node only differentiates parameters)
+        return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == ne.in_features \
+            and not x.requires_grad and getattr(batched_data, "node_depth", None) is None
     return x.is_cuda and x.dtype == torch.int64 and x.dim() == 2
 
 
@@ -277,7 +289,10 @@ def _eligible_static(model):
         if not model._use_packed() or gnn.JK not in ("last", "cat"):
             return False
         ne = gnn.node_encoder
-        if not (hasattr(ne, "type_encoder") or hasattr(ne, "atom_embedding_list")):
+        if type(ne) is torch.nn.Linear:
+            if ne.bias is None:
+                return False
+        elif not (hasattr(ne, "type_encoder") or hasattr(ne, "atom_embedding_list")):
             return False
         if hasattr(ne, "atom_embedding_list") and len(ne.atom_embedding_list) > 16:
             return False
@@ -429,6 +444,9 @@ class _FusedModel(torch.autograd.Function):
             o["sto"] = b.take(2 * rows * 4)
         tab_rows_total = sum(plan.table_rows)
         o["etab"] = b.take(tab_rows_total * D * 4)
+        if plan.embed_kind == "linear" and plan.ne_Kp != plan.ne_K:   # K-padded copies of x and W (16-byte chunks)
+            o["ne_x"] = b.take(N * plan.ne_Kp * 4)
+            o["ne_w"] = b.take(D * plan.ne_Kp * 4)
         o["hg"] = b.take(B * d * 4)
         o["wcat"] = b.take(plan.Nh * d * 4)
         o["bcat"] = b.take(plan.Nh * 4)
@@ -455,16 +473,28 @@ class _FusedModel(torch.autograd.Function):
         # ---- input encoder: h0 = sum of embedding rows   (dataset/utils.py:28-30 / ogb AtomEncoder)
         x = batched_data.x
         T = len(plan.embed)
-        if plan.embed_kind == "ast":
+        ne_x = ne_w = None
+        if plan.embed_kind == "linear":   # h0 = x W^T + b on the MFMA GEMM (K zero-padded to 16-byte chunks)
+            x = x.contiguous()
+            nl, K, Kp = plan.ne_lin, plan.ne_K, plan.ne_Kp
+            ne_x, ne_w = x.data_ptr(), nl.weight.data_ptr()
+            if Kp != K:
+                ne_x, ne_w = P("ne_x"), P("ne_w")
+                _call("gt_repitch", ne_x, Kp, x.data_ptr(), K, N, 4, st)
+                _call("gt_repitch", ne_w, Kp, nl.weight.data_ptr(), K, D, 4, st)
+            _call("gt_linear_fwd", GT_F32, GT_F32, compute, ne_x, ne_w, nl.bias.data_ptr(), P("h", 0), N, D, Kp, 0, 0.0, 0, st)
+            e_idx = e_str = e_clamp = cols = None
+        elif plan.embed_kind == "ast":
             depth = batched_data.node_depth.reshape(-1)
             cols = [(x.data_ptr(), x.stride(0)), (x.data_ptr() + 8 * x.stride(1), x.stride(0)), (depth.data_ptr(), depth.stride(0) if N > 1 else 1)]
         else:
             cols = [(x.data_ptr() + 8 * i * x.stride(1), x.stride(0)) for i in range(T)]
-        I64, PT = C.c_int64 * T, C.c_void_p * T
-        e_idx, e_str = PT(*[c[0] for c in cols]), I64(*[c[1] for c in cols])
-        e_clamp = I64(*plan.embed_clamp)
-        e_tabs = PT(*[t.data_ptr() for t in plan.embed])
-        _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
+        if plan.embed_kind != "linear":
+            I64, PT = C.c_int64 * T, C.c_void_p * T
+            e_idx, e_str = PT(*[c[0] for c in cols]), I64(*[c[1] for c in cols])
+            e_clamp = I64(*plan.embed_clamp)
+            e_tabs = PT(*[t.data_ptr() for t in plan.embed])
+            _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
 
         # ---- message passing   (modules/gnn_module.py:181-224)
         if plan.has_vn:
@@ -542,7 +572,7 @@ class _FusedModel(torch.autograd.Function):
         snap = lambda ds: [type(x_).from_buffer_copy(x_) for x_ in ds]
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
-                         embed=(T, e_idx, e_str, e_clamp, cols), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
+                         embed=(T, e_idx, e_str, e_clamp, cols), ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
                          dims=(N, E, B, rows), sync=model.__dict__.get("_gt_sync"))
         ctx.set_materialize_grads(False)
         out = logits[:, :plan.Nh] if plan.ldy != plan.Nh else logits
@@ -585,7 +615,11 @@ class _FusedModel(torch.autograd.Function):
         ln_ws = lib.gt_layernorm_bwd_workspace_bytes(rows, d)
         lin_ws = max(lib.gt_linear_bwd_workspace_bytes(compute, B, plan.Nh, d), lib.gt_linear_bwd_workspace_bytes(compute, N, d, Kc))
         emb_rows = (C.c_int64 * len(plan.embed))(*[t.shape[0] for t in plan.embed])
-        emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
+        if plan.embed_kind == "linear":
+            emb_ws = lib.gt_linear_bwd_workspace_bytes(compute, N, D, plan.ne_Kp)
+            q["ne_dw"] = b.take(D * plan.ne_Kp * 4 if plan.ne_Kp != plan.ne_K else 0)
+        else:
+            emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
         q["ws"] = b.take(ws_bytes)
         q["ws2"] = b.take(s["ws2_bytes"])
@@ -699,9 +733,19 @@ class _FusedModel(torch.autograd.Function):
         if sync is not None:
             sync.reduce_flat(flat, gnn_lo, plan.g2t_off[0])
         # ---- input encoder tables
-        T, e_idx, e_str, e_clamp, _cols = s["embed"]
-        d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
-        _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
+        if plan.embed_kind == "linear":   # dW = d_h0^T x, db = colsum(d_h0); the features need no gradient
+            ne_x, ne_w = s["ne"]
+            K, Kp = plan.ne_K, plan.ne_Kp
+            dw = G + plan.ne_off[0] * 4 if Kp == K else Q("ne_dw")
+            _call("gt_linear_bwd", GT_F32, GT_F32, s["compute"], ne_x, ne_w, d_h0, None, None, None, None, dw,
+                  G + plan.ne_off[1] * 4, N, D, Kp, 0.0, Q("ws"), ws_bytes, st)
+            dw_sync()
+            if Kp != K:
+                _call("gt_repitch", G + plan.ne_off[0] * 4, K, dw, Kp, D, 4, st)
+        else:
+            T, e_idx, e_str, e_clamp, _cols = s["embed"]
+            d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
+            _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
 
         if sync is not None:
             sync.reduce_flat(flat, 0, gnn_lo)

@@ -33,6 +33,8 @@ def _encode_nodes(node_encoder, batched_data):
     node_depth = batched_data.node_depth if hasattr(batched_data, "node_depth") else None
     if node_encoder is None:
         return x
+    if type(node_encoder) is torch.nn.Linear and node_depth is None and x.is_cuda and x.dim() == 2:
+        return ops.linear_module(node_encoder, x)   # TU datasets: nn.Linear(F, D) (dataset/tud.py:65) on the HIP GEMM
     return node_encoder(x) if node_depth is None else node_encoder(x, node_depth.view(-1))
 
 

@@ -500,23 +500,44 @@ def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None
     return _Linear.apply(x, weight, bias, a, float(dropout_p), int(seed), compute, out_dtype, ldy)
 
 
+class _PadCols(torch.autograd.Function):
+    """(rows, K) -> (rows, Kp >= K), zero filled; the adjoint drops the padding columns (gt_repitch)."""
+
+    @staticmethod
+    def forward(ctx, x, cols):
+        x = _dev(x, "x")
+        out = torch.empty((x.shape[0], cols), dtype=x.dtype, device=x.device)
+        _lib.launch("gt_repitch", _ptr(out), cols, _ptr(x), x.shape[1], x.shape[0], x.element_size(), _stream())
+        ctx.k = x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        out = torch.empty((g.shape[0], ctx.k), dtype=g.dtype, device=g.device)
+        _lib.launch("gt_repitch", _ptr(out), ctx.k, _ptr(g), g.shape[1], g.shape[0], g.element_size(), _stream())
+        return out, None
+
+
+def pad_cols(x, cols):
+    return x if x.shape[1] == cols else _PadCols.apply(x, cols)
+
+
 def linear_module(mod, x, act=None, dropout_p=0.0, seed=0):
-    """Apply an nn.Linear through the HIP kernel when its shape is supported (K a multiple of 4 / 8;
-    an odd N is written into row-padded storage), else through torch's GEMM (e.g. the 37-feature TU
-    node encoder)."""
-    if linear_supported(x, mod.weight):
-        return linear(x, mod.weight, mod.bias, act=act, dropout_p=dropout_p, seed=seed)
+    """Apply an nn.Linear through the HIP GEMM.  The kernel moves 16-byte chunks: an output width N that is
+    not a multiple of 4 (fp32) / 8 (bf16) is written into row-padded storage; an input width K that is not
+    (the 37-feature TU node encoder, dataset/tud.py:65) gets x and W zero-padded along K, which leaves every
+    product unchanged."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or x.shape[-1] != mod.weight.shape[1]:
+        raise RuntimeError("graphtrans_amd.ops.linear_module: expected a 2-D fp32/bf16 GPU tensor of %d features, got %s %s on %s "
+                           "(no CPU / eager fallback)" % (mod.weight.shape[1], tuple(x.shape), x.dtype, x.device))
     q = 8 if x.dtype == torch.bfloat16 else 4
-    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] == mod.weight.shape[1] \
-            and mod.weight.shape[1] % q == 0 and x.dim() == 2:
-        N = mod.weight.shape[0]
-        return linear(x, mod.weight, mod.bias, act=act, dropout_p=dropout_p, seed=seed, ldy=(N + q - 1) // q * q)
-    y = torch.nn.functional.linear(x, mod.weight.to(x.dtype), None if mod.bias is None else mod.bias.to(x.dtype))
-    if act == "relu":
-        y = torch.relu(y)
-    if dropout_p > 0:
-        y = torch.nn.functional.dropout(y, dropout_p, True)
-    return y
+    N, K = mod.weight.shape
+    w = mod.weight
+    if K % q:
+        Kp = (K + q - 1) // q * q
+        x, w = pad_cols(x.contiguous(), Kp), pad_cols(w, Kp)
+    return linear(x, w, mod.bias, act=act, dropout_p=dropout_p, seed=seed, ldy=None if N % q == 0 else (N + q - 1) // q * q)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -508,7 +508,12 @@ int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void
  * gt_rows_gather: out[i] (fp32) = x[idx[i]] -- transformer_out[-1] of every sequence for the cls / last
  *   pooling (models/gnn_transformer.py:113-114); gt_rows_scatter: its adjoint into a zeroed
  *   [total_rows][dim] buffer of the given dtype (idx must not repeat).
+ * gt_repitch: dst[r][c] = c < src_cols ? src[r][c] : 0 for c < dst_cols (contiguous rows, 2- or 4-byte elements):
+ *   zero-pads / truncates the columns of a feature matrix or weight whose width is not a multiple of the
+ *   16-byte chunk the GEMM needs (the 37-feature TU node encoder nn.Linear(F, D), dataset/tud.py:65).
  */
+int gt_repitch(void* dst, int64_t dst_cols, const void* src, int64_t src_cols, int64_t rows, int elt_bytes,
+               gt_stream_t stream);
 int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes, int64_t width_bytes,
               int64_t rows, gt_stream_t stream);
 int gt_add3(const float* a, const float* b, const float* c /* or NULL */, int64_t n, float* out, gt_stream_t stream);

@@ -237,3 +237,45 @@ def test_fused_gin_model_matches_module_path(kw):
             assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-4, atol=1e-6), n
     finally:
         ops.set_matmul_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("case", ["tud", "tud_bf16", "er"])
+def test_fused_model_dense_node_features(case):
+    """nn.Linear node encoders (dataset/tud.py:65): 37 one-hot features with the TU "no edge features" encoder
+    (K zero-padded to 40 for the GEMM), and 64 dense features with Code2-style edges (the ER stress layout)."""
+    from graphtrans_amd import engine, losses, ops, synth
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    bf16 = case.endswith("bf16")
+    args = _args(max_seq_len=None, gnn_virtual_node=False, gnn_JK="last", compute_dtype=torch.bfloat16 if bf16 else torch.float32)
+    ops.set_matmul_dtype(torch.bfloat16 if bf16 else torch.float32)
+    try:
+        torch.manual_seed(0)
+        if case.startswith("tud"):
+            zero = lambda d: (lambda _e: 0)   # dataset/tud.py:67-71
+            model = GNNTransformer(2, torch.nn.Linear(37, 64), zero, args).to(DEV)
+            b = synth.nci1_like(B=16, seed=3).to(DEV)
+        else:
+            model = GNNTransformer(2, torch.nn.Linear(64, 64), lambda d: torch.nn.Linear(2, d), args).to(DEV)
+            b = synth.er_stress(B=6, seed=3, n=40, avg_deg=4.0, feat_dim=64).to(DEV)
+        y = b.y
+        model.train()
+        assert engine.eligible(model, b, None)
+
+        def run(m, fused):
+            m.fused = fused
+            for p in m.parameters():
+                p.grad = None
+            torch.manual_seed(9)
+            loss = losses.tud_loss(m(b), y)
+            loss.backward()
+            return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+        l0, g0 = run(copy.deepcopy(model), False)
+        l1, g1 = run(model, True)
+        tol = dict(rtol=2e-2, atol=2e-3) if bf16 else dict(rtol=1e-4, atol=1e-6)
+        assert torch.allclose(l0, l1, **tol), (l0, l1)
+        for n in g0:
+            scale = max(1.0, float(g0[n].abs().max()))
+            assert torch.allclose(g0[n] / scale, g1[n] / scale, **tol), (n, (g0[n] - g1[n]).abs().max())
+    finally:
+        ops.set_matmul_dtype(torch.float32)

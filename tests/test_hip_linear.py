@@ -132,3 +132,26 @@ def test_linear_padded_rows_and_split_dx(M, N, K, mode):
     assert_close(xd.grad.cpu(), xr.grad, atol=tol, rtol=tol, what="dx")
     assert_close(wd.grad.cpu(), wr.grad, atol=tol, rtol=tol, what="dw")
     assert_close(bd.grad.cpu(), br.grad, atol=tol, rtol=tol, what="db")
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 64, 37), (33, 6, 5), (1, 128, 1)])
+def test_linear_module_odd_K(M, N, K):
+    """K not a multiple of the 16-byte chunk (TU node encoder, 37 features): x and W are zero-padded along K by
+    gt_repitch; outputs and all three gradients equal the plain fp32 GEMM (no torch fallback)."""
+    from graphtrans_amd import ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(K, N).cuda()
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    y = ops.linear_module(lin, x)
+    g = torch.randn(M, N, device="cuda")
+    y.backward(g)
+    xr = x.detach().double().requires_grad_()
+    w, b = lin.weight.detach().double().requires_grad_(), lin.bias.detach().double().requires_grad_()
+    yr = torch.nn.functional.linear(xr, w, b)
+    yr.backward(g.double())
+    assert y.shape == (M, N)
+    for got, want in ((y, yr), (x.grad, xr.grad), (lin.weight.grad, w.grad), (lin.bias.grad, b.grad)):
+        assert got.shape == want.shape
+        assert (got.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    with pytest.raises(RuntimeError):
+        ops.linear_module(lin.cpu(), x.detach().cpu())
