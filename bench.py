@@ -238,6 +238,14 @@ def cpu_baseline(workload, model, args, sample_graphs=64, iters=2, threads=16, b
     elif workload == "code2-pna":
         b = synth.code2_like(B=sample_graphs, seed=0)
         fwd, loss_of, what = rm.pna_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like (PNA)"
+    elif workload == "nci1":   # BASELINE configs[0]: the reference's own CPU-runnable case
+        sample_graphs = 256
+        b = synth.nci1_like(B=sample_graphs, seed=0)
+        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "NCI1-like"
+    elif workload == "er":
+        sample_graphs = 16
+        b = synth.er_stress(B=sample_graphs, seed=0)
+        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "Erdos-Renyi stress"
     else:
         return None
     threads = min(threads, os.cpu_count() or 1)
@@ -271,6 +279,9 @@ def main():
     ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er", "code2-pna"])
     ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch graphs on EVERY GPU (default); strong: --batch is the global batch, split evenly "
+                         "over the GPUs (SURVEY.md 8d: b256 -> 32 graphs per GPU at 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -300,6 +311,10 @@ def main():
     from graphtrans_amd import ops as gt_ops
     gt_ops.set_matmul_dtype(dtype)  # GNN linears: fp32 storage, MFMA compute type follows --dtype
     per_gpu = opt.batch or {"nci1": 32, "code2-pna": 128}.get(opt.workload, 256)
+    if opt.scaling == "strong":
+        if per_gpu % world:
+            raise SystemExit("--scaling strong: the global batch %d does not divide over %d GPUs" % (per_gpu, world))
+        per_gpu //= world
     torch.manual_seed(1234)  # identical initial parameters on every rank
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()
@@ -372,7 +387,7 @@ def main():
             "metric": "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}",
             "value": round(total_graphs / elapsed, 1), "unit": "graphs/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
+            "scaling": opt.scaling, "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
             "config": {"workload": wl_name, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
