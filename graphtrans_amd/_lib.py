@@ -69,6 +69,8 @@ SIGNATURES = {
     "gt_linear_bwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_xent_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "gt_xent_bwd": (_i, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "gt_bce_masked_fwd": (_i, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
+    "gt_bce_masked_bwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "gt_linear_bwd_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "gt_linear_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     # composite layers (descriptor structs are passed by pointer; see graphtrans_amd/layers.py)

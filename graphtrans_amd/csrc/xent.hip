@@ -97,7 +97,85 @@ __global__ void __launch_bounds__(XT) k_xent_bwd(const float* __restrict__ logit
     for (int64_t c = L * C + threadIdx.x; c < ld; c += XT) dlogits[b * ld + c] = 0.f;
 }
 
+// ---- masked binary cross-entropy with logits (the Molpcba loss, dataset/mol.py:24-31) ---------------------
+//   is_labeled = y == y;  loss = BCEWithLogitsLoss()(pred[is_labeled], y[is_labeled])   (mean over labelled entries)
+//   k_bce_row : per graph row: sum and count of the labelled entries
+//   k_bce_mean: fixed-order totals; loss = S / den with den = the local count, or a caller-supplied
+//               denominator (data parallel: the global count / world size keeps the averaged gradient exact)
+//   k_bce_bwd : dlogits = labelled ? (sigmoid(x) - y) * grad / den : 0
+__device__ __forceinline__ float bce_logits(float x, float y) {
+  return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+__global__ void __launch_bounds__(XT) k_bce_row(const float* __restrict__ logits, const float* __restrict__ target,
+                                                int64_t T, int64_t ld, int64_t tld, float* __restrict__ row_sum,
+                                                float* __restrict__ row_cnt) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  float s = 0.f, n = 0.f;
+  for (int64_t t = threadIdx.x; t < T; t += XT) {
+    const float y = target[b * tld + t];
+    if (y == y) { s += bce_logits(logits[b * ld + t], y); n += 1.f; }
+  }
+  s = block_sum(s, red);
+  n = block_sum(n, red);
+  if (threadIdx.x == 0) { row_sum[b] = s; row_cnt[b] = n; }
+}
+
+__global__ void __launch_bounds__(XT) k_bce_mean(const float* __restrict__ row_sum, const float* __restrict__ row_cnt,
+                                                 int64_t B, const float* __restrict__ den_in, float* __restrict__ out2) {
+  __shared__ float red[4];
+  float s = 0.f, n = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += XT) { s += row_sum[b]; n += row_cnt[b]; }
+  s = block_sum(s, red);
+  n = block_sum(n, red);
+  if (threadIdx.x == 0) {
+    const float den = den_in ? *den_in : n;
+    out2[0] = s / den;  // 0 / 0 = NaN like torch's mean over an empty selection
+    out2[1] = den;
+  }
+}
+
+__global__ void __launch_bounds__(XT) k_bce_bwd(const float* __restrict__ logits, const float* __restrict__ target,
+                                                const float* __restrict__ out2, const float* __restrict__ grad_loss,
+                                                int64_t T, int64_t ld, int64_t tld, float* __restrict__ dlogits) {
+  const int64_t b = blockIdx.x;
+  const float sc = *grad_loss / out2[1];
+  for (int64_t t = threadIdx.x; t < ld; t += XT) {
+    float d = 0.f;
+    if (t < T) {
+      const float y = target[b * tld + t];
+      if (y == y) d = (1.f / (1.f + expf(-logits[b * ld + t])) - y) * sc;
+    }
+    dlogits[b * ld + t] = d;
+  }
+}
+
 }  // namespace
+
+extern "C" int gt_bce_masked_fwd(const float* logits, const float* target, int64_t B, int64_t T, int64_t ld,
+                                 int64_t target_ld, const float* den_in, float* row_sum, float* row_cnt, float* out2,
+                                 gt_stream_t stream_) {
+  GT_CHECK_ARG(B > 0 && T > 0 && ld >= T && target_ld >= T, "bad sizes");
+  GT_CHECK_ARG(logits && target && row_sum && row_cnt && out2, "null buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  GtProfScope prof__(GT_PROF_NORM, "gt_bce_masked_fwd", stream_, {B, T});
+  hipLaunchKernelGGL(k_bce_row, dim3((unsigned)B), dim3(XT), 0, stream, logits, target, T, ld, target_ld, row_sum, row_cnt);
+  hipLaunchKernelGGL(k_bce_mean, dim3(1), dim3(XT), 0, stream, (const float*)row_sum, (const float*)row_cnt, B, den_in, out2);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_bce_masked_bwd(const float* logits, const float* target, const float* out2, const float* grad_loss,
+                                 int64_t B, int64_t T, int64_t ld, int64_t target_ld, float* dlogits, gt_stream_t stream_) {
+  GT_CHECK_ARG(B > 0 && T > 0 && ld >= T && target_ld >= T, "bad sizes");
+  GT_CHECK_ARG(logits && target && out2 && grad_loss && dlogits, "null buffer");
+  GtProfScope prof__(GT_PROF_NORM, "gt_bce_masked_bwd", stream_, {B, T});
+  hipLaunchKernelGGL(k_bce_bwd, dim3((unsigned)B), dim3(XT), 0, (hipStream_t)stream_, logits, target, out2, grad_loss, T, ld,
+                     target_ld, dlogits);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
 
 extern "C" int gt_xent_fwd(const float* logits, int64_t B, int64_t L, int64_t C, int64_t ld, const int64_t* target,
                            int64_t target_stride, float* lse, float* row_loss, float* head_scale, float* loss,

@@ -18,18 +18,37 @@ def code2_loss(pred_list, y_arr):
     return loss / len(pred_list)
 
 
-def mol_loss(pred, y):
-    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries only.  Written without
-    boolean indexing (`pred[is_labeled]` is a device->host sync on the number of kept entries): the
-    mean over the labelled entries is sum(mask * bce) / sum(mask)."""
-    pred = pred.to(torch.float32)
-    is_labeled = y == y
-    target = torch.where(is_labeled, y.to(torch.float32), torch.zeros((), dtype=torch.float32, device=y.device))
-    per = F.binary_cross_entropy_with_logits(pred, target, reduction="none")
-    m = is_labeled.to(torch.float32)
-    return (per * m).sum() / m.sum()
+def dp_label_denominator(y, group=None):
+    """Global number of labelled entries / world size as a 1-element fp32 tensor (None when not data parallel)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    den = (y == y).sum().to(torch.float32).reshape(1)
+    dist.all_reduce(den, group=group)
+    return den / dist.get_world_size(group)
+
+
+def mol_loss(pred, y, group=None):
+    """dataset/mol.py:24-31: BCE-with-logits over labelled (non-NaN) entries only, mean over them
+    (`ops.masked_bce`: no boolean indexing, which would be a device->host sync on the number of kept entries).
+
+    Data parallel (torch.distributed initialised, world > 1): the denominator is the GLOBAL labelled count / world,
+    so that the all-reduce AVERAGE of the rank gradients is the gradient of the global-batch loss (SURVEY.md 8e);
+    the returned value is this rank's share, their mean over ranks is the global loss."""
+    if pred.is_cuda and y.is_cuda:
+        from . import ops
+        return ops.masked_bce(pred.to(torch.float32), y.to(torch.float32), dp_label_denominator(y, group))
+    raise RuntimeError("graphtrans_amd.losses.mol_loss runs on the GPU only (no CPU fallback); "
+                       "the CPU statement is oracle/reference_math.py:mol_loss")
 
 
 def tud_loss(pred, y):
-    """dataset/tud.py:25-27."""
-    return F.cross_entropy(pred, y)
+    """dataset/tud.py:25-27: CrossEntropyLoss()(pred, y) = the one-head case of the fused cross-entropy."""
+    if pred.is_cuda and pred.dim() == 2 and y.dim() == 1:
+        from . import ops
+        p = pred.to(torch.float32)
+        if p.stride(1) != 1:
+            p = p.contiguous()
+        return ops.softmax_xent(p.unsqueeze(1), y.reshape(-1, 1))
+    raise RuntimeError("graphtrans_amd.losses.tud_loss runs on the GPU only (no CPU fallback); "
+                       "the CPU statement is oracle/reference_math.py:tud_loss")

@@ -669,6 +669,42 @@ def softmax_xent(stacked, target):
     return _Xent.apply(stacked, target)
 
 
+class _MaskedBce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, y, den):
+        B, T = pred.shape
+        if pred.dtype != torch.float32 or pred.stride(1) != 1 or y.dtype != torch.float32 or y.stride(1) != 1:
+            raise TypeError("masked_bce: fp32 (B, T) logits and targets with contiguous rows expected")
+        if not pred.is_cuda:
+            raise RuntimeError("logits must be a GPU tensor: graphtrans_amd has no CPU fallback")
+        ld = pred.stride(0) if B > 1 else T
+        tld = y.stride(0) if B > 1 else T
+        aux = torch.empty(2 * B + 2, dtype=torch.float32, device=pred.device)
+        _lib.launch("gt_bce_masked_fwd", _ptr(pred), _ptr(y), B, T, ld, tld, _ptr(den), _ptr(aux), aux.data_ptr() + 4 * B,
+                    aux.data_ptr() + 8 * B, _stream())
+        ctx.save_for_backward(pred, y, aux)
+        ctx.ld, ctx.tld = ld, tld
+        return aux[2 * B].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, y, aux = ctx.saved_tensors
+        B, T = pred.shape
+        g = g.to(torch.float32).contiguous()
+        buf = torch.empty((B, ctx.ld), dtype=torch.float32, device=pred.device)
+        _lib.launch("gt_bce_masked_bwd", _ptr(pred), _ptr(y), aux.data_ptr() + 8 * B, _ptr(g), B, T, ctx.ld, ctx.tld, _ptr(buf),
+                    _stream())
+        return buf[:, :T], None, None
+
+
+def masked_bce(pred, y, den=None):
+    """BCEWithLogitsLoss over the labelled (non-NaN) entries of y (dataset/mol.py:24-31) in two launches, backward in
+    one; `den` (1-element fp32 GPU tensor) replaces the local labelled count as the denominator."""
+    if pred.dim() != 2 or pred.shape != y.shape:
+        raise TypeError("masked_bce: (B, T) logits and targets of the same shape expected")
+    return _MaskedBce.apply(pred, y, den)
+
+
 # ------------------------------------------------------------------------------------------------
 # per-tower linears (PNAConv's pre_nns / post_nns): column slices in, column slices out
 # ------------------------------------------------------------------------------------------------

@@ -392,6 +392,20 @@ int gt_xent_bwd(const float* logits, const float* lse, const float* head_scale, 
                 int64_t target_stride, const float* grad_loss, int64_t B, int64_t L, int64_t C, int64_t ld,
                 float* dlogits, gt_stream_t stream);
 
+/* Masked binary cross-entropy with logits (the Molpcba loss, dataset/mol.py:24-31: BCEWithLogitsLoss over
+ * the entries with y == y, i.e. not NaN).  logits [B][ld] fp32 (T <= ld columns used), target [B][target_ld]
+ * fp32 with NaN = unlabelled.
+ *   fwd: row_sum / row_cnt [B]; out2 = { loss = S / den, den }, den = number of labelled entries, or
+ *        *den_in when given (data parallel: global count / world size, so that the rank-averaged gradient is
+ *        the gradient of the global mean); no labelled entry -> NaN like torch
+ *   bwd: dlogits [B][ld] = labelled ? (sigmoid(x) - y) * grad_loss[0] / den : 0 (pad columns zeroed)
+ */
+int gt_bce_masked_fwd(const float* logits, const float* target, int64_t B, int64_t T, int64_t ld, int64_t target_ld,
+                      const float* den_in /* or NULL */, float* row_sum, float* row_cnt, float* out2,
+                      gt_stream_t stream);
+int gt_bce_masked_bwd(const float* logits, const float* target, const float* out2, const float* grad_loss, int64_t B,
+                      int64_t T, int64_t ld, int64_t target_ld, float* dlogits, gt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composite layer entry points: ONE call enqueues every kernel of a layer's forward or backward
  * (the gt_* primitives above, in order, on `stream`).  Purpose: host cost — a training step is

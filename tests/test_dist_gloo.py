@@ -122,3 +122,49 @@ def test_gradsync_flat_buffer_protocol_world2():
     for r in (0, 1):
         for a, b in zip(out[r], ref):
             assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+
+
+def _mol_data():
+    g = torch.Generator().manual_seed(2)
+    pred = torch.randn(8, 5, generator=g)
+    y = (torch.rand(8, 5, generator=g) > 0.5).float()
+    y[torch.rand(8, 5, generator=g) < 0.5] = float("nan")
+    y[0::2, :3] = float("nan")   # rank 0's shard (rows 0, 2, 4, 6) holds far fewer labels than rank 1's
+    return pred, y
+
+
+def _mol_worker(rank, world, port, out):
+    from graphtrans_amd import losses
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pred, y = _mol_data()
+    p, ys = pred[rank::world].clone().requires_grad_(), y[rank::world]
+    den = losses.dp_label_denominator(ys)
+    # what gt_bce_masked_fwd/bwd compute with den_in = den (csrc/xent.hip), stated with torch on the CPU
+    m = ys == ys
+    per = torch.nn.functional.binary_cross_entropy_with_logits(p, torch.where(m, ys, torch.zeros(())), reduction="none")
+    loss = (per * m).sum() / den
+    loss.backward()
+    out[rank] = (float(den), loss.item(), p.grad.clone())
+    dist.destroy_process_group()
+
+
+def test_molpcba_loss_denominator_world2_is_the_global_mean():
+    """the Molpcba loss normalises by the labelled-entry count (dataset/mol.py:25-27); with shards
+    of different counts the rank losses use global count / world so that the AVERAGED gradient is exact."""
+    from oracle import reference_math as rm
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_mol_worker, args=(2, port, out), nprocs=2, join=True)
+    pred, y = _mol_data()
+    pr = pred.clone().requires_grad_()
+    want = rm.mol_loss(pr, y)
+    want.backward()
+    n = float((y == y).sum())
+    assert out[0][0] == out[1][0] == n / 2
+    assert abs((out[0][1] + out[1][1]) / 2 - want.item()) < 1e-6          # mean of the rank losses = global loss
+    for r in (0, 1):                                                       # rank-averaged gradient = global gradient
+        assert torch.allclose(out[r][2] / 2, pr.grad[r::2], atol=1e-7)

@@ -65,3 +65,59 @@ def test_code2_loss_uses_fused_path_and_matches_reference_formula():
     assert_close(loss.detach().cpu().double(), ref.detach(), atol=1e-4, rtol=1e-4, what="loss")
     assert_close(h.grad.cpu().double(), hr.grad, atol=1e-4, rtol=1e-4, what="dh")
     assert all(m.weight.grad is not None and m.bias.grad is not None for m in heads)
+
+
+@pytest.mark.parametrize("B,T,ld", [(256, 128, 128), (7, 5, 8), (1, 3, 3), (300, 1000, 1000)])
+def test_masked_bce_matches_oracle(B, T, ld):
+    """dataset/mol.py:24-31 (oracle/reference_math.py:mol_loss): mean BCE-with-logits over the non-NaN labels."""
+    from graphtrans_amd import losses, ops
+    from oracle import reference_math as rm
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    buf = torch.randn(B, ld, generator=g) * 3
+    y = (torch.rand(B, T, generator=g) > 0.5).float()
+    y[torch.rand(B, T, generator=g) < 0.6] = float("nan")
+    if B > 2:
+        y[1] = float("nan")        # a graph without any label
+    y[0, 0] = 1.0                  # ... but never an empty selection (that case: test_masked_bce_no_labels_is_nan)
+    pred_ref = buf[:, :T].clone().requires_grad_()
+    want = rm.mol_loss(pred_ref, y)
+    want.backward()
+    dbuf = buf.cuda()
+    pred = dbuf[:, :T].requires_grad_()       # rows padded to ld like the head GEMM's output
+    got = losses.mol_loss(pred, y.cuda())
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * max(1.0, abs(want.item()))
+    assert (pred.grad.cpu() - pred_ref.grad).abs().max().item() <= 1e-6
+    # an explicit denominator (the data-parallel global count / world) rescales loss and gradient alike
+    n = float((y == y).sum())
+    p2 = dbuf[:, :T].detach().clone().requires_grad_()
+    l2 = ops.masked_bce(p2, y.cuda(), torch.tensor([2.0 * n], device="cuda"))
+    l2.backward()
+    assert abs(l2.item() * 2 - want.item()) <= 1e-5 * max(1.0, abs(want.item()))
+    assert (p2.grad.cpu() * 2 - pred_ref.grad).abs().max().item() <= 1e-6
+
+
+def test_masked_bce_no_labels_is_nan():
+    from graphtrans_amd import losses
+    pred = torch.randn(4, 8, device="cuda", requires_grad=True)
+    y = torch.full((4, 8), float("nan"), device="cuda")
+    assert torch.isnan(losses.mol_loss(pred, y))
+
+
+@pytest.mark.parametrize("B,C,ld", [(32, 2, 4), (5, 7, 7), (1, 2, 2)])
+def test_tud_loss_is_the_one_head_cross_entropy(B, C, ld):
+    """dataset/tud.py:25-27"""
+    from graphtrans_amd import losses
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randn(B, ld, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    ref = buf[:, :C].clone().requires_grad_()
+    want = torch.nn.functional.cross_entropy(ref, y)
+    want.backward()
+    pred = buf.cuda()[:, :C].requires_grad_()
+    got = losses.tud_loss(pred, y.cuda())
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5
+    assert (pred.grad.cpu() - ref.grad).abs().max().item() <= 1e-6
+    with pytest.raises(RuntimeError):
+        losses.tud_loss(ref, y)
