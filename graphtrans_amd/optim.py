@@ -11,7 +11,10 @@ from .graph import _stream
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, max_grad_norm=None):
+        """max_grad_norm: clip the global gradient norm like `torch.nn.utils.clip_grad_norm_(model.parameters(),
+        args.grad_clip)` before the step (trainers/base_trainer.py:34-35) — two small launches, the coefficient is
+        applied inside the AdamW kernel and `.grad` itself is left unscaled; `last_grad_norm` holds the norm."""
         if amsgrad:
             raise NotImplementedError("FusedAdamW: amsgrad is not supported")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= weight_decay:
@@ -20,6 +23,11 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError(f"invalid betas {betas}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._plans = {}
+        if max_grad_norm is not None and not max_grad_norm > 0:
+            raise ValueError("max_grad_norm must be positive")
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm = None
+        self._clip_buf = None
 
     # ---- per-group launch plan (device tables), rebuilt when a parameter's storage moves ----------
     def _plan(self, gi, group):
@@ -87,16 +95,13 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         MAXT = 384  # GT_ADAMW_MAX_TENSORS
+        work = []
         for gi, group in enumerate(self.param_groups):
             if not any(p.requires_grad for p in group["params"]):
                 continue
             plan = self._plan(gi, group)
-            params, steps = plan["params"], plan["steps"]
-            beta1, beta2 = group["betas"]
+            params = plan["params"]
             grads = [p.grad for p in params]
-            # parameters normally share one step count; those that skipped steps (no gradient, as torch
-            # skips them) form extra launches
-            by_step = {}
             for t, g in enumerate(grads):
                 if g is None:
                     continue
@@ -104,6 +109,35 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW: dense fp32 GPU gradients only")
                 if not g.is_contiguous():
                     grads[t] = g.contiguous()
+            work.append((group, plan, grads))
+        scale_ptr = None
+        if self.max_grad_norm is not None and work:
+            total = sum(plan["tensor_chunk0"][-1] for _, plan, _ in work)
+            dev = work[0][1]["m"].device
+            if self._clip_buf is None or self._clip_buf.numel() < total + 2 or self._clip_buf.device != dev:
+                self._clip_buf = torch.empty(total + 2, dtype=torch.float32, device=dev)
+            buf, off = self._clip_buf, 0
+            for _, plan, grads in work:
+                n = len(plan["params"])
+                for t0 in range(0, n, MAXT):
+                    t1 = min(t0 + MAXT, n)
+                    arr = (C.c_void_p * (t1 - t0))(*[(g.data_ptr() if g is not None else None) for g in grads[t0:t1]])
+                    c0, c1 = plan["tensor_chunk0"][t0], plan["tensor_chunk0"][t1]
+                    _lib.launch("gt_grad_sqnorm", plan["table"].data_ptr(), plan["chunk_tensor"].data_ptr(),
+                                plan["chunk_local"].data_ptr(), c0, c1 - c0, t0, t1 - t0, arr, buf.data_ptr() + 4 * off, _stream())
+                off += plan["tensor_chunk0"][-1]
+            _lib.launch("gt_grad_clip_coef", buf.data_ptr(), total, float(self.max_grad_norm), buf.data_ptr() + 4 * total, _stream())
+            self.last_grad_norm = buf[total]
+            scale_ptr = buf.data_ptr() + 4 * (total + 1)
+        for group, plan, grads in work:
+            params, steps = plan["params"], plan["steps"]
+            beta1, beta2 = group["betas"]
+            # parameters normally share one step count; those that skipped steps (no gradient, as torch
+            # skips them) form extra launches
+            by_step = {}
+            for t, g in enumerate(grads):
+                if g is None:
+                    continue
                 steps[t] += 1
                 by_step.setdefault(steps[t], []).append(t)
             for step, tensors in by_step.items():
@@ -117,7 +151,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     _lib.launch("gt_adamw_step", plan["table"].data_ptr(), plan["chunk_tensor"].data_ptr(),
                                 plan["chunk_local"].data_ptr(), c0, c1 - c0, t0, t1 - t0, arr, float(group["lr"]),
                                 float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), step,
-                                _stream())
+                                scale_ptr, _stream())
         return loss
 
     def _sync_step_tensors(self):

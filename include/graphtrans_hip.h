@@ -555,7 +555,16 @@ int gt_adamw_chunk_elems(void);
 int gt_adamw_step(const gt_adamw_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_local,
                   int64_t chunk_begin, int64_t num_chunks, int tensor_begin, int num_tensors,
                   const float* const* grads_host, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int64_t step, gt_stream_t stream);
+                  int64_t step, const float* grad_scale /* device scalar or NULL */, gt_stream_t stream);
+/* Gradient clipping by global norm (torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_clip),
+ * trainers/base_trainer.py:34-35) without touching the gradients: gt_grad_sqnorm writes one partial sum of
+ * squares per chunk of the same chunk map (partial [total chunks], indexed by absolute chunk id),
+ * gt_grad_clip_coef reduces them in fixed order to out2 = { total_norm, min(1, max_norm / (total_norm + 1e-6)) };
+ * &out2[1] is then passed to gt_adamw_step as grad_scale. */
+int gt_grad_sqnorm(const gt_adamw_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_local,
+                   int64_t chunk_begin, int64_t num_chunks, int tensor_begin, int num_tensors,
+                   const float* const* grads_host, float* partial, gt_stream_t stream);
+int gt_grad_clip_coef(const float* partial, int64_t num_partials, float max_norm, float* out2, gt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -74,3 +74,26 @@ def test_fused_adamw_rejects_cpu_parameters():
     m(torch.randn(2, 4)).sum().backward()
     with pytest.raises(RuntimeError):
         o.step()
+
+
+@pytest.mark.parametrize("max_norm", [0.05, 1e3])
+def test_fused_adamw_grad_clip_matches_clip_grad_norm(max_norm):
+    """trainers/base_trainer.py:34-36: clip_grad_norm_(model.parameters(), grad_clip) then optimizer.step();
+    0.05 clips on every step here, 1e3 never does (coefficient clamped to 1)."""
+    from graphtrans_amd.optim import FusedAdamW
+    a, b = _models()
+    oa = torch.optim.AdamW(a.parameters(), lr=3e-3, weight_decay=0.01)
+    ob = FusedAdamW(b.parameters(), lr=3e-3, weight_decay=0.01, max_grad_norm=max_norm)
+    for i in range(5):
+        x = torch.randn(64, 37, device=DEV)
+        use_emb = i != 2
+        oa.zero_grad(set_to_none=True)
+        _loss(a, x, use_emb).backward()
+        norm = torch.nn.utils.clip_grad_norm_(a.parameters(), max_norm)
+        oa.step()
+        ob.zero_grad(set_to_none=True)
+        _loss(b, x, use_emb).backward()
+        ob.step()
+        assert torch.allclose(ob.last_grad_norm, norm, rtol=1e-5), (ob.last_grad_norm, norm)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), (pa - pb).abs().max()
