@@ -322,7 +322,16 @@ def main():
     from graphtrans_amd.optim import FusedAdamW
     optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams
-    batches = [attach_sizes(gen(1000 * rank + i)).to(device) for i in range(4)]  # .to() keeps the host-side sizes
+    if opt.scaling == "strong" and opt.workload in RAW_GEN and world > 1:
+        # one GLOBAL batch per seed (identical on every rank), dealt to the ranks by size so that the quadratic
+        # attention cost is even (dist.balanced_shards), assembled on the device from the raw graphs
+        from graphtrans_amd.dist import balanced_shards
+        batches = []
+        for i in range(4):
+            st_i = make_store(opt.workload, per_gpu * world, i)
+            batches.append(st_i.collate(balanced_shards(st_i.nodes, world)[rank]))
+    else:
+        batches = [attach_sizes(gen(1000 * rank + i)).to(device) for i in range(4)]  # .to() keeps the host-side sizes
     store = None
     if opt.from_store:
         store = make_store(opt.workload, 4 * per_gpu, 1000 * rank)

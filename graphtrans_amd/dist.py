@@ -102,3 +102,25 @@ class GradSync:
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+
+
+def balanced_shards(sizes, world, cost=None):
+    """Split one global batch of graphs over `world` ranks with equal graph counts (+-1) and balanced work.
+
+    sizes: nodes per graph (host array).  cost(n) defaults to n^2 + 64 n: attention is quadratic in the graph
+    size, message passing and the GEMMs linear (SURVEY.md 8e "size-balanced assignment").  Greedy longest-
+    processing-time: graphs in decreasing cost order go to the least-loaded rank that still has room.
+    Returns a list of `world` int64 index arrays (each in increasing order, so that collation order within a
+    shard follows the sampler's order).  Deterministic; every rank computes the same split from the same ids."""
+    import numpy as np
+    sizes = np.asarray(sizes, dtype=np.int64)
+    n = sizes.size
+    c = (sizes.astype(np.float64) ** 2 + 64.0 * sizes) if cost is None else np.asarray([cost(int(s)) for s in sizes], np.float64)
+    cap = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in np.argsort(-c, kind="stable"):
+        r = min((r for r in range(world) if len(out[r]) < cap[r]), key=lambda r: (load[r], r))
+        out[r].append(int(i))
+        load[r] += float(c[i])
+    return [np.array(sorted(o), dtype=np.int64) for o in out]

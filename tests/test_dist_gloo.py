@@ -168,3 +168,21 @@ def test_molpcba_loss_denominator_world2_is_the_global_mean():
     assert abs((out[0][1] + out[1][1]) / 2 - want.item()) < 1e-6          # mean of the rank losses = global loss
     for r in (0, 1):                                                       # rank-averaged gradient = global gradient
         assert torch.allclose(out[r][2] / 2, pr.grad[r::2], atol=1e-7)
+
+
+def test_balanced_shards():
+    import numpy as np
+    from graphtrans_amd import synth
+    from graphtrans_amd.dist import balanced_shards
+    sizes = np.bincount(synth.code2_like(B=256, seed=0).batch.numpy(), minlength=256)
+    for world in (1, 2, 4, 8):
+        shards = balanced_shards(sizes, world)
+        assert sorted(np.concatenate(shards).tolist()) == list(range(256))          # a partition
+        assert {len(s) for s in shards} == {256 // world}                           # equal graph counts
+        cost = [float((sizes[s].astype(np.float64) ** 2 + 64.0 * sizes[s]).sum()) for s in shards]
+        naive = [float((sizes[r::world].astype(np.float64) ** 2 + 64.0 * sizes[r::world]).sum()) for r in range(world)]
+        assert max(cost) <= max(naive) + 1e-9
+        if world > 1:
+            assert max(cost) / (sum(cost) / world) < 1.05, cost                     # within 5 % of perfect balance
+    # uneven division: counts differ by at most one
+    assert sorted(len(s) for s in balanced_shards(sizes[:10], 4)) == [2, 2, 3, 3]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Host enqueue time per phase of bench.py's step (perf_counter, no device sync inside the loop).
-usage: python tools/host_phases.py [graphs_per_gpu=8] [steps=200]   -- a tiny batch keeps the GPU
+usage: python tools/host_phases.py [graphs_per_gpu=8] [steps=200] [workload=code2]   -- a tiny batch keeps the GPU
 ahead of the host, so the numbers are pure host cost."""
 import os
 import sys
@@ -15,11 +15,12 @@ from graphtrans_amd.dist import GradSync
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+WL = sys.argv[3] if len(sys.argv) > 3 else "code2"
 device = torch.device("cuda:0")
 torch.cuda.set_device(device)
 gt_ops.set_matmul_dtype(torch.bfloat16)
 torch.manual_seed(1234)
-args, model, gen, loss_fn, _ = bench.build("code2", torch.bfloat16, device, B)
+args, model, gen, loss_fn, _ = bench.build(WL, torch.bfloat16, device, B)
 model.train()
 sync = GradSync(model.parameters(), world_size=1)
 from graphtrans_amd.optim import FusedAdamW
