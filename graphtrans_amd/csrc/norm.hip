@@ -293,6 +293,142 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
   }
 }
 
+// ---- few rows (the virtual-node MLP normalises B = 256 graph rows, modules/gnn_module.py:161-170): ONE launch
+// per direction instead of three.  A block owns 32 columns x all rows (8 row lanes); statistics and apply in
+// the same kernel, the second sweep over the <= 1024 x 32 slab comes from L1 / L2.
+constexpr int SMALL_ROWS = 1024;
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p) {
+  if constexpr (sizeof(T) == 4) return (float)*reinterpret_cast<const float*>(p);
+  else return gt_bf16_to_f32(*reinterpret_cast<const gt_bf16*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void st1(T* p, float v) {
+  if constexpr (sizeof(T) == 4) *reinterpret_cast<float*>(p) = v;
+  else *reinterpret_cast<gt_bf16*>(p) = gt_f32_to_bf16(v);
+}
+// sum over the 8 row lanes of a column, valid in row lane 0
+__device__ __forceinline__ float lanes_sum(float v, float* sm) {
+  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
+  sm[p * FIN_COLS + cl] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (p == 0) {
+#pragma unroll
+    for (int q = 0; q < FIN_LANES; ++q) t += sm[q * FIN_COLS + cl];
+  }
+  __syncthreads();
+  return t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_fwd(
+    const T* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
+    const float* __restrict__ b, const T* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
+    float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+    int64_t* __restrict__ num_batches_tracked, T* __restrict__ y) {
+  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float s_mu[FIN_COLS], s_rs[FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
+  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
+  const bool act = c < D;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  const float piv = act ? ld1<T>(x + c) : 0.f;  // shifted sums: no cancellation for large means
+  float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+  if (act) {
+    int64_t r = p;
+    for (; r + FIN_LANES < N; r += 2 * FIN_LANES) {
+      const float v0 = ld1<T>(x + r * D + c) - piv, v1 = ld1<T>(x + (r + FIN_LANES) * D + c) - piv;
+      a1[0] += v0; a2[0] = fmaf(v0, v0, a2[0]);
+      a1[1] += v1; a2[1] = fmaf(v1, v1, a2[1]);
+    }
+    if (r < N) {
+      const float v0 = ld1<T>(x + r * D + c) - piv;
+      a1[0] += v0; a2[0] = fmaf(v0, v0, a2[0]);
+    }
+  }
+  const float s1 = lanes_sum(a1[0] + a1[1], sm), s2 = lanes_sum(a2[0] + a2[1], sm);
+  if (p == 0 && act) {
+    const float inv_n = 1.0f / (float)N;
+    const float m1 = s1 * inv_n;
+    float var = s2 * inv_n - m1 * m1;
+    var = var < 0.f ? 0.f : var;
+    const float mu = piv + m1, rs = 1.0f / sqrtf(var + eps);
+    mean[c] = mu;
+    rstd[c] = rs;
+    s_mu[cl] = mu;
+    s_rs[cl] = rs;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      const float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  const float mu = s_mu[cl], rs = s_rs[cl], ww = w[c], bb = b[c];
+  for (int64_t r = p; r < N; r += FIN_LANES) {
+    float v = (ld1<T>(x + r * D + c) - mu) * rs * ww + bb;
+    if (relu) v = fmaxf(v, 0.f);
+    if (drop.thr) v = bn_hash(drop.s0, drop.s1, (uint32_t)r, (uint32_t)c) >= drop.thr ? v * drop.inv_keep : 0.f;
+    if (resid) v += ld1<T>(resid + r * D + c);
+    st1<T>(y + r * D + c, v);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_bwd(
+    const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ w, const float* __restrict__ b, int relu, int training, BnDrop drop, int64_t N, int64_t D,
+    float* __restrict__ dbias, float* __restrict__ dweight, T* __restrict__ dx) {
+  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float s_db[FIN_COLS], s_dw[FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
+  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
+  const bool act = c < D;
+  const float mu = act ? mean[c] : 0.f, rs = act ? rstd[c] : 0.f, ww = act ? w[c] : 0.f, bb = act ? b[c] : 0.f;
+  auto grad_at = [&](int64_t r, float& xh) {
+    float g = ld1<T>(dy + r * D + c);
+    const float v = ld1<T>(x + r * D + c);
+    xh = (v - mu) * rs;
+    if (drop.thr) g = bn_hash(drop.s0, drop.s1, (uint32_t)r, (uint32_t)c) >= drop.thr ? g * drop.inv_keep : 0.f;
+    if (relu) g = (v - mu) * rs * ww + bb > 0.f ? g : 0.f;
+    return g;
+  };
+  float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+  if (act) {
+    int64_t r = p;
+    for (; r + FIN_LANES < N; r += 2 * FIN_LANES) {
+      float xh0, xh1;
+      const float g0 = grad_at(r, xh0), g1 = grad_at(r + FIN_LANES, xh1);
+      a0[0] += g0; a1[0] = fmaf(g0, xh0, a1[0]);
+      a0[1] += g1; a1[1] = fmaf(g1, xh1, a1[1]);
+    }
+    if (r < N) {
+      float xh0;
+      const float g0 = grad_at(r, xh0);
+      a0[0] += g0; a1[0] = fmaf(g0, xh0, a1[0]);
+    }
+  }
+  const float s0 = lanes_sum(a0[0] + a0[1], sm), s1 = lanes_sum(a1[0] + a1[1], sm);
+  if (p == 0 && act) {
+    dbias[c] = s0;
+    dweight[c] = s1;
+    s_db[cl] = s0;
+    s_dw[cl] = s1;
+  }
+  __syncthreads();
+  if (!act) return;
+  const float inv_n = training ? 1.0f / (float)N : 0.f;
+  const float db = s_db[cl] * inv_n, dw = s_dw[cl] * inv_n;
+  for (int64_t r = p; r < N; r += FIN_LANES) {
+    float xh;
+    const float g = grad_at(r, xh);
+    st1<T>(dx + r * D + c, ww * rs * (g - db - xh * dw));
+  }
+}
+
 int part_blocks(int64_t N) {
   int64_t b = gt_cdiv(N, 64);
   return (int)(b < 1 ? 1 : (b > MAX_PART ? MAX_PART : b));
@@ -626,6 +762,18 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
   const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   if (training) {
     GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
+    if (rows <= SMALL_ROWS) {
+      if (dtype == GT_F32)
+        hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const float*)x, rows, dim,
+                           eps, momentum, weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean,
+                           running_var, num_batches_tracked, (float*)y);
+      else
+        hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const gt_bf16*)x, rows,
+                           dim, eps, momentum, weight, bias, (const gt_bf16*)resid, relu, drop, save_mean, save_rstd,
+                           running_mean, running_var, num_batches_tracked, (gt_bf16*)y);
+      GT_CHECK_LAUNCH();
+      return GT_OK;
+    }
     const int nb = part_blocks(rows);
     if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
       gt_set_error("gt_batchnorm_fwd: workspace too small");
@@ -677,6 +825,18 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const size_t lds = rowlane_lds(dim, 2);
   const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   const int g = flat_blocks(rows * (dim / 4));
+  if (rows <= SMALL_ROWS) {
+    if (dtype == GT_F32)
+      hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const float*)x,
+                         (const float*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias, dweight,
+                         (float*)dx);
+    else
+      hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const gt_bf16*)x,
+                         (const gt_bf16*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias,
+                         dweight, (gt_bf16*)dx);
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);

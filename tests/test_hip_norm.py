@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("rows,D", [(257, 300), (5000, 600), (4, 16), (32407, 300), (300, 2048)])
+@pytest.mark.parametrize("rows,D", [(257, 300), (5000, 600), (4, 16), (32407, 300), (300, 2048), (1024, 600), (1025, 36), (2, 4)])
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_batchnorm_matches_torch(rows, D, relu, training):
