@@ -11,7 +11,7 @@ import torch  # noqa: F401  must come first: PyTorch-ROCm bundles its own libamd
 #               (same device context, streams and allocations).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphtrans_hip.so")
+LIB_PATH = os.environ.get("GT_LIB_PATH") or os.path.join(_HERE, "libgraphtrans_hip.so")   # GT_LIB_PATH: A/B builds
 
 GT_F32, GT_BF16 = 0, 1
 GT_CONV_GCN, GT_CONV_GIN = 0, 1

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   constexpr int BM = BMT, MI = BMT / 32;  // rows per block, m16-tiles per wave
   constexpr int TILE_ELEMS = (BM + BN) * LD;
   constexpr int PATCH_ELEMS = (int)(4 * PATCH_FLOATS * sizeof(float) / sizeof(TC));
-  constexpr int LDS_ELEMS = TILE_ELEMS > PATCH_ELEMS ? TILE_ELEMS : PATCH_ELEMS;  // the epilogue patches reuse the tiles
+  constexpr int LDS_ELEMS = 2 * TILE_ELEMS > PATCH_ELEMS ? 2 * TILE_ELEMS : PATCH_ELEMS;  // the epilogue patches reuse the tiles
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
   TC* sX = smem;
   TC* sW = smem + BM * LD;
@@ -230,30 +230,43 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   lw.init(a.K);
   lx.load(xo, Mx, a.K, nullptr);
   lw.load(wo, Nw, a.K, nullptr);
-  for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
-    __syncthreads();
-    lx.store(sX, false, 1.f);
-    lw.store(sW, false, 1.f);
-    __syncthreads();
-    if (k0 + BK < a.K) {
-      lx.load(xo + k0 + BK, Mx, a.K - k0 - BK, nullptr);
-      lw.load(wo + k0 + BK, Nw, a.K - k0 - BK, nullptr);
-    }
-    if (a.dbg & 8) continue;
+  auto compute = [&](const TC* cX, const TC* cW) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       Frag<TC> fx[MI], fw[4];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fx[i] = frag_load(sX + (wm * (BM / 2) + i * 16 + n) * LD + kk * 32 + g * 8);
+      for (int i = 0; i < MI; ++i) fx[i] = frag_load(cX + (wm * (BM / 2) + i * 16 + n) * LD + kk * 32 + g * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fw[j] = frag_load(sW + (wn * 64 + j * 16 + n) * LD + kk * 32 + g * 8);
+      for (int j = 0; j < 4; ++j) fw[j] = frag_load(cW + (wn * 64 + j * 16 + n) * LD + kk * 32 + g * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = mma(fw[j], fx[i], acc[j][i]);
     }
+  };
+  // two LDS stages, ONE barrier per k-step: stage s+1 is written while stage s is being multiplied (the
+  // barrier that ended step s-1 freed that buffer); the global loads of stage s+2 are issued before the MFMAs
+  // of stage s and land in registers during them
+  lx.store(sX, false, 1.f);
+  lw.store(sW, false, 1.f);
+  if (BK < a.K) {
+    lx.load(xo + BK, Mx, a.K - BK, nullptr);
+    lw.load(wo + BK, Nw, a.K - BK, nullptr);
   }
   __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = 0; k0 < a.K; k0 += BK, cur ^= 1) {
+    if (k0 + BK < a.K) {
+      lx.store(sX + (cur ^ 1) * TILE_ELEMS, false, 1.f);
+      lw.store(sW + (cur ^ 1) * TILE_ELEMS, false, 1.f);
+      if (k0 + 2 * BK < a.K) {
+        lx.load(xo + k0 + 2 * BK, Mx, a.K - k0 - 2 * BK, nullptr);
+        lw.load(wo + k0 + 2 * BK, Nw, a.K - k0 - 2 * BK, nullptr);
+      }
+    }
+    if (!(a.dbg & 8)) compute(sX + cur * TILE_ELEMS, sW + cur * TILE_ELEMS);
+    __syncthreads();
+  }
   // epilogue: acc[j][i][r] = C[col n0+wn*64+j*16+g*4+r][row m0+wm*64+i*16+n] -> patch[row n][col ...]
   float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TY* Y = reinterpret_cast<TY*>(a.out);
@@ -301,7 +314,7 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
   constexpr int LDW = BN + Tile<TC>::PAD;      // W tile [BKc n][BN k]
   constexpr int TILE_ELEMS = BM * LDZ + BKc * LDW;
   constexpr int PATCH_ELEMS = (int)(4 * PATCH_FLOATS * sizeof(float) / sizeof(TC));
-  constexpr int LDS_ELEMS = TILE_ELEMS > PATCH_ELEMS ? TILE_ELEMS : PATCH_ELEMS;
+  constexpr int LDS_ELEMS = 2 * TILE_ELEMS > PATCH_ELEMS ? 2 * TILE_ELEMS : PATCH_ELEMS;  // two stages (see k_linear_fwd)
   __shared__ __attribute__((aligned(16))) TC smem[LDS_ELEMS];
   TC* sZ = smem;
   TC* sW = smem + BM * LDZ;
@@ -335,30 +348,39 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
     lz.load(zo + cb, a.M - m0, ce - cb, has_mask ? mo + cb : nullptr);
     lw.load(wo + cb * a.K, ce - cb, a.K - kk0, nullptr);
   }
-  for (int64_t c0 = cb; c0 < ce; c0 += BKc) {
-    __syncthreads();
+  auto load_stage = [&](int64_t c1) {
+    lz.load(zo + c1, a.M - m0, ce - c1, has_mask ? mo + c1 : nullptr);
+    lw.load(wo + c1 * a.K, ce - c1, a.K - kk0, nullptr);
+  };
+  if (cb < ce) {
     lz.store(sZ, has_mask, a.inv_keep);
     lw.store(sW, false, 1.f);
-    __syncthreads();
+    if (cb + BKc < ce) load_stage(cb + BKc);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t c0 = cb; c0 < ce; c0 += BKc, cur ^= 1) {
     if (c0 + BKc < ce) {
-      const int64_t c1 = c0 + BKc;
-      lz.load(zo + c1, a.M - m0, ce - c1, has_mask ? mo + c1 : nullptr);
-      lw.load(wo + c1 * a.K, ce - c1, a.K - kk0, nullptr);
+      lz.store(sZ + (cur ^ 1) * TILE_ELEMS, has_mask, a.inv_keep);
+      lw.store(sW + (cur ^ 1) * TILE_ELEMS, false, 1.f);
+      if (c0 + 2 * BKc < ce) load_stage(c0 + 2 * BKc);
     }
+    const TC* cZ = sZ + cur * TILE_ELEMS;
+    const TC* cW = sW + cur * TILE_ELEMS;
 #pragma unroll
     for (int s = 0; s < BKc / 32; ++s) {
       Frag<TC> fz[MI], fw[4];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fz[i] = frag_load(sZ + (wm * (BM / 2) + i * 16 + n) * LDZ + s * 32 + g * 8);
+      for (int i = 0; i < MI; ++i) fz[i] = frag_load(cZ + (wm * (BM / 2) + i * 16 + n) * LDZ + s * 32 + g * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fw[j] = frag_load_tr(sW, LDW, s * 32, wk * 64 + j * 16, n, g);
+      for (int j = 0; j < 4; ++j) fw[j] = frag_load_tr(cW, LDW, s * 32, wk * 64 + j * 16, n, g);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = mma(fw[j], fz[i], acc[j][i]);
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* patch = reinterpret_cast<float*>(smem) + wid * PATCH_FLOATS;
   TX* dX = reinterpret_cast<TX*>(a.out);
 #pragma unroll
@@ -436,6 +458,8 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
     lz.load(dY + mb * a.ldy + n0, me - mb, a.N - n0, has_mask ? Ym + mb * a.ldy + n0 : nullptr);
     lx.load(X + mb * a.ldx + k0, me - mb, a.K - k0, nullptr);
   }
+  // (single LDS stage here: a second one costs this kernel, with its 64 accumulator registers and 17 KB tiles,
+  // more occupancy than the saved barrier returns -- measured 4-8 % slower)
   for (int64_t m0 = mb; m0 < me; m0 += BMc) {
     __syncthreads();
     lz.store(sZ, has_mask, a.inv_keep);
