@@ -47,6 +47,11 @@ SIGNATURES = {
     "gt_embed_sum_fwd": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "gt_embed_sum_bwd_workspace_bytes": (_sz, [_i, _p, _i64]),
     "gt_embed_sum_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
+    "gt_embed_sort_plan_bytes": (_sz, [_i, _p, _i64]),
+    "gt_embed_sort_workspace_bytes": (_sz, [_i, _p, _i64]),
+    "gt_embed_sort": (_i, [_i, _p, _p, _p, _p, _i64, _p, _sz, _p, _sz, _p]),
+    "gt_embed_sum_bwd_sorted_workspace_bytes": (_sz, [_i, _i64, _i64]),
+    "gt_embed_sum_bwd_sorted": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gt_segment_bcast_add": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_segment_sum": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),

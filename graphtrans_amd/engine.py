@@ -192,11 +192,14 @@ class _Plan:
         self.ev_vn = [lib.gt_event_create() for _ in range(nev)]     # vn_{l+1} ready (side -> main)
         self.ev_dvn = [lib.gt_event_create() for _ in range(nev)]    # d vn_{l+1} complete (main -> side)
         self.ev_extra = [lib.gt_event_create() for _ in range(nev)]  # d x_l extra complete (side -> main)
+        # the node-id sort for the embedding backward runs beside the forward on the dW stream
+        self.ev_sort = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []
+        self.embed_sorted = bool(self.embed) and max(int(t.shape[0]) for t in self.embed) <= 16384
 
     def __del__(self):
         try:
             lib = _lib.lib()
-            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra:
+            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra + self.ev_sort:
                 lib.gt_event_destroy(ev)
         except Exception:
             pass
@@ -444,6 +447,14 @@ class _FusedModel(torch.autograd.Function):
             o["sto"] = b.take(2 * rows * 4)
         tab_rows_total = sum(plan.table_rows)
         o["etab"] = b.take(tab_rows_total * D * 4)
+        will_bwd = bool(ctx.needs_input_grad[0])
+        esort = will_bwd and plan.embed_sorted and plan.embed_kind != "linear"
+        if esort:   # sorted node ids per table row (kept for the backward) + the sort's own scratch
+            emb_rows_c = (C.c_int64 * len(plan.embed))(*[t.shape[0] for t in plan.embed])
+            eplan_bytes = lib.gt_embed_sort_plan_bytes(len(plan.embed), emb_rows_c, N)
+            esort_ws_bytes = lib.gt_embed_sort_workspace_bytes(len(plan.embed), emb_rows_c, N)
+            o["eplan"] = b.take(eplan_bytes)
+            o["esort_ws"] = b.take(esort_ws_bytes)
         if plan.embed_kind == "linear" and plan.ne_Kp != plan.ne_K:   # K-padded copies of x and W (16-byte chunks)
             o["ne_x"] = b.take(N * plan.ne_Kp * 4)
             o["ne_w"] = b.take(D * plan.ne_Kp * 4)
@@ -495,6 +506,16 @@ class _FusedModel(torch.autograd.Function):
             e_clamp = I64(*plan.embed_clamp)
             e_tabs = PT(*[t.data_ptr() for t in plan.embed])
             _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
+            if esort:
+                sst = st
+                if plan.side_dw is not None:   # beside the forward: only the index columns are read
+                    sst = plan.side_dw.cuda_stream
+                    _call("gt_event_record", plan.ev_sort[0], st)
+                    _call("gt_stream_wait_event", sst, plan.ev_sort[0])
+                _call("gt_embed_sort", T, e_idx, e_str, e_clamp, emb_rows_c, N, P("eplan"), eplan_bytes, P("esort_ws"),
+                      esort_ws_bytes, sst)
+                if plan.side_dw is not None:
+                    _call("gt_event_record", plan.ev_sort[1], sst)
 
         # ---- message passing   (modules/gnn_module.py:181-224)
         if plan.has_vn:
@@ -572,9 +593,11 @@ class _FusedModel(torch.autograd.Function):
         snap = lambda ds: [type(x_).from_buffer_copy(x_) for x_ in ds]
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
-                         embed=(T, e_idx, e_str, e_clamp, cols), ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
+                         embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
                          dims=(N, E, B, rows), sync=model.__dict__.get("_gt_sync"))
         ctx.set_materialize_grads(False)
+        if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
+            _call("gt_stream_wait_event", st, plan.ev_sort[1])
         out = logits[:, :plan.Nh] if plan.ldy != plan.Nh else logits
         return out
 
@@ -618,6 +641,8 @@ class _FusedModel(torch.autograd.Function):
         if plan.embed_kind == "linear":
             emb_ws = lib.gt_linear_bwd_workspace_bytes(compute, N, D, plan.ne_Kp)
             q["ne_dw"] = b.take(D * plan.ne_Kp * 4 if plan.ne_Kp != plan.ne_K else 0)
+        elif s["esort"]:
+            emb_ws = lib.gt_embed_sum_bwd_sorted_workspace_bytes(len(plan.embed), N, D)
         else:
             emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
@@ -745,7 +770,10 @@ class _FusedModel(torch.autograd.Function):
         else:
             T, e_idx, e_str, e_clamp, _cols = s["embed"]
             d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
-            _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
+            if s["esort"]:
+                _call("gt_embed_sum_bwd_sorted", T, emb_rows, d_h0, N, D, P("eplan"), d_tabs, Q("ws"), ws_bytes, st)
+            else:
+                _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
 
         if sync is not None:
             sync.reduce_flat(flat, 0, gnn_lo)

@@ -574,6 +574,9 @@ def pna_aggregate(U, V, gs, towers):
     return _PnaAggregate.apply(U, V, gs, towers)
 
 
+EMBED_SORT_MAX_ROWS = 16384   # gt_embed_sort's per-block LDS histogram
+
+
 class _EmbedSum(torch.autograd.Function):
     """sum_t table_t[min(idx_t, clamp_t)] (gt_embed_sum_fwd / _bwd).  `cols` is a list of
     (int64 tensor, element offset, element stride, clamp) column descriptors."""
@@ -593,8 +596,19 @@ class _EmbedSum(torch.autograd.Function):
         tabs = P(*[t.data_ptr() for t in tables])
         out = torch.empty((N, D), dtype=torch.float32, device=tables[0].device)
         _lib.launch("gt_embed_sum_fwd", T, idx, strides, clamp, tabs, N, D, _ptr(out), _stream())
-        ctx.cols, ctx.meta = cols, (T, N, D, [t.shape[0] for t in tables], tables[0].device)
+        rows = [t.shape[0] for t in tables]
+        ctx.cols, ctx.meta = cols, (T, N, D, rows, tables[0].device)
         ctx.desc = (idx, strides, clamp)
+        ctx.plan = None
+        if any(t.requires_grad for t in tables) and max(rows) <= EMBED_SORT_MAX_ROWS:
+            # the backward sums each table row's gradient rows in node order: sort the node ids by row now
+            L = _lib.lib()
+            rows_c = I64(*rows)
+            plan = torch.empty(L.gt_embed_sort_plan_bytes(T, rows_c, N), dtype=torch.uint8, device=out.device)
+            wsb = L.gt_embed_sort_workspace_bytes(T, rows_c, N)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=out.device)
+            _lib.launch("gt_embed_sort", T, idx, strides, clamp, rows_c, N, _ptr(plan), plan.numel(), _ptr(ws), wsb, _stream())
+            ctx.plan = plan
         return out
 
     @staticmethod
@@ -607,7 +621,12 @@ class _EmbedSum(torch.autograd.Function):
         grads = [torch.empty((r, D), dtype=torch.float32, device=device) if ctx.needs_input_grad[1 + t] else None
                  for t, r in enumerate(rows)]
         dt = P(*[(x.data_ptr() if x is not None else None) for x in grads])
-        ws_bytes = _lib.lib().gt_embed_sum_bwd_workspace_bytes(T, rows_c, D)
+        if ctx.plan is not None:
+            ws_bytes = _lib.lib().gt_embed_sum_bwd_sorted_workspace_bytes(T, N, D)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            _lib.launch("gt_embed_sum_bwd_sorted", T, rows_c, _ptr(g), N, D, _ptr(ctx.plan), dt, _ptr(ws), ws_bytes, _stream())
+            return (None, *grads)
+        ws_bytes = _lib.lib().gt_embed_sum_bwd_workspace_bytes(T, rows_c, D)   # huge tables: fixed-point atomics
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         _lib.launch("gt_embed_sum_bwd", T, idx, strides, clamp, rows_c, _ptr(g), N, D, dt, _ptr(ws), ws_bytes, _stream())
         return (None, *grads)

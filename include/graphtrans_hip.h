@@ -215,6 +215,20 @@ int gt_embed_sum_bwd(int num_tables, const int64_t* const* idx_ptrs_host, const 
                      const int64_t* clamp_max_host, const int64_t* table_rows_host, const float* grad_out,
                      int64_t num_nodes, int64_t dim, float* const* d_tables_host, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
+/* Sorted variant (the default of the Python layers): gt_embed_sort, once per batch, orders the node ids of every
+ * table by row (stable counting sort; tables of up to 16384 rows) into `plan` (gt_embed_sort_plan_bytes, kept
+ * until the backward); gt_embed_sum_bwd_sorted then sums the gradient rows of every table row in node order with
+ * plain fp32 adds and no atomics: bitwise reproducible, no fixed-point rounding, insensitive to skewed
+ * vocabularies.  Index values outside [0, rows) are dropped. */
+size_t gt_embed_sort_plan_bytes(int num_tables, const int64_t* table_rows_host, int64_t num_nodes);
+size_t gt_embed_sort_workspace_bytes(int num_tables, const int64_t* table_rows_host, int64_t num_nodes);
+int gt_embed_sort(int num_tables, const int64_t* const* idx_ptrs_host, const int64_t* idx_strides_host,
+                  const int64_t* clamp_max_host, const int64_t* table_rows_host, int64_t num_nodes, void* plan,
+                  size_t plan_bytes, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+size_t gt_embed_sum_bwd_sorted_workspace_bytes(int num_tables, int64_t num_nodes, int64_t dim);
+int gt_embed_sum_bwd_sorted(int num_tables, const int64_t* table_rows_host, const float* grad_out, int64_t num_nodes,
+                            int64_t dim, const void* plan, float* const* d_tables_host, void* workspace,
+                            size_t workspace_bytes, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-graph segment ops on the sorted `batch` vector (virtual node + pooling).

@@ -93,3 +93,62 @@ def test_embed_sum_bwd_hot_row():
     ref = torch.zeros(R, D, dtype=torch.float64, device="cuda").index_add_(0, idx, gout.double())
     scale = gout.abs().max().item()
     assert (tab.grad.double() - ref).abs().max().item() <= scale * 2.0 ** -29 * N + 1e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case", ["code2", "atom", "hot", "one_row", "tiny", "chunk_edges"])
+def test_embed_sorted_backward(case):
+    """gt_embed_sort + gt_embed_sum_bwd_sorted: every table row is the fp32 sum of its nodes' gradient rows in node
+    order, associated per 64-position chunk -> equals the float64 sum within fp32 rounding of the partial sums."""
+    from graphtrans_amd import ops
+    g = torch.Generator().manual_seed(5)
+    if case == "code2":
+        N, D, rows, clamps = 3000, 300, [98, 10030, 21], [None, None, 20]
+    elif case == "atom":
+        N, D, rows, clamps = 700, 64, [119, 4, 12, 12, 10, 6, 6, 2, 2], None
+    elif case == "hot":
+        N, D, rows, clamps = 5000, 32, [50, 4000], None
+    elif case == "one_row":
+        N, D, rows, clamps = 1000, 16, [1], None
+    elif case == "tiny":
+        N, D, rows, clamps = 1, 8, [5, 3], None
+    else:   # segments that end exactly on / one off the 64-position chunk boundaries
+        N, D, rows, clamps = 64 * 5, 8, [7], None
+    idx = [torch.randint(0, r + (5 if clamps and clamps[t] is not None else 0), (N,), generator=g) for t, r in enumerate(rows)]
+    if case == "hot":
+        idx[1][torch.rand(N, generator=g) < 0.85] = 7
+    if case == "chunk_edges":
+        idx[0] = torch.tensor([0] * 64 + [1] * 63 + [2] * 1 + [3] * 65 + [4] * 127).long()[torch.arange(N)]
+        idx[0] = idx[0][torch.randperm(N, generator=g)]
+    tabs = [torch.randn(r, D, generator=g).cuda().requires_grad_() for r in rows]
+    cols = [i.cuda() for i in idx]
+    out = ops.embed_sum(cols, tabs, clamps=clamps)
+    gout = torch.randn(N, D, generator=g)
+    out.backward(gout.cuda())
+    for t, r in enumerate(rows):
+        key = idx[t].clamp(max=clamps[t]) if clamps and clamps[t] is not None else idx[t]
+        want = torch.zeros(r, D, dtype=torch.float64).index_add_(0, key, gout.double())
+        mag = torch.zeros(r, D, dtype=torch.float64).index_add_(0, key, gout.double().abs())   # sum of |terms| per entry
+        got = tabs[t].grad.cpu().double()
+        assert ((got - want).abs() <= 4e-7 * mag + 1e-30).all(), (case, t, (got - want).abs().max())
+        untouched = torch.bincount(key, minlength=r) == 0
+        assert (got[untouched] == 0).all()
+
+
+def test_embed_sorted_backward_is_deterministic_and_matches_fixed_point_path():
+    from graphtrans_amd import ops
+    g = torch.Generator().manual_seed(6)
+    N, D, rows = 20000, 300, [98, 10030, 21]
+    cols = [torch.randint(0, r, (N,), generator=g).cuda() for r in rows]
+    gout = torch.randn(N, D, generator=g).cuda()
+    res = []
+    for limit in (16384, 16384, 0):    # 0: force the fixed-point atomic path
+        old, ops.EMBED_SORT_MAX_ROWS = ops.EMBED_SORT_MAX_ROWS, limit
+        try:
+            tabs = [torch.zeros(r, D, device="cuda").requires_grad_() for r in rows]
+            ops.embed_sum(cols, tabs).backward(gout)
+            res.append([t.grad.clone() for t in tabs])
+        finally:
+            ops.EMBED_SORT_MAX_ROWS = old
+    for a, b, c in zip(*res):
+        assert torch.equal(a, b)
+        assert (a - c).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
