@@ -96,8 +96,13 @@ __global__ void __launch_bounds__(NT) k_bn_stats_partial(const T* __restrict__ x
 // sums partial rows p, p+8, ... (8 independent loads in flight), then the 8 lanes are combined in a
 // fixed order through LDS.  Returns the total to the threads with p == 0 (others get garbage).
 constexpr int FIN_COLS = 32, FIN_LANES = 8;
+// the finish kernels sum up to 512 partial rows per column: 32 lanes per column (1024-thread blocks) keep the
+// dependent-load chain at 2 batches of 8 -- with 8 lanes these 4..10-block kernels took 7-10 us each
+constexpr int FINK_LANES = 32;
+template <int LANES>
 __device__ __forceinline__ float finish_sum(const float* __restrict__ part, int nblk, int64_t stride, int64_t off,
-                                            bool active, float* sm /* [FIN_LANES][FIN_COLS] */) {
+                                            bool active, float* sm /* [LANES][FIN_COLS] */) {
+  constexpr int FIN_LANES = LANES;
   const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -125,11 +130,11 @@ __global__ void k_bn_stats_finish(const T* __restrict__ x, const float* __restri
                                   int64_t D, float eps, float momentum, float* __restrict__ mean,
                                   float* __restrict__ rstd, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
-  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float sm[FINK_LANES * FIN_COLS];
   const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
-  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  const float s1 = finish_sum<FINK_LANES>(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum<FINK_LANES>(part, nblk, 2 * D, D + c, c < D, sm);
   if (c >= D || threadIdx.x >= FIN_COLS) return;
   const float piv = sizeof(T) == 4 ? (float)reinterpret_cast<const float*>(x)[c]
                                    : gt_bf16_to_f32(reinterpret_cast<const gt_bf16*>(x)[c]);
@@ -256,10 +261,10 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_partial(const T* __restrict__ x, 
 
 __global__ void k_bn_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dbias,
                                 float* __restrict__ dweight) {
-  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float sm[FINK_LANES * FIN_COLS];
   const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
-  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
-  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  const float s1 = finish_sum<FINK_LANES>(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum<FINK_LANES>(part, nblk, 2 * D, D + c, c < D, sm);
   if (c >= D || threadIdx.x >= FIN_COLS) return;
   dbias[c] = s1;
   dweight[c] = s2;
@@ -683,10 +688,10 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd(LnArgs a) {
 
 __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dweight,
                                 float* __restrict__ dbias) {
-  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float sm[FINK_LANES * FIN_COLS];
   const int64_t c = (int64_t)blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
-  const float s1 = finish_sum(part, nblk, 2 * D, c, c < D, sm);
-  const float s2 = finish_sum(part, nblk, 2 * D, D + c, c < D, sm);
+  const float s1 = finish_sum<FINK_LANES>(part, nblk, 2 * D, c, c < D, sm);
+  const float s2 = finish_sum<FINK_LANES>(part, nblk, 2 * D, D + c, c < D, sm);
   if (c >= D || threadIdx.x >= FIN_COLS) return;
   dweight[c] = s1;
   dbias[c] = s2;
@@ -783,11 +788,11 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
     size_t lds = rowlane_lds(dim, 2);
     if (dtype == GT_F32) {
       hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
-      hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(256), 0, stream, (const float*)x, part, nb, rows,
+      hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)x, part, nb, rows,
                          dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
     } else {
       hipLaunchKernelGGL(k_bn_stats_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, rows, dim, part);
-      hipLaunchKernelGGL(k_bn_stats_finish<gt_bf16>, dim3(cgrid), dim3(256), 0, stream, (const gt_bf16*)x, part, nb,
+      hipLaunchKernelGGL(k_bn_stats_finish<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const gt_bf16*)x, part, nb,
                          rows, dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
     }
   } else {
@@ -840,13 +845,13 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
                        save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (float*)dx);
   } else {
     hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(256), 0, stream, part, nb, dim, dbias, dweight);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
                        save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (gt_bf16*)dx);
   }
@@ -903,7 +908,7 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
-  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(256), 0, stream, (const float*)workspace, grid,
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)workspace, grid,
                      dim, dweight, dbias);
   GT_CHECK_LAUNCH();
   return GT_OK;
