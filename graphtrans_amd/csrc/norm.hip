@@ -313,7 +313,8 @@ __device__ __forceinline__ void st1(T* p, float v) {
   if constexpr (sizeof(T) == 4) *reinterpret_cast<float*>(p) = v;
   else *reinterpret_cast<gt_bf16*>(p) = gt_f32_to_bf16(v);
 }
-// sum over the 8 row lanes of a column, valid in row lane 0
+constexpr int SM_LANES = 32;  // row lanes per column: 8 rows per thread at B = 256, 4 loads in flight
+// sum over the SM_LANES row lanes of a column, valid in row lane 0
 __device__ __forceinline__ float lanes_sum(float v, float* sm) {
   const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
   sm[p * FIN_COLS + cl] = v;
@@ -321,19 +322,19 @@ __device__ __forceinline__ float lanes_sum(float v, float* sm) {
   float t = 0.f;
   if (p == 0) {
 #pragma unroll
-    for (int q = 0; q < FIN_LANES; ++q) t += sm[q * FIN_COLS + cl];
+    for (int q = 0; q < SM_LANES; ++q) t += sm[q * FIN_COLS + cl];
   }
   __syncthreads();
   return t;
 }
 
 template <typename T>
-__global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_fwd(
+__global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_fwd(
     const T* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
     const float* __restrict__ b, const T* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
     float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
     int64_t* __restrict__ num_batches_tracked, T* __restrict__ y) {
-  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float sm[SM_LANES * FIN_COLS];
   __shared__ float s_mu[FIN_COLS], s_rs[FIN_COLS];
   const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
   const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
@@ -343,12 +344,14 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_fwd(
   float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
   if (act) {
     int64_t r = p;
-    for (; r + FIN_LANES < N; r += 2 * FIN_LANES) {
-      const float v0 = ld1<T>(x + r * D + c) - piv, v1 = ld1<T>(x + (r + FIN_LANES) * D + c) - piv;
-      a1[0] += v0; a2[0] = fmaf(v0, v0, a2[0]);
-      a1[1] += v1; a2[1] = fmaf(v1, v1, a2[1]);
+    for (; r + 3 * SM_LANES < N; r += 4 * SM_LANES) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld1<T>(x + (r + u * SM_LANES) * D + c) - piv;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1[u & 1] += v[u]; a2[u & 1] = fmaf(v[u], v[u], a2[u & 1]); }
     }
-    if (r < N) {
+    for (; r < N; r += SM_LANES) {
       const float v0 = ld1<T>(x + r * D + c) - piv;
       a1[0] += v0; a2[0] = fmaf(v0, v0, a2[0]);
     }
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_fwd(
   __syncthreads();
   if (!act) return;
   const float mu = s_mu[cl], rs = s_rs[cl], ww = w[c], bb = b[c];
-  for (int64_t r = p; r < N; r += FIN_LANES) {
+  for (int64_t r = p; r < N; r += SM_LANES) {
     float v = (ld1<T>(x + r * D + c) - mu) * rs * ww + bb;
     if (relu) v = fmaxf(v, 0.f);
     if (drop.thr) v = bn_hash(drop.s0, drop.s1, (uint32_t)r, (uint32_t)c) >= drop.thr ? v * drop.inv_keep : 0.f;
@@ -383,11 +386,11 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_fwd(
 }
 
 template <typename T>
-__global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_bwd(
+__global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_bwd(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ b, int relu, int training, BnDrop drop, int64_t N, int64_t D,
     float* __restrict__ dbias, float* __restrict__ dweight, T* __restrict__ dx) {
-  __shared__ float sm[FIN_LANES * FIN_COLS];
+  __shared__ float sm[SM_LANES * FIN_COLS];
   __shared__ float s_db[FIN_COLS], s_dw[FIN_COLS];
   const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
   const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
@@ -404,9 +407,9 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_bwd(
   float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
   if (act) {
     int64_t r = p;
-    for (; r + FIN_LANES < N; r += 2 * FIN_LANES) {
+    for (; r + SM_LANES < N; r += 2 * SM_LANES) {
       float xh0, xh1;
-      const float g0 = grad_at(r, xh0), g1 = grad_at(r + FIN_LANES, xh1);
+      const float g0 = grad_at(r, xh0), g1 = grad_at(r + SM_LANES, xh1);
       a0[0] += g0; a1[0] = fmaf(g0, xh0, a1[0]);
       a0[1] += g1; a1[1] = fmaf(g1, xh1, a1[1]);
     }
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_LANES) k_bn_small_bwd(
   if (!act) return;
   const float inv_n = training ? 1.0f / (float)N : 0.f;
   const float db = s_db[cl] * inv_n, dw = s_dw[cl] * inv_n;
-  for (int64_t r = p; r < N; r += FIN_LANES) {
+  for (int64_t r = p; r < N; r += SM_LANES) {
     float xh;
     const float g = grad_at(r, xh);
     st1<T>(dx + r * D + c, ww * rs * (g - db - xh * dw));
@@ -769,11 +772,11 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
     GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
     if (rows <= SMALL_ROWS) {
       if (dtype == GT_F32)
-        hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const float*)x, rows, dim,
+        hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const float*)x, rows, dim,
                            eps, momentum, weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean,
                            running_var, num_batches_tracked, (float*)y);
       else
-        hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const gt_bf16*)x, rows,
+        hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const gt_bf16*)x, rows,
                            dim, eps, momentum, weight, bias, (const gt_bf16*)resid, relu, drop, save_mean, save_rstd,
                            running_mean, running_var, num_batches_tracked, (gt_bf16*)y);
       GT_CHECK_LAUNCH();
@@ -832,11 +835,11 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const int g = flat_blocks(rows * (dim / 4));
   if (rows <= SMALL_ROWS) {
     if (dtype == GT_F32)
-      hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const float*)x,
+      hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const float*)x,
                          (const float*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias, dweight,
                          (float*)dx);
     else
-      hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FIN_LANES), 0, stream, (const gt_bf16*)x,
+      hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const gt_bf16*)x,
                          (const gt_bf16*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias,
                          dweight, (gt_bf16*)dx);
     GT_CHECK_LAUNCH();
