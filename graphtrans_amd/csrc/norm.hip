@@ -700,7 +700,7 @@ __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_
   dbias[c] = s2;
 }
 
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 256;
 
 template <typename T, bool BWD>
 void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
