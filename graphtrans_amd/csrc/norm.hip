@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAX_PART = 512;  // column-partial blocks
+constexpr int MAX_PART = 256;  // column-partial blocks
 
 // thread -> (chunk column, row lane) mapping for an [rows][D] matrix walked by a 256-thread block
 struct ColMap {
