@@ -433,6 +433,7 @@ def main():
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()   # rank 0 is still writing its report: leave the group together
         dist.destroy_process_group()
 
 
