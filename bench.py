@@ -295,12 +295,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): GT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # GT_BENCH_BACKEND=gloo reduces through the host, which exercises the whole multi-rank path of this script
+    if os.environ.get("GT_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("GT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if opt.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {opt.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
