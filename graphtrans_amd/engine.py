@@ -267,7 +267,13 @@ def eligible(model, batched_data, perturb):
     """True when the fused path covers this model / call (cached per model and mode)."""
     if perturb is not None or not getattr(model, "fused", True):
         return False
-    key = (model.training, torch.is_grad_enabled())
+    # the fused node differentiates EVERY parameter: frozen parameters (epoch_callback's freeze_gnn, or a user's
+    # requires_grad_(False)) send the model through the module path; three probes keep the cache honest cheaply
+    g2t_w = model.gnn2transformer.weight
+    key = (model.training, torch.is_grad_enabled(), g2t_w.requires_grad,
+           model.gnn_node.convs[0].root_emb.weight.requires_grad if hasattr(model.gnn_node.convs[0], "root_emb")
+           else model.gnn_node.convs[0].eps.requires_grad,
+           model.gnn_node.batch_norms[-1].weight.requires_grad)
     cache = model.__dict__.setdefault("_gt_eligible", {})
     ok = cache.get(key)
     if ok is None:

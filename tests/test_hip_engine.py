@@ -279,3 +279,32 @@ def test_fused_model_dense_node_features(case):
             assert torch.allclose(g0[n] / scale, g1[n] / scale, **tol), (n, (g0[n] - g1[n]).abs().max())
     finally:
         ops.set_matmul_dtype(torch.float32)
+
+
+def test_freeze_gnn_leaves_the_fused_path():
+    """epoch_callback (models/gnn_transformer.py:130-135) freezes gnn_node from epoch `freeze_gnn`: the fused node
+    differentiates every parameter, so the model must go back to the module path and the frozen ones get no grad."""
+    from graphtrans_amd import engine, losses, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    args = _args(freeze_gnn=1)
+    torch.manual_seed(0)
+    model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV).train()
+    b = synth.code2_like(B=6, seed=5, num_nodeattributes=300).to(DEV)
+    y = torch.randint(0, 50, (6, 5), device=DEV)
+    model.epoch_callback(0)
+    assert engine.eligible(model, b, None)
+    losses.code2_loss(model(b), y).backward()
+    assert all(p.grad is not None for p in model.parameters())
+    for p in model.parameters():
+        p.grad = None
+    model.epoch_callback(1)
+    assert not engine.eligible(model, b, None)
+    losses.code2_loss(model(b), y).backward()
+    assert all(p.grad is None for p in model.gnn_node.parameters())
+    assert model.gnn2transformer.weight.grad is not None
+    # a parameter frozen by hand (no callback) is noticed as well
+    model2 = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), _args()).to(DEV).train()
+    assert engine.eligible(model2, b, None)
+    model2.gnn2transformer.weight.requires_grad_(False)
+    assert not engine.eligible(model2, b, None)
