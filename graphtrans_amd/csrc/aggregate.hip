@@ -319,6 +319,14 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   if constexpr (EDGE == GT_EDGE_TABLES) {
     wl = lds + (int64_t)wid * a.table_rows * D;
     for (int64_t i = lane; i < (int64_t)a.table_rows * D; i += 64) wl[i] = 0.f;
+    // the tables themselves (needed for the relu gate h[u] + e_k > 0) are parked in LDS as in the forward: read
+    // from global they are a third dependent round trip per edge (eid -> attr -> table row), ~1.4 us per edge.
+    // They share the space of the reduction stage, which is only used after the walk.
+    float* tab = lds + (int64_t)AGG_WAVES * a.table_rows * D;
+    for (int64_t i = threadIdx.x * 4; i < (int64_t)a.table_rows * D; i += AGG_THREADS * 4)
+      *reinterpret_cast<float4*>(tab + i) = *reinterpret_cast<const float4*>(a.w + i);
+    __syncthreads();
+    a.w = tab;
   }
 
   // persistent grid: every wave-tile walks its own contiguous run of source nodes, software pipelined
@@ -456,6 +464,7 @@ __global__ void __launch_bounds__(AGG_THREADS) k_agg_bwd(AggArgs a) {
   }
 
   // ---- block reduction of the register accumulators: sub-groups (shuffle) -> waves (LDS) -> partial
+  if constexpr (EDGE == GT_EDGE_TABLES) __syncthreads();  // every wave is done with the staged tables (same LDS as `stage`)
   float* stage = lds + (EDGE == GT_EDGE_TABLES ? (int64_t)AGG_WAVES * a.table_rows * D : 0);  // [AGG_WAVES][D]
   float* part = a.partial + (int64_t)blockIdx.x * nslots * D;
 #pragma unroll
@@ -636,7 +645,10 @@ int check_common(const char* fn, int conv, int edge_mode, int dtype, int64_t N, 
 
 size_t bwd_lds_bytes(int edge_mode, int64_t D, int64_t table_rows) {
   size_t stage = (size_t)AGG_WAVES * D * sizeof(float);
-  if (edge_mode == GT_EDGE_TABLES) return stage + (size_t)AGG_WAVES * table_rows * D * sizeof(float);
+  if (edge_mode == GT_EDGE_TABLES) {   // per-wave gradient rows + max(reduction stage, staged tables)
+    const size_t tab = (size_t)table_rows * D * sizeof(float);
+    return (size_t)AGG_WAVES * table_rows * D * sizeof(float) + (stage > tab ? stage : tab);
+  }
   return stage;
 }
 

@@ -308,7 +308,7 @@ def _eligible_static(model):
         D = gnn.convs[0].emb_dim
         if D % 4:
             return False
-        from .modules.conv import GINConv, _LDS_TABLE_BUDGET
+        from .modules.conv import GINConv, tables_fit_lds
         kinds = {type(conv) for conv in gnn.convs}
         if len(kinds) != 1 or not (kinds <= {GCNConv, GINConv}):
             return False
@@ -327,7 +327,7 @@ def _eligible_static(model):
             tabs = getattr(ee, "bond_embedding_list", None)
             if tabs is not None:
                 rows = sum(int(t.weight.shape[0]) for t in tabs)
-                if len(tabs) > 4 or (rows + 1) * D * 4 * 4 > _LDS_TABLE_BUDGET:
+                if len(tabs) > 4 or not tables_fit_lds(rows, D):
                     return False
             elif isinstance(ee, torch.nn.Module):
                 if not (isinstance(ee, torch.nn.Linear) and ee.in_features <= 4 and ee.bias is not None):

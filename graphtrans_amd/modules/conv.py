@@ -7,7 +7,13 @@ from .. import ops
 from ..graph import GraphStructure
 from .norm import BatchNorm1d, mlp_bn_relu
 
-_LDS_TABLE_BUDGET = 160 * 1024  # per-wave table-gradient rows in the backward kernel (LDS per CU)
+_LDS_TABLE_BUDGET = 160 * 1024  # LDS per CU
+
+
+def tables_fit_lds(rows, emb_dim):
+    """The backward kernel keeps 4 per-wave copies of the table-gradient rows plus the tables themselves (sharing
+    the space of the 4-row reduction stage) in LDS: csrc/aggregate.hip:bwd_lds_bytes."""
+    return (4 * rows + max(4, rows)) * emb_dim * 4 <= _LDS_TABLE_BUDGET
 
 
 def edge_spec(edge_encoder, edge_attr, emb_dim):
@@ -23,7 +29,7 @@ def edge_spec(edge_encoder, edge_attr, emb_dim):
     if tabs is not None and edge_attr.dtype == torch.int64 and edge_attr.shape[1] <= 4:
         k = edge_attr.shape[1]
         rows = sum(int(t.weight.shape[0]) for t in list(tabs)[:k])
-        if (rows + 1) * emb_dim * 4 * 4 <= _LDS_TABLE_BUDGET:
+        if tables_fit_lds(rows, emb_dim):
             off, acc = [], 0
             for t in list(tabs)[:k]:
                 off.append(acc)
