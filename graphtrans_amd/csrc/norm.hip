@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_bwd(
 }
 
 int part_blocks(int64_t N) {
-  int64_t b = gt_cdiv(N, 64);
+  int64_t b = gt_cdiv(N, 32);
   return (int)(b < 1 ? 1 : (b > MAX_PART ? MAX_PART : b));
 }
 int flat_blocks(int64_t items) {
