@@ -44,6 +44,8 @@ SIGNATURES = {
                               C.POINTER(C.c_int32), _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_pna_aggregate_fwd": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
     "gt_pna_aggregate_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gt_scale_combine_fwd": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
+    "gt_scale_combine_bwd": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
     "gt_embed_sum_fwd": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "gt_embed_sum_bwd_workspace_bytes": (_sz, [_i, _p, _i64]),
     "gt_embed_sum_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),

@@ -185,6 +185,34 @@ int pna_check(const char* fn, int64_t N, int64_t D, int towers) {
   return GT_OK;
 }
 
+// ---- degree scalers applied to the post-Linear's S output blocks (modules/pna/scalers.py:10-31):
+//   out[n][t][f] = sum_s Y[n][t][s][f] * sc[n][s]        bwd: dY[n][t][s][f] = dout[n][t][f] * sc[n][s]
+// (the post-Linear runs once on [x | agg]; scaling its per-scaler output blocks equals scaling the aggregates first)
+__global__ void __launch_bounds__(256) k_scale_combine_fwd(const float* __restrict__ Y, const float* __restrict__ sc, int64_t N,
+                                                           int T, int S, int F, float* __restrict__ out) {
+  const int64_t F4 = F / 4, total = N * T * F4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / (T * F4), r = i % (T * F4);
+    const int t = (int)(r / F4), f = (int)(r % F4) * 4;
+    float4 acc = gt_zero4();
+    for (int s = 0; s < S; ++s)
+      acc = gt_fma4(*reinterpret_cast<const float4*>(Y + ((n * T + t) * S + s) * F + f), sc[n * S + s], acc);
+    *reinterpret_cast<float4*>(out + (n * T + t) * F + f) = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scale_combine_bwd(const float* __restrict__ dout, const float* __restrict__ sc, int64_t N,
+                                                           int T, int S, int F, float* __restrict__ dY) {
+  const int64_t F4 = F / 4, total = N * T * F4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / (T * F4), r = i % (T * F4);
+    const int t = (int)(r / F4), f = (int)(r % F4) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(dout + (n * T + t) * F + f);
+    for (int s = 0; s < S; ++s)
+      *reinterpret_cast<float4*>(dY + ((n * T + t) * S + s) * F + f) = gt_scale4(g, sc[n * S + s]);
+  }
+}
+
 }  // namespace
 
 extern "C" int gt_pna_aggregate_fwd(const float* U, const float* V, int64_t N, int64_t D, int towers, const int32_t* in_ptr,
@@ -217,6 +245,31 @@ extern "C" int gt_pna_aggregate_bwd(const float* V, const float* out, const floa
   a.N = N; a.D = D; a.T = towers; a.F = (int)(D / towers);
   GtProfScope prof__(GT_PROF_AGGREGATE, "gt_pna_aggregate_bwd", stream_, {N, 0, D, 4, 0, 0});
   pna_launch<true>(a, (hipStream_t)stream_);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_scale_combine_fwd(const float* Y, const float* scales, int64_t N, int towers, int num_scalers, int F,
+                                    float* out, gt_stream_t stream_) {
+  GT_CHECK_ARG(N >= 0 && towers > 0 && num_scalers > 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
+  if (N == 0) return GT_OK;
+  GT_CHECK_ARG(Y && scales && out, "null buffer");
+  const int64_t items = N * towers * (F / 4);
+  const int grid = (int)(gt_cdiv(items, 256) < 4096 ? gt_cdiv(items, 256) : 4096);
+  hipLaunchKernelGGL(k_scale_combine_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, Y, scales, N, towers, num_scalers, F, out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_scale_combine_bwd(const float* grad_out, const float* scales, int64_t N, int towers, int num_scalers, int F,
+                                    float* dY, gt_stream_t stream_) {
+  GT_CHECK_ARG(N >= 0 && towers > 0 && num_scalers > 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
+  if (N == 0) return GT_OK;
+  GT_CHECK_ARG(grad_out && scales && dY, "null buffer");
+  const int64_t items = N * towers * (F / 4);
+  const int grid = (int)(gt_cdiv(items, 256) < 4096 ? gt_cdiv(items, 256) : 4096);
+  hipLaunchKernelGGL(k_scale_combine_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, grad_out, scales, N, towers, num_scalers, F,
+                     dY);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -23,7 +23,7 @@ class GraphStructure:
     """graph_ptr, node_graph, CSR by destination (in_*), CSC by source (out_*), deg, dis."""
 
     __slots__ = ("N", "E", "B", "device", "graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr",
-                 "out_dst", "out_eid", "deg", "dis", "status", "_sizes", "_layouts")
+                 "out_dst", "out_eid", "deg", "dis", "status", "_sizes", "_layouts", "_pna_scales")
 
     @staticmethod
     def build(edge_index, batch, num_graphs=None, sizes=None):
@@ -61,6 +61,7 @@ class GraphStructure:
                     _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes, _stream())
         gs._sizes = None if sizes is None else np.asarray(sizes, dtype=np.int64)
         gs._layouts = {}
+        gs._pna_scales = None
         return gs
 
     def validate(self):

@@ -120,11 +120,18 @@ class PNAConv(nn.Module):
         Wst = torch.cat([Wq.reshape(T, -1), Wq.new_zeros(T, 1)], 1).index_select(1, wmap).view(T, S * Fo, 5 * Fi)
         bst = torch.cat([bq, bq.new_zeros(T, 1)], 1).index_select(1, bmap)
         Y = ops.tower_linear(torch.cat([xt, agg4], dim=-1), Wst, bst).view(N, T, S, Fo)
-        deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(x.dtype).view(-1, 1, 1)
-        out = None
-        for s, sc in enumerate(self._scales(deg)):
-            term = Y[:, :, s] if sc is None else Y[:, :, s] * sc
-            out = term if out is None else out + term
+        # the degree scalers depend on the batch's graph structure only: computed by the first layer, reused by the rest
+        cache = getattr(gs, "_pna_scales", None)
+        key = (tuple(self.scalers), self.avg_deg["log"], self.avg_deg["lin"])
+        if cache is None or cache[0] != key:
+            deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(torch.float32).view(-1, 1)
+            cols = [torch.ones_like(deg) if sc is None else sc for sc in self._scales(deg)]
+            cache = (key, torch.cat(cols, dim=1).contiguous())   # (N, S)
+            try:
+                gs._pna_scales = cache
+            except AttributeError:
+                pass
+        out = ops.scale_combine(Y, cache[1])   # sum_s scale_s * Y[:, :, s]
         return ops.linear_module(self.lin, out.reshape(N, T * Fo))
 
 

@@ -119,6 +119,35 @@ def aggregate(h, gs, conv, self_param, edge):
     raise ValueError(edge.kind)
 
 
+class _ScaleCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, scales):
+        Y = _dev(Y.float(), "Y")           # (N, T, S, F)
+        N, T, S, F = Y.shape
+        out = torch.empty((N, T, F), dtype=torch.float32, device=Y.device)
+        _lib.launch("gt_scale_combine_fwd", _ptr(Y), _ptr(scales), N, T, S, F, _ptr(out), _stream())
+        ctx.save_for_backward(scales)
+        ctx.dims = (N, T, S, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scales,) = ctx.saved_tensors
+        N, T, S, F = ctx.dims
+        g = _dev(g.float(), "grad")
+        dY = torch.empty((N, T, S, F), dtype=torch.float32, device=g.device)
+        _lib.launch("gt_scale_combine_bwd", _ptr(g), _ptr(scales), N, T, S, F, _ptr(dY), _stream())
+        return dY, None
+
+
+def scale_combine(Y, scales):
+    """sum_s Y[:, :, s] * scales[:, s] for Y (N, T, S, F) and per-node scaler factors (N, S) (PNAConv's degree
+    scalers on the post-Linear's output blocks); scales carry no gradient."""
+    if scales.dtype != torch.float32 or scales.shape != (Y.shape[0], Y.shape[2]) or not scales.is_contiguous():
+        raise TypeError("scale_combine: contiguous fp32 (N, S) scales expected")
+    return _ScaleCombine.apply(Y, scales)
+
+
 # ------------------------------------------------------------------------------------------------
 # per-graph segment ops (virtual node)
 # ------------------------------------------------------------------------------------------------

@@ -198,6 +198,12 @@ int gt_pna_aggregate_bwd(const float* V, const float* out, const float* mean_v, 
                          const float* grad_out, int64_t num_nodes, int64_t dim, int towers, const int32_t* in_ptr,
                          const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* dU, float* dV,
                          gt_stream_t stream);
+/* Degree scalers of PNAConv (modules/pna/scalers.py:10-31) applied to the S per-scaler output blocks of the
+ * post-Linear: out[n][t][f] = sum_s Y[n][t][s][f] * scales[n][s]; bwd: dY = grad_out (x) scales (scales: no grad). */
+int gt_scale_combine_fwd(const float* Y, const float* scales, int64_t num_nodes, int towers, int num_scalers, int F,
+                         float* out, gt_stream_t stream);
+int gt_scale_combine_bwd(const float* grad_out, const float* scales, int64_t num_nodes, int towers, int num_scalers, int F,
+                         float* dY, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input node encoders: out[n] = sum_t table_t[min(idx_t[n * stride_t], clamp_t)]  (clamp_t < 0: none).

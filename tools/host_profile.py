@@ -5,7 +5,9 @@ import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 batch = sys.argv[1] if len(sys.argv) > 1 else "8"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--no-kernel-timing", "--batch", batch]
+workload = sys.argv[3] if len(sys.argv) > 3 else "code2"
+sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--no-kernel-timing", "--batch", batch,
+            "--workload", workload]
 import bench
 pr = cProfile.Profile()
 pr.enable()
