@@ -24,6 +24,21 @@ from ..norm import BatchNorm1d
 _AGG_SLOT = {"mean": 0, "max": 1, "min": 2, "std": 3}
 
 
+class _Restack(torch.autograd.Function):
+    """out[:, i] = src[:, map[i]] (map == src.shape[1] selects an appended zero); the map is injective on the used
+    source columns, so the backward is a gather through the inverse map instead of torch's sort-based index_add."""
+
+    @staticmethod
+    def forward(ctx, src, fmap, inv):
+        ctx.save_for_backward(inv)
+        return torch.cat([src, src.new_zeros(src.shape[0], 1)], 1).index_select(1, fmap)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return torch.cat([g, g.new_zeros(g.shape[0], 1)], 1).index_select(1, inv), None, None
+
+
 class PNAConv(nn.Module):
     def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
                  post_layers=1, divide_input=False):
@@ -93,7 +108,15 @@ class PNAConv(nn.Module):
                 wmap[rows, Fi + slot * Fi:Fi + (slot + 1) * Fi] = o * cols + Fi + s * A * Fi + ai * Fi + f
         bmap = torch.full((S * Fo,), Fo, dtype=torch.int64)
         bmap[:Fo] = torch.arange(Fo)
-        self._wmap, self._bmap, self._maps_key = wmap.reshape(-1).to(device), bmap.to(device), key
+        # inverse maps for the backward (every source element lands at most once): source j <- restacked position
+        # inv[j], or the appended zero when j is not used
+        wflat = wmap.reshape(-1)
+        winv = torch.full((zero_w,), wflat.numel(), dtype=torch.int64)
+        used = wflat < zero_w
+        winv[wflat[used]] = torch.nonzero(used).reshape(-1)
+        binv = torch.arange(Fo)
+        self._wmap, self._bmap, self._maps_key = wflat.to(device), bmap.to(device), key
+        self._winv, self._binv = winv.to(device), binv.to(device)
         return self._wmap, self._bmap
 
     def forward(self, x, edge_index, edge_attr=None, graph=None):
@@ -117,8 +140,8 @@ class PNAConv(nn.Module):
         wmap, bmap = self._post_maps(x.device)
         Wq = torch.stack([m[0].weight for m in self.post_nns])           # (T, F_out, (A*S+1)F)
         bq = torch.stack([m[0].bias for m in self.post_nns])             # (T, F_out)
-        Wst = torch.cat([Wq.reshape(T, -1), Wq.new_zeros(T, 1)], 1).index_select(1, wmap).view(T, S * Fo, 5 * Fi)
-        bst = torch.cat([bq, bq.new_zeros(T, 1)], 1).index_select(1, bmap)
+        Wst = _Restack.apply(Wq.reshape(T, -1), wmap, self._winv).view(T, S * Fo, 5 * Fi)
+        bst = _Restack.apply(bq, bmap, self._binv)
         Y = ops.tower_linear(torch.cat([xt, agg4], dim=-1), Wst, bst).view(N, T, S, Fo)
         # the degree scalers depend on the batch's graph structure only: computed by the first layer, reused by the rest
         cache = getattr(gs, "_pna_scales", None)
