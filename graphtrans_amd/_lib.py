@@ -75,6 +75,10 @@ SIGNATURES = {
     "gt_overlap_dw_sync": (_i, []),
     "gt_overlap_dw_end": (_i, []),
     "gt_linear_fwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
+    "gt_linear_fwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i, _f, _u64, _p]),
+    "gt_linear_bwd_grouped_workspace_bytes": (_sz, [_i, _i64, _i64, _i64, _i]),
+    "gt_linear_bwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _f,
+                                   _p, _sz, _p]),
     "gt_linear_bwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_xent_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "gt_xent_bwd": (_i, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p]),

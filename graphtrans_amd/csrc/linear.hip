@@ -49,7 +49,15 @@ struct LinArgs {
   int64_t m_per_split;
   int64_t n_per_split;  // dx: contraction range per blockIdx.z when splits > 1 (partials [splits][M][K] fp32 in `out`)
   int dbg;  // ablation bits (GT_LINEAR_DBG): 1 no W loads, 2 no X loads, 4 no stores, 8 no MFMA
+  // grouped launch (blockIdx.y = group g, e.g. the towers of PNAConv): element offsets added per group
+  int64_t g_x, g_y, g_w, g_b;   // X / dX / addends ; Y / dY / ymask ; W [N][K] ; bias [N]
+  int64_t g_part;               // dw: floats between the groups' partial buffers (dW partials + db partials)
 };
+
+template <typename TA>
+__device__ __forceinline__ const void* goff(const void* p, int64_t elems) {
+  return p ? static_cast<const void*>(static_cast<const TA*>(p) + elems) : nullptr;
+}
 
 __device__ __forceinline__ uint32_t lin_hash(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col) {
   uint32_t x = (row * 0x9E3779B1u + s0) ^ (col * 0x85EBCA77u + s1);
@@ -215,6 +223,13 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
   tile_of_block(a.ntiles, mt_, nt_);
   const int64_t m0 = mt_ * BM, n0 = (int64_t)nt_ * BN;
   if (m0 >= a.M) return;
+  if (blockIdx.y) {
+    const int64_t grp = blockIdx.y;
+    a.a = goff<TX>(a.a, grp * a.g_x);
+    a.w += grp * a.g_w;
+    if (a.bias) a.bias += grp * a.g_b;
+    a.out = const_cast<void*>(goff<TY>(a.out, grp * a.g_y));
+  }
   const TX* X = reinterpret_cast<const TX*>(a.a);
   f32x4 acc[4][MI];  // [n tile j][m tile i]
 #pragma unroll
@@ -326,6 +341,15 @@ __global__ void __launch_bounds__(LT) k_linear_dx(LinArgs a) {
   tile_of_block(a.ntiles, mt_, nt_);
   const int64_t m0 = mt_ * BM, kk0 = (int64_t)nt_ * BN;  // output column tile (k)
   if (m0 >= a.M) return;
+  if (blockIdx.y) {
+    const int64_t grp = blockIdx.y;
+    a.a = goff<TY>(a.a, grp * a.g_y);
+    a.ymask = goff<TY>(a.ymask, grp * a.g_y);
+    a.w += grp * a.g_w;
+    a.add1 = goff<TX>(a.add1, grp * a.g_x);
+    a.add2 = goff<TX>(a.add2, grp * a.g_x);
+    a.out = const_cast<void*>(goff<TX>(a.out, grp * a.g_x));
+  }
   const TY* dY = reinterpret_cast<const TY*>(a.a);
   const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
   const bool has_mask = Ym != nullptr;
@@ -435,6 +459,14 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
   int tile_;
   tile_of_block(a.ntiles, split_, tile_);
   if (split_ >= a.splits) return;
+  if (blockIdx.y) {
+    const int64_t grp = blockIdx.y;
+    a.a = goff<TY>(a.a, grp * a.g_y);
+    a.ymask = goff<TY>(a.ymask, grp * a.g_y);
+    a.x = goff<TX>(a.x, grp * a.g_x);
+    a.out = static_cast<float*>(a.out) + grp * a.g_part;
+    if (a.dbpart) a.dbpart += grp * a.g_part;
+  }
   const int split = (int)split_;
   const int tx = tile_ % a.ntx, ty = tile_ / a.ntx;
   const int64_t n0 = (int64_t)tx * BN, k0 = (int64_t)ty * BN;
@@ -523,7 +555,12 @@ __global__ void __launch_bounds__(LT) k_linear_dw(LinArgs a) {
 // dW (len N*K -> out) and, when len2 > 0, db (len2 = N -> out2).
 __global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ part, int splits, int64_t len,
                                                       float* __restrict__ out, const float* __restrict__ part2, int64_t len2,
-                                                      float* __restrict__ out2) {
+                                                      float* __restrict__ out2, int64_t g_part) {
+  if (blockIdx.y) {   // grouped launch: the groups' partial buffers are g_part floats apart, outputs back to back
+    part += blockIdx.y * g_part;
+    out += blockIdx.y * len;
+    if (part2) { part2 += blockIdx.y * g_part; out2 += blockIdx.y * len2; }
+  }
   for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < len + len2; i0 += (int64_t)gridDim.x * 256) {
     const bool second = i0 >= len;
     const float* p = second ? part2 : part;
@@ -637,6 +674,18 @@ extern "C" int gt_linear_fwd_ld(int x_dtype, int y_dtype, int compute, const voi
 extern "C" int gt_linear_fwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                                  const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
                                  int act, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  return gt_linear_fwd_grouped(x_dtype, y_dtype, compute, x, weight, bias, y, M, N, K, ldx, ldy, 1, 0, 0, act, dropout_p, seed,
+                               stream_);
+}
+
+extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
+                                     const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
+                                     int groups, int64_t x_group_stride, int64_t y_group_stride, int act, float dropout_p,
+                                     uint64_t seed, gt_stream_t stream_) {
+  GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
+  GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
+                               (N * K) % 4 == 0),
+               "group strides must keep 16-byte alignment");
   int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K, ldy);
   if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
     gt_set_error("gt_linear_fwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
@@ -654,9 +703,10 @@ extern "C" int gt_linear_fwd_ld2(int x_dtype, int y_dtype, int compute, const vo
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act;
   { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
+  a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   const int bm = pick_bm(M);
   a.ntiles = (int)gt_cdiv(N, BN);
-  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles));
+  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups);
   const int t0 = x_dtype, t1 = y_dtype;
   if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_fwd, 64, grid, a);
   else GT_LIN_DISPATCH_BM(k_linear_fwd, 128, grid, a);
@@ -691,6 +741,23 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                                  float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
                                  void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
+                               ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+extern "C" size_t gt_linear_bwd_grouped_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K, int groups) {
+  return (size_t)(groups < 1 ? 1 : groups) * gt_linear_bwd_workspace_bytes(compute, M, N, K);
+}
+
+extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                     const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                                     float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
+                                     int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
+                                     size_t workspace_bytes, gt_stream_t stream_) {
+  GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
+  GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
+                               (N * K) % 4 == 0),
+               "group strides must keep 16-byte alignment");
   int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K, ldy);
   if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
     gt_set_error("gt_linear_bwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
@@ -708,22 +775,25 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
   a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx;
   a.add1 = dx_add1; a.add2 = dx_add2;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
+  a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   if (M == 0) {
-    if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)N * K * sizeof(float), stream);
-    if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream);
+    if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)groups * N * K * sizeof(float), stream);
+    if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)groups * N * sizeof(float), stream);
     return GT_OK;
   }
-  const size_t need = gt_linear_bwd_workspace_bytes(compute, M, N, K);
+  const size_t need1 = gt_linear_bwd_workspace_bytes(compute, M, N, K);   // per group
+  const size_t need = (size_t)groups * need1;
+  a.g_part = (int64_t)(need1 / sizeof(float));
   if (dx) {
     const int bm = pick_bm(M);
-    // split-N partials are plain fp32 sums: only for fp32 dX without fused addends
-    int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2 && ldx == K) ? dx_splits(M, N, K, bm) : 1;
+    // split-N partials are plain fp32 sums: only for fp32 dX without fused addends (and not for grouped launches)
+    int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2 && ldx == K && groups == 1) ? dx_splits(M, N, K, bm) : 1;
     if (splits > 1 && (!workspace || workspace_bytes < need)) splits = 1;
     a.splits = splits;
     a.n_per_split = gt_cdiv(gt_cdiv(N, splits), 64) * 64;
     a.out = splits > 1 ? workspace : dx;
     a.ntiles = (int)gt_cdiv(K, BN);
-    dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), 1, (unsigned)splits);
+    dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups, (unsigned)splits);
     const int t0 = y_dtype, t1 = x_dtype;
     if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_dx, 64, grid, a);
     else GT_LIN_DISPATCH_BM(k_linear_dx, 128, grid, a);
@@ -731,7 +801,7 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
       const int64_t len = M * K;
       const int rg = (int)(gt_cdiv(len, 256) < 2048 ? gt_cdiv(len, 256) : 2048);
       hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len,
-                         reinterpret_cast<float*>(dx), (const float*)nullptr, (int64_t)0, (float*)nullptr);
+                         reinterpret_cast<float*>(dx), (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);
     }
   }
   if (dweight) {
@@ -755,13 +825,13 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
     a.dbpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)splits * N * K : nullptr;
     a.ntx = (int)gt_cdiv(N, BN);
     a.ntiles = a.ntx * (int)gt_cdiv(K, BN);
-    dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * a.ntiles));
+    dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * a.ntiles), (unsigned)groups);
     const int t0 = y_dtype, t1 = x_dtype;
     GT_LIN_DISPATCH(k_linear_dw, grid, a);
     const int64_t len = N * K, len2 = dbias ? N : 0;
     int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-    hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
-                       (const float*)a.dbpart, len2, dbias);
+    hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
+                       (const float*)a.dbpart, len2, dbias, a.g_part);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;

@@ -765,11 +765,11 @@ class _TowerLinear(torch.autograd.Function):
         w32 = _f32(weight)                    # (T, Nout, K)
         b32 = _f32(bias)                      # (T, Nout) or None
         y = torch.empty((M, T, Nout), dtype=x.dtype, device=x.device)
-        es = x.element_size()
-        for t in range(T):
-            _lib.launch("gt_linear_fwd_ld2", _dtype_code(x), _dtype_code(y), compute, x.data_ptr() + t * K * es,
-                        w32.data_ptr() + t * Nout * K * 4, None if b32 is None else b32.data_ptr() + t * Nout * 4,
-                        y.data_ptr() + t * Nout * es, M, Nout, K, T * K, T * Nout, 0, 0.0, 0, _stream())
+        w32 = w32.contiguous()
+        b32 = None if b32 is None else b32.contiguous()
+        # one grouped launch: group t = column slice [t*K, (t+1)*K) of x -> [t*Nout, (t+1)*Nout) of y
+        _lib.launch("gt_linear_fwd_grouped", _dtype_code(x), _dtype_code(y), compute, _ptr(x), _ptr(w32), _ptr(b32), _ptr(y),
+                    M, Nout, K, T * K, T * Nout, T, K, Nout, 0, 0.0, 0, _stream())
         ctx.save_for_backward(x, w32)
         ctx.cfg = (compute, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -785,21 +785,16 @@ class _TowerLinear(torch.autograd.Function):
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty((T, Nout, K), dtype=torch.float32, device=x.device) if need_w else None
         db = torch.empty((T, Nout), dtype=torch.float32, device=x.device) if (need_w and bdt is not None) else None
-        ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(compute, M, Nout, K)
+        ws_bytes = _lib.lib().gt_linear_bwd_grouped_workspace_bytes(compute, M, Nout, K, T)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-        es = x.element_size()
-        for t in range(T):
-            _lib.launch("gt_linear_bwd_ld2", _dtype_code(x), _dtype_code(dy), compute, x.data_ptr() + t * K * es,
-                        w32.data_ptr() + t * Nout * K * 4, dy.data_ptr() + t * Nout * es, None, None, None,
-                        None if dx is None else dx.data_ptr() + t * K * es, None if dw is None else dw.data_ptr() + t * Nout * K * 4,
-                        None if db is None else db.data_ptr() + t * Nout * 4, M, Nout, K, T * K, T * Nout, 0.0, _ptr(ws), ws_bytes,
-                        _stream())
+        _lib.launch("gt_linear_bwd_grouped", _dtype_code(x), _dtype_code(dy), compute, _ptr(x), _ptr(w32), _ptr(dy), None, None, None,
+                    _ptr(dx), _ptr(dw), _ptr(db), M, Nout, K, T * K, T * Nout, T, K, Nout, 0.0, _ptr(ws), ws_bytes, _stream())
         return dx, (None if dw is None else dw.to(wdt)), (None if db is None else db.to(bdt)), None
 
 
 def tower_linear(x, weight, bias=None):
-    """y[:, t] = x[:, t] @ weight[t].T + bias[t] for (M, T, K) x, (T, Nout, K) weight -> (M, T, Nout): T launches of
-    gt_linear_*_ld2 on column slices (no transposes, no per-tower copies).  K and Nout multiples of 4 (8 for bf16)."""
+    """y[:, t] = x[:, t] @ weight[t].T + bias[t] for (M, T, K) x, (T, Nout, K) weight -> (M, T, Nout): one grouped
+    launch (gt_linear_*_grouped, grid.y = tower) on column slices (no transposes, no per-tower copies).  K and Nout multiples of 4 (8 for bf16)."""
     if x.dim() != 3 or weight.dim() != 3 or x.shape[1] != weight.shape[0] or x.shape[2] != weight.shape[2]:
         raise ValueError("tower_linear: x (M, T, K), weight (T, Nout, K)")
     compute = GT_BF16 if (x.dtype == torch.bfloat16 or _MATMUL_DTYPE == torch.bfloat16) else GT_F32

@@ -397,6 +397,20 @@ int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, cons
                       const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                       float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
                       void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* Grouped launch: `groups` independent GEMMs of the same shape in ONE launch per kernel (grid.y = group): the T
+ * towers of PNAConv's pre_nns / post_nns (modules/pna/pna_module.py:33-41).  Group g reads x + g * x_group_stride
+ * (elements, row stride ldx), weight + g * N * K, bias + g * N and writes y + g * y_group_stride (row stride ldy);
+ * the backward mirrors it (dweight [groups][N][K], dbias [groups][N]); workspace = groups x the plain size. */
+int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                          void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
+                          int64_t x_group_stride, int64_t y_group_stride, int act, float dropout_p, uint64_t seed,
+                          gt_stream_t stream);
+size_t gt_linear_bwd_grouped_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K, int groups);
+int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                          const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                          float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
+                          int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
+                          size_t workspace_bytes, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy over the stacked prediction heads (the Code2 loss, dataset/code.py:39-45:

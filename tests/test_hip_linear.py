@@ -155,3 +155,36 @@ def test_linear_module_odd_K(M, N, K):
         assert (got.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
     with pytest.raises(RuntimeError):
         ops.linear_module(lin.cpu(), x.detach().cpu())
+
+
+@pytest.mark.parametrize("M,T,K,N,bias", [(1000, 4, 68, 68, True), (257, 4, 340, 204, True), (64, 1, 16, 8, False), (5000, 3, 32, 100, True)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_tower_linear_grouped(M, T, K, N, bias, mode):
+    """gt_linear_fwd/bwd_grouped (grid.y = tower): PNAConv's per-tower pre_nns / post_nns (modules/pna/pna_module.py:33-41),
+    y[:, t] = x[:, t] W[t]^T + b[t], against float64 einsum; all gradients."""
+    from graphtrans_amd import ops
+    torch.manual_seed(M + T)
+    ops.set_matmul_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    try:
+        x = torch.randn(M, T, K, device="cuda", requires_grad=True)
+        w = torch.randn(T, N, K, device="cuda", requires_grad=True)
+        b = torch.randn(T, N, device="cuda", requires_grad=True) if bias else None
+        y = ops.tower_linear(x, w, b)
+        g = torch.randn(M, T, N, device="cuda")
+        y.backward(g)
+        xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+        br = b.detach().double().requires_grad_() if bias else None
+        if mode == "bf16":   # the kernel rounds both operands to bf16 (fp32 accumulate)
+            xq, wq = xr.float().bfloat16().double(), wr.float().bfloat16().double()
+            xq, wq = xr + (xq - xr).detach(), wr + (wq - wr).detach()
+        else:
+            xq, wq = xr, wr
+        yr = torch.einsum("mtk,tnk->mtn", xq, wq) + (br if bias else 0)
+        yr.backward(g.double())
+        tol = 2e-2 if mode == "bf16" else 1e-4
+        pairs = [(y, yr), (x.grad, xr.grad), (w.grad, wr.grad)] + ([(b.grad, br.grad)] if bias else [])
+        for got, want in pairs:
+            assert got.shape == want.shape
+            assert (got.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    finally:
+        ops.set_matmul_dtype(torch.float32)
