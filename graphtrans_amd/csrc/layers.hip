@@ -149,8 +149,8 @@ GcnGrads gcn_grads(const gt_gcn_layer* L, float* g) {
   return r;
 }
 struct GcnWork {
-  void *d_agg, *d_lin, *bn_ws, *agg_ws, *lin_ws;
-  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, bytes;
+  void *d_agg, *d_lin, *bn_ws, *agg_ws, *lin_ws, *seg_ws;
+  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, seg_ws_bytes, bytes;
 };
 GcnWork gcn_work(const gt_gcn_layer* L, void* p) {
   Bump b(p);
@@ -163,6 +163,8 @@ GcnWork gcn_work(const gt_gcn_layer* L, void* p) {
   w.agg_ws = b.take(w.agg_ws_bytes);
   w.lin_ws_bytes = gt_linear_bwd_workspace_bytes(L->compute, L->N, L->D, L->D);
   w.lin_ws = b.take(w.lin_ws_bytes);
+  w.seg_ws_bytes = L->has_vn ? gt_segment_sum_workspace_bytes(L->N, L->D) : 0;   // d vn = pooled d x (its own slot: the
+  w.seg_ws = b.take(w.seg_ws_bytes);                                             // dW GEMM may still use lin_ws)
   w.bytes = b.off;
   return w;
 }
@@ -208,8 +210,8 @@ VnGrads vn_grads(const gt_vn_update* L, float* g) {
   return r;
 }
 struct VnWork {
-  void *d_z2, *d_a1, *d_z1, *d_t0, *bn_ws, *lin_ws;
-  size_t bn_ws_bytes, lin_ws_bytes, bytes;
+  void *d_z2, *d_a1, *d_z1, *d_t0, *bn_ws, *lin_ws, *seg_ws;
+  size_t bn_ws_bytes, lin_ws_bytes, seg_ws_bytes, bytes;
 };
 VnWork vn_work(const gt_vn_update* L, void* p) {
   Bump b(p);
@@ -224,6 +226,8 @@ VnWork vn_work(const gt_vn_update* L, void* p) {
   size_t c = gt_linear_bwd_workspace_bytes(L->compute, L->B, L->D, 2 * L->D);
   w.lin_ws_bytes = a > c ? a : c;
   w.lin_ws = b.take(w.lin_ws_bytes);
+  w.seg_ws_bytes = gt_segment_sum_workspace_bytes(L->N, L->D);   // the pooling of the forward
+  w.seg_ws = b.take(w.seg_ws_bytes);
   w.bytes = b.off;
   return w;
 }
@@ -341,8 +345,8 @@ GinGrads gin_grads(const gt_gin_layer* L, float* g) {
   return r;
 }
 struct GinWork {
-  void *d_z2, *d_a1, *d_z1, *d_agg, *d_x, *bn_ws, *agg_ws, *lin_ws;
-  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, bytes;
+  void *d_z2, *d_a1, *d_z1, *d_agg, *d_x, *bn_ws, *agg_ws, *lin_ws, *seg_ws;
+  size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, seg_ws_bytes, bytes;
 };
 GinWork gin_work(const gt_gin_layer* L, void* p) {
   Bump b(p);
@@ -360,6 +364,8 @@ GinWork gin_work(const gt_gin_layer* L, void* p) {
   size_t a = gt_linear_bwd_workspace_bytes(L->compute, N, 2 * D, D), c = gt_linear_bwd_workspace_bytes(L->compute, N, D, 2 * D);
   w.lin_ws_bytes = a > c ? a : c;
   w.lin_ws = b.take(w.lin_ws_bytes);
+  w.seg_ws_bytes = gt_segment_sum_workspace_bytes(L->N, L->D);   // the pooling of the forward
+  w.seg_ws = b.take(w.seg_ws_bytes);
   w.bytes = b.off;
   return w;
 }
@@ -423,7 +429,8 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
   if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, x, L->lin_w, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr, d_h_in,
                        g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-  if (L->has_vn) GT_TRY(gt_segment_sum(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, st));
+  if (L->has_vn)
+    GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
 }
 
@@ -441,7 +448,7 @@ extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void
   const VnSaved s = vn_saved(L, saved);
   const int64_t B = L->B, D = L->D;
   // global_add_pool(h_list[layer], batch) + vn   (gnn_module.py:219)
-  GT_TRY(gt_segment_sum(GT_F32, x, vn, L->graph_ptr, L->N, B, D, s.t0, st));
+  GT_TRY(gt_segment_sum_ws(GT_F32, x, vn, L->graph_ptr, L->N, B, D, s.t0, w.seg_ws, w.seg_ws_bytes, st));
   // mlp_virtualnode_list[layer]: Linear(D,2D) BN ReLU Linear(2D,D) BN ReLU   (gnn_module.py:161-170)
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, L->b1, s.z1, B, 2 * D, D, 0, 0.f, 0, st));
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
@@ -553,6 +560,6 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
     const float* e2 = (dx_extra && L->residual) ? (const float*)dy : nullptr;
     GT_TRY(gt_add3((const float*)w.d_x, e1, e2, N * D, (float*)d_h_in, st));
   }
-  if (L->has_vn) GT_TRY(gt_segment_sum(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, st));
+  if (L->has_vn) GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
 }

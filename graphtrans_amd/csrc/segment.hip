@@ -61,6 +61,97 @@ __global__ void __launch_bounds__(SEG_THREADS) k_segment_sum(const T* __restrict
   }
 }
 
+// ---- the same sum in two load-balanced phases (needs a workspace): graph sizes are ragged (11 .. 2000 nodes in
+// a Code2 batch) and with one block per graph the largest graph is the kernel's tail (2.4 MB through one CU).
+// Phase 1: a block walks SS_CH consecutive ROWS with the running sum in a register (8 rows in flight), starting
+// a new sum at every graph boundary; graphs inside the chunk are stored directly, the (at most two) graphs
+// that cross its ends leave head / tail partials.  Phase 2: one block per graph adds its partials in chunk
+// order (and handles empty graphs).  Fixed order -> reproducible.
+constexpr int SS_CH = 64, SS_T = 320;
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) {
+  if constexpr (sizeof(T) == 4) return (float)*reinterpret_cast<const float*>(p);
+  else return gt_bf16_to_f32(*reinterpret_cast<const gt_bf16*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void stf(T* p, float v) {
+  if constexpr (sizeof(T) == 4) *reinterpret_cast<float*>(p) = v;
+  else *reinterpret_cast<gt_bf16*>(p) = gt_f32_to_bf16(v);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SS_T) k_segsum_chunks(const T* __restrict__ x, const T* __restrict__ add,
+                                                        const int32_t* __restrict__ gptr, int B, int64_t N, int64_t D,
+                                                        T* __restrict__ out, float* __restrict__ head, float* __restrict__ tail) {
+  const int64_t p0 = (int64_t)blockIdx.x * SS_CH;
+  const int64_t p1 = p0 + SS_CH < N ? p0 + SS_CH : N;
+  if (p0 >= p1) return;
+  // graph of row p0: last b with gptr[b] <= p0 (empty graphs share a start: take the one that owns the row)
+  int lo = 0, hi = B;   // invariant: gptr[lo] <= p0 < gptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (gptr[mid] <= p0) lo = mid; else hi = mid;
+  }
+  const int g0 = lo;
+  float* hd = head + (int64_t)blockIdx.x * D;
+  float* tl = tail + (int64_t)blockIdx.x * D;
+  for (int64_t c = threadIdx.x; c < D; c += SS_T) {
+    int g = g0;
+    int64_t gend = gptr[g + 1];
+    float acc = 0.f;
+    auto flush = [&](int gg, float v) {
+      const bool before = gptr[gg] < p0, after = (int64_t)gptr[gg + 1] > p1;
+      if (before) hd[c] = v;
+      else if (after) tl[c] = v;
+      else stf<T>(out + (int64_t)gg * D + c, v + (add ? ldf<T>(add + (int64_t)gg * D + c) : 0.f));
+    };
+    for (int64_t rb = p0; rb < p1; rb += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = rb + u < p1 ? ldf<T>(x + (rb + u) * D + c) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = rb + u;
+        if (r >= p1) break;
+        if (r == gend) {            // row r opens the next non-empty graph
+          flush(g, acc);
+          acc = 0.f;
+          do { ++g; gend = gptr[g + 1]; } while (gend <= r);
+        }
+        acc += v[u];
+      }
+    }
+    flush(g, acc);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SS_T) k_segsum_fixup(const T* __restrict__ add, const int32_t* __restrict__ gptr, int64_t D,
+                                                       const float* __restrict__ head, const float* __restrict__ tail,
+                                                       T* __restrict__ out) {
+  const int b = blockIdx.x;
+  const int64_t beg = gptr[b], end = gptr[b + 1];
+  if (end > beg && beg / SS_CH == (end - 1) / SS_CH) return;   // inside one chunk: phase 1 stored it
+  const int64_t c0 = beg / SS_CH, c1 = end > beg ? (end - 1) / SS_CH : 0;
+  for (int64_t c = threadIdx.x; c < D; c += SS_T) {
+    float acc = 0.f;
+    if (end > beg) {
+      acc = tail[c0 * D + c];
+      int64_t j = c0 + 1;
+      for (; j + 7 <= c1; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = head[(j + u) * D + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; j <= c1; ++j) acc += head[j * D + c];
+    }
+    stf<T>(out + (int64_t)b * D + c, acc + (add ? ldf<T>(add + (int64_t)b * D + c) : 0.f));
+  }
+}
+
 // tokens[row(b,p)] <- node row | cls | 0 ; grid (position tiles, B)
 template <typename T>
 __global__ void __launch_bounds__(SEG_THREADS) k_seq_gather(const T* __restrict__ h, const T* __restrict__ cls,
@@ -223,6 +314,39 @@ extern "C" int gt_seq_scatter(int dtype, const void* tokens, const void* base, c
     hipLaunchKernelGGL(k_seq_scatter<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)tokens,
                        (const gt_bf16*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
                        (gt_bf16*)h_out, (gt_bf16*)cls_out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" size_t gt_segment_sum_workspace_bytes(int64_t N, int64_t D) {
+  return (size_t)2 * gt_cdiv(N > 0 ? N : 1, SS_CH) * D * sizeof(float) + 256;
+}
+
+extern "C" int gt_segment_sum_ws(int dtype, const void* x, const void* add, const int32_t* graph_ptr, int64_t N, int64_t B,
+                                 int64_t D, void* out, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  // small inputs: the one-block-per-graph kernel is a single launch and just as fast
+  if (N < 4096 || !workspace || workspace_bytes < gt_segment_sum_workspace_bytes(N, D))
+    return gt_segment_sum(dtype, x, add, graph_ptr, N, B, D, out, stream_);
+  int rc = check("gt_segment_sum_ws", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && graph_ptr && out, "null buffer");
+  if (B == 0) return GT_OK;
+  GT_CHECK_ARG(B <= 0x7fffffff && N <= 0x7fffffff, "sizes beyond int32");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t nch = gt_cdiv(N, SS_CH);
+  float* head = static_cast<float*>(workspace);
+  float* tail = head + nch * D;
+  if (dtype == GT_F32) {
+    hipLaunchKernelGGL(k_segsum_chunks<float>, dim3((unsigned)nch), dim3(SS_T), 0, stream, (const float*)x, (const float*)add,
+                       graph_ptr, (int)B, N, D, (float*)out, head, tail);
+    hipLaunchKernelGGL(k_segsum_fixup<float>, dim3((unsigned)B), dim3(SS_T), 0, stream, (const float*)add, graph_ptr, D,
+                       (const float*)head, (const float*)tail, (float*)out);
+  } else {
+    hipLaunchKernelGGL(k_segsum_chunks<gt_bf16>, dim3((unsigned)nch), dim3(SS_T), 0, stream, (const gt_bf16*)x,
+                       (const gt_bf16*)add, graph_ptr, (int)B, N, D, (gt_bf16*)out, head, tail);
+    hipLaunchKernelGGL(k_segsum_fixup<gt_bf16>, dim3((unsigned)B), dim3(SS_T), 0, stream, (const gt_bf16*)add, graph_ptr, D,
+                       (const float*)head, (const float*)tail, (gt_bf16*)out);
+  }
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -164,8 +164,14 @@ def _segment_sum_raw(x, add, gs):
     x = _dev(x, "x")
     D = x.shape[1]
     out = torch.empty((gs.B, D), dtype=x.dtype, device=x.device)
-    _lib.launch("gt_segment_sum", _dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
-                _stream())
+    if gs.N >= 4096:   # load-balanced over row chunks (ragged graph sizes): needs a small workspace
+        wsb = _lib.lib().gt_segment_sum_workspace_bytes(gs.N, D)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        _lib.launch("gt_segment_sum_ws", _dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
+                    _ptr(ws), wsb, _stream())
+    else:
+        _lib.launch("gt_segment_sum", _dtype_code(x), _ptr(x), _ptr(add), _ptr(gs.graph_ptr), gs.N, gs.B, D, _ptr(out),
+                    _stream())
     return out
 
 

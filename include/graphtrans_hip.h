@@ -247,6 +247,13 @@ int gt_segment_bcast_add(int dtype, const void* x, const void* seg, const int32_
                          int64_t num_graphs, int64_t dim, void* out, gt_stream_t stream);
 int gt_segment_sum(int dtype, const void* x, const void* add, const int32_t* graph_ptr, int64_t num_nodes,
                    int64_t num_graphs, int64_t dim, void* out, gt_stream_t stream);
+/* Same result class (fixed summation order, different association) with a workspace: load-balanced over ROW chunks
+ * instead of one block per graph, for batches whose largest graph would otherwise be the tail of the kernel.
+ * Falls back to gt_segment_sum for small inputs or a missing workspace. */
+size_t gt_segment_sum_workspace_bytes(int64_t num_nodes, int64_t dim);
+int gt_segment_sum_ws(int dtype, const void* x, const void* add, const int32_t* graph_ptr, int64_t num_nodes,
+                      int64_t num_graphs, int64_t dim, void* out, void* workspace, size_t workspace_bytes,
+                      gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sequence layout: flat node rows <-> transformer token rows.

@@ -284,3 +284,36 @@ def test_gnn_transformer_golden(name, layout):
         b.x = b.x.requires_grad_(True)
         fi["x"] = b.x
     _run_and_compare(g, m, lambda: m(b), fi)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["code2", "one_giant", "empties", "small"])
+def test_segment_sum_two_phase(case, dtype):
+    """global_add_pool(h, batch) + vn (modules/gnn_module.py:219): the load-balanced two-phase kernel (row chunks +
+    per-graph fix-up, N >= 4096) and the one-block-per-graph kernel against a float64 index_add, with graphs that
+    sit inside one chunk, end exactly on chunk boundaries, span many chunks, or are empty."""
+    from graphtrans_amd import ops, synth
+    from graphtrans_amd.graph import GraphStructure
+    g = torch.Generator().manual_seed(3)
+    if case == "code2":
+        sizes = torch.bincount(synth.code2_like(B=256, seed=0).batch, minlength=256)
+    elif case == "one_giant":
+        sizes = torch.tensor([64, 1, 63, 128, 9000, 2, 64, 65])
+    elif case == "empties":
+        sizes = torch.tensor([0, 0, 70, 0, 5000, 0, 0, 58, 6, 0])
+    else:
+        sizes = torch.tensor([5, 0, 17, 1])
+    B, N, D = sizes.numel(), int(sizes.sum()), 300
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    gs = GraphStructure.build(torch.zeros(2, 0, dtype=torch.int64, device=DEV), batch.to(DEV), num_graphs=B)
+    x = torch.randn(N, D, generator=g).to(dtype)
+    add = torch.randn(B, D, generator=g).to(dtype)
+    got = ops._segment_sum_raw(x.to(DEV), add.to(DEV), gs).float().cpu()
+    want = add.double().index_add(0, batch, x.double())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    scale = max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() <= tol * scale
+    got0 = ops._segment_sum_raw(x.to(DEV), None, gs).float().cpu()
+    want0 = torch.zeros(B, D, dtype=torch.float64).index_add(0, batch, x.double())
+    assert (got0.double() - want0).abs().max().item() <= tol * scale
+    assert torch.equal(got, ops._segment_sum_raw(x.to(DEV), add.to(DEV), gs).float().cpu())   # reproducible
