@@ -22,7 +22,7 @@ def timeit(fn, iters=30, warm=5):
 
 
 def bench_linear():
-    shapes = [(31598, 300, 300, "f32s"), (31598, 128, 600, "f32s"), (31855, 384, 128, "bf16"), (31855, 128, 128, "bf16"),
+    shapes = [(256, 600, 300, "f32s"), (256, 300, 600, "f32s"), (6651, 600, 300, "f32s"), (31598, 300, 300, "f32s"), (31598, 128, 600, "f32s"), (31855, 384, 128, "bf16"), (31855, 128, 128, "bf16"),
               (31855, 512, 128, "bf16"), (31855, 128, 512, "bf16")]
     print(f"{'shape':28s} {'mode':6s} {'fwd us':>8s} {'dx us':>8s} {'dw us':>8s} {'torch fwd':>10s} {'torch bwd':>10s}  fwd TF/s  min-bytes us")
     for M, N, K, mode in shapes:
