@@ -654,7 +654,8 @@ int pick_bm(int64_t M) {
     env = e ? atoi(e) : 0;
   }
   if (env == 64 || env == 128) return env;
-  return M >= 4096 ? 64 : 128;
+  (void)M;
+  return 64;   // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs
 }
 
 }  // namespace
