@@ -308,3 +308,40 @@ def test_freeze_gnn_leaves_the_fused_path():
     assert engine.eligible(model2, b, None)
     model2.gnn2transformer.weight.requires_grad_(False)
     assert not engine.eligible(model2, b, None)
+
+
+@pytest.mark.parametrize("workload", ["code2", "molpcba"])
+def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload):
+    """BASELINE configs[1] / [2] at full size (b256), three streams in play (main, virtual node, dW): ten fused
+    backward passes must agree bit for bit -- stream-ordering mistakes do not show at the small sizes of the other
+    tests because the GPU drains each kernel before the next one is enqueued."""
+    import importlib.util
+    import os
+    from graphtrans_amd import ops
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ops.set_matmul_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        args, model, gen, loss_fn, _ = bench.build(workload, torch.bfloat16, torch.device(DEV), 256)
+        for m in model.modules():
+            if hasattr(m, "dropout_p"):
+                m.dropout_p = 0.0
+        model.gnn_node.drop_ratio = 0.0
+        model.train()
+        b = bench.attach_sizes(gen(0)).to(DEV)
+        first = None
+        for it in range(10):
+            for p in model.parameters():
+                p.grad = None
+            b.__dict__.pop("_gt_structure", None)
+            loss_fn(model(b), b).backward()
+            g = [p.grad.detach().clone() for p in model.parameters()]
+            if first is None:
+                first = g
+            else:
+                bad = [n for (n, _), a, f in zip(model.named_parameters(), g, first) if not torch.equal(a, f)]
+                assert not bad, (it, len(bad), bad[:4])
+    finally:
+        ops.set_matmul_dtype(torch.float32)
