@@ -278,7 +278,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er", "code2-pna"])
     ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "bf16", "fp32"],
+                    help="mixed (default, the reference's arithmetic where BASELINE.json asks for it): exact-fp32 MFMA for "
+                         "message passing / gnn2transformer / heads, bf16 token rows + bf16 MFMA in the encoder layers; "
+                         "bf16: bf16 MFMA everywhere (fp32 storage on the GNN side); fp32: exact fp32 everywhere")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="deprecated alias of --mode bf16|fp32")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch graphs on EVERY GPU (default); strong: --batch is the global batch, split evenly "
                          "over the GPUs (SURVEY.md 8d: b256 -> 32 graphs per GPU at 8)")
@@ -315,9 +319,13 @@ def main():
     from graphtrans_amd import _lib
     from graphtrans_amd.dist import GradSync
 
-    dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
+    if opt.dtype is not None:
+        opt.mode = opt.dtype
+    matmul_dtype, dtype = {"mixed": (torch.float32, torch.bfloat16), "bf16": (torch.bfloat16, torch.bfloat16),
+                           "fp32": (torch.float32, torch.float32)}[opt.mode]   # (GNN-side GEMM compute, token rows)
+    opt.dtype = "bf16" if dtype == torch.bfloat16 else "fp32"
     from graphtrans_amd import ops as gt_ops
-    gt_ops.set_matmul_dtype(dtype)  # GNN linears: fp32 storage, MFMA compute type follows --dtype
+    gt_ops.set_matmul_dtype(matmul_dtype)
     per_gpu = opt.batch or {"nci1": 32, "code2-pna": 128}.get(opt.workload, 256)
     if opt.scaling == "strong":
         if per_gpu % world:
@@ -410,7 +418,9 @@ def main():
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
                        "step": ("collate+" if store is not None else "") + "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
-                       "gnn_dtype": "fp32 storage, %s MFMA linears" % opt.dtype, "transformer_dtype": opt.dtype,
+                       "mode": opt.mode,
+                       "gnn_dtype": "fp32 storage, %s MFMA linears" % ("bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32"),
+                       "transformer_dtype": opt.dtype,
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }

@@ -579,7 +579,9 @@ __global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ 
 int check_lin(const char* fn, int x_dtype, int y_dtype, int compute, int64_t M, int64_t N, int64_t K, int64_t ldy) {
   if ((x_dtype != GT_F32 && x_dtype != GT_BF16) || (y_dtype != GT_F32 && y_dtype != GT_BF16) ||
       (compute != GT_F32 && compute != GT_BF16)) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
-  if (compute == GT_F32 && (x_dtype != GT_F32 || y_dtype != GT_F32)) { gt_set_error("%s: fp32 compute needs fp32 storage", fn); return GT_ERR_UNSUPPORTED; }
+  // exact-fp32 MFMA over mixed storage: fp32 x with bf16 y (gnn2transformer writing bf16 token rows; its backward reads
+  // the bf16 token gradient) is supported; bf16 x with fp32 compute is not a combination of this path
+  if (compute == GT_F32 && x_dtype != GT_F32) { gt_set_error("%s: fp32 compute needs fp32 x storage", fn); return GT_ERR_UNSUPPORTED; }
   if (M < 0 || N <= 0 || K <= 0) { gt_set_error("%s: bad sizes", fn); return GT_ERR_INVALID_ARG; }
   if (ldy < N) { gt_set_error("%s: ldy (%lld) < N (%lld)", fn, (long long)ldy, (long long)N); return GT_ERR_INVALID_ARG; }
   if (ldy % 4 != 0 || K % 4 != 0) { gt_set_error("%s: ldy (= N unless given) and K must be multiples of 4 (got %lld, %lld)", fn, (long long)ldy, (long long)K); return GT_ERR_UNSUPPORTED; }
@@ -623,7 +625,9 @@ int dx_splits(int64_t M, int64_t N, int64_t K, int bm) {
 // dispatch over (storage of the M-sized operands, compute type)
 #define GT_LIN_DISPATCH(KERNEL, grid, args)                                                                        \
   do {                                                                                                             \
-    if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float>), grid, dim3(LT), 0, stream, args);     \
+    if (compute == GT_F32 && t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float>), grid, dim3(LT), 0, stream, args); \
+    else if (compute == GT_F32 && t0 == GT_F32) hipLaunchKernelGGL((KERNEL<float, gt_bf16, float>), grid, dim3(LT), 0, stream, args); \
+    else if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, float>), grid, dim3(LT), 0, stream, args); \
     else if (t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, gt_bf16>), grid, dim3(LT), 0, stream, args);   \
     else if (t0 == GT_F32 && t1 == GT_BF16) hipLaunchKernelGGL((KERNEL<float, gt_bf16, gt_bf16>), grid, dim3(LT), 0, stream, args); \
     else if (t0 == GT_BF16 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, gt_bf16>), grid, dim3(LT), 0, stream, args); \
@@ -632,7 +636,9 @@ int dx_splits(int64_t M, int64_t N, int64_t K, int bm) {
 
 #define GT_LIN_DISPATCH_BM(KERNEL, BMV, grid, args)                                                                \
   do {                                                                                                             \
-    if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float, BMV>), grid, dim3(LT), 0, stream, args); \
+    if (compute == GT_F32 && t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, float, BMV>), grid, dim3(LT), 0, stream, args); \
+    else if (compute == GT_F32 && t0 == GT_F32) hipLaunchKernelGGL((KERNEL<float, gt_bf16, float, BMV>), grid, dim3(LT), 0, stream, args); \
+    else if (compute == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, float, BMV>), grid, dim3(LT), 0, stream, args); \
     else if (t0 == GT_F32 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<float, float, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args);   \
     else if (t0 == GT_F32 && t1 == GT_BF16) hipLaunchKernelGGL((KERNEL<float, gt_bf16, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args); \
     else if (t0 == GT_BF16 && t1 == GT_F32) hipLaunchKernelGGL((KERNEL<gt_bf16, float, gt_bf16, BMV>), grid, dim3(LT), 0, stream, args); \

@@ -59,7 +59,8 @@ class GradSync:
 
     def attach(self, model):
         """Let the fused model path (engine.py) hand its flat gradient buffer to this reducer."""
-        model.__dict__["_gt_sync"] = self
+        from . import engine
+        engine.state(model)["sync"] = self
         return self
 
     def reduce_flat(self, flat, lo, hi):

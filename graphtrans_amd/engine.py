@@ -17,6 +17,7 @@ modules/transformer_encoder.py:42-61.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -255,11 +256,33 @@ class _Plan:
         return c
 
 
+# Per-model engine state (plan with its ctypes descriptors / HIP events / streams, eligibility cache, attached
+# GradSync) lives OUTSIDE the module: nothing unpicklable ends up in `model.__dict__`, so copy.deepcopy(model),
+# torch.save(model) and EMA snapshots keep working after the first fused forward, and a copy builds its own plan.
+_STATE = weakref.WeakKeyDictionary()
+
+
+def state(model):
+    st = _STATE.get(model)
+    if st is None:
+        st = _STATE[model] = {}
+    return st
+
+
+def invalidate(model):
+    """Forget the cached plan / eligibility of `model` (parameters were frozen, replaced or re-registered)."""
+    st = _STATE.get(model)
+    if st is not None:
+        st.pop("plan", None)
+        st.pop("eligible", None)
+        st.pop("params", None)
+
+
 def _plan(model):
-    plan = model.__dict__.get("_gt_plan")
+    st = state(model)
+    plan = st.get("plan")
     if plan is None or plan.param_ptrs != tuple(p.data_ptr() for p in plan.plist):
-        plan = _Plan(model)
-        model.__dict__["_gt_plan"] = plan
+        plan = st["plan"] = _Plan(model)
     return plan
 
 
@@ -267,26 +290,50 @@ def eligible(model, batched_data, perturb):
     """True when the fused path covers this model / call (cached per model and mode)."""
     if perturb is not None or not getattr(model, "fused", True):
         return False
-    # the fused node differentiates EVERY parameter: frozen parameters (epoch_callback's freeze_gnn, or a user's
-    # requires_grad_(False)) send the model through the module path; three probes keep the cache honest cheaply
-    g2t_w = model.gnn2transformer.weight
-    key = (model.training, torch.is_grad_enabled(), g2t_w.requires_grad,
-           model.gnn_node.convs[0].root_emb.weight.requires_grad if hasattr(model.gnn_node.convs[0], "root_emb")
-           else model.gnn_node.convs[0].eps.requires_grad,
-           model.gnn_node.batch_norms[-1].weight.requires_grad)
-    cache = model.__dict__.setdefault("_gt_eligible", {})
+    # the fused node differentiates EVERY parameter: any frozen parameter (epoch_callback's freeze_gnn, or a user's
+    # requires_grad_(False) on any submodule) sends the model through the module path.  The cache key holds every
+    # parameter's requires_grad flag, so freezing anything after the first forward invalidates the cached answer.
+    st = state(model)
+    plist = st.get("params")
+    if plist is None:
+        plist = st["params"] = list(model.parameters())
+    key = (model.training, torch.is_grad_enabled(), tuple(p.requires_grad for p in plist))
+    cache = st.setdefault("eligible", {})
     ok = cache.get(key)
     if ok is None:
         ok = cache[key] = _eligible_static(model)
     if not ok:
         return False
     x = batched_data.x
-    ne = model.gnn_node.node_encoder
+    gnn = model.gnn_node
+    ne = gnn.node_encoder
     if type(ne) is torch.nn.Linear:
         # (features that require a gradient go through the module path: the fused node only differentiates parameters)
-        return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == ne.in_features \
-            and not x.requires_grad and getattr(batched_data, "node_depth", None) is None
-    return x.is_cuda and x.dtype == torch.int64 and x.dim() == 2
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == ne.in_features
+                and not x.requires_grad and getattr(batched_data, "node_depth", None) is None):
+            return False
+    else:
+        if not (x.is_cuda and x.dtype == torch.int64 and x.dim() == 2):
+            return False
+        if hasattr(ne, "type_encoder"):   # ASTNodeEncoder reads columns 0, 1 of x and node_depth (dataset/utils.py:28-30)
+            nd = getattr(batched_data, "node_depth", None)
+            if x.shape[1] < 2 or nd is None or nd.numel() != x.shape[0]:
+                return False
+        elif x.shape[1] != len(ne.atom_embedding_list):
+            # e.g. the reference's `--feature simple` (dataset/mol.py:65-69) slices x to 2 columns: the fused kernels
+            # index one column per table, so a different column count goes through the module path
+            return False
+    # edge features: the aggregate kernels read `edge_cols` values per edge at that pitch
+    ee = gnn.convs[0].edge_encoder
+    ea = getattr(batched_data, "edge_attr", None)
+    tabs = getattr(ee, "bond_embedding_list", None)
+    if tabs is not None:
+        if ea is None or ea.dim() != 2 or ea.shape[1] != len(tabs) or ea.dtype != torch.int64 or not ea.is_cuda:
+            return False
+    elif isinstance(ee, torch.nn.Linear):
+        if ea is None or ea.dim() != 2 or ea.shape[1] != ee.in_features or not ea.is_cuda or not ea.is_floating_point():
+            return False
+    return True
 
 
 def _eligible_static(model):
@@ -344,8 +391,6 @@ def _eligible_static(model):
                     return False
         if enc.activation != "relu" or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
             return False
-        if enc.compute_dtype == torch.bfloat16 and ops.get_matmul_dtype() != torch.bfloat16:
-            return False
         for mod in enc.transformer.layers:
             if mod.linear1.weight.shape[0] % 8:
                 return False
@@ -376,6 +421,9 @@ class _FusedModel(torch.autograd.Function):
         st = _stream()
         lib = _lib.lib()
         training = 1 if model.training else 0
+        # compute type of the fp32-stored GEMMs (message passing, gnn2transformer, heads): exact-fp32 MFMA or bf16 MFMA
+        # (ops.set_matmul_dtype); the encoder layers compute in bf16 whenever their token rows are stored in bf16
+        # (layers.hip: dtype == bf16 ? bf16 : compute), i.e. (fp32, bf16 tokens) is the mixed mode of bench.py
         compute = GT_BF16 if ops.get_matmul_dtype() == torch.bfloat16 else GT_F32
         enc = model.transformer_encoder
         tdt = GT_BF16 if enc.compute_dtype == torch.bfloat16 else GT_F32
@@ -600,7 +648,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
-                         dims=(N, E, B, rows), sync=model.__dict__.get("_gt_sync"))
+                         dims=(N, E, B, rows), sync=state(model).get("sync"))
         ctx.set_materialize_grads(False)
         if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
             _call("gt_stream_wait_event", st, plan.ev_sort[1])

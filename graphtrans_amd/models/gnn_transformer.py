@@ -155,8 +155,7 @@ class GNNTransformer(BaseModel):
         if self.freeze_gnn is not None and epoch >= self.freeze_gnn:
             for param in self.gnn_node.parameters():
                 param.requires_grad = False
-            self.__dict__.pop("_gt_eligible", None)   # the fused path covers fully trainable models only
-            self.__dict__.pop("_gt_plan", None)
+            engine.invalidate(self)   # the fused path covers fully trainable models only
 
     def _gnn_node_state(self, state_dict):
         module_name = "gnn_node"

@@ -56,6 +56,12 @@ class PNAConv(nn.Module):
         self.towers, self.divide_input = towers, divide_input
         self.F_in = in_channels // towers if divide_input else in_channels
         self.F_out = out_channels // towers
+        if self.F_in % 4 or self.F_out % 4:
+            raise ValueError("graphtrans_amd PNAConv: per-tower widths must be multiples of 4 (16-byte rows for the grouped "
+                             f"GEMM); got F_in = {self.F_in}, F_out = {self.F_out}")
+        # the post-Linear is evaluated per scaler block (see forward); the x_i columns and the bias are NOT scaled, so
+        # they ride in a block of their own unless the first scaler is the identity
+        self._blocks = list(self.scalers) if self.scalers and self.scalers[0] == "identity" else [None] + list(self.scalers)
         deg = torch.as_tensor(deg).to(torch.float)
         # avg_deg over the degree HISTOGRAM tensor, exactly as PyG 1.6.3 / modules/pna_layer.py:92-97 do
         self.avg_deg = {"lin": deg.mean().item(), "log": (deg + 1).log().mean().item(), "exp": deg.exp().mean().item()}
@@ -69,8 +75,8 @@ class PNAConv(nn.Module):
     def _scales(self, deg):
         """per-node scaler factors (modules/pna/scalers.py:10-31), deg = in-degree (N,1,1)."""
         out = []
-        for s in self.scalers:
-            if s == "identity":
+        for s in self._blocks:
+            if s is None or s == "identity":
                 out.append(None)
             elif s == "amplification":
                 out.append(torch.log(deg + 1) / self.avg_deg["log"])
@@ -93,19 +99,22 @@ class PNAConv(nn.Module):
         key = str(device)
         if getattr(self, "_maps_key", None) == key:
             return self._wmap, self._bmap
-        Fi, Fo, A, S = self.F_in, self.F_out, len(self.aggregators), len(self.scalers)
-        cols = (A * S + 1) * Fi
+        Fi, Fo, A, S = self.F_in, self.F_out, len(self.aggregators), len(self._blocks)
+        cols = (A * len(self.scalers) + 1) * Fi
         zero_w = Fo * cols   # index of the appended zero
         wmap = torch.full((S * Fo, 5 * Fi), zero_w, dtype=torch.int64)
         o = torch.arange(Fo).view(Fo, 1)
         f = torch.arange(Fi).view(1, Fi)
+        first = S - len(self.scalers)   # 1 when block 0 only carries x_i and the bias
         for s in range(S):
             rows = slice(s * Fo, (s + 1) * Fo)
             if s == 0:
                 wmap[rows, 0:Fi] = o * cols + f
+            if s < first:
+                continue
             for ai, a in enumerate(self.aggregators):
                 slot = _AGG_SLOT[a]
-                wmap[rows, Fi + slot * Fi:Fi + (slot + 1) * Fi] = o * cols + Fi + s * A * Fi + ai * Fi + f
+                wmap[rows, Fi + slot * Fi:Fi + (slot + 1) * Fi] = o * cols + Fi + (s - first) * A * Fi + ai * Fi + f
         bmap = torch.full((S * Fo,), Fo, dtype=torch.int64)
         bmap[:Fo] = torch.arange(Fo)
         # inverse maps for the backward (every source element lands at most once): source j <- restacked position
@@ -127,7 +136,7 @@ class PNAConv(nn.Module):
             from ...graph import GraphStructure
             gs = GraphStructure.build(edge_index, torch.zeros(x.shape[0], dtype=torch.int64, device=x.device), num_graphs=1)
         N, T, Fi, Fo = x.shape[0], self.towers, self.F_in, self.F_out
-        S = len(self.scalers)
+        S = len(self._blocks)
         xt = (x.view(N, T, Fi) if self.divide_input else x.view(N, 1, Fi).expand(N, T, Fi)).contiguous()
         Wp = torch.stack([m[0].weight for m in self.pre_nns])  # (T, F, 2F): [A | B] on [x_i || x_j]
         bp = torch.stack([m[0].bias for m in self.pre_nns])    # (T, F)
@@ -145,7 +154,7 @@ class PNAConv(nn.Module):
         Y = ops.tower_linear(torch.cat([xt, agg4], dim=-1), Wst, bst).view(N, T, S, Fo)
         # the degree scalers depend on the batch's graph structure only: computed by the first layer, reused by the rest
         cache = getattr(gs, "_pna_scales", None)
-        key = (tuple(self.scalers), self.avg_deg["log"], self.avg_deg["lin"])
+        key = (tuple(self._blocks), self.avg_deg["log"], self.avg_deg["lin"])
         if cache is None or cache[0] != key:
             deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(torch.float32).view(-1, 1)
             cols = [torch.ones_like(deg) if sc is None else sc for sc in self._scales(deg)]

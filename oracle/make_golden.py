@@ -95,8 +95,9 @@ def randomize(module, seed):
                 b.copy_(torch.rand(b.shape, generator=g) + 0.5)
 
 
-def dump(name, meta, inputs, module, outs, grad_inputs):
+def dump(name, meta, inputs, module, outs, grad_inputs, extra=None):
     d = {"meta": np.array(json.dumps(meta))}
+    d.update(extra or {})
     for k, v in inputs.items():
         if v is not None:
             d["in." + k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
@@ -380,6 +381,131 @@ def g9_pna():
     print("G9_pna_aggr_scalers")
 
 
+def _load_ref_pna():
+    """The reference's OWN statement of PNAConv (modules/pna_layer.py:20-171) is dead code in the tree: its ctor uses
+    the bare names ModuleList / Sequential / ReLU / Linear (`:102-118`) that the file never imports, so constructing
+    it raises NameError.  The four names are bound in that module's namespace here (to torch.nn's classes, what PyG
+    1.6.3's own `pna_conv.py` imports); the class body -- ctor, forward (`:131-146`), message (`:148-160`),
+    aggregate (`:162-168`) -- runs UNMODIFIED.  modules/pna/pna_module.py then imports
+    `torch_geometric.nn.PNAConv` (third party, absent): that name is bound to this in-tree class, which has PyG's
+    constructor signature, so PNANodeEmbedding / PNATransformer run unmodified too."""
+    import importlib
+
+    import torch_geometric.nn as tgnn
+
+    pl = importlib.import_module("modules.pna_layer")
+    for name in ("ModuleList", "Sequential", "ReLU", "Linear"):
+        if not hasattr(pl, name):
+            setattr(pl, name, getattr(nn, name))
+    tgnn.PNAConv = pl.PNAConv
+    pm = importlib.import_module("modules.pna.pna_module")
+    pm.PNAConv = pl.PNAConv
+    pt = importlib.import_module("models.pna_transformer")
+    return pl.PNAConv, pm.PNANodeEmbedding, pt.PNATransformer
+
+
+PNA_DEG_HIST = [0, 41, 30, 12, 6, 3, 1, 1]   # in-degree histogram (dataset/code.py:122-130 builds an 800-bin one)
+
+
+def run_and_dump64(name, meta, inputs, module, fwd, float_inputs=()):
+    """Like run_and_dump, plus the SAME module evaluated in float64 (parameters and float inputs cast up from
+    their fp32 values): out64.* / gin64.* / gsd64.* give the conditioning-free answer of the reference's own code.
+    `fwd(module, inputs)` -> tensor or list of tensors."""
+    import copy
+
+    g = torch.Generator().manual_seed(1234)
+    for k in float_inputs:
+        inputs[k].requires_grad_(True)
+    outs = fwd(module, inputs)
+    outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+    loss = 0
+    for i, o in enumerate(outs):
+        w = torch.randn(o.shape, generator=g)
+        inputs[f"w{i}"] = w
+        loss = loss + (o * w).sum()
+    loss.backward()
+    gin = {k: inputs[k].grad for k in float_inputs if inputs[k].grad is not None}
+    m64 = copy.deepcopy(module).double()
+    m64.zero_grad()
+    in64 = {k: (v.detach().double().requires_grad_(k in float_inputs) if isinstance(v, torch.Tensor) and v.is_floating_point() else v)
+            for k, v in inputs.items()}
+    outs64 = fwd(m64, in64)
+    outs64 = list(outs64) if isinstance(outs64, (list, tuple)) else [outs64]
+    sum((o * in64[f"w{i}"]).sum() for i, o in enumerate(outs64)).backward()
+    extra = {}
+    for i, o in enumerate(outs64):
+        extra[f"out64.{i}"] = o.detach().numpy()
+    for k, p in m64.named_parameters():
+        if p.grad is not None:
+            extra["gsd64." + k] = p.grad.detach().numpy()
+    for k in float_inputs:
+        if in64[k].grad is not None:
+            extra["gin64." + k] = in64[k].grad.numpy()
+    dump(name, meta, inputs, module, outs, gin, extra)
+
+
+class _B:   # attribute bag standing in for a PyG Batch
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def g12_pna():
+    """G12: pins the PNA conv wiring (a11).  PNAConv = the reference's in-tree class, PNANodeEmbedding /
+    PNATransformer = the reference's modules, all unmodified (see _load_ref_pna).  Every case is stored twice: as the
+    fp32 run, and as the float64 run of the same code and parameter values -- the fp32 `std` aggregator
+    sqrt(relu(E[m^2] - E[m]^2) + 1e-5) (modules/pna/aggregators.py:27-34) cancels catastrophically for in-degree <= 1
+    segments, so the fp32 reference's own gradients carry up to ~1e-3 relative rounding noise there."""
+    PNAConv, PNANodeEmbedding, PNATransformer = _load_ref_pna()
+    aggregators, scalers = ["mean", "max", "min", "std"], ["identity", "amplification", "attenuation"]
+    deg = torch.tensor(PNA_DEG_HIST)
+    # ---- the conv alone (towers=4, divide_input=True, no edge features: modules/pna/pna_module.py:43-51,73)
+    for i, (D, sizes, aggs, scs) in enumerate(((16, (14, 1, 23, 12), aggregators, scalers),
+                                               (32, (9, 2, 17), ["mean", "max", "min", "std"], ["identity", "linear", "inverse_linear"]),
+                                               (16, (30,), ["max", "std"], ["attenuation"]))):
+        torch.manual_seed(i)
+        b = synth.tiny_mixed(seed=30 + i, sizes=sizes, feat="dense", num_features=D)
+        conv = PNAConv(D, D, aggregators=aggs, scalers=scs, deg=deg, towers=4, divide_input=True)
+        randomize(conv, 80 + i)
+        inputs = dict(x=torch.randn(b.num_nodes, D), edge_index=b.edge_index, batch=b.batch)
+        meta = dict(kind="pna_conv", D=D, towers=4, aggregators=aggs, scalers=scs, deg=PNA_DEG_HIST)
+        run_and_dump64(f"G12_pnaconv_{i}", meta, inputs, conv, lambda m, a: m(a["x"], a["edge_index"]), float_inputs=("x",))
+
+    def as_batch(a):
+        return _B(x=a["x"], edge_index=a["edge_index"], edge_attr=a.get("edge_attr"), batch=a["batch"],
+                  node_depth=a["node_depth"].clone())
+
+    # ---- PNANodeEmbedding (modules/pna/pna_module.py:57-78)
+    D = 16
+    for i, (res, mode, with_perturb) in enumerate(((True, "train", False), (True, "eval", False), (False, "train", True))):
+        torch.manual_seed(10 + i)
+        args = default_args(gnn_num_layer=2, gnn_emb_dim=D, gnn_residual=res, gnn_dropout=0.0, graph_pooling="cls",
+                            aggregators=aggregators, scalers=scalers, deg=deg)
+        b = synth.tiny_mixed(seed=40 + i, sizes=(9, 1, 17, 6), feat="code2")
+        m = PNANodeEmbedding(make_node_encoder("code2", D), args)
+        randomize(m, 90 + i)
+        m.train(mode == "train")
+        inputs = batch_inputs(b)
+        if with_perturb:
+            inputs["perturb"] = torch.randn(b.num_nodes, D) * 0.1
+        meta = dict(kind="pna_node", args=dict(vars(args), deg=PNA_DEG_HIST), training=(mode == "train"), feat="code2")
+        run_and_dump64(f"G12_pnanode_{'res' if res else 'nores'}_{mode}", meta, inputs, m,
+                       lambda mm, a: mm(as_batch(a), a.get("perturb")), float_inputs=("perturb",) if with_perturb else ())
+    # ---- PNATransformer end to end (models/pna_transformer.py:78-100)
+    for i, (pool, msl, mode) in enumerate((("cls", 5, "train"), ("cls", 5, "eval"), ("mean", None, "train"), ("last", None, "train"))):
+        torch.manual_seed(20 + i)
+        args = default_args(gnn_num_layer=2, gnn_emb_dim=D, gnn_residual=True, gnn_dropout=0.0, graph_pooling=pool,
+                            d_model=16, nhead=2, dim_feedforward=24, transformer_dropout=0.0, num_encoder_layers=2,
+                            transformer_norm_input=(pool == "cls"), max_seq_len=msl, aggregators=aggregators,
+                            scalers=scalers, deg=deg, max_input_len=(12 if pool == "last" else 1000))
+        b = synth.tiny_mixed(seed=50 + i, sizes=(9, 1, 17, 6), feat="code2")
+        m = PNATransformer(7, make_node_encoder("code2", D), None, args)
+        randomize(m, 95 + i)
+        m.train(mode == "train")
+        meta = dict(kind="pna_transformer", args=dict(vars(args), deg=PNA_DEG_HIST), training=(mode == "train"),
+                    feat="code2", num_tasks=7)
+        run_and_dump64(f"G12_pnatrans_{pool}_{mode}", meta, batch_inputs(b), m, lambda mm, a: mm(as_batch(a)))
+
+
 def g10_struct():
     for name, b in (("tiny", synth.tiny_mixed(seed=3, sizes=(14, 1, 23, 12), feat="dense", num_features=4)),
                     ("code2", synth.code2_like(B=6, seed=1)), ("mol", synth.molpcba_like(B=12, seed=2))):
@@ -467,5 +593,7 @@ if __name__ == "__main__":
     g8_model()
     g9_pna()
     g10_struct()
+    g11_collate()
+    g12_pna()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total {total / 1024:.0f} KB in {len(os.listdir(OUT))} files")

@@ -20,7 +20,8 @@ Pinning: the reference has no tests / golden vectors for this path (SURVEY.md §
 is pinned instead against outputs of the reference itself, imported unmodified from
 /root/reference in the build container by `oracle/make_golden.py` (third-party imports satisfied
 by `oracle/stubs/`), committed as `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks
-every one of them (outputs, input grads, parameter grads).
+every one of them (outputs, input grads, parameter grads).  Rows a1-a10, a12: fixtures G1-G8, G10, G11;
+row a11 (PNA): G9 + G12 (see the a11 section below).
 
 Parameters are addressed by the reference's own state_dict keys, so a reference
 checkpoint drives the oracle directly.
@@ -480,9 +481,12 @@ def tud_loss(pred, y):
 
 # --------------------------------------------------------------------------------------------
 # a11: PNA  (PyG 1.6.3 PNAConv is third-party and absent: restated from the in-tree copy
-# modules/pna_layer.py:131-167 + modules/pna/aggregators.py:11-34 + modules/pna/scalers.py:10-31;
-# the aggregator / scaler functions are pinned by the G9 golden fixtures, the conv wiring is
-# PARITY-UNPINNED: no runnable reference implementation of it exists in this container)
+# modules/pna_layer.py:131-167 + modules/pna/aggregators.py:11-34 + modules/pna/scalers.py:10-31.
+# Pinning: aggregators / scalers by the G9 fixtures; the conv wiring, PNANodeEmbedding and PNATransformer by the
+# G12 fixtures = the reference's in-tree PNAConv class run UNMODIFIED (forward/message/aggregate; its ctor's four
+# missing torch.nn names bound from outside, oracle/make_golden.py:_load_ref_pna) inside the reference's unmodified
+# modules/pna/pna_module.py and models/pna_transformer.py, in fp32 and in float64.  What stays third-party-unverified:
+# that PyG 1.6.3's own PNAConv equals the in-tree copy -- the reference's authors state it does, pna_layer.py:16-17)
 # --------------------------------------------------------------------------------------------
 
 

@@ -85,9 +85,22 @@ class Set2Set(_Unavailable):
     pass
 
 
-class BatchNorm(torch.nn.BatchNorm1d):
-    """PyG 1.6.3 BatchNorm wraps nn.BatchNorm1d as `.module`; kept flat here (import-only)."""
+class BatchNorm(torch.nn.Module):
+    """PyG 1.6.3 `torch_geometric.nn.norm.BatchNorm`: an nn.BatchNorm1d held as `.module` (so the
+    state_dict keys read `...batch_norms.<i>.module.weight`), forward = self.module(x)."""
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.module = torch.nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+
+    def reset_parameters(self):
+        self.module.reset_parameters()
+
+    def forward(self, x):
+        return self.module(x)
 
 
 class PNAConv(_Unavailable):
-    """PyG's PNAConv is third-party code absent from /root/reference; not restated here."""
+    """PyG's PNAConv is third-party code absent from /root/reference; not restated here.
+    oracle/make_golden.py:g12_pna rebinds this name to the reference's own in-tree statement of the
+    class (modules/pna_layer.py:20-171) before importing modules/pna/pna_module.py."""

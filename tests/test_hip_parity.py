@@ -113,7 +113,8 @@ def test_conv_golden(name):
 @pytest.mark.parametrize("conv_name,edge,D,dtype", [
     ("gcn", "linear", 300, torch.float32), ("gin", "linear", 300, torch.float32), ("gcn", "none", 128, torch.float32),
     ("gin", "bond", 300, torch.float32), ("gcn", "dense", 272, torch.float32), ("gcn", "linear", 1024, torch.float32),
-    ("gcn", "linear", 300, torch.bfloat16), ("gin", "bond", 128, torch.bfloat16)])
+    ("gcn", "linear", 300, torch.bfloat16), ("gin", "bond", 128, torch.bfloat16),
+    ("gcn", "linear", 256, torch.float32), ("gcn", "linear", 256, torch.bfloat16)])   # D = 256: the ER stress config (C5)
 def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     """Seeded Code2 / Molpcba-shaped batches at the real emb dims; checked against the CPU oracle
     (gcn_aggregate / gin_aggregate) incl. every parameter gradient."""
@@ -123,7 +124,10 @@ def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     from oracle import reference_math as rm
 
     torch.manual_seed(0)
-    b = synth.molpcba_like(B=24, seed=3) if edge == "bond" else synth.code2_like(B=12, seed=3)
+    if D == 256:   # BASELINE configs[4]: G(512, 8/511) graphs, both edge directions stored
+        b = synth.er_stress(B=3, seed=3)
+    else:
+        b = synth.molpcba_like(B=24, seed=3) if edge == "bond" else synth.code2_like(B=12, seed=3)
     N = b.num_nodes
     h = torch.randn(N, D).to(dtype).float()  # the oracle sees the same (storage-rounded) inputs
     w = torch.randn(N, D)

@@ -155,3 +155,67 @@ def test_pna_aggregators_scalers_golden():
     avg = {"lin": 2.5, "log": 1.1, "exp": 20.0}
     for name in ("identity", "amplification", "attenuation", "linear", "inverse_linear"):
         assert_close(rm.pna_scalers(x, deg, avg, [name]), g.outs["scale_" + name], what=name)
+
+
+# ---- G12: the PNA conv wiring, pinned to the reference's in-tree PNAConv (modules/pna_layer.py:131-167) and its
+# ---- PNANodeEmbedding / PNATransformer (modules/pna/pna_module.py:57-78, models/pna_transformer.py:78-100).
+# Each fixture holds the reference's fp32 run AND its float64 run.  The float64 comparison (1e-9) pins the wiring
+# exactly; the fp32 comparison allows the reference's own fp32 rounding noise where that exceeds 1e-4 (the fp32
+# `std` aggregator cancels catastrophically on in-degree <= 1 segments, modules/pna/aggregators.py:27-34).
+def _pna_args(g):
+    a = g.args()
+    a.deg = torch.tensor(a.deg)
+    return a
+
+
+def _pna_run(g, dtype):
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in g.sd.items()}
+    for k in g.gsd:
+        sd[k].requires_grad_(True)
+    fi = {}
+    kind = g.meta["kind"]
+    if kind == "pna_conv":
+        x = g.inputs["x"].to(dtype).requires_grad_(True)
+        fi["x"] = x
+        out = rm.pna_conv({"c." + k: v for k, v in sd.items()}, "c", x, g.inputs["edge_index"], g.meta["aggregators"],
+                          g.meta["scalers"], rm.pna_avg_deg(g.meta["deg"]), towers=g.meta["towers"])
+    elif kind == "pna_node":
+        perturb = g.inputs.get("perturb")
+        if perturb is not None:
+            perturb = perturb.to(dtype).requires_grad_(True)
+            fi["perturb"] = perturb
+        out = rm.pna_node_embedding(sd, "", _pna_args(g), g.batch(), perturb, g.meta["training"])
+    else:
+        out = rm.pna_transformer(sd, _pna_args(g), g.batch(), None, g.meta["training"])
+    outs = list(out) if isinstance(out, (list, tuple)) else [out]
+    sum((o * g.inputs[f"w{i}"].to(dtype)).sum() for i, o in enumerate(outs)).backward()
+    return outs, sd, fi
+
+
+@pytest.mark.parametrize("name", golden_names("G12_"))
+def test_pna_golden_float64_wiring(name):
+    g = Golden(name)
+    outs, sd, fi = _pna_run(g, torch.float64)
+    for i, o in enumerate(outs):
+        assert_close(o, g.out64_list[i], atol=1e-9, rtol=1e-9, what=f"{name} out{i}")
+    for k, v in g.gsd64.items():
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(v)
+        assert_close(got, v, atol=1e-9, rtol=1e-9, what=f"{name} grad {k}")
+    for k, v in g.gin64.items():
+        assert_close(fi[k].grad, v, atol=1e-9, rtol=1e-9, what=f"{name} grad input {k}")
+
+
+@pytest.mark.parametrize("name", golden_names("G12_"))
+def test_pna_golden_fp32(name):
+    g = Golden(name)
+    outs, sd, fi = _pna_run(g, torch.float32)
+    for i, o in enumerate(outs):
+        tol = max(1e-4, 3 * g.ref_noise("out", str(i)))
+        assert_close(o, g.out_list[i], atol=tol, rtol=tol, what=f"{name} out{i}")
+    for k, v in g.gsd.items():
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(v)
+        tol = max(1e-4, 3 * g.ref_noise("gsd", k))
+        assert_close(got, v, atol=tol, rtol=tol, what=f"{name} grad {k}")
+    for k, v in g.gin.items():
+        tol = max(1e-4, 3 * g.ref_noise("gin", k))
+        assert_close(fi[k].grad, v, atol=tol, rtol=tol, what=f"{name} grad input {k}")
