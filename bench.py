@@ -1,22 +1,36 @@
 #!/usr/bin/env python
 """bench.py — GraphTrans training-step throughput on MI355X (driver contract).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload code2|molpcba|nci1|er] [--dtype bf16|fp32]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--workload code2|molpcba|nci1|er|code2-pna] [--mode mixed|bf16|fp32]
 
-Metric (BASELINE.json): graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256.  One "step" = the whole
-hot path over one synthetic, HBM-resident, pre-collated batch of 256 graphs PER GPU (weak scaling):
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under `torch.distributed.run` with N ranks
+(one per GPU, RCCL); the driver's own `python -m torch.distributed.run ... bench.py --gpus N` works as before.
+
+Metric (BASELINE.json): graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256.  One "step" = the whole hot path over one
+synthetic, HBM-resident, pre-collated batch of 256 graphs PER GPU (weak scaling: the graphs are independent units, no
+data-path collective):
     zero grads -> graph_prep -> GNNTransformer forward -> loss (dataset/code.py:39-45) -> backward
     -> [RCCL gradient all-reduce, overlapped] -> fused AdamW step
-Nothing is skipped or cached across steps (the per-batch graph structure is rebuilt every step;
-dropout runs at the reference's configured rates).  Inputs rotate over 4 seeded batches.
+Nothing is skipped or cached across steps (the per-batch graph structure is rebuilt every step; dropout runs at the
+reference's configured rates).  Inputs rotate over 4 seeded batches.
 
+Precision modes (`config.mode`):
+  mixed (default, the headline `value`): the reference's fp32 arithmetic (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32) for
+         message passing, the virtual-node MLPs, gnn2transformer and the prediction heads; bf16 token rows and bf16 MFMA
+         inside the encoder layers (attention / in- and out-projection / FFN) -- what BASELINE.json's north_star sanctions;
+  bf16:  bf16 MFMA for every GEMM (fp32 storage and master weights on the GNN side);
+  fp32:  exact fp32 everywhere.
 Rank 0 prints ONE JSON line with the contract keys plus
-  "roofline":     the dominant hand-written kernel (largest total HIP-event time inside the timed
-                  region): algorithmic bytes|flops per launch (SURVEY.md §8d formulas) / avg launch time,
+  "roofline":     the dominant hand-written kernel (largest total HIP-event time inside the timed region): algorithmic
+                  bytes|flops per launch (SURVEY.md 8d formulas) / average launch time; "traffic" = PMC bytes of the same
+                  build (profiles/*_pmc_traffic.json, attached only when its build id matches the sources that run),
   "kernels":      the same for every timed C-ABI entry point,
-  "cpu_baseline": the CPU oracle (oracle/reference_math.py, kind "port") timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+  "modes":        value / ms_per_step / roofline of the other precision modes measured in the same process (N = 1),
+  "strong_scaling": (N > 1) the same step on a GLOBAL batch of 256 graphs split over the N ranks,
+  "precision_vs_oracle": per reported mode, loss and gradient errors of the fused path against the float64 oracle on a
+                  24-graph sample at the real dims (N = 1),
+  "cpu_baseline": the CPU oracle (oracle/reference_math.py, kind "port") timed on this box's host cores on a bounded
+                  sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -167,25 +181,50 @@ def _unused_attn_flops(meta, bwd):
     return f * (2.5 if bwd else 1.0)
 
 
-def pmc_traffic(workload, dtype, per_gpu):
-    best = {}
+def build_id():
+    """sha256 over the sources that decide what runs on the GPU (kernels, C-ABI, the fused path): PMC traffic files carry
+    the id of the build they were measured on, and are attached only to runs of the same build (no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    roots = [os.path.join(REPO, "graphtrans_amd", "csrc"), os.path.join(REPO, "include")]
+    files = sorted(os.path.join(r, f) for r in roots for f in os.listdir(r) if f.endswith((".hip", ".h")))
+    files += [os.path.join(REPO, "graphtrans_amd", f) for f in ("engine.py", "layers.py", "ops.py", "graph.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, mode, per_gpu):
+    """-> (traffic dict, note).  The newest profiles/*_pmc_traffic.json of this workload / mode / batch whose build id is
+    the build that is running; a file from another build is NOT attached (note says so)."""
     pdir = os.path.join(REPO, "profiles")
+    bid, stale = build_id(), None
     try:
-        for fn in sorted(os.listdir(pdir)):
-            if fn.endswith("_pmc_traffic.json"):
-                d = json.load(open(os.path.join(pdir, fn)))
-                if d.get("workload") == workload and d.get("dtype") == dtype and d.get("graphs_per_gpu") == per_gpu:
-                    best = d.get("traffic", {})  # the latest round's file wins (sorted names)
+        for fn in sorted(os.listdir(pdir), reverse=True):
+            if not fn.endswith("_pmc_traffic.json"):
+                continue
+            d = json.load(open(os.path.join(pdir, fn)))
+            if d.get("workload") != workload or d.get("mode", d.get("dtype")) != mode or d.get("graphs_per_gpu") != per_gpu:
+                continue
+            if d.get("build_id") == bid:
+                return d.get("traffic", {}), "profiles/%s (build %s)" % (fn, bid)
+            stale = stale or fn
     except OSError:
         pass
-    return best
+    return {}, ("not attached: profiles/%s was measured on another build (running build %s)" % (stale, bid)) if stale \
+        else "no PMC profile for this workload / mode (running build %s)" % bid
 
 
-def kernel_report(records, attn_flops_fwd, dtype):
+def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
     """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the launch stream,
-    recorded inside the timed region).  -> per entry point roofline dicts."""
+    recorded inside the timed region).  -> per entry point roofline dicts.  The GEMM entry points are split by
+    compute type: exact-fp32 MFMA GEMMs (64 flop/clk/SIMD = 157 TFLOP/s) are MFMA-bound on every shape of this path
+    (arithmetic intensity 75 flop/B against a ridge of 20), the bf16 ones are HBM-bound (ridge 312 flop/B)."""
     groups = {}
     for name, ms, dims in records:
+        if name.startswith("gt_linear"):
+            name = name + ("[fp32]" if dims[5] == 0 else "[bf16]")   # GT_F32 = 0, GT_BF16 = 1
         groups.setdefault(name, []).append((ms, dims))
     rep = {}
     for name, items in groups.items():
@@ -206,128 +245,199 @@ def kernel_report(records, attn_flops_fwd, dtype):
             rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 5),
                              algorithmic_flops=int(per), **base)
         elif name.startswith("gt_linear"):
-            # skinny GEMMs (K, N <= 600): arithmetic intensity < 100 flop/B, i.e. HBM-bound on this chip
+            base_name = name.split("[")[0]
+
             def lin_bytes(d):
                 M, N, K, xd, yd, _ = d
                 ex, ey = (2 if xd == 1 else 4), (2 if yd == 1 else 4)
                 b = M * K * ex + M * N * ey + N * K * 4
-                return b if name == "gt_linear_fwd" else (b + M * N * ey if name == "gt_linear_bwd" else b)
+                return b + M * N * ey if base_name == "gt_linear_bwd" else b
             per = float(np.mean([lin_bytes(d) for _, d in items]))
             gbs = per / (avg_us * 1e-6) / 1e9
-            fl = float(np.mean([2.0 * d[0] * d[1] * d[2] * (2 if name == "gt_linear_bwd" else 1) for _, d in items]))
-            rep[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=int(per),
-                             tflops=round(fl / (avg_us * 1e-6) / 1e12, 1), **base)
+            fl = float(np.mean([2.0 * d[0] * d[1] * d[2] * (2 if base_name == "gt_linear_bwd" else 1) for _, d in items]))
+            tf = fl / (avg_us * 1e-6) / 1e12
+            if name.endswith("[fp32]"):
+                rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                 frac=round(tf / MFMA_F32_PEAK_TF, 4), algorithmic_flops=int(fl), algorithmic_bytes=int(per),
+                                 gbs=round(gbs, 1), **base)
+            else:
+                rep[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=int(per), tflops=round(tf, 1), **base)
     return rep
 
 
 # ---- CPU baseline (the oracle as a timed port) --------------------------------------------------
-def cpu_baseline(workload, model, args, sample_graphs=64, iters=2, threads=16, budget_s=25.0):
-    """The oracle timed as a CPU port, bounded to ~budget_s of CPU work.  16 threads: torch's CPU
-    kernels on this many tiny ops get slower, not faster, with more (256 threads: 148 s/step)."""
+def _oracle_case(workload, graphs):
     from graphtrans_amd import synth
     from oracle import reference_math as rm
-
     if workload == "code2":
-        b = synth.code2_like(B=sample_graphs, seed=0)
-        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like"
-    elif workload == "molpcba":
-        sample_graphs = 256
-        b = synth.molpcba_like(B=sample_graphs, seed=0)
-        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.mol_loss(out, b.y)), "Molpcba-like"
-    elif workload == "code2-pna":
-        b = synth.code2_like(B=sample_graphs, seed=0)
-        fwd, loss_of, what = rm.pna_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like (PNA)"
-    elif workload == "nci1":   # BASELINE configs[0]: the reference's own CPU-runnable case
-        sample_graphs = 256
-        b = synth.nci1_like(B=sample_graphs, seed=0)
-        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "NCI1-like"
-    elif workload == "er":
-        sample_graphs = 16
-        b = synth.er_stress(B=sample_graphs, seed=0)
-        fwd, loss_of, what = rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "Erdos-Renyi stress"
-    else:
-        return None
-    threads = min(threads, os.cpu_count() or 1)
+        b = synth.code2_like(B=graphs, seed=0)
+        return b, rm.gnn_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like"
+    if workload == "molpcba":
+        b = synth.molpcba_like(B=graphs, seed=0)
+        return b, rm.gnn_transformer, (lambda out: rm.mol_loss(out, b.y)), "Molpcba-like"
+    if workload == "code2-pna":
+        b = synth.code2_like(B=graphs, seed=0)
+        return b, rm.pna_transformer, (lambda out: rm.code2_loss(out, b.y_arr)), "Code2-like (PNA)"
+    if workload == "nci1":   # BASELINE configs[0]: the reference's own CPU-runnable case
+        b = synth.nci1_like(B=graphs, seed=0)
+        return b, rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "NCI1-like"
+    if workload == "er":
+        b = synth.er_stress(B=graphs, seed=0)
+        return b, rm.gnn_transformer, (lambda out: rm.tud_loss(out, b.y)), "Erdos-Renyi stress"
+    raise ValueError(workload)
+
+
+def _time_oracle(sd, args, b, fwd, loss_of, threads, budget_s, min_iters=1):
+    """median seconds of forward + loss + backward; one untimed warm-up when the budget allows it"""
     torch.set_num_threads(threads)
-    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     times, t_start = [], time.perf_counter()
-    for it in range(iters + 1):
+    it = 0
+    while True:
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
-        out = fwd(sd, args, b, None, True)
-        loss_of(out).backward()
+        loss_of(fwd(sd, args, b, None, True)).backward()
         dt = time.perf_counter() - t0
-        if it > 0 or dt > budget_s / 2:  # a slow box: keep the warm-up iteration as the sample
+        if it > 0 or dt > budget_s / 2:   # a slow point: the first iteration is the sample
             times.append(dt)
-        if time.perf_counter() - t_start > budget_s:
+        it += 1
+        spent = time.perf_counter() - t_start
+        if (len(times) >= min_iters and spent + dt > budget_s) or len(times) >= 7:
             break
-    t = float(np.median(times))
-    return dict(value=round(sample_graphs / t, 2), unit="graphs/s", cores=threads, kind="port",
-                sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on a {sample_graphs}-graph "
-                       f"seed-0 {what} batch, median of {len(times)} timed iteration(s); padded layout like the "
-                       f"reference (S = max nodes of the sample); host has {os.cpu_count()} logical cores",
-                s_per_step=round(t, 3))
+    return float(np.median(times)), len(times)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er", "code2-pna"])
-    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
-    ap.add_argument("--mode", default="mixed", choices=["mixed", "bf16", "fp32"],
-                    help="mixed (default, the reference's arithmetic where BASELINE.json asks for it): exact-fp32 MFMA for "
-                         "message passing / gnn2transformer / heads, bf16 token rows + bf16 MFMA in the encoder layers; "
-                         "bf16: bf16 MFMA everywhere (fp32 storage on the GNN side); fp32: exact fp32 everywhere")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="deprecated alias of --mode bf16|fp32")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --batch graphs on EVERY GPU (default); strong: --batch is the global batch, split evenly "
-                         "over the GPUs (SURVEY.md 8d: b256 -> 32 graphs per GPU at 8)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--from-store", action="store_true",
-                    help="assemble every batch on the device from an HBM graph store inside the timed step "
-                         "(gt_collate: sampling + augment_edge + collation; code2 / molpcba / code2-pna)")
-    opt = ap.parse_args()
+CPU_SAMPLE = {"code2": 64, "code2-pna": 64, "molpcba": 256, "nci1": 256, "er": 16}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # test hooks (a 1-GPU box cannot host two RCCL ranks): GT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
-    # GT_BENCH_BACKEND=gloo reduces through the host, which exercises the whole multi-rank path of this script
-    if os.environ.get("GT_BENCH_SHARE_GPU"):
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GT_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if opt.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {opt.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+def cpu_baseline(workload, model, args, budget_s=24.0):
+    """The oracle timed as a CPU port, bounded to ~budget_s of CPU work so that the default run
+    stays within minutes: the best multi-thread point (32 threads: torch's CPU kernels get SLOWER with more on these
+    many small ops -- 256 threads: 154 s per 64-graph step; tools/cpu_sweep.py, profiles/r02_cpu_sweep.json) and one
+    thread (the per-core figure), both on a 64-graph sample.  The full protocol (256 graphs, every thread count up to os.cpu_count(), median of 5)
+    is `python bench.py --cpu-baseline-full` (minutes of CPU time; its output is committed under profiles/)."""
+    from types import SimpleNamespace
+    graphs = CPU_SAMPLE[workload]
+    b, fwd, loss_of, what = _oracle_case(workload, graphs)
+    oargs = SimpleNamespace(**{k: v for k, v in vars(args).items() if k not in ("compute_dtype", "token_layout")})
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cores = os.cpu_count() or 1
+    threads = min(32, cores)
+    t, n = _time_oracle(sd, oargs, b, fwd, loss_of, threads, 0.55 * budget_s)
+    g1 = graphs
+    t1, n1 = _time_oracle(sd, oargs, b, fwd, loss_of, 1, 0.45 * budget_s)
+    torch.set_num_threads(threads)
+    return dict(value=round(graphs / t, 2), unit="graphs/s", cores=threads, kind="port",
+                sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on a {graphs}-graph seed-0 {what} "
+                       f"batch, median of {n} timed iteration(s) on {threads} threads; padded layout like the reference (S = max "
+                       f"nodes of the sample); host has {cores} logical cores (more threads are slower: profiles/r02_cpu_sweep.json)",
+                s_per_step=round(t, 3),
+                one_thread=dict(value=round(g1 / t1, 2), unit="graphs/s", cores=1, graphs=g1, iters=n1, s_per_step=round(t1, 3)))
+
+
+def cpu_baseline_full(workload, model, args, graphs=256, iters=5, limit_s=900.0):
+    """BASELINE.md section 3 in full: `graphs` graphs, 2 warm-ups + `iters` timed iterations (median) per thread count,
+    thread counts 1 .. os.cpu_count() in powers of two; a point that would exceed limit_s is cut short.  The 256-graph
+    batch costs 34-60 s per iteration (229 s on all 256 threads): ~1 h in full, which is why the default run is a sample;
+    profiles/r02_cpu_sweep.json holds one full sweep of this box (7.5 graphs/s at 32 threads, 4.3 at one)."""
+    from types import SimpleNamespace
+    b, fwd, loss_of, what = _oracle_case(workload, graphs)
+    oargs = SimpleNamespace(**{k: v for k, v in vars(args).items() if k not in ("compute_dtype", "token_layout")})
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cores = os.cpu_count() or 1
+    counts = sorted({1, cores} | {2 ** i for i in range(1, 12) if 2 ** i <= cores})
+    points = []
+    for th in counts:
+        torch.set_num_threads(th)
+        ts, t_start = [], time.perf_counter()
+        for it in range(2 + iters):
+            for v in sd.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            loss_of(fwd(sd, oargs, b, None, True)).backward()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > limit_s:
+                break
+        timed = ts[2:] if len(ts) > 2 else ts[-1:]
+        points.append(dict(threads=th, s_per_step=round(float(np.median(timed)), 3), graphs_per_s=round(graphs / float(np.median(timed)), 2),
+                           timed_iterations=len(timed)))
+        print("cpu_baseline_full:", points[-1], file=sys.stderr, flush=True)
+    best = max(points, key=lambda p: p["graphs_per_s"])
+    return dict(workload=what, graphs=graphs, nodes=int(b.num_nodes), cpu_count=cores, points=points, best=best,
+                one_thread=points[0], all_threads=points[-1])
+
+
+# ---- precision of the benchmarked modes against the float64 oracle --------------------------------------------------
+MODES = {"mixed": (torch.float32, torch.bfloat16), "bf16": (torch.bfloat16, torch.bfloat16), "fp32": (torch.float32, torch.float32)}
+
+
+def precision_vs_oracle(workload, modes, device, graphs=24):
+    """Fused path in each mode vs the float64 oracle on a `graphs`-graph sample at the real dims, dropout 0 (train-mode
+    BatchNorm): relative loss error and the relative L2 error of every parameter gradient (worst / median over the
+    tensors whose exact gradient is not ~0).  Same metric as tests/test_hip_configs.py, which bounds it."""
+    from types import SimpleNamespace
+    from graphtrans_amd import ops as gt_ops
+    if workload not in ("code2", "molpcba"):
+        return None
+    out = {"sample": f"{graphs} graphs, dropout 0, vs oracle/reference_math.py in float64"}
+    ref = None
+    for mode in modes:
+        matmul, tok = MODES[mode]
+        gt_ops.set_matmul_dtype(matmul)
+        torch.manual_seed(7)
+        args, model, gen, loss_fn, _ = build(workload, tok, "cpu", graphs)
+        args.gnn_dropout = args.transformer_dropout = 0.0
+        model.gnn_node.drop_ratio = 0.0
+        model.transformer_encoder.dropout_p = 0.0
+        b = gen(5)
+        if ref is None:   # identical parameters in every mode (same seed): one oracle run
+            b64, fwd, loss_of, _ = _oracle_case(workload, graphs)
+            oargs = SimpleNamespace(**{k: v for k, v in vars(args).items() if k not in ("compute_dtype", "token_layout")})
+            sd = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+            torch.set_default_dtype(torch.float64)
+            try:
+                from oracle import reference_math as rm
+                o = rm.gnn_transformer(sd, oargs, b, None, True)
+                l64 = rm.code2_loss(o, b.y_arr) if workload == "code2" else rm.mol_loss(o, b.y)
+                l64.backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
+            ref = (float(l64), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None})
+        model = model.to(device).train()
+        bd = attach_sizes(b).to(device)
+        loss = loss_fn(model(bd), bd)
+        loss.backward()
+        torch.cuda.synchronize()
+        l64v, g64 = ref
+        rms = {k: float(r.norm()) / r.numel() ** 0.5 for k, r in g64.items()}
+        top = max(rms.values())
+        errs = {}
+        for k, p in model.named_parameters():
+            if k in g64 and rms[k] >= 1e-3 * top:
+                errs[k] = float((p.grad.detach().double().cpu() - g64[k]).norm() / g64[k].norm())
+        worst = max(errs, key=errs.get)
+        vals = sorted(errs.values())
+        out[mode] = dict(loss_rel_err=float(f"{abs(float(loss) - l64v) / abs(l64v):.3e}"), grad_rel_l2_worst=float(f"{errs[worst]:.3e}"),
+                         grad_rel_l2_worst_param=worst, grad_rel_l2_median=float(f"{vals[len(vals) // 2]:.3e}"), tensors=len(errs))
+        del model
+    return out
+
+
+# ---- one timed measurement ------------------------------------------------------------------------------------------
+def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
+    """Build the model of `mode`, run opt.warmup + opt.steps steps, return (result dict for rank 0, model, args)."""
+    import torch.distributed as dist
 
     from graphtrans_amd import _lib
-    from graphtrans_amd.dist import GradSync
-
-    if opt.dtype is not None:
-        opt.mode = opt.dtype
-    matmul_dtype, dtype = {"mixed": (torch.float32, torch.bfloat16), "bf16": (torch.bfloat16, torch.bfloat16),
-                           "fp32": (torch.float32, torch.float32)}[opt.mode]   # (GNN-side GEMM compute, token rows)
-    opt.dtype = "bf16" if dtype == torch.bfloat16 else "fp32"
     from graphtrans_amd import ops as gt_ops
+    from graphtrans_amd.dist import GradSync
+    from graphtrans_amd.optim import FusedAdamW
+
+    matmul_dtype, dtype = MODES[mode]   # (GNN-side GEMM compute, token rows)
     gt_ops.set_matmul_dtype(matmul_dtype)
     per_gpu = opt.batch or {"nci1": 32, "code2-pna": 128}.get(opt.workload, 256)
-    if opt.scaling == "strong":
+    if scaling == "strong":
         if per_gpu % world:
             raise SystemExit("--scaling strong: the global batch %d does not divide over %d GPUs" % (per_gpu, world))
         per_gpu //= world
@@ -335,10 +445,9 @@ def main():
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()
     sync = GradSync(model.parameters(), world_size=world).attach(model)
-    from graphtrans_amd.optim import FusedAdamW
     optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams
-    if opt.scaling == "strong" and opt.workload in RAW_GEN and world > 1:
+    if scaling == "strong" and opt.workload in RAW_GEN and world > 1:
         # one GLOBAL batch per seed (identical on every rank), dealt to the ranks by size so that the quadratic
         # attention cost is even (dist.balanced_shards), assembled on the device from the raw graphs
         from graphtrans_amd.dist import balanced_shards
@@ -370,7 +479,6 @@ def main():
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -380,47 +488,49 @@ def main():
     # HIP events around the aggregate / attention / linear launches of every 10th timed step (each event pair
     # costs ~3 us of stream time and the dW GEMMs stay on the main stream while bracketed: a sampled step is
     # ~20 % slower, sampling keeps the timed region within ~2 % of a run with --no-kernel-timing)
-    sample = (lambda i: i % 10 == 0) if not opt.no_kernel_timing else (lambda i: False)
+    timing = want_kernels and not opt.no_kernel_timing
+    sample = (lambda i: i % 10 == 0) if timing else (lambda i: False)
     L = _lib.lib()
-    if not opt.no_kernel_timing:
+    if timing:
         _lib.profile_enable(1 | 2 | 4)
         L.gt_profile_enable(0)  # pool allocated, records cleared; recording toggled per step below
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(opt.steps + 1)]   # per-step device times (median)
 
     t0 = time.perf_counter()
     for i in range(opt.steps):
+        marks[i].record()
         if sample(i):
             L.gt_profile_resume(1 | 2 | 4)
         loss = step(opt.warmup + i)
         if sample(i):
             L.gt_profile_resume(0)
+    marks[opt.steps].record()
     t_enqueued = time.perf_counter() - t0  # host time to enqueue all steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
-    records = [] if opt.no_kernel_timing else _lib.profile_records()
+    records = _lib.profile_records() if timing else []
     _lib.profile_enable(0)
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
-
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps) if not sample(i))
+    res = None
     if rank == 0:
         total_graphs = per_gpu * world * opt.steps
         nodes = int(np.mean([b.num_nodes for b in batches]))
         edges = int(np.mean([b.edge_index.shape[1] for b in batches]))
         res = {
-            "metric": "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}",
-            "value": round(total_graphs / elapsed, 1), "unit": "graphs/s", "n_gpus": world, "steps": opt.steps,
-            "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 4), "higher_is_better": True,
-            "scaling": opt.scaling, "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
-            "config": {"workload": wl_name, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
+            "value": round(total_graphs / elapsed, 1), "ms_per_step": round(1e3 * elapsed / opt.steps, 4),
+            "ms_per_step_median_device": round(step_ms[len(step_ms) // 2], 4) if step_ms else None,
+            "scaling": scaling, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+            "config": {"workload": wl_name, "mode": mode, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
                        "step": ("collate+" if store is not None else "") + "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
-                       "mode": opt.mode,
-                       "gnn_dtype": "fp32 storage, %s MFMA linears" % ("bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32"),
-                       "transformer_dtype": opt.dtype,
+                       "gnn_dtype": "fp32 storage, %s MFMA GEMMs (message passing, VN MLP, gnn2transformer, heads)" % ("bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32"),
+                       "transformer_dtype": "%s token rows, %s MFMA (encoder layers)" % (("bf16", "bf16") if dtype == torch.bfloat16 else ("fp32", "bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32")),
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }
@@ -430,24 +540,153 @@ def main():
             for b in batches:  # attention core flops over VALID lengths: 4 n^2 d per graph and layer
                 n = np.minimum(np.asarray(b._sizes, dtype=np.float64), max_len) + (1 if args.graph_pooling == "cls" else 0)
                 fl.append(float((4.0 * n * n * d_model).sum()))
-            rep = kernel_report(records, float(np.mean(fl)), dtype)
-            # "traffic": HBM-side bytes per call from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, collected
-            # offline in separate rocprofv3 --pmc passes over this very command, committed under profiles/);
-            # null for configurations that were not measured
-            tr = pmc_traffic(opt.workload, opt.dtype, per_gpu)
+            rep = kernel_report(records, float(np.mean(fl)), dtype, matmul_dtype)
+            # "traffic": HBM-side bytes per call from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+            # --pmc passes over this very command: tools/pmc_round.sh), attached only when measured on THIS build
+            tr, note = pmc_traffic(opt.workload, mode, per_gpu)
             for k in rep:
                 if k in tr:
                     rep[k]["traffic"] = tr[k]
+                elif k.split("[")[0] in tr and sum(1 for q in rep if q.split("[")[0] == k.split("[")[0]) == 1:
+                    rep[k]["traffic"] = tr[k.split("[")[0]]
             if rep:
                 dom = max(rep, key=lambda k: rep[k]["total_ms"])
                 r = dict(rep[dom])
                 r["kernel"] = dom
+                r["traffic_source"] = note
                 res["roofline"] = r
                 res["kernels"] = rep
+    del optim, sync
+    return res, model, args, per_gpu
+
+
+def self_spawn(opt):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="code2", choices=["code2", "molpcba", "nci1", "er", "code2-pna"])
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default 256; nci1 32)")
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "bf16", "fp32"], help="precision mode of the headline value (see the module docstring)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="deprecated alias of --mode bf16|fp32")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (the headline): --batch graphs on EVERY GPU; strong: --batch is the global batch, split evenly "
+                         "over the GPUs (b256 -> 32 graphs per GPU at 8).  With N > 1 the other one is measured too and "
+                         'reported as "strong_scaling" / "weak_scaling" in the same JSON line')
+    ap.add_argument("--no-extra", action="store_true", help="only the headline measurement (no other modes / scaling / precision report)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md section 3 in full (minutes of CPU time) instead of the bounded sample")
+    ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check only (runs without a GPU): rendezvous, barrier, max-over-ranks reduction and the "
+                         "JSON line with value 0 -- what tests/test_dist_gloo.py uses to cover `--gpus N` self-spawn on gloo")
+    ap.add_argument("--from-store", action="store_true",
+                    help="assemble every batch on the device from an HBM graph store inside the timed step "
+                         "(gt_collate: sampling + augment_edge + collation; code2 / molpcba / code2-pna)")
+    opt = ap.parse_args()
+    if opt.dtype is not None:
+        opt.mode = opt.dtype
+
+    if "WORLD_SIZE" not in os.environ and opt.gpus > 1:
+        self_spawn(opt)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if opt.dry_run:
+        import torch.distributed as dist
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "graphs/s", "n_gpus": world, "steps": opt.steps,
+                              "warmup": opt.warmup, "max_over_ranks": float(t.item()), "scaling": opt.scaling}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): GT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # GT_BENCH_BACKEND=gloo reduces through the host, which exercises the whole multi-rank path of this script
+    if os.environ.get("GT_BENCH_SHARE_GPU"):
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("GT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if opt.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {opt.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    head, model, args, per_gpu = measure(opt, opt.mode, opt.scaling, world, rank, device)
+    res = None
+    if rank == 0:
+        res = {"metric": "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}",
+               "value": head["value"], "unit": "graphs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None,
+               "dtype": head["dtype"], "data": "synthetic"}
+        res.update({k: v for k, v in head.items() if k not in res})
+    extra = not opt.no_extra
+    if extra and world > 1:   # the other scaling of the same step, same ranks
+        other = "strong" if opt.scaling == "weak" else "weak"
+        del model
+        o, model, _, _ = measure(opt, opt.mode, other, world, rank, device, want_kernels=False)
+        if rank == 0:
+            res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step")} | \
+                {"graphs_per_gpu": o["config"]["graphs_per_gpu"], "global_batch": o["config"]["global_batch"]}
+    if extra and world == 1:
+        others = [m for m in ("mixed", "bf16") if m != opt.mode]
+        res["modes"] = {}
+        for m in others:
+            del model
+            o, model, _, _ = measure(opt, m, opt.scaling, world, rank, device)
+            res["modes"][m] = {k: o[k] for k in ("value", "ms_per_step", "ms_per_step_median_device", "dtype", "host_enqueue_ms_per_step", "final_loss") if k in o}
+            res["modes"][m]["config"] = {k: o["config"][k] for k in ("mode", "gnn_dtype", "transformer_dtype")}
+            if "roofline" in o:
+                res["modes"][m]["roofline"] = o["roofline"]
+                res["modes"][m]["kernels"] = o["kernels"]
+        try:
+            res["precision_vs_oracle"] = precision_vs_oracle(opt.workload, [opt.mode] + others, device)
+        except Exception as e:   # the report must not take the bench line down
+            res["precision_vs_oracle"] = {"error": repr(e)}
+        MODES_RESET = MODES[opt.mode]
+        from graphtrans_amd import ops as gt_ops
+        gt_ops.set_matmul_dtype(MODES_RESET[0])
+    if rank == 0:
         if opt.workload in RAW_GEN:
             res["collate"] = collate_report(opt.workload, per_gpu, with_cpu=(world == 1 and not opt.no_cpu_baseline))
         if world == 1 and not opt.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(opt.workload, model, args)
+            if opt.cpu_baseline_full:
+                full = cpu_baseline_full(opt.workload, model, args)
+                b = full["best"]
+                res["cpu_baseline"] = dict(value=b["graphs_per_s"], unit="graphs/s", cores=b["threads"], kind="port",
+                                           sample=f"oracle/reference_math.py fwd+loss+bwd fp32, full {full['graphs']}-graph batch, median of "
+                                                  f"{b['timed_iterations']} after 2 warm-ups, best of the thread counts below", full=full)
+            else:
+                res["cpu_baseline"] = cpu_baseline(opt.workload, model, args)
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist

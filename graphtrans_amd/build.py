@@ -27,7 +27,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "gt_common.h"), os.path.join(CSRC, "mfma_frag.h"), os.path.join(INCLUDE, "graphtrans_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INCLUDE, "graphtrans_hip.h")]
     hdr_m = max(os.path.getmtime(h) for h in headers)
     objs, rebuilt = [], False
     procs = []

@@ -201,6 +201,8 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
   return b;
 }
 
+#include "linear32.h"
+
 // ------------------------------------------------------------------------------------------------
 // forward: Y = act(X W^T + b) [dropout]
 // MFMA rows = output columns n (W rows), MFMA cols = output rows m (X rows).
@@ -664,6 +666,55 @@ int pick_bm(int64_t M) {
   return 64;   // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs
 }
 
+
+// ---- exact-fp32 wide-tile path (linear32.h): the big-M GEMMs of the message-passing side --------------------------------
+constexpr int64_t W32_MIN_M = 1024;   // below this the grid of 64-row blocks cannot fill the chip: 128-wide tiles + splits
+
+bool w32_eligible(int compute, int x_dtype, int64_t M, int groups) {
+  return compute == GT_F32 && x_dtype == GT_F32 && groups == 1 && M >= W32_MIN_M;
+}
+
+template <typename TA, typename TO, bool MASK>
+void w32_launch_nt(int nt, dim3 grid, hipStream_t stream, const L32Args& a) {
+  switch (nt) {
+    case 19: hipLaunchKernelGGL((k_lin32<TA, TO, 19, MASK>), grid, dim3(256), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((k_lin32<TA, TO, 16, MASK>), grid, dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((k_lin32<TA, TO, 12, MASK>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((k_lin32<TA, TO, 8, MASK>), grid, dim3(256), 0, stream, a); break;
+  }
+}
+
+// out[M][Nout] = epilogue(A[M][Kc] W[Nout][Kc]^T): ta / to = storage of A / out
+template <bool MASK>
+void w32_launch(int ta, int to, hipStream_t stream, L32Args& a) {
+  const int nt = w32_pick_nt(a.Nout);
+  a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
+  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, W32_BM), 8) * 8 * a.ncb));
+  if (ta == GT_F32 && to == GT_F32) w32_launch_nt<float, float, MASK>(nt, grid, stream, a);
+  else if (ta == GT_F32) w32_launch_nt<float, gt_bf16, MASK>(nt, grid, stream, a);
+  else if (to == GT_F32) w32_launch_nt<gt_bf16, float, MASK>(nt, grid, stream, a);
+  else w32_launch_nt<gt_bf16, gt_bf16, MASK>(nt, grid, stream, a);
+}
+
+int w32_dw_splits(int64_t M, int nkb, int nnb) {
+  int64_t s = 768 / ((int64_t)nkb * nnb);          // 3 blocks per CU = what the 48 KB LDS footprint admits (the dispatcher fills CUs greedily: 2 per CU leaves a third of them idle); every split costs N*K*4 bytes of partials twice
+  const int64_t maxs = gt_cdiv(M, 16 * 8);          // at least 8 stages per split
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+template <typename TY, typename TX>
+void w32_launch_dw_nt(int nt, dim3 grid, hipStream_t stream, const L32DwArgs& a) {
+  switch (nt) {
+    case 19: hipLaunchKernelGGL((k_lin32_dw<TY, TX, 19, true>), grid, dim3(256), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((k_lin32_dw<TY, TX, 16, true>), grid, dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((k_lin32_dw<TY, TX, 12, true>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((k_lin32_dw<TY, TX, 8, true>), grid, dim3(256), 0, stream, a); break;
+  }
+}
+
 }  // namespace
 
 extern "C" int gt_linear_fwd(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
@@ -711,6 +762,14 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
   { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
+  if (w32_eligible(compute, x_dtype, M, groups)) {
+    L32Args w{};
+    w.a = x; w.w = weight; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
+    w.act = act; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;
+    w32_launch<false>(x_dtype, y_dtype, stream, w);
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   const int bm = pick_bm(M);
   a.ntiles = (int)gt_cdiv(N, BN);
   dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups);
@@ -722,6 +781,11 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
 }
 
 extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K) {
+  if (compute == GT_F32 && M >= W32_MIN_M) {   // wide-tile fp32 path: [dW / db partials | W^T for the dX GEMM]
+    const int nt = w32_pick_nt(N);
+    const int splits = w32_dw_splits(M, (int)gt_cdiv(K, 64), (int)gt_cdiv(gt_cdiv(N, 16), nt));
+    return (size_t)splits * (size_t)(N * K + N) * sizeof(float) + (size_t)N * K * sizeof(float) + 512;
+  }
   const size_t dw = (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float);
   const int dxs = dx_splits(M, N, K, pick_bm(M));
   const size_t dx = dxs > 1 ? (size_t)dxs * M * K * sizeof(float) : 0;
@@ -791,6 +855,46 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
   const size_t need1 = gt_linear_bwd_workspace_bytes(compute, M, N, K);   // per group
   const size_t need = (size_t)groups * need1;
   a.g_part = (int64_t)(need1 / sizeof(float));
+  if (w32_eligible(compute, x_dtype, M, groups)) {
+    if (!workspace || workspace_bytes < need) {
+      gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return GT_ERR_WORKSPACE;
+    }
+    const int nt = w32_pick_nt(N);
+    const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
+    const int splits = w32_dw_splits(M, nkb, nnb);
+    float* part = reinterpret_cast<float*>(workspace);
+    float* wt = part + (size_t)splits * (size_t)(N * K + N) + 64;   // 256-byte offset keeps 16-byte alignment
+    wt = reinterpret_cast<float*>(((uintptr_t)wt + 255) & ~(uintptr_t)255);
+    if (dx) {   // dX = dZ (W^T)^T: the forward-form kernel on the transposed weight
+      hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
+      L32Args w{};
+      w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
+      w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldw = N; w.ldo = ldx; w.inv_keep = a.inv_keep;
+      w32_launch<true>(y_dtype, x_dtype, stream, w);
+    }
+    if (dweight) {
+      if (g_dw.active && stream == g_dw.main && dx && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+        (void)hipEventRecord(g_dw.ev_fork, stream);
+        (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+        stream = g_dw.side;
+      }
+      L32DwArgs d{};
+      d.dy = dy; d.ymask = y_for_mask; d.x = x; d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;
+      d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx; d.inv_keep = a.inv_keep;
+      d.splits = splits; d.nkb = nkb; d.nnb = nnb;
+      d.m_per_split = gt_cdiv(gt_cdiv(M, splits), 16) * 16;
+      dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * nkb * nnb));
+      if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
+      else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
+      const int64_t len = N * K, len2 = dbias ? N : 0;
+      int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+      hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, splits, len, dweight,
+                         (const float*)d.dbpart, len2, dbias, (int64_t)0);
+    }
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (dx) {
     const int bm = pick_bm(M);
     // split-N partials are plain fp32 sums: only for fp32 dX without fused addends (and not for grouped launches)

@@ -186,3 +186,23 @@ def test_balanced_shards():
             assert max(cost) / (sum(cost) / world) < 1.05, cost                     # within 5 % of perfect balance
     # uneven division: counts differ by at most one
     assert sorted(len(s) for s in balanced_shards(sizes[:10], 4)) == [2, 2, 3, 3]
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with 2 ranks
+    (bench.py:self_spawn); --dry-run keeps the GPU out of it: rendezvous on 127.0.0.1, barrier, MAX over ranks, ONE
+    JSON line from rank 0 with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["max_over_ranks"] == 2.0

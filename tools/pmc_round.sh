@@ -1,17 +1,30 @@
-# usage (on the GPU box): bash tools/pmc_round.sh <round tag, e.g. r01p>
-# Two separate rocprofv3 --pmc passes per workload (FETCH_SIZE, WRITE_SIZE), counters only: no trace domains.
+# usage (on the GPU box): bash tools/pmc_round.sh <round tag, e.g. r02a> [modes...]
+# Separate rocprofv3 --pmc passes per workload and mode, counters only (no trace domains):
+#   FETCH_SIZE, WRITE_SIZE                      -> <tag>_<workload>_<mode>_pmc_traffic.json (build-id stamped; bench.py's roofline.traffic)
+#   SQ MFMA / LDS counters                      -> <tag>_<workload>_<mode>_pmc_mfma.txt  (k_attn_*, k_linear_*)
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-tag=${1:-r01p}
+tag=${1:-r02a}
+shift || true
+modes=${@:-mixed bf16}
 mkdir -p gpurun_out/$tag
 for w in code2 molpcba; do
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_${w}_$c
-    timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_${w}_$c -o res -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > gpurun_out/$tag/pmc_${w}_$c.log 2>&1 || true
+  for m in $modes; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rm -rf /tmp/pmc_${w}_${m}_$c
+      timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_${w}_${m}_$c -o res -- python bench.py --workload $w --mode $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_${w}_${m}_$c.log 2>&1 || true
+    done
+    f=$(find /tmp/pmc_${w}_${m}_FETCH_SIZE -name "*.db" | head -1)
+    wr=$(find /tmp/pmc_${w}_${m}_WRITE_SIZE -name "*.db" | head -1)
+    python tools/pmc_traffic.py $f $wr $w $m 256 gpurun_out/$tag/${tag}_${w}_${m} || true
   done
-  f=$(find /tmp/pmc_${w}_FETCH_SIZE -name "*.db" | head -1)
-  wr=$(find /tmp/pmc_${w}_WRITE_SIZE -name "*.db" | head -1)
-  python tools/pmc_traffic.py $f $wr $w bf16 256 gpurun_out/$tag/${tag}_${w} || true
+done
+# MFMA / LDS issue counters of the GEMM and attention kernels (Code2 only; one SQ pass, 8 slots)
+for m in $modes; do
+  rm -rf /tmp/pmc_mfma_$m
+  timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU -d /tmp/pmc_mfma_$m -o res -- python bench.py --workload code2 --mode $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_mfma_$m.log 2>&1 || true
+  db=$(find /tmp/pmc_mfma_$m -name "*.db" | head -1)
+  python tools/rocpd_pmc.py $db k_ > gpurun_out/$tag/${tag}_code2_${m}_pmc_mfma.txt 2>&1 || true
 done
 ls gpurun_out/$tag

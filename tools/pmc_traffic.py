@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM-side traffic per entry-point call from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: python tools/pmc_traffic.py <fetch.db> <write.db> <workload> <dtype> <graphs_per_gpu> <out_prefix>
+usage: python tools/pmc_traffic.py <fetch.db> <write.db> <workload> <mode> <graphs_per_gpu> <out_prefix>
 Writes <out_prefix>_pmc_traffic.json (read by bench.py for roofline.traffic) and <out_prefix>_pmc_traffic_raw.txt.
 Counter handling as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KB, and
 FETCH_SIZE under-reports wide coalesced reads by a factor 2 -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -37,7 +37,10 @@ def per_kernel(db, counter):
 
 
 def main():
-    fdb, wdb, workload, dtype, per_gpu, prefix = sys.argv[1:7]
+    fdb, wdb, workload, mode, per_gpu, prefix = sys.argv[1:7]
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench   # build_id(): the sources these counters were measured on; bench.py attaches the file to that build only
     fetch, write = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     with open(prefix + "_pmc_traffic_raw.txt", "w") as f:
         for name, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
@@ -51,7 +54,7 @@ def main():
         kb = sum(2.0 * t for (k, _), (_c, t) in fetch.items() if k in prefixes) + \
             sum(t for (k, _), (_c, t) in write.items() if k in prefixes)
         traffic[ep] = int(kb * 1024 / calls)
-    out = {"workload": workload, "dtype": dtype, "graphs_per_gpu": int(per_gpu),
+    out = {"workload": workload, "mode": mode, "graphs_per_gpu": int(per_gpu), "build_id": bench.build_id(),
            "unit": "bytes per entry-point call (2*FETCH_SIZE + WRITE_SIZE, KB counters, rocprofv3 --pmc, one counter per pass)",
            "traffic": traffic}
     json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
