@@ -867,6 +867,13 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     float* wt = part + (size_t)splits * (size_t)(N * K + N) + 64;   // 256-byte offset keeps 16-byte alignment
     wt = reinterpret_cast<float*>(((uintptr_t)wt + 255) & ~(uintptr_t)255);
     if (dx) {   // dX = dZ (W^T)^T: the forward-form kernel on the transposed weight
+      // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
+      // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
+      // layer) -> join it first.  (Message-passing layers have one GEMM per workspace and join anyway.)
+      if (g_dw.active && stream == g_dw.main) {
+        (void)hipEventRecord(g_dw.ev_join, g_dw.side);
+        (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
+      }
       hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
       L32Args w{};
       w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
