@@ -202,6 +202,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 }
 
 #include "linear32.h"
+#include "linear_small.h"
 
 // ------------------------------------------------------------------------------------------------
 // forward: Y = act(X W^T + b) [dropout]
@@ -667,6 +668,11 @@ int pick_bm(int64_t M) {
 }
 
 
+// ---- short-M path (linear_small.h): one wave per output tile pair, no LDS, no partials ---------------------------------------
+bool small_eligible(int x_dtype, int y_dtype, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups) {
+  return groups == 1 && x_dtype == GT_F32 && y_dtype == GT_F32 && M > 0 && M <= 512 && N <= 2048 && K <= 2048 && ldx % 4 == 0 && ldy % 4 == 0;
+}
+
 // ---- exact-fp32 wide-tile path (linear32.h): the big-M GEMMs of the message-passing side --------------------------------
 constexpr int64_t W32_MIN_M = 1024;   // below this the grid of 64-row blocks cannot fill the chip: 128-wide tiles + splits
 
@@ -762,6 +768,16 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
   { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
+  if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups)) {
+    SmallArgs sa{};
+    sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
+    sa.act = act; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
+    const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(M, 16) * gt_cdiv(N, 32), 4);
+    if (compute == GT_F32) hipLaunchKernelGGL(k_small_fwd<float>, dim3(blocks), dim3(256), 0, stream, sa);
+    else hipLaunchKernelGGL(k_small_fwd<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (w32_eligible(compute, x_dtype, M, groups)) {
     L32Args w{};
     w.a = x; w.w = weight; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
@@ -855,6 +871,31 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
   const size_t need1 = gt_linear_bwd_workspace_bytes(compute, M, N, K);   // per group
   const size_t need = (size_t)groups * need1;
   a.g_part = (int64_t)(need1 / sizeof(float));
+  if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups)) {
+    SmallArgs sa{};
+    sa.x = (const float*)x; sa.w = weight; sa.dy = (const float*)dy; sa.ymask = (const float*)y_for_mask;
+    sa.add1 = (const float*)dx_add1; sa.add2 = (const float*)dx_add2; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
+    sa.inv_keep = a.inv_keep;
+    if (dx) {
+      sa.out = (float*)dx;
+      const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(M, 16) * gt_cdiv(K, 32), 4);
+      if (compute == GT_F32) hipLaunchKernelGGL(k_small_dx<float>, dim3(blocks), dim3(256), 0, stream, sa);
+      else hipLaunchKernelGGL(k_small_dx<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    }
+    if (dweight) {
+      if (g_dw.active && stream == g_dw.main && dx && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+        (void)hipEventRecord(g_dw.ev_fork, stream);
+        (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+        stream = g_dw.side;
+      }
+      sa.out = dweight; sa.db = dbias;
+      const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(N, 32) * gt_cdiv(K, 16), 4);
+      if (compute == GT_F32) hipLaunchKernelGGL(k_small_dw<float>, dim3(blocks), dim3(256), 0, stream, sa);
+      else hipLaunchKernelGGL(k_small_dw<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    }
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (w32_eligible(compute, x_dtype, M, groups)) {
     if (!workspace || workspace_bytes < need) {
       gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);

@@ -10,7 +10,7 @@ from conftest import assert_close
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-SHAPES = [(31598, 300, 300), (31855, 384, 128), (31855, 512, 128), (31855, 128, 512), (1000, 128, 600), (256, 600, 300),
+SHAPES = [(31598, 300, 300), (31855, 384, 128), (31855, 512, 128), (31855, 128, 512), (1000, 128, 600), (256, 600, 300), (256, 300, 600), (512, 1024, 2048),
           (77, 12, 20), (129, 132, 68), (5, 4, 4)]
 
 
