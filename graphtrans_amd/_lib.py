@@ -62,6 +62,7 @@ SIGNATURES = {
     "gt_seq_scatter": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
     "gt_batchnorm_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_batchnorm_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
+    "gt_batchnorm_fwd_bcast": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_batchnorm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_layernorm_fwd": (_i, [_i, _p, _p, _p, _p, _f, _f, _u64, _i64, _i64, _p, _p, _p, _p]),
     "gt_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),

@@ -388,24 +388,26 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
                                 void* workspace, size_t workspace_bytes, gt_stream_t st) {
   GT_TRY(gcn_check("gt_gcn_layer_fwd", L));
   GT_CHECK_ARG(h_in && y && saved && workspace, "null buffer");
-  GT_CHECK_ARG(!L->has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
+  GT_CHECK_ARG(!L->has_vn || L->x_has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
   const GcnWork w = gcn_work(L, workspace);
   if (workspace_bytes < w.bytes) { gt_set_error("gt_gcn_layer_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
   if (L->N == 0) return GT_OK;
   const GcnSaved s = gcn_saved(L, saved);
   const void* x = h_in;
-  if (L->has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
+  if (L->has_vn && !L->x_has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
     GT_TRY(gt_segment_bcast_add(GT_F32, h_in, vn, L->node_graph, L->N, L->B, L->D, x_out, st));
     x = x_out;
-    if (L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));
   }
+  if (L->has_vn && L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));   // x (with its virtual-node add) is complete
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_b, s.lin, L->N, L->D, L->D, 0, 0.f, 0, st));
   GT_TRY(gt_aggregate_fwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, L->N, L->E, L->D, L->in_ptr, L->in_src, L->in_eid, L->deg,
                           L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr, s.agg, st));
   // h = batch_norm(h) [relu] [+ h_list[layer]]   (gnn_module.py:204-212; dropout p = 0 or eval here)
-  GT_TRY(gt_batchnorm_fwd(GT_F32, s.agg, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr,
-                          L->bn_momentum, L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->N, L->D, y, s.stats,
-                          s.stats + L->D, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
+  // (+ vn_next[batch]: the next layer's virtual-node add, folded into this layer's apply pass)
+  GT_TRY(gt_batchnorm_fwd_bcast(GT_F32, s.agg, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr,
+                                L->bn_momentum, L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->vn_next,
+                                L->vn_next ? L->node_graph : nullptr, L->vn_next ? L->ev_vn_next : nullptr, L->N, L->D, y, s.stats,
+                                s.stats + L->D, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   return GT_OK;
 }
 
@@ -501,18 +503,18 @@ extern "C" int gt_gin_layer_fwd(const gt_gin_layer* L, const void* h_in, const v
                                 void* workspace, size_t workspace_bytes, gt_stream_t st) {
   GT_TRY(gin_check("gt_gin_layer_fwd", L));
   GT_CHECK_ARG(h_in && y && saved && workspace, "null buffer");
-  GT_CHECK_ARG(!L->has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
+  GT_CHECK_ARG(!L->has_vn || L->x_has_vn || (vn && x_out), "virtual-node layer needs vn and x_out");
   const GinWork w = gin_work(L, workspace);
   if (workspace_bytes < w.bytes) { gt_set_error("gt_gin_layer_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
   if (L->N == 0) return GT_OK;
   const GinSaved s = gin_saved(L, saved);
   const int64_t N = L->N, D = L->D;
   const void* x = h_in;
-  if (L->has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
+  if (L->has_vn && !L->x_has_vn) {  // h_list[layer] = h_list[layer] + vn[batch]   (gnn_module.py:199)
     GT_TRY(gt_segment_bcast_add(GT_F32, h_in, vn, L->node_graph, N, L->B, D, x_out, st));
     x = x_out;
-    if (L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));
   }
+  if (L->has_vn && L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));   // x (with its virtual-node add) is complete
   // GINConv: mlp((1 + eps) x + sum_k relu(x_j + e_k))   (conv.py:26-36)
   GT_TRY(gt_aggregate_fwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, N, L->E, D, L->in_ptr, L->in_src, L->in_eid, nullptr, nullptr,
                           L->eps, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr, s.agg, st));
@@ -522,9 +524,10 @@ extern "C" int gt_gin_layer_fwd(const gt_gin_layer* L, const void* h_in, const v
                           w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, L->b2, s.z2, N, D, 2 * D, 0, 0.f, 0, st));
   // h = drop(batch_norm(h) [relu]) [+ h_list[layer]]   (gnn_module.py:204-212)
-  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z2, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr, L->bn_momentum,
-                          L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, N, D, y, s.st, s.st + D, L->dropout_p,
-                          L->seed, w.bn_ws, w.bn_ws_bytes, st));
+  GT_TRY(gt_batchnorm_fwd_bcast(GT_F32, s.z2, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr, L->bn_momentum,
+                                L->bn_eps, L->training, L->relu, L->residual ? x : nullptr, L->vn_next,
+                                L->vn_next ? L->node_graph : nullptr, L->vn_next ? L->ev_vn_next : nullptr, N, D, y, s.st, s.st + D,
+                                L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   return GT_OK;
 }
 

@@ -181,12 +181,15 @@ __device__ __forceinline__ float4 bn_drop4(float4 v, const BnDrop& d, uint32_t r
                      bn_hash(d.s0, d.s1, row, col + 3) >= d.thr ? v.w * d.inv_keep : 0.f);
 }
 
-// pass 3: y = drop((x - mean) * rstd * w + b  [relu]) [+ resid]
+// pass 3: y = drop((x - mean) * rstd * w + b  [relu]) [+ resid] [+ bcast[bidx[row]]]
+// (the last term is the NEXT layer's virtual-node add h_list[l+1] + vn[batch], gnn_module.py:199, folded into the
+// producer of h_list[l+1]: no separate N x D read-modify-write pass)
 template <typename T>
 __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ w,
                                                  const float* __restrict__ b, const T* __restrict__ resid, int relu,
-                                                 BnDrop drop, int64_t N, int64_t D, T* __restrict__ y) {
+                                                 BnDrop drop, int64_t N, int64_t D, T* __restrict__ y,
+                                                 const T* __restrict__ bcast, const int32_t* __restrict__ bidx) {
   const int64_t C = D / 4, total = N * C;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t c = (i % C) * 4;
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply(const T* __restrict__ x, const 
     if (relu) v = gt_relu4(v);
     if (drop.thr) v = bn_drop4(v, drop, (uint32_t)(i / C), (uint32_t)c);
     if (resid) v = gt_add4(v, gt_load4<T>(resid + i * 4));
+    if (bcast) v = gt_add4(v, gt_load4<T>(bcast + (int64_t)bidx[i / C] * D + c));
     gt_store4<T>(y + i * 4, v);
   }
 }
@@ -333,7 +337,7 @@ __global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_fwd(
     const T* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
     const float* __restrict__ b, const T* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
     float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ num_batches_tracked, T* __restrict__ y) {
+    int64_t* __restrict__ num_batches_tracked, T* __restrict__ y, const T* __restrict__ bcast, const int32_t* __restrict__ bidx) {
   __shared__ float sm[SM_LANES * FIN_COLS];
   __shared__ float s_mu[FIN_COLS], s_rs[FIN_COLS];
   const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
@@ -381,6 +385,7 @@ __global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_fwd(
     if (relu) v = fmaxf(v, 0.f);
     if (drop.thr) v = bn_hash(drop.s0, drop.s1, (uint32_t)r, (uint32_t)c) >= drop.thr ? v * drop.inv_keep : 0.f;
     if (resid) v += ld1<T>(resid + r * D + c);
+    if (bcast) v += ld1<T>(bcast + (int64_t)bidx[r] * D + c);
     st1<T>(y + r * D + c, v);
   }
 }
@@ -759,7 +764,20 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
                                 float momentum, float eps, int training, int relu, const void* resid, int64_t rows,
                                 int64_t dim, void* y, float* save_mean, float* save_rstd, float dropout_p,
                                 uint64_t seed, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  return gt_batchnorm_fwd_bcast(dtype, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, training,
+                                relu, resid, nullptr, nullptr, nullptr, rows, dim, y, save_mean, save_rstd, dropout_p, seed, workspace,
+                                workspace_bytes, stream_);
+}
+
+extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* weight, const float* bias,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      float momentum, float eps, int training, int relu, const void* resid,
+                                      const void* bcast, const int32_t* bcast_index, void* ev_bcast_ready, int64_t rows,
+                                      int64_t dim, void* y, float* save_mean, float* save_rstd, float dropout_p,
+                                      uint64_t seed, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   int rc = check_norm("gt_batchnorm_fwd", dtype, rows, dim);
+  GT_CHECK_ARG(!bcast || bcast_index, "bcast needs bcast_index");
+
   if (rc) return rc;
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
   const BnDrop drop = make_bn_drop(training ? dropout_p : 0.f, seed);
@@ -771,14 +789,18 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
   if (training) {
     GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
     if (rows <= SMALL_ROWS) {
+      if (bcast && ev_bcast_ready) {
+        rc = gt_stream_wait_event(stream_, ev_bcast_ready);
+        if (rc) return rc;
+      }
       if (dtype == GT_F32)
         hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const float*)x, rows, dim,
                            eps, momentum, weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean,
-                           running_var, num_batches_tracked, (float*)y);
+                           running_var, num_batches_tracked, (float*)y, (const float*)bcast, bcast_index);
       else
         hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const gt_bf16*)x, rows,
                            dim, eps, momentum, weight, bias, (const gt_bf16*)resid, relu, drop, save_mean, save_rstd,
-                           running_mean, running_var, num_batches_tracked, (gt_bf16*)y);
+                           running_mean, running_var, num_batches_tracked, (gt_bf16*)y, (const gt_bf16*)bcast, bcast_index);
       GT_CHECK_LAUNCH();
       return GT_OK;
     }
@@ -803,12 +825,16 @@ extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, c
                        save_rstd);
   }
   const int g = flat_blocks(rows * (dim / 4));
+  if (bcast && ev_bcast_ready) {   // the rows to add come from another stream (the virtual-node update): join it here
+    rc = gt_stream_wait_event(stream_, ev_bcast_ready);
+    if (rc) return rc;
+  }
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, save_mean, save_rstd, weight,
-                       bias, (const float*)resid, relu, drop, rows, dim, (float*)y);
+                       bias, (const float*)resid, relu, drop, rows, dim, (float*)y, (const float*)bcast, bcast_index);
   else
     hipLaunchKernelGGL(k_bn_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, save_mean, save_rstd, weight,
-                       bias, (const gt_bf16*)resid, relu, drop, rows, dim, (gt_bf16*)y);
+                       bias, (const gt_bf16*)resid, relu, drop, rows, dim, (gt_bf16*)y, (const gt_bf16*)bcast, bcast_index);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -210,6 +210,10 @@ class _Plan:
         # the node-id sort for the embedding backward runs beside the forward on the dW stream
         self.ev_sort = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []
         self.embed_sorted = bool(self.embed) and max(int(t.shape[0]) for t in self.embed) <= 16384
+        # x_0 = h_0 + vn_0[batch] with vn_0 = the ONE row of virtualnode_embedding for every graph (gnn_module.py:195):
+        # the embedding-sum kernel takes it as one more table whose index column is a stride-0 zero
+        self.vn0_in_embed = self.has_vn and self.embed_kind != "linear" and len(self.embed) < 16
+        self.zero_i64 = torch.zeros(1, dtype=torch.int64, device=self.dev)
 
     def __del__(self):
         try:
@@ -469,8 +473,12 @@ class _FusedModel(torch.autograd.Function):
             if plan.gcn_edge[l] and E > 0:
                 desc.edge_attr = ea_f.data_ptr()
             ov = plan.side is not None and l < L - 1
-            desc.ev_x_ready = plan.ev_x[l] if ov else None
+            desc.ev_x_ready = None   # (x_l exists before the layer starts: the event is recorded from here, see below)
             desc.ev_dx_wait = plan.ev_extra[l] if ov else None
+            # the virtual-node add of layer l+1 (h_list[l+1] + vn[batch], gnn_module.py:199) rides in layer l's BatchNorm
+            # apply pass: layer l+1 then finds x_{l+1} ready (x_has_vn) -- no N x D read-modify-write pass per layer
+            desc.x_has_vn = 1 if plan.has_vn else 0
+            desc.vn_next, desc.ev_vn_next = None, None   # (pointers are arena-relative: filled below)
         for l, desc in enumerate(plan.vn_desc):
             desc.dropout_p, desc.seed = gnn_p, vn_seed(gnn_base, l)
             desc.N, desc.B = N, B
@@ -493,7 +501,7 @@ class _FusedModel(torch.autograd.Function):
         ND4 = N * D * 4
         o = dict(h=[b.take(ND4) for _ in range(L + 1)])
         if plan.has_vn:
-            o["x"] = [b.take(ND4) for _ in range(L)]
+            o["x"] = [b.take(ND4 if (l == 0 and not plan.vn0_in_embed) else 0) for l in range(L)]
             o["vn"] = [b.take(B * D * 4) for _ in range(L)]
             vn_saved_bytes = [lib.gt_vn_update_saved_bytes(C.byref(dsc)) for dsc in plan.vn_desc]
             o["vn_saved"] = [b.take(n) for n in vn_saved_bytes]
@@ -573,7 +581,12 @@ class _FusedModel(torch.autograd.Function):
             e_idx, e_str = PT(*[c[0] for c in cols]), I64(*[c[1] for c in cols])
             e_clamp = I64(*plan.embed_clamp)
             e_tabs = PT(*[t.data_ptr() for t in plan.embed])
-            _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
+            if plan.vn0_in_embed:   # + virtualnode_embedding.weight[0] for every node
+                I64f, PTf = C.c_int64 * (T + 1), C.c_void_p * (T + 1)
+                _call("gt_embed_sum_fwd", T + 1, PTf(*[c[0] for c in cols], plan.zero_i64.data_ptr()), I64f(*[c[1] for c in cols], 0),
+                      I64f(*plan.embed_clamp, -1), PTf(*[t.data_ptr() for t in plan.embed], plan.vn_emb.data_ptr()), N, D, P("h", 0), st)
+            else:
+                _call("gt_embed_sum_fwd", T, e_idx, e_str, e_clamp, e_tabs, N, D, P("h", 0), st)
             if esort:
                 sst = st
                 if plan.side_dw is not None:   # beside the forward: only the index columns are read
@@ -586,27 +599,40 @@ class _FusedModel(torch.autograd.Function):
                     _call("gt_event_record", plan.ev_sort[1], sst)
 
         # ---- message passing   (modules/gnn_module.py:181-224)
+        # x_l (= h_list[l] after its in-place virtual-node add): layer 0's comes from the embedding kernel (or a broadcast
+        # add for Linear node encoders), layer l+1's is written by layer l's BatchNorm apply pass (vn_next)
+        def X(l):
+            if not plan.has_vn:
+                return P("h", l)
+            return P("x", 0) if (l == 0 and not plan.vn0_in_embed) else P("h", l)
+
         if plan.has_vn:
             _call("gt_segment_bcast_add", GT_F32, None, plan.vn_emb.data_ptr(), sm["zeros"].data_ptr(), B, 1, D, P("vn", 0), st)
         for l in range(L):
             dsc = plan.gcn_desc[l]
             if plan.has_vn:
-                if l > 0 and side is not None:   # vn_l comes from the side stream
-                    _call("gt_stream_wait_event", st, plan.ev_vn[l - 1])
-                _call(plan.conv_api + "_fwd", C.byref(dsc), P("h", l), P("vn", l), P("x", l), P("h", l + 1), P("gcn_saved", l),
-                      P("ws"), ws_bytes, st)
-                if l < L - 1 and side is not None:
+                last = l == L - 1
+                dsc.vn_next = None if last else P("vn", l + 1)
+                dsc.ev_vn_next = plan.ev_vn[l] if (not last and side is not None) else None
+                if l == 0 and not plan.vn0_in_embed:   # Linear node encoder: x_0 = h_0 + vn_0[batch] as its own pass
+                    _call("gt_segment_bcast_add", GT_F32, P("h", 0), P("vn", 0), gs.node_graph.data_ptr(), N, B, D, P("x", 0), st)
+                if not last and side is not None:
+                    # the update of vn_{l+1} runs beside layer l's GEMM / aggregate on the second stream (it needs x_l,
+                    # which exists when layer l starts: ev_x); layer l's apply pass waits for it (ev_vn_next)
+                    _call("gt_event_record", plan.ev_x[l], st)
                     _call("gt_stream_wait_event", side, plan.ev_x[l])
-                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
+                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), X(l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
                           P("ws2"), ws2_bytes, side)
                     _call("gt_event_record", plan.ev_vn[l], side)
-                elif l < L - 1:
-                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), P("x", l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
+                elif not last:
+                    _call("gt_vn_update_fwd", C.byref(plan.vn_desc[l]), X(l), P("vn", l), P("vn", l + 1), P("vn_saved", l),
                           P("ws"), ws_bytes, st)
+                _call(plan.conv_api + "_fwd", C.byref(dsc), X(l), P("vn", l), None, P("h", l + 1), P("gcn_saved", l), P("ws"),
+                      ws_bytes, st)
             else:
                 _call(plan.conv_api + "_fwd", C.byref(dsc), P("h", l), None, None, P("h", l + 1), P("gcn_saved", l), P("ws"),
                       ws_bytes, st)
-        first = P("x", 0) if plan.has_vn else P("h", 0)   # h_list[0] after the in-place virtual-node add
+        first = X(0)   # h_list[0] after the in-place virtual-node add
         if plan.jk_cat:   # torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
             _call("gt_copy2d", P("cat"), Kc * 4, first, D * 4, D * 4, N, st)
             _call("gt_copy2d", P("cat") + D * 4, Kc * 4, P("h", L), D * 4, D * 4, N, st)
@@ -660,7 +686,7 @@ class _FusedModel(torch.autograd.Function):
         # the plan's descriptors are rewritten by the next forward: the backward gets its own copies
         snap = lambda ds: [type(x_).from_buffer_copy(x_) for x_ in ds]
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
-                         ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
+                         ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
                          dims=(N, E, B, rows), sync=state(model).get("sync"))
         ctx.set_materialize_grads(False)
@@ -804,7 +830,7 @@ class _FusedModel(torch.autograd.Function):
                           G + plan.vn_off[l] * 4, Q("ws"), ws_bytes, st)
                 extra = Q("dC")
             out = Q("dB") if dy == Q("dA") else Q("dA")
-            xin = P("x", l) if plan.has_vn else P("h", l)
+            xin = s["xptr"][l]
             dw_sync()
             _call(plan.conv_api + "_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
                   Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)

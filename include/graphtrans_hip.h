@@ -324,6 +324,14 @@ int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float*
                      int relu, const void* resid /* optional: y = bn(x)[relu] + resid */, int64_t rows, int64_t dim,
                      void* y, float* save_mean, float* save_rstd, float dropout_p, uint64_t seed, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
+/* The same with `bcast[bcast_index[row]]` (rows of a [segments][dim] matrix, e.g. the NEXT layer's virtual-node
+ * embedding per graph: h_list[l+1] + vn[batch], modules/gnn_module.py:199) added to every output row in the apply
+ * pass.  ev_bcast_ready: optional gt_event the stream waits for before that pass (bcast produced on another stream). */
+int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* weight, const float* bias, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
+                           int relu, const void* resid, const void* bcast, const int32_t* bcast_index, void* ev_bcast_ready,
+                           int64_t rows, int64_t dim, void* y, float* save_mean, float* save_rstd, float dropout_p,
+                           uint64_t seed, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 /* dx w.r.t. the BN input (the residual branch's gradient is dy itself).  The ReLU gate is recomputed
  * from x, the saved statistics, weight and bias: the forward output is not needed. */
 int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
@@ -493,7 +501,11 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
   /* F.dropout(h, drop_ratio) after the layer BatchNorm[+ReLU] (gnn_module.py:88-90,209-212), training only */
   uint64_t seed;
   float dropout_p;
-  int32_t pad2_;
+  int32_t x_has_vn;   /* 1: h_in already holds h + vn[batch] (the previous layer added it, see vn_next): no add, x_out unused */
+  /* vn_next [B][D]: the NEXT layer's virtual-node rows, added to y in the BatchNorm apply pass (y then IS the next
+   * layer's x); ev_vn_next: optional gt_event recorded by the stream that produces vn_next, waited for before that pass */
+  const void* vn_next;
+  void* ev_vn_next;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
@@ -523,7 +535,11 @@ typedef struct gt_gin_layer {  /* x = h_in [+ vn[batch]]; y = drop(BN(GINConv(x)
   void *ev_x_ready, *ev_dx_wait; /* as in gt_gcn_layer (the backward waits right before its last add) */
   uint64_t seed;
   float dropout_p;
-  int32_t pad2_;
+  int32_t x_has_vn;   /* 1: h_in already holds h + vn[batch] (the previous layer added it, see vn_next): no add, x_out unused */
+  /* vn_next [B][D]: the NEXT layer's virtual-node rows, added to y in the BatchNorm apply pass (y then IS the next
+   * layer's x); ev_vn_next: optional gt_event recorded by the stream that produces vn_next, waited for before that pass */
+  const void* vn_next;
+  void* ev_vn_next;
 } gt_gin_layer;
 size_t gt_gin_layer_saved_bytes(const gt_gin_layer* layer);
 size_t gt_gin_layer_workspace_bytes(const gt_gin_layer* layer);
