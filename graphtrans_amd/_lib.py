@@ -23,6 +23,7 @@ _i = C.c_int
 _f = C.c_float
 _sz = C.c_size_t
 _u64 = C.c_uint64
+_d = C.c_double
 
 # name -> (restype, argtypes); mirrors include/graphtrans_hip.h exactly
 SIGNATURES = {
@@ -62,6 +63,8 @@ SIGNATURES = {
     "gt_seq_scatter": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
     "gt_batchnorm_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_batchnorm_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
+    "gt_batchnorm_apply": (_i, [_i, _p, _p, _p, _p, _p, _i, _p, _i64, _i64, _p, _f, _u64, _p]),
+    "gt_batchnorm_bwd_apply": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _d, _i, _i64, _i64, _p, _f, _u64, _p]),
     "gt_batchnorm_fwd_bcast": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_batchnorm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_layernorm_fwd": (_i, [_i, _p, _p, _p, _p, _f, _f, _u64, _i64, _i64, _p, _p, _p, _p]),

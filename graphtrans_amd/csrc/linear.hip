@@ -18,14 +18,12 @@
 // consecutive output columns as accumulator registers -> 8/16-byte stores, float4 bias loads.
 #include "gt_common.h"
 #include "mfma_frag.h"
-#include <stdlib.h>
 
 namespace {
 using namespace gtf;
 
 constexpr int LT = 256;  // threads
 constexpr int BN = 128;
-int g_bm_override = 0;  // tuning knob (GT_LINEAR_BM env): rows per block for fwd/dx, 64 or 128
 
 struct LinArgs {
   const void* a;      // fwd: X[M][K]; dx: dY[M][N]; dw: dY[M][N]
@@ -48,7 +46,6 @@ struct LinArgs {
   int ntx;              // dw: tiles along N
   int64_t m_per_split;
   int64_t n_per_split;  // dx: contraction range per blockIdx.z when splits > 1 (partials [splits][M][K] fp32 in `out`)
-  int dbg;  // ablation bits (GT_LINEAR_DBG): 1 no W loads, 2 no X loads, 4 no stores, 8 no MFMA
   // grouped launch (blockIdx.y = group g, e.g. the towers of PNAConv): element offsets added per group
   int64_t g_x, g_y, g_w, g_b;   // X / dX / addends ; Y / dY / ymask ; W [N][K] ; bias [N]
   int64_t g_part;               // dw: floats between the groups' partial buffers (dW partials + db partials)
@@ -241,7 +238,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   Loader<TX, TC, BM, BK, LD, false> lx;
   Loader<float, TC, BN, BK, LD, false> lw;
-  const int64_t Mx = (a.dbg & 2) ? 0 : a.M - m0, Nw = (a.dbg & 1) ? 0 : a.N - n0;
+  const int64_t Mx = a.M - m0, Nw = a.N - n0;
   const TX* xo = X + m0 * a.ldx;
   const float* wo = a.w + n0 * a.K;
   lx.init(a.ldx);
@@ -282,7 +279,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
         lw.load(wo + k0 + 2 * BK, Nw, a.K - k0 - 2 * BK, nullptr);
       }
     }
-    if (!(a.dbg & 8)) compute(sX + cur * TILE_ELEMS, sW + cur * TILE_ELEMS);
+    compute(sX + cur * TILE_ELEMS, sW + cur * TILE_ELEMS);
     __syncthreads();
   }
   // epilogue: acc[j][i][r] = C[col n0+wn*64+j*16+g*4+r][row m0+wm*64+i*16+n] -> patch[row n][col ...]
@@ -302,7 +299,7 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
       const int r = c >> 4, c4 = (c & 15) * 4;
       const int64_t m = m0 + wm * (BM / 2) + i * 16 + r;
       const int64_t col = n0 + wn * 64 + c4;
-      if (m < a.M && col < a.N && !(a.dbg & 4)) {
+      if (m < a.M && col < a.N) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
         if (a.bias) v = gt_add4(v, bias_chunk(a.bias, col, a.N));
         if (a.act == 1) v = gt_relu4(v);
@@ -602,8 +599,7 @@ void fill_drop(LinArgs& a, float dropout_p, uint64_t seed) {
 
 int dw_splits(int64_t M, int64_t N, int64_t K, int compute) {
   const int64_t bmc = compute == GT_BF16 ? 64 : 32;
-  static int target = -1;  // blocks per launch (GT_DW_BLOCKS): partial traffic grows with it, parallelism too
-  if (target < 0) { const char* e = getenv("GT_DW_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+  constexpr int target = 512;  // blocks per launch: partial traffic grows with it, parallelism too (flat 256..768 end to end)
   int64_t tiles = gt_cdiv(N, BN) * gt_cdiv(K, BN);
   int64_t s = target / tiles;
   int64_t maxs = gt_cdiv(M, bmc * 4);  // at least 4 stages per split
@@ -657,12 +653,6 @@ struct DwOverlap {
 thread_local DwOverlap g_dw;
 
 int pick_bm(int64_t M) {
-  static int env = -1;
-  if (env < 0) {
-    const char* e = getenv("GT_LINEAR_BM");
-    env = e ? atoi(e) : 0;
-  }
-  if (env == 64 || env == 128) return env;
   (void)M;
   return 64;   // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs
 }
@@ -765,7 +755,6 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act;
-  { const char* e = getenv("GT_LINEAR_DBG"); a.dbg = e ? atoi(e) : 0; }
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups)) {

@@ -280,10 +280,9 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ dbias, const float* __restrict__ dweight,
-                                                     int relu, int training, BnDrop drop, int64_t N, int64_t D,
+                                                     int relu, float inv_n, BnDrop drop, int64_t N, int64_t D,
                                                      T* __restrict__ dx) {
-  const int64_t C = D / 4, total = N * C;
-  const float inv_n = training ? 1.0f / (float)N : 0.f;
+  const int64_t C = D / 4, total = N * C;   // inv_n: 1 / (rows the statistics were taken over) in training, 0 in eval
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t c = (i % C) * 4;
     float4 g = gt_load4<T>(dy + i * 4);
@@ -876,14 +875,61 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (float*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx);
   } else {
     hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training, drop, rows, dim, (gt_bf16*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx);
   }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+// ---- the apply passes on their own: synchronised BatchNorm across data-parallel ranks --------------------
+// The statistics (forward) and the two gradient sums (backward) are reduced over the ranks by the caller between the
+// library's local pass and these apply passes (graphtrans_amd/ops.py:sync_batch_norm).
+extern "C" int gt_batchnorm_apply(int dtype, const void* x, const float* mean, const float* rstd, const float* weight,
+                                  const float* bias, int relu, const void* resid, int64_t rows, int64_t dim, void* y,
+                                  float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  int rc = check_norm("gt_batchnorm_apply", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && mean && rstd && weight && bias && y, "null buffer");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  if (rows == 0) return GT_OK;
+  const BnDrop drop = make_bn_drop(dropout_p, seed);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int g = flat_blocks(rows * (dim / 4));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, mean, rstd, weight, bias,
+                       (const float*)resid, relu, drop, rows, dim, (float*)y, (const float*)nullptr, (const int32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(k_bn_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, mean, rstd, weight, bias,
+                       (const gt_bf16*)resid, relu, drop, rows, dim, (gt_bf16*)y, (const gt_bf16*)nullptr, (const int32_t*)nullptr);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_batchnorm_bwd_apply(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
+                                      const float* mean, const float* rstd, const float* sum_dy, const float* sum_dy_xhat,
+                                      double count, int relu, int64_t rows, int64_t dim, void* dx, float dropout_p,
+                                      uint64_t seed, gt_stream_t stream_) {
+  int rc = check_norm("gt_batchnorm_bwd_apply", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && dy && weight && bias && mean && rstd && sum_dy && sum_dy_xhat && dx, "null buffer");
+  GT_CHECK_ARG(count >= 1.0, "count = rows the statistics were taken over (all ranks)");
+  if (rows == 0) return GT_OK;
+  const BnDrop drop = make_bn_drop(dropout_p, seed);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int g = flat_blocks(rows * (dim / 4));
+  const float inv_n = (float)(1.0 / count);
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy, mean, rstd, weight,
+                       bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (float*)dx);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, mean, rstd,
+                       weight, bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (gt_bf16*)dx);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -414,6 +414,9 @@ def _eligible_static(model):
                 return False
         if model.gnn2transformer.weight.shape[1] % 4:
             return False
+        from .modules.norm import any_sync
+        if any_sync(*[m for m in model.modules() if isinstance(m, BatchNorm1d)]):
+            return False   # synchronised BatchNorm (statistics over all ranks) runs module by module
         for p in model.parameters():
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad):
                 return False

@@ -58,6 +58,11 @@ class VnUpdateDesc(C.Structure):
                [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
 
 
+def _any_sync(*bns):
+    from .modules.norm import any_sync
+    return any_sync(*bns)
+
+
 def _bind():
     return _lib.lib()  # signatures are declared in _lib.SIGNATURES (descriptor pointers as void*)
 
@@ -261,7 +266,7 @@ def gcn_layer_eligible(conv, bn, h, spec, drop_ratio, training):
     from .modules.conv import GCNConv
     return (isinstance(conv, GCNConv) and h.is_cuda and h.dtype == torch.float32 and h.shape[1] % 4 == 0
             and spec.kind in ("linear", "tables", "none")
-            and bn.affine and bn.track_running_stats and bn.momentum is not None)
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and not _any_sync(bn))
 
 
 def gcn_layer(h_in, vn, gs, conv, bn, spec, relu, residual, training, dropout_p=0.0, seed=0):
@@ -335,7 +340,7 @@ def vn_update_eligible(seq, x, drop_ratio, training):
     mods = list(seq)
     return (len(mods) == 6 and isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], BatchNorm1d)
             and isinstance(mods[3], torch.nn.Linear) and isinstance(mods[4], BatchNorm1d) and x.is_cuda
-            and x.dtype == torch.float32 and x.shape[1] % 4 == 0)
+            and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and not _any_sync(mods[1], mods[4]))
 
 
 def vn_update(x, vn, gs, seq, residual, training, dropout_p=0.0, seed=0):

@@ -13,8 +13,13 @@ def code2_loss(pred_list, y_arr):
             return ops.softmax_xent(stacked, y_arr)
         return F.cross_entropy(stacked.to(torch.float32).reshape(B * L, C), y_arr[:, :L].reshape(B * L))
     loss = 0
-    for i, pred in enumerate(pred_list):
-        loss = loss + F.cross_entropy(pred.to(torch.float32), y_arr[:, i])
+    for i, pred in enumerate(pred_list):   # separate heads (the module path without stacked heads): gt_xent_* per head
+        p32 = pred.to(torch.float32)
+        if p32.is_cuda and p32.stride(-1) == 1:
+            from . import ops
+            loss = loss + ops.softmax_xent(p32.unsqueeze(1), y_arr[:, i:i + 1])
+        else:
+            loss = loss + F.cross_entropy(p32, y_arr[:, i])
     return loss / len(pred_list)
 
 

@@ -386,6 +386,94 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
                             dropout_p if training else 0.0, seed)
 
 
+def _dist_reduce(t, group, gather):
+    """all_gather (gather=True: returns [world, ...]) or all_reduce(sum) of a small fp32 device tensor over `group`.
+    RCCL takes device tensors; other backends (gloo in the tests) go through the host."""
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    src = t if backend == "nccl" else t.cpu()
+    if gather:
+        out = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(out, src, group=group)
+        res = torch.stack(out)
+    else:
+        dist.all_reduce(src, group=group)
+        res = src
+    return res.to(t.device)
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """BatchNorm1d (training) whose statistics are taken over the rows of ALL data-parallel ranks: what the reference's
+    single-device batch of 256 graphs sees (modules/gnn_module.py:204).  Forward: local mean / variance
+    (gt_batchnorm_fwd), all-gather of (count, mean, var) = 2D + 1 floats, Chan's merge, gt_batchnorm_apply.  Backward:
+    local sum(dy') and sum(dy' xhat) (gt_batchnorm_bwd), all-reduce of 2D floats, gt_batchnorm_bwd_apply."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, dropout_p, seed, group):
+        x = _dev(x, "x")
+        rows, D = x.shape
+        dev = x.device
+        w32, b32 = _f32(weight), _f32(bias)
+        L = _lib.lib()
+        ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        local = torch.empty((2, D), dtype=torch.float32, device=dev)
+        scratch = torch.empty_like(x)
+        if rows > 1:   # local statistics (the apply pass of this call is discarded)
+            _lib.launch("gt_batchnorm_fwd", _dtype_code(x), _ptr(x), _ptr(w32), _ptr(b32), None, None, None, float(momentum),
+                        float(eps), 1, 0, None, rows, D, _ptr(scratch), _ptr(local[0]), _ptr(local[1]), 0.0, 0, _ptr(ws), ws_bytes,
+                        _stream())
+            mean_l, var_l = local[0], (local[1].reciprocal().square() - eps).clamp_min(0.0)
+        else:
+            mean_l, var_l = x[0].float() if rows == 1 else torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        packed = torch.cat([torch.full((1,), float(rows), device=dev), mean_l, var_l])
+        allp = _dist_reduce(packed, group, gather=True).double()          # (world, 2D + 1)
+        n_r, mean_r, var_r = allp[:, :1], allp[:, 1:D + 1], allp[:, D + 1:]
+        n = n_r.sum()
+        mean = (n_r * mean_r).sum(0) / n
+        var = (n_r * (var_r + (mean_r - mean).square())).sum(0) / n         # biased, over all rows of all ranks
+        stats = torch.stack([mean, (var + eps).rsqrt()]).float().contiguous()
+        with torch.no_grad():
+            if running_mean is not None:
+                unbiased = var * (n / (n - 1)) if float(n) > 1 else var
+                running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+                running_var.mul_(1 - momentum).add_(momentum * unbiased.to(running_var.dtype))
+            if nbt is not None:
+                nbt.add_(1)
+        y = torch.empty_like(x)
+        _lib.launch("gt_batchnorm_apply", _dtype_code(x), _ptr(x), _ptr(stats[0]), _ptr(stats[1]), _ptr(w32), _ptr(b32),
+                    1 if relu else 0, None, rows, D, _ptr(y), float(dropout_p), int(seed), _stream())
+        ctx.save_for_backward(x, b32, w32, stats)
+        ctx.cfg = (relu, weight.dtype, bias.dtype, float(dropout_p), int(seed), group, float(n))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, b32, w32, stats = ctx.saved_tensors
+        relu, wdt, bdt, dropout_p, seed, group, count = ctx.cfg
+        dy = _dev(dy.to(x.dtype), "grad")
+        rows, D = x.shape
+        dev = x.device
+        L = _lib.lib()
+        ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        sums = torch.empty((2, D), dtype=torch.float32, device=dev)   # [sum dy' xhat, sum dy'] over the LOCAL rows
+        _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(w32), _ptr(b32), _ptr(stats[0]), _ptr(stats[1]), 1,
+                    1 if relu else 0, rows, D, _ptr(dx), _ptr(sums[0]), _ptr(sums[1]), dropout_p, seed, _ptr(ws), ws_bytes, _stream())
+        glob = _dist_reduce(sums.clone(), group, gather=False)
+        _lib.launch("gt_batchnorm_bwd_apply", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(w32), _ptr(b32), _ptr(stats[0]), _ptr(stats[1]),
+                    _ptr(glob[1]), _ptr(glob[0]), float(count), 1 if relu else 0, rows, D, _ptr(dx), dropout_p, seed, _stream())
+        # parameter gradients stay LOCAL sums: the gradient all-reduce averages them like every other parameter
+        return dx, sums[0].to(wdt), sums[1].to(bdt), None, None, None, None, None, None, None, None, None
+
+
+def sync_batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu=False, dropout_p=0.0,
+                    seed=0, group=None):
+    return _SyncBatchNorm.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu,
+                                dropout_p, seed, group)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, resid, weight, bias, eps, dropout_p, seed):

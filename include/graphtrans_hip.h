@@ -338,6 +338,15 @@ int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weig
                      const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
                      int64_t dim, void* dx, float* dweight, float* dbias, float dropout_p, uint64_t seed, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
+/* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
+ * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
+ * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */
+int gt_batchnorm_apply(int dtype, const void* x, const float* mean, const float* rstd, const float* weight,
+                       const float* bias, int relu, const void* resid, int64_t rows, int64_t dim, void* y, float dropout_p,
+                       uint64_t seed, gt_stream_t stream);
+int gt_batchnorm_bwd_apply(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
+                           const float* mean, const float* rstd, const float* sum_dy, const float* sum_dy_xhat, double count,
+                           int relu, int64_t rows, int64_t dim, void* dx, float dropout_p, uint64_t seed, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(resid + dropout(x)) over the last dim of [rows][dim] token rows (dim <= 1024).

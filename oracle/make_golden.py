@@ -25,8 +25,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 REF = "/root/reference"
 sys.path.insert(0, os.path.join(HERE, "stubs"))
-sys.path.insert(0, REF)
-sys.path.insert(0, REPO)
+sys.path.insert(0, REF)     # `models` / `modules` / `dataset` must resolve to the REFERENCE here ...
+sys.path.append(REPO)       # ... not to the repository's top-level alias packages of the same names
 
 import models  # noqa: E402,F401  (must precede modules.transformer_encoder: circular import, main.py:21)
 from models.gnn_transformer import GNNTransformer  # noqa: E402

@@ -23,11 +23,13 @@ def _args():
                            token_layout="auto")
 
 
-def _model():
+def _model(gnn_type="gcn"):
     from graphtrans_amd.encoders import ASTNodeEncoder
     from graphtrans_amd.models.gnn_transformer import GNNTransformer
     torch.manual_seed(0)
-    m = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), _args()).to("cuda:0")
+    a = _args()
+    a.gnn_type = gnn_type
+    m = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), a).to("cuda:0")
     with torch.no_grad():
         m.gnn_node.virtualnode_embedding.weight.normal_(0, 0.3)
     return m.train()
@@ -82,3 +84,61 @@ def test_two_rank_fused_backward_averages_the_shard_gradients():
             assert torch.allclose(got / scale, want / scale, rtol=1e-5, atol=1e-6), (r, name, (got - want).abs().max())
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)   # both ranks hold the same reduced gradients
+
+
+# ---- synchronised BatchNorm: two shards of ONE global batch reproduce the single-device gradients -------------------------
+def _global_batch(ids):
+    from graphtrans_amd import synth
+    from graphtrans_amd.data import GraphStore
+    raw = synth.code2_raw(B=12, seed=21, mean_nodes=30.0, max_nodes=80, num_nodeattributes=300, num_vocab=50)
+    return GraphStore(raw).collate(ids)
+
+
+def _sync_worker(rank, world, port, out, gnn_type):
+    import numpy as np
+
+    from graphtrans_amd import engine, losses
+    from graphtrans_amd.dist import GradSync
+    from graphtrans_amd.modules.norm import convert_sync_batchnorm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = convert_sync_batchnorm(_model(gnn_type))
+    sync = GradSync(model.parameters(), world_size=world).attach(model)
+    b = _global_batch(np.arange(6 * rank, 6 * rank + 6))
+    assert not engine.eligible(model, b, None)      # synchronised statistics: module by module
+    for p in model.parameters():
+        p.grad = None
+    losses.code2_loss(model(b), b.y_arr).backward()
+    sync.finish()
+    out[rank] = ([p.grad.detach().float().cpu().clone() for p in model.parameters()],
+                 {k: v.detach().float().cpu().clone() for k, v in model.named_buffers() if "running" in k})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gnn_type", ["gcn", "gin"])
+def test_sync_batchnorm_shards_equal_the_single_device_batch(gnn_type):
+    """with graphs sharded over ranks, per-rank BatchNorm statistics are a different model from the
+    reference's single-device batch; convert_sync_batchnorm restores it.  Two ranks x 6 graphs with synchronised
+    statistics + gradient averaging == one process on the 12-graph batch (gradients AND running statistics)."""
+    import numpy as np
+
+    from graphtrans_amd import losses
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_sync_worker, args=(2, port, out, gnn_type), nprocs=2, join=True)
+    model = _model(gnn_type)
+    b = _global_batch(np.arange(12))
+    losses.code2_loss(model(b), b.y_arr).backward()
+    ref = [p.grad.detach().float().cpu() for p in model.parameters()]
+    ref_buf = {k: v.detach().float().cpu() for k, v in model.named_buffers() if "running" in k}
+    for r in (0, 1):
+        grads, bufs = out[r]
+        for got, want, (name, _) in zip(grads, ref, model.named_parameters()):
+            scale = max(1e-3, float(want.abs().max()))
+            assert float((got - want).abs().max()) <= 2e-4 * scale, (r, name, float((got - want).abs().max()), scale)
+        for k, want in ref_buf.items():
+            assert torch.allclose(bufs[k], want, rtol=1e-4, atol=1e-5), (r, k)
