@@ -224,7 +224,9 @@ def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
     groups = {}
     for name, ms, dims in records:
         if name.startswith("gt_linear"):
-            name = name + ("[fp32]" if dims[5] == 0 else "[bf16]")   # GT_F32 = 0, GT_BF16 = 1
+            # one entry per compute type AND shape class: big-M (node / token rows) vs short-M (one row per graph: the
+            # virtual-node MLPs and the prediction heads), whose flop counts differ by 100x
+            name = name + ("[fp32" if dims[5] == 0 else "[bf16") + (",rows=graphs]" if dims[0] <= 1024 else "]")
         groups.setdefault(name, []).append((ms, dims))
     rep = {}
     for name, items in groups.items():
@@ -256,7 +258,7 @@ def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
             gbs = per / (avg_us * 1e-6) / 1e9
             fl = float(np.mean([2.0 * d[0] * d[1] * d[2] * (2 if base_name == "gt_linear_bwd" else 1) for _, d in items]))
             tf = fl / (avg_us * 1e-6) / 1e12
-            if name.endswith("[fp32]"):
+            if "[fp32" in name:
                 rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                  frac=round(tf / MFMA_F32_PEAK_TF, 4), algorithmic_flops=int(fl), algorithmic_bytes=int(per),
                                  gbs=round(gbs, 1), **base)

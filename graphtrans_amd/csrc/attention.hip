@@ -142,6 +142,39 @@ __device__ __forceinline__ void load_tile(T* lds, const T* src, int64_t src_ld, 
   }
 }
 
+// Register-staged pair of [TILE][HD] tiles (K and V, or Q and dO): load() issues this thread's two 16-byte chunks of
+// the NEXT key / query tile before the current tile's MFMAs, store() parks them in the other LDS buffer behind them --
+// one barrier per 32-position step and the global latency off the step (the step of a 1000-token sequence is walked 32
+// times in a row by one block: with a synchronous load between two barriers per step that block WAS the kernel time).
+template <typename T, int HD>
+struct TilePair {
+  static constexpr int LD = Lds<HD, T>::LD;
+  static constexpr int CH = HD / 8;
+  Frag<T> fa, fb;
+  int r, col;
+  bool has;
+  __device__ __forceinline__ void init() {
+    const int c = threadIdx.x;
+    has = c < TILE * CH;
+    r = c / CH;
+    col = (c % CH) * 8;
+  }
+  __device__ __forceinline__ void load(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride,
+                                       int pos0, int lo, int hi) {
+    const int pos = pos0 + r;
+    const bool ok = has && pos >= lo && pos < hi;
+    const int64_t row = row0 + (int64_t)pos * row_stride;
+    fa = ok ? frag_load(srcA + row * ldA + col) : frag_zero<T>();
+    fb = ok ? frag_load(srcB + row * ldB + col) : frag_zero<T>();
+  }
+  __device__ __forceinline__ void store(T* sA, T* sB) const {
+    if (has) {
+      frag_store_lds(sA + r * LD + col, fa);
+      frag_store_lds(sB + r * LD + col, fb);
+    }
+  }
+};
+
 // =================================================================================================
 // forward
 // =================================================================================================
@@ -150,8 +183,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;  // 32-deep steps over head_dim
   constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
-  __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sKb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sVb[2][TILE * LD];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -170,8 +203,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
     bq[kk] = frag_load_head<T, HD>(qkv + qrow * ld3 + head * HD, kk * 32 + g * 8, qvalid);
-  zero_pad_cols<T, HD>(sK);
-  zero_pad_cols<T, HD>(sV);
+  zero_pad_cols<T, HD>(sKb[0]);
+  zero_pad_cols<T, HD>(sVb[0]);
+  zero_pad_cols<T, HD>(sKb[1]);
+  zero_pad_cols<T, HD>(sVb[1]);
 
   float m = -INFINITY, lsum = 0.f;
   f32x4 acc[DT];
@@ -182,11 +217,21 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
-  for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
-    __syncthreads();
-    load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
-    load_tile<T, HD>(sV, qkv + 2 * a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
-    __syncthreads();
+  TilePair<T, HD> stg;
+  stg.init();
+  const T* srcK = qkv + a.d_model + head * HD;
+  const T* srcV = qkv + 2 * a.d_model + head * HD;
+  const int k_first = (kv_off / TILE) * TILE;
+  if (HD < 32) __syncthreads();   // the zero fill above and the first store touch the same rows
+  stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k_first, kv_off, kv_end);
+  stg.store(sKb[0], sVb[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
+    const bool more = k0 + TILE < kv_end;
+    if (more) stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k0 + TILE, kv_off, kv_end);
+    const T* sK = sKb[cur];
+    const T* sV = sVb[cur];
     // S^T: two 16-key tiles; row m of tile t <-> key (m>>2)*8 + t*4 + (m&3)
     float s[8];
 #pragma unroll
@@ -245,6 +290,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
       o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
       acc[dt] = mma(frag_load_tr(sV, LD, 0, dt * 16, n, g), bp, o);
     }
+    if (more) stg.store(sKb[cur ^ 1], sVb[cur ^ 1]);
+    __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -271,8 +318,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  __shared__ __attribute__((aligned(16))) T sK[TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sV[TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sKb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sVb[2][TILE * LD];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -313,8 +360,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const float logl = qvalid ? a.lse[((int64_t)a.nhead + head) * a.rows + qrow] : 0.f;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
-  zero_pad_cols<T, HD>(sK);
-  zero_pad_cols<T, HD>(sV);
+  zero_pad_cols<T, HD>(sKb[0]);
+  zero_pad_cols<T, HD>(sVb[0]);
+  zero_pad_cols<T, HD>(sKb[1]);
+  zero_pad_cols<T, HD>(sVb[1]);
 
   f32x4 acc[DT];
 #pragma unroll
@@ -322,11 +371,21 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
-  for (int k0 = (kv_off / TILE) * TILE; k0 < kv_end; k0 += TILE) {
-    __syncthreads();
-    load_tile<T, HD>(sK, qkv + a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
-    load_tile<T, HD>(sV, qkv + 2 * a.d_model + head * HD, ld3, row0, a.row_stride, k0, kv_off, kv_end);
-    __syncthreads();
+  TilePair<T, HD> stg;
+  stg.init();
+  const T* srcK = qkv + a.d_model + head * HD;
+  const T* srcV = qkv + 2 * a.d_model + head * HD;
+  const int k_first = (kv_off / TILE) * TILE;
+  if (HD < 32) __syncthreads();
+  stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k_first, kv_off, kv_end);
+  stg.store(sKb[0], sVb[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
+    const bool more = k0 + TILE < kv_end;
+    if (more) stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k0 + TILE, kv_off, kv_end);
+    const T* sK = sKb[cur];
+    const T* sV = sVb[cur];
     float ds[8];
     const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
 #pragma unroll
@@ -356,6 +415,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
     const Frag<T> bds = frag_from_f32<T>(ds);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = mma(frag_load_tr(sK, LD, 0, dt * 16, n, g), bds, acc[dt]);
+    if (more) stg.store(sKb[cur ^ 1], sVb[cur ^ 1]);
+    __syncthreads();
   }
   if (!qvalid) return;
   T* dqkv = reinterpret_cast<T*>(a.out);
@@ -375,9 +436,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   constexpr int LD = Lds<HD, T>::LD;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  __shared__ __attribute__((aligned(16))) T sQ[TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sDO[TILE * LD];
-  __shared__ float sLse[TILE], sLogl[TILE], sDelta[TILE];
+  __shared__ __attribute__((aligned(16))) T sQb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) T sDOb[2][TILE * LD];
+  __shared__ float sAux[2][3 * TILE];   // per query of the tile: running max, log2(sum), delta
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -401,8 +462,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     bk[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + a.d_model + head * HD, kk * 32 + g * 8, kvalid);
     bv[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + 2 * a.d_model + head * HD, kk * 32 + g * 8, kvalid);
   }
-  zero_pad_cols<T, HD>(sQ);
-  zero_pad_cols<T, HD>(sDO);
+  zero_pad_cols<T, HD>(sQb[0]);
+  zero_pad_cols<T, HD>(sDOb[0]);
+  zero_pad_cols<T, HD>(sQb[1]);
+  zero_pad_cols<T, HD>(sDOb[1]);
   f32x4 dk[DT], dv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -415,19 +478,38 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
-  for (int q0 = 0; any_valid && q0 < npos; q0 += TILE) {
-    __syncthreads();
-    load_tile<T, HD>(sQ, qkv + head * HD, ld3, row0, a.row_stride, q0, 0, npos);
-    load_tile<T, HD>(sDO, dctx + head * HD, a.d_model, row0, a.row_stride, q0, 0, npos);
-    if (threadIdx.x < 3 * TILE) {
-      const int r = threadIdx.x & (TILE - 1);
-      const int which = threadIdx.x / TILE;  // 0: running max, 1: log2(sum), 2: delta
-      const int pos = q0 + r;
-      const float* src = which == 0 ? a.lse : (which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
-      float v = pos < npos ? src[(int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride] : 0.f;
-      (which == 0 ? sLse : (which == 1 ? sLogl : sDelta))[r] = v;
+  TilePair<T, HD> stg;
+  stg.init();
+  const T* srcQ = qkv + head * HD;
+  const T* srcDO = dctx + head * HD;
+  // threads 0..95 also carry one statistic of one query of the tile (0: running max, 1: log2(sum), 2: delta)
+  const int aux_r = threadIdx.x & (TILE - 1), aux_which = threadIdx.x / TILE;
+  const float* aux_src = aux_which == 0 ? a.lse : (aux_which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
+  float aux_v = 0.f;
+  auto load_aux = [&](int q0) {
+    const int pos = q0 + aux_r;
+    aux_v = (threadIdx.x < 3 * TILE && pos < npos) ? aux_src[(int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride] : 0.f;
+  };
+  if (HD < 32) __syncthreads();
+  if (any_valid) {
+    stg.load(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride, 0, 0, npos);
+    load_aux(0);
+    stg.store(sQb[0], sDOb[0]);
+    if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int q0 = 0; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
+    const bool more = q0 + TILE < npos;
+    if (more) {
+      stg.load(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride, q0 + TILE, 0, npos);
+      load_aux(q0 + TILE);
     }
-    __syncthreads();
+    const T* sQ = sQb[cur];
+    const T* sDO = sDOb[cur];
+    const float* sLse = sAux[cur];
+    const float* sLogl = sAux[cur] + TILE;
+    const float* sDelta = sAux[cur] + 2 * TILE;
     float pd[8], ds[8];
     const uint32_t qmul0 = (uint32_t)(q0 + g * 8) * RNG_CQ;
 #pragma unroll
@@ -466,6 +548,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
       dv[dt] = mma(frag_load_tr(sDO, LD, 0, dt * 16, n, g), bp, dv[dt]);
       dk[dt] = mma(frag_load_tr(sQ, LD, 0, dt * 16, n, g), bds, dk[dt]);
     }
+    if (more) {
+      stg.store(sQb[cur ^ 1], sDOb[cur ^ 1]);
+      if (threadIdx.x < 3 * TILE) sAux[cur ^ 1][threadIdx.x] = aux_v;
+    }
+    __syncthreads();
   }
   if (!kin) return;
   T* dqkv = reinterpret_cast<T*>(a.out);

@@ -416,8 +416,7 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
                                 size_t workspace_bytes, gt_stream_t st) {
   GT_TRY(gcn_check("gt_gcn_layer_bwd", L));
   GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
-  GT_CHECK_ARG(!L->has_vn || d_vn, "virtual-node layer needs d_vn");
-  const GcnWork w = gcn_work(L, workspace);
+  const GcnWork w = gcn_work(L, workspace);   // d_vn may be NULL: the caller pools d_h_in itself (e.g. on another stream)
   if (workspace_bytes < w.bytes) { gt_set_error("gt_gcn_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
   if (L->N == 0) return GT_OK;
   const GcnSaved s = gcn_saved(L, const_cast<void*>(saved));
@@ -431,7 +430,7 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
   if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, x, L->lin_w, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr, d_h_in,
                        g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-  if (L->has_vn)
+  if (L->has_vn && d_vn)
     GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
 }
@@ -536,8 +535,7 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
                                 size_t workspace_bytes, gt_stream_t st) {
   GT_TRY(gin_check("gt_gin_layer_bwd", L));
   GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
-  GT_CHECK_ARG(!L->has_vn || d_vn, "virtual-node layer needs d_vn");
-  const GinWork w = gin_work(L, workspace);
+  const GinWork w = gin_work(L, workspace);   // d_vn may be NULL: the caller pools d_h_in itself
   if (workspace_bytes < w.bytes) { gt_set_error("gt_gin_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
   if (L->N == 0) return GT_OK;
   const GinSaved s = gin_saved(L, const_cast<void*>(saved));
@@ -563,6 +561,6 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
     const float* e2 = (dx_extra && L->residual) ? (const float*)dy : nullptr;
     GT_TRY(gt_add3((const float*)w.d_x, e1, e2, N * D, (float*)d_h_in, st));
   }
-  if (L->has_vn) GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
+  if (L->has_vn && d_vn) GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
 }

@@ -207,6 +207,8 @@ class _Plan:
         self.ev_vn = [lib.gt_event_create() for _ in range(nev)]     # vn_{l+1} ready (side -> main)
         self.ev_dvn = [lib.gt_event_create() for _ in range(nev)]    # d vn_{l+1} complete (main -> side)
         self.ev_extra = [lib.gt_event_create() for _ in range(nev)]  # d x_l extra complete (side -> main)
+        self.ev_pool = [lib.gt_event_create() for _ in range(self.L if self.side is not None else 0)]   # d x_l complete (main -> side)
+        self.ev_vnemb = [lib.gt_event_create()] if self.side is not None else []                        # d vn_0 reduced (side -> main)
         # the node-id sort for the embedding backward runs beside the forward on the dW stream
         self.ev_sort = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []
         self.embed_sorted = bool(self.embed) and max(int(t.shape[0]) for t in self.embed) <= 16384
@@ -218,7 +220,7 @@ class _Plan:
     def __del__(self):
         try:
             lib = _lib.lib()
-            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra + self.ev_sort:
+            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra + self.ev_sort + self.ev_pool + self.ev_vnemb:
                 lib.gt_event_destroy(ev)
         except Exception:
             pass
@@ -745,6 +747,9 @@ class _FusedModel(torch.autograd.Function):
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
         q["ws"] = b.take(ws_bytes)
         q["ws2"] = b.take(s["ws2_bytes"])
+        seg_ws_bytes = lib.gt_segment_sum_workspace_bytes(N, D) if plan.has_vn else 0
+        q["ws3"] = b.take(seg_ws_bytes)   # the per-graph pooling of d x_l runs on the second stream with its own scratch
+        s["seg_ws_bytes"] = seg_ws_bytes
         barena = torch.empty(b.off, dtype=torch.uint8, device=dev)
         bb = barena.data_ptr()
         side = plan.side.cuda_stream if plan.side is not None else None
@@ -835,20 +840,32 @@ class _FusedModel(torch.autograd.Function):
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = s["xptr"][l]
             dw_sync()
+            pool_on_side = plan.has_vn and side is not None
             _call(plan.conv_api + "_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
-                  Q("dvn", 3) if plan.has_vn else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
-            if plan.has_vn:   # d vn_l = (layer l's broadcast add) + (update l's pooled + residual inputs)
+                  Q("dvn", 3) if (plan.has_vn and not pool_on_side) else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
+            if plan.has_vn:   # d vn_l = (layer l's broadcast add: per-graph sum of d x_l) + (update l's pooled + residual inputs)
+                # off the main chain: only the NEXT virtual-node update backward (second stream) reads it
+                vst = side if pool_on_side else st
+                if pool_on_side:
+                    _call("gt_event_record", plan.ev_pool[l], st)
+                    _call("gt_stream_wait_event", side, plan.ev_pool[l])
+                    _call("gt_segment_sum_ws", GT_F32, out, None, gs.graph_ptr.data_ptr(), N, B, D, Q("dvn", 3), Q("ws3"),
+                          s["seg_ws_bytes"], side)
                 tgt = Q("dvn", l % 2)
                 if upd:
-                    _call("gt_segment_bcast_add", GT_F32, Q("dvn", 3), Q("dvn", 2), sm["ident"].data_ptr(), B, B, D, tgt, st)
+                    _call("gt_segment_bcast_add", GT_F32, Q("dvn", 3), Q("dvn", 2), sm["ident"].data_ptr(), B, B, D, tgt, vst)
                 else:
-                    _call("gt_copy2d", tgt, D * 4, Q("dvn", 3), D * 4, D * 4, B, st)
+                    _call("gt_copy2d", tgt, D * 4, Q("dvn", 3), D * 4, D * 4, B, vst)
                 d_vn_next = tgt
             dy = out
         d_h0 = dy
         dw_sync()
         if plan.has_vn:
-            _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, st)
+            vst = side if side is not None else st
+            _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, vst)
+            if side is not None:
+                _call("gt_event_record", plan.ev_vnemb[0], side)
+                _call("gt_stream_wait_event", st, plan.ev_vnemb[0])
         # the message-passing gradients (everything between the embedding tables and gnn2transformer) are final:
         # on the wire while the embedding backward runs; the tables themselves follow right after it
         gnn_lo = plan.vn_emb_off if plan.has_vn else plan.gcn_off[0]

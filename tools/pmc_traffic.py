@@ -11,13 +11,20 @@ import re
 import sqlite3
 import sys
 
-ENTRY = {   # entry point -> (kernel name prefixes, the kernel whose call count = the entry point's call count)
-    "gt_linear_fwd": (("k_linear_fwd",), "k_linear_fwd"),
-    "gt_linear_bwd": (("k_linear_dx", "k_linear_dw", "k_split_reduce"), "k_linear_dw"),
-    "gt_aggregate_fwd": (("k_agg_fwd",), "k_agg_fwd"),
-    "gt_aggregate_bwd": (("k_agg_bwd", "k_agg_reduce"), "k_agg_bwd"),
-    "gt_attn_fwd": (("k_attn_fwd",), "k_attn_fwd"),
-    "gt_attn_bwd": (("k_attn_bwd_dq", "k_attn_bwd_dkv", "k_attn_bwd_prep"), "k_attn_bwd_dq"),
+# bench.py kernel-report key -> (regexes over the demangled kernel names it launches, regex of the kernel whose call count
+# = the entry point's call count).  k_split_reduce (the fixed-order reduce of the dW partials) is shared by the fp32 and
+# bf16 GEMM paths and is reported on its own.
+BF16 = r"unsigned short"
+ENTRY = {
+    "gt_linear_fwd[fp32]": ((r"k_lin32<.*, false>",), r"k_lin32<.*, false>"),
+    "gt_linear_bwd[fp32]": ((r"k_lin32<.*, true>", r"k_transpose32", r"k_lin32_dw<"), r"k_lin32_dw<"),
+    "gt_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
+    "gt_linear_bwd[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>", r"k_linear_dw<[^>]*" + BF16 + r">"), r"k_linear_dw<[^>]*" + BF16 + r">"),
+    "k_split_reduce": ((r"k_split_reduce",), r"k_split_reduce"),
+    "gt_aggregate_fwd": ((r"k_agg_fwd<",), r"k_agg_fwd<"),
+    "gt_aggregate_bwd": ((r"k_agg_bwd<", r"k_agg_reduce"), r"k_agg_bwd<"),
+    "gt_attn_fwd": ((r"k_attn_fwd<",), r"k_attn_fwd<"),
+    "gt_attn_bwd": ((r"k_attn_bwd_dq<", r"k_attn_bwd_dkv<"), r"k_attn_bwd_dq<"),
 }
 
 
@@ -27,16 +34,45 @@ def per_kernel(db, counter):
     for n, c, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
         if c != counter:
             continue
-        m = re.search(r"\b(k_[a-z_0-9]+)", n)
-        if not m:
+        full = re.sub(r"\(anonymous namespace\)::", "", n)[:90]
+        if not re.search(r"\bk_[a-z_0-9]+", full):
             continue
-        a = agg.setdefault((m.group(1), re.sub(r"\(anonymous namespace\)::", "", n)[:90]), [0, 0.0])
+        a = agg.setdefault(full, [0, 0.0])
         a[0] += 1
         a[1] += v
     return agg
 
 
+def per_kernel_raw(path, counter):
+    """the same from a *_pmc_traffic_raw.txt written by an earlier run (name, counter, calls=, avg=)"""
+    agg = {}
+    for line in open(path):
+        m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+calls=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
+        if m and m.group(2) == counter:
+            agg[m.group(1).strip()] = [int(m.group(3)), int(m.group(3)) * float(m.group(4))]
+    return agg
+
+
+def traffic_of(fetch, write):
+    traffic = {}
+    for ep, (patterns, counted) in ENTRY.items():
+        calls = sum(c for full, (c, _t) in fetch.items() if re.search(counted, full))
+        if not calls:
+            continue
+        kb = sum(2.0 * t for full, (_c, t) in fetch.items() if any(re.search(p, full) for p in patterns)) + \
+            sum(t for full, (_c, t) in write.items() if any(re.search(p, full) for p in patterns))
+        traffic[ep] = int(kb * 1024 / calls)
+    return traffic
+
+
 def main():
+    if sys.argv[1] == "--from-raw":   # python tools/pmc_traffic.py --from-raw <raw.txt> <existing.json>: re-key an earlier run
+        raw, js = sys.argv[2:4]
+        d = json.load(open(js))
+        d["traffic"] = traffic_of(per_kernel_raw(raw, "FETCH_SIZE"), per_kernel_raw(raw, "WRITE_SIZE"))
+        json.dump(d, open(js, "w"), indent=1)
+        print(json.dumps(d["traffic"]))
+        return
     fdb, wdb, workload, mode, per_gpu, prefix = sys.argv[1:7]
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,16 +80,9 @@ def main():
     fetch, write = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     with open(prefix + "_pmc_traffic_raw.txt", "w") as f:
         for name, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-            for (k, full), (calls, tot) in sorted(agg.items(), key=lambda kv: kv[0][1]):
+            for full, (calls, tot) in sorted(agg.items()):
                 f.write(f"{full:92s} {name:12s} calls={calls:5d} avg={tot / calls:14.1f}\n")
-    traffic = {}
-    for ep, (prefixes, counted) in ENTRY.items():
-        calls = sum(c for (k, _), (c, _t) in fetch.items() if k == counted)
-        if not calls:
-            continue
-        kb = sum(2.0 * t for (k, _), (_c, t) in fetch.items() if k in prefixes) + \
-            sum(t for (k, _), (_c, t) in write.items() if k in prefixes)
-        traffic[ep] = int(kb * 1024 / calls)
+    traffic = traffic_of(fetch, write)
     out = {"workload": workload, "mode": mode, "graphs_per_gpu": int(per_gpu), "build_id": bench.build_id(),
            "unit": "bytes per entry-point call (2*FETCH_SIZE + WRITE_SIZE, KB counters, rocprofv3 --pmc, one counter per pass)",
            "traffic": traffic}

@@ -1,23 +1,26 @@
-# usage (GPU box): bash tools/profile_round.sh <round tag>   -- PMC passes first (bench.py reads their JSON), then the
-# bench lines of all workloads and the rocprofv3 kernel summaries; everything lands in gpurun_out/<tag>/
+# usage (GPU box): bash tools/profile_round.sh <round tag>   -- PMC passes first (bench.py attaches their build-stamped JSON),
+# then the bench lines of all workloads and the rocprofv3 kernel summaries; everything lands in gpurun_out/<tag>/
 set -e
-TAG=${1:-r01s}
+TAG=${1:-r02a}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
-bash tools/pmc_round.sh $TAG > gpurun_out/$TAG/pmc.log 2>&1 || true
-cp gpurun_out/$TAG/${TAG}_*_pmc_traffic.json profiles/ 2>/dev/null || true   # picked up by bench.py below
+bash tools/pmc_round.sh $TAG mixed bf16 > gpurun_out/$TAG/pmc.log 2>&1 || true
+cp gpurun_out/$TAG/${TAG}_*_pmc_traffic.json profiles/ 2>/dev/null || true   # picked up by bench.py below (same build id)
 python bench.py > gpurun_out/$TAG/bench_code2.json 2> gpurun_out/$TAG/bench_code2.err
 python bench.py --workload molpcba > gpurun_out/$TAG/bench_molpcba.json 2> gpurun_out/$TAG/bench_molpcba.err
-python bench.py --workload nci1 > gpurun_out/$TAG/bench_nci1.json 2> gpurun_out/$TAG/bench_nci1.err
-python bench.py --workload er --steps 20 --warmup 5 > gpurun_out/$TAG/bench_er.json 2> gpurun_out/$TAG/bench_er.err
-python bench.py --workload code2-pna > gpurun_out/$TAG/bench_code2pna.json 2> gpurun_out/$TAG/bench_code2pna.err
-python bench.py --no-kernel-timing --no-cpu-baseline --steps 100 > gpurun_out/$TAG/bench_code2_clean.json 2>/dev/null
-python bench.py --no-kernel-timing --no-cpu-baseline --steps 100 --workload molpcba > gpurun_out/$TAG/bench_molpcba_clean.json 2>/dev/null
-for w in code2 molpcba nci1; do
-  rm -rf /tmp/prof_$w
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o res -- python bench.py --workload $w --steps 30 --warmup 10 --no-cpu-baseline --no-kernel-timing > gpurun_out/$TAG/prof_$w.log 2>&1 || true
-  db=$(find /tmp/prof_$w -name "*.db" | head -1)
-  python tools/rocpd_summary.py $db 40 gpurun_out/$TAG/${w} >> gpurun_out/$TAG/prof_$w.log 2>&1 || true
+python bench.py --workload nci1 --no-extra > gpurun_out/$TAG/bench_nci1.json 2> gpurun_out/$TAG/bench_nci1.err
+python bench.py --workload er --steps 20 --warmup 5 --no-extra > gpurun_out/$TAG/bench_er.json 2> gpurun_out/$TAG/bench_er.err
+python bench.py --workload er --steps 20 --warmup 5 --no-extra --mode bf16 --no-cpu-baseline > gpurun_out/$TAG/bench_er_bf16.json 2> gpurun_out/$TAG/bench_er_bf16.err
+python bench.py --workload code2-pna --no-extra > gpurun_out/$TAG/bench_code2pna.json 2> gpurun_out/$TAG/bench_code2pna.err
+python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 > gpurun_out/$TAG/bench_code2_mixed_clean.json 2>/dev/null
+python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --mode bf16 > gpurun_out/$TAG/bench_code2_bf16_clean.json 2>/dev/null
+for m in mixed bf16; do
+  for w in code2 molpcba; do
+    rm -rf /tmp/prof_${w}_$m
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_${w}_$m -o res -- python bench.py --workload $w --mode $m --steps 30 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$TAG/prof_${w}_$m.log 2>&1 || true
+    db=$(find /tmp/prof_${w}_$m -name "*.db" | head -1)
+    python tools/rocpd_summary.py $db 40 gpurun_out/$TAG/${TAG}_${w}_b256_${m} >> gpurun_out/$TAG/prof_${w}_$m.log 2>&1 || true
+  done
 done
 ls gpurun_out/$TAG
