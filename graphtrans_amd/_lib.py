@@ -57,6 +57,7 @@ SIGNATURES = {
     "gt_embed_sum_bwd_sorted": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gt_segment_bcast_add": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_segment_sum": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "gt_seq_layout_packed": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _i64, _p, _p]),
     "gt_segment_sum_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_segment_sum_ws": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),

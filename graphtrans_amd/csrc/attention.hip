@@ -98,6 +98,7 @@ __device__ __forceinline__ bool block_item(const AttnArgs& a, int& seq, int& til
     head = slot % a.nhead;
     seq = a.work[w * 2];
     tile = a.work[w * 2 + 1];
+    if (seq < 0) return false;   // padding entry of a device-built work list (gt_seq_layout_packed)
   } else {
     head = blockIdx.y;
     seq = blockIdx.z;

@@ -350,3 +350,91 @@ extern "C" int gt_segment_sum_ws(int dtype, const void* x, const void* add, cons
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
+
+// ---- packed token layout built on the device (graph.py:SeqLayout.packed_on_device) -----------------------------------------
+// For a batch whose per-graph sizes are NOT known on the host (a bare device-resident PyG Batch): desc / last_rows / the
+// attention work list from graph_ptr alone, no device->host copy.  One block; graphs are walked in chunks of 1024 with
+// running prefix carries.  meta = {rows, num_work, max kv_len, S}.  Work entries past num_work are {-1, -1} (the
+// attention kernels skip them): the host sizes its launches by the upper bounds rows <= N + B*cls, num_work <= B +
+// rows / 64.
+__global__ void __launch_bounds__(1024) k_seq_layout_packed(const int32_t* __restrict__ gptr, int B, int max_len, int cls,
+                                                            int32_t* __restrict__ desc, int64_t* __restrict__ last_rows,
+                                                            int32_t* __restrict__ work, int64_t work_cap, int32_t* __restrict__ meta) {
+  __shared__ int sred[32];
+  __shared__ int sscan[2][1024];
+  __shared__ int scarry[2];
+  const int t = threadIdx.x;
+  // S = min(max nodes per graph, max_input_len)   (modules/utils.py:16)
+  int mx = 0;
+  for (int b = t; b < B; b += 1024) mx = max(mx, gptr[b + 1] - gptr[b]);
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  if ((t & 63) == 0) sred[t >> 6] = mx;
+  __syncthreads();
+  if (t == 0) {
+    int m = 0;
+    for (int i = 0; i < 16; ++i) m = max(m, sred[i]);
+    sred[16] = m < max_len ? m : max_len;
+    scarry[0] = 0;
+    scarry[1] = 0;
+  }
+  __syncthreads();
+  const int S = sred[16];
+  int max_kv = 0;
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + t;
+    int kv = 0, tiles = 0;
+    if (b < B) {
+      const int n = gptr[b + 1] - gptr[b];
+      kv = (n < S ? n : S) + cls;
+      tiles = (kv + 63) >> 6;
+      max_kv = max(max_kv, kv);
+    }
+    sscan[0][t] = kv;
+    sscan[1][t] = tiles;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan of both columns
+      int a0 = 0, a1 = 0;
+      if (t >= o) { a0 = sscan[0][t - o]; a1 = sscan[1][t - o]; }
+      __syncthreads();
+      sscan[0][t] += a0;
+      sscan[1][t] += a1;
+      __syncthreads();
+    }
+    const int row0 = scarry[0] + sscan[0][t] - kv, w0 = scarry[1] + sscan[1][t] - tiles;
+    if (b < B) {
+      desc[b * 4 + 0] = row0;
+      desc[b * 4 + 1] = kv;
+      desc[b * 4 + 2] = 0;
+      desc[b * 4 + 3] = kv;
+      last_rows[b] = (int64_t)row0 + kv - 1;
+      for (int i = 0; i < tiles; ++i)
+        if (w0 + i < work_cap) { work[(int64_t)(w0 + i) * 2] = b; work[(int64_t)(w0 + i) * 2 + 1] = i; }
+    }
+    __syncthreads();
+    if (t == 1023) { scarry[0] += sscan[0][1023]; scarry[1] += sscan[1][1023]; }
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) max_kv = max(max_kv, __shfl_xor(max_kv, o));
+  if ((t & 63) == 0) sred[t >> 6] = max_kv;
+  __syncthreads();
+  const int rows = scarry[0], nwork = scarry[1];
+  for (int64_t w = nwork + t; w < work_cap; w += 1024) { work[w * 2] = -1; work[w * 2 + 1] = -1; }
+  if (t == 0) {
+    int m = 0;
+    for (int i = 0; i < 16; ++i) m = max(m, sred[i]);
+    meta[0] = rows; meta[1] = nwork; meta[2] = m; meta[3] = S;
+  }
+}
+
+extern "C" int gt_seq_layout_packed(const int32_t* graph_ptr, int64_t B, int64_t max_input_len, int with_cls, int32_t* seq_desc,
+                                    int64_t* last_rows, int32_t* work_items, int64_t work_capacity, int32_t* meta,
+                                    gt_stream_t stream_) {
+  GT_CHECK_ARG(graph_ptr && seq_desc && last_rows && work_items && meta, "null buffer");
+  GT_CHECK_ARG(B >= 0 && B <= 65535 && max_input_len > 0 && work_capacity >= 0, "bad sizes");
+  if (B == 0) return GT_OK;
+  hipLaunchKernelGGL(k_seq_layout_packed, dim3(1), dim3(1024), 0, (hipStream_t)stream_, graph_ptr, (int)B,
+                     (int)(max_input_len > 0x3fffffff ? 0x3fffffff : max_input_len), with_cls ? 1 : 0, seq_desc, last_rows, work_items,
+                     work_capacity, meta);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}

@@ -547,7 +547,9 @@ class _FusedModel(torch.autograd.Function):
         o["ws"] = b.take(ws_bytes)
         ws2_bytes = max([lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
         o["ws2"] = b.take(ws2_bytes)   # the side stream's workspace
-        arena = torch.empty(b.off, dtype=torch.uint8, device=dev)
+        # a device-built token layout only has an upper bound on the row count: zero-filled buffers keep the rows past the
+        # true count finite (they contribute exactly 0 to every weight gradient)
+        arena = (torch.empty if lay.exact else torch.zeros)(b.off, dtype=torch.uint8, device=dev)
         base = arena.data_ptr()
         side = plan.side.cuda_stream if plan.side is not None else None
 
@@ -750,7 +752,7 @@ class _FusedModel(torch.autograd.Function):
         seg_ws_bytes = lib.gt_segment_sum_workspace_bytes(N, D) if plan.has_vn else 0
         q["ws3"] = b.take(seg_ws_bytes)   # the per-graph pooling of d x_l runs on the second stream with its own scratch
         s["seg_ws_bytes"] = seg_ws_bytes
-        barena = torch.empty(b.off, dtype=torch.uint8, device=dev)
+        barena = (torch.empty if lay.exact else torch.zeros)(b.off, dtype=torch.uint8, device=dev)
         bb = barena.data_ptr()
         side = plan.side.cuda_stream if plan.side is not None else None
 

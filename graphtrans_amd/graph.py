@@ -81,17 +81,47 @@ class GraphStructure:
     def layout(self, kind, max_input_len, with_cls):
         key = (kind, int(max_input_len), bool(with_cls))
         if key not in self._layouts:
-            self._layouts[key] = SeqLayout(self, kind, int(max_input_len), bool(with_cls))
+            if kind == "packed" and self._sizes is None and torch.device(self.device).type == "cuda":
+                # sizes unknown on the host (a bare device batch): build the layout on the device, no D2H sync
+                self._layouts[key] = SeqLayout.packed_on_device(self, int(max_input_len), bool(with_cls))
+            else:
+                self._layouts[key] = SeqLayout(self, kind, int(max_input_len), bool(with_cls))
         return self._layouts[key]
 
 
 class SeqLayout:
     """seq_desc[B][4] = {row0, npos, kv_off, kv_len} (see include/graphtrans_hip.h).
 
+    exact: rows / num_work / max_npos are the true counts (host-built).  A device-built layout (packed_on_device) only
+    knows upper bounds on the host: its token buffers must be ZERO-initialised, the rows past the true count then stay
+    finite through every row-wise kernel and contribute exactly 0 to every weight gradient.
+
     padded: the reference layout of pad_batch + CLS (modules/utils.py:5-29,
             modules/transformer_encoder.py:50-55): rows = S' x B, position-major, left padded.
     packed: only real tokens, graph after graph: rows = sum_b (kept_b + cls).
     """
+
+    exact = True
+
+    @classmethod
+    def packed_on_device(cls, gs, max_input_len, with_cls):
+        """gt_seq_layout_packed: desc / last_rows / work list from graph_ptr on the device (the reference's pad_batch loop,
+        modules/utils.py:9-16, costs O(B) device syncs; the host-built layout one D2H copy when sizes are unknown)."""
+        self = cls.__new__(cls)
+        B, N, c = gs.B, gs.N, 1 if with_cls else 0
+        dev = gs.device
+        self.kind, self.with_cls, self.B, self.exact = "packed", with_cls, B, False
+        self.row_stride = 1
+        self.rows = N + B * c                      # upper bound: truncation (n > max_input_len) only removes rows
+        self.max_npos = min(int(max_input_len), N) + c
+        self.num_work = B + self.rows // 64        # upper bound on sum_b ceil(kv_len_b / 64)
+        self.desc = torch.empty((B, 4), dtype=torch.int32, device=dev)
+        self.last_rows = torch.empty(B, dtype=torch.int64, device=dev)
+        self.work = torch.empty((max(self.num_work, 1), 2), dtype=torch.int32, device=dev)
+        self.meta = torch.empty(4, dtype=torch.int32, device=dev)
+        _lib.launch("gt_seq_layout_packed", _ptr(gs.graph_ptr), B, int(max_input_len), c, _ptr(self.desc), _ptr(self.last_rows),
+                    _ptr(self.work), self.num_work, _ptr(self.meta), _stream())
+        return self
 
     def __init__(self, gs, kind, max_input_len, with_cls):
         n = gs.sizes

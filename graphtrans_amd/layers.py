@@ -125,6 +125,8 @@ class _EncoderLayer(torch.autograd.Function):
                             "n2_b"), params):
             setattr(desc, name, _ptr(_f32c(p)))
         saved = _bytes(L.gt_encoder_layer_saved_bytes(C.byref(desc)), x.device)
+        if not getattr(lay, "exact", True):
+            saved.zero_()   # device-built layout (upper-bound row count): the attention kernels skip the rows past the true count
         y = torch.empty_like(x)
         _lib.check(L.gt_encoder_layer_fwd(C.byref(desc), _ptr(x), _ptr(y), _ptr(saved), _stream()), "gt_encoder_layer_fwd")
         ctx.save_for_backward(x, saved, *params)
@@ -144,6 +146,8 @@ class _EncoderLayer(torch.autograd.Function):
         grads = torch.empty(L.gt_encoder_layer_grad_elems(C.byref(desc)), dtype=torch.float32, device=x.device)
         ws_bytes = L.gt_encoder_layer_workspace_bytes(C.byref(desc))
         ws = _bytes(ws_bytes, x.device)
+        if not getattr(ctx.lay, "exact", True):
+            ws.zero_()
         _lib.check(L.gt_encoder_layer_bwd(C.byref(desc), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), _ptr(grads), _ptr(ws),
                                           ws_bytes, _stream()), "gt_encoder_layer_bwd")
         return (dx, None, None, None, None, None, None, *_split(grads, params))

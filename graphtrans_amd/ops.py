@@ -217,7 +217,7 @@ def segment_sum(x, gs, add=None):
 # ------------------------------------------------------------------------------------------------
 def _gather_raw(h, cls, gs, lay, want_mask):
     D = h.shape[1]
-    tokens = torch.empty((lay.rows, D), dtype=h.dtype, device=h.device)
+    tokens = (torch.empty if getattr(lay, "exact", True) else torch.zeros)((lay.rows, D), dtype=h.dtype, device=h.device)
     mask = torch.empty((lay.B, lay.max_npos), dtype=torch.bool, device=h.device) if want_mask else None
     _lib.launch("gt_seq_gather", _dtype_code(h), _ptr(h), _ptr(cls), _ptr(gs.graph_ptr), _ptr(lay.desc), lay.B,
                 lay.row_stride, lay.max_npos, 1 if lay.with_cls else 0, D, _ptr(tokens), _ptr(mask), _stream())
@@ -302,7 +302,8 @@ class _Attention(torch.autograd.Function):
         key_valid = None if key_valid is None else _dev(key_valid.float(), "valid_input_mask")
         rows, d3 = qkv.shape
         d = d3 // 3
-        out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
+        alloc = torch.empty if getattr(lay, "exact", True) else torch.zeros   # device-built layout: rows past the true count stay 0
+        out = alloc((rows, d), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((2, nhead, rows), dtype=torch.float32, device=qkv.device)
         meta = dict(lay=lay, d=d, nhead=nhead, elt=qkv.element_size())
         _lib.launch("gt_attn_fwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(lse), rows, d, nhead, _ptr(lay.desc),
@@ -320,7 +321,7 @@ class _Attention(torch.autograd.Function):
         g = _dev(g.to(qkv.dtype), "grad")
         rows, d3 = qkv.shape
         # rows that belong to no sequence position do not exist in either layout -> fully written
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty_like(qkv) if getattr(lay, "exact", True) else torch.zeros_like(qkv)
         delta = torch.empty((nhead, rows), dtype=torch.float32, device=qkv.device)
         _lib.launch("gt_attn_bwd", _dtype_code(qkv), _ptr(qkv), _ptr(out), _ptr(g), _ptr(lse), _ptr(delta),
                     _ptr(dqkv), rows, d3 // 3, nhead, _ptr(lay.desc), lay.B, lay.row_stride, lay.max_npos,

@@ -275,6 +275,12 @@ int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_
                    const int32_t* node_graph, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
                    int with_cls, int64_t num_nodes, int64_t dim, void* h_out, void* cls_out /* [B][dim] or NULL */,
                    gt_stream_t stream);
+/* The PACKED token layout (seq_desc / last token row per sequence / attention work list of {sequence, 64-row tile}) built
+ * on the device from graph_ptr alone: for batches whose per-graph sizes are not known on the host, where the reference's
+ * pad_batch (modules/utils.py:9-16) synchronises B times.  meta[4] = {rows, num_work, max kv_len, S}; work entries past
+ * num_work are {-1,-1}.  Callers size their launches by rows <= N + B*with_cls and num_work <= B + rows/64. */
+int gt_seq_layout_packed(const int32_t* graph_ptr, int64_t B, int64_t max_input_len, int with_cls, int32_t* seq_desc,
+                         int64_t* last_rows, int32_t* work_items, int64_t work_capacity, int32_t* meta, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused masked multi-head self-attention over the token rows (flash-style, never materialises

@@ -345,3 +345,48 @@ def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload):
                 assert not bad, (it, len(bad), bad[:4])
     finally:
         ops.set_matmul_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("max_input_len", [1000, 40])
+def test_device_built_token_layout_equals_the_host_built_one(max_input_len):
+    """A batch without host-side sizes (a bare device-resident PyG Batch) gets its packed token layout from
+    gt_seq_layout_packed: no device->host copy.  It must describe the same sequences as the host-built layout (desc,
+    last rows, work list incl. truncation to max_input_len) and drive the model to the same loss and gradients."""
+    import numpy as np
+    from graphtrans_amd import losses, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.graph import GraphStructure
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    b = synth.code2_like(B=12, seed=5, num_nodeattributes=300).to(DEV)
+    sizes = torch.bincount(b.batch).cpu().numpy()
+    assert max_input_len == 1000 or sizes.max() > max_input_len    # the small limit truncates some graphs
+    g_host = GraphStructure.build(b.edge_index, b.batch, num_graphs=12, sizes=sizes)
+    g_dev = GraphStructure.build(b.edge_index, b.batch, num_graphs=12)
+    lh, ld = g_host.layout("packed", max_input_len, True), g_dev.layout("packed", max_input_len, True)
+    assert lh.exact and not ld.exact
+    meta = ld.meta.cpu().numpy()
+    assert meta[0] == lh.rows and meta[1] == lh.num_work and meta[2] == lh.max_npos and meta[3] == lh.S
+    assert ld.rows >= lh.rows and ld.num_work >= lh.num_work and ld.max_npos >= lh.max_npos
+    assert torch.equal(ld.desc, lh.desc) and torch.equal(ld.last_rows, lh.last_rows)
+    assert torch.equal(ld.work[:lh.num_work], lh.work) and bool((ld.work[lh.num_work:] == -1).all())
+    # the model on both
+    args = _args(max_input_len=max_input_len, transformer_dropout=0.0)
+    torch.manual_seed(0)
+    model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV).train()
+    y = torch.randint(0, 50, (12, 5), device=DEV)
+    res = []
+    for fused in (True, False):
+        for with_sizes in (True, False):
+            bb = synth.code2_like(B=12, seed=5, num_nodeattributes=300).to(DEV)
+            if with_sizes:
+                bb._sizes = sizes
+            model.fused = fused
+            for p in model.parameters():
+                p.grad = None
+            loss = losses.code2_loss(model(bb), y)
+            loss.backward()
+            res.append((float(loss), [p.grad.detach().clone() for p in model.parameters()]))
+    for k in (1, 3):   # (fused, no sizes) vs (fused, sizes); (modules, no sizes) vs (modules, sizes)
+        assert abs(res[k][0] - res[k - 1][0]) <= 1e-6 * max(1.0, abs(res[k - 1][0]))
+        for a, c in zip(res[k][1], res[k - 1][1]):
+            assert torch.allclose(a, c, rtol=1e-5, atol=1e-7), float((a - c).abs().max())
