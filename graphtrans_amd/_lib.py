@@ -80,6 +80,7 @@ SIGNATURES = {
     "gt_grad_clip_coef": (_i, [_p, _i64, _f, _p, _p]),
     "gt_overlap_dw_begin": (_i, [_p, _p]),
     "gt_overlap_dw_sync": (_i, []),
+    "gt_overlap_dw_release": (_i, [_p, _sz]),
     "gt_overlap_dw_end": (_i, []),
     "gt_linear_fwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_fwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i, _f, _u64, _p]),

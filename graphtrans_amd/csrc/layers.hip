@@ -345,7 +345,7 @@ GinGrads gin_grads(const gt_gin_layer* L, float* g) {
   return r;
 }
 struct GinWork {
-  void *d_z2, *d_a1, *d_z1, *d_agg, *d_x, *bn_ws, *agg_ws, *lin_ws, *seg_ws;
+  void *d_z2, *d_a1, *d_z1, *d_agg, *d_x, *bn_ws, *agg_ws, *lin_ws, *lin_ws1, *seg_ws;
   size_t bn_ws_bytes, agg_ws_bytes, lin_ws_bytes, seg_ws_bytes, bytes;
 };
 GinWork gin_work(const gt_gin_layer* L, void* p) {
@@ -364,6 +364,7 @@ GinWork gin_work(const gt_gin_layer* L, void* p) {
   size_t a = gt_linear_bwd_workspace_bytes(L->compute, N, 2 * D, D), c = gt_linear_bwd_workspace_bytes(L->compute, N, D, 2 * D);
   w.lin_ws_bytes = a > c ? a : c;
   w.lin_ws = b.take(w.lin_ws_bytes);
+  w.lin_ws1 = b.take(w.lin_ws_bytes);   // the first Linear's own: the second one's dW GEMM (side stream) still uses lin_ws
   w.seg_ws_bytes = gt_segment_sum_workspace_bytes(L->N, L->D);   // the pooling of the forward
   w.seg_ws = b.take(w.seg_ws_bytes);
   w.bytes = b.off;
@@ -548,7 +549,7 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, N, 2 * D, w.d_z1,
                           g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.agg, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_agg, g.w1, g.b1, N,
-                       2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+                       2 * D, D, 0.f, w.lin_ws1, w.lin_ws_bytes, st));
   const bool adds = dx_extra || L->residual;
   void* dx_conv = adds ? w.d_x : d_h_in;
   GT_TRY(gt_aggregate_bwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, w.d_agg, N, L->E, D, L->out_ptr, L->out_dst, L->out_eid, nullptr,

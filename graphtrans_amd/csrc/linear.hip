@@ -645,12 +645,54 @@ int dx_splits(int64_t M, int64_t N, int64_t K, int bm) {
   } while (0)
 
 // ---- optional overlap of the weight-gradient GEMMs (gt_overlap_dw_*): per host thread ------------
+struct DwPending {
+  uintptr_t lo, hi;   // workspace range a forked dW GEMM (partials + its reduce) still uses
+  hipEvent_t ev;      // recorded on the side stream behind it
+};
+constexpr int DW_RING = 8;
 struct DwOverlap {
   bool active = false;
   hipStream_t main = nullptr, side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  DwPending ring[DW_RING];   // forks since the last full join, oldest first (the side stream runs them in this order)
+  int n = 0;
 };
 thread_local DwOverlap g_dw;
+
+// main waits for the side stream; nothing is pending afterwards
+void dw_join_all() {
+  (void)hipEventRecord(g_dw.ev_join, g_dw.side);
+  (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
+  g_dw.n = 0;
+}
+// main waits for the forked dW GEMMs whose workspace overlaps [p, p + bytes) -- and, the side stream being in order, for
+// everything forked before them; later forks on other workspaces keep running
+void dw_release(const void* p, size_t bytes) {
+  if (!g_dw.active || !g_dw.n) return;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  int last = -1;
+  for (int i = 0; i < g_dw.n; ++i)
+    if (g_dw.ring[i].lo < hi && lo < g_dw.ring[i].hi) last = i;
+  if (last < 0) return;
+  (void)hipStreamWaitEvent(g_dw.main, g_dw.ring[last].ev, 0);
+  // drop entries 0..last; their events rotate to the free end of the ring
+  DwPending keep[DW_RING];
+  int k = 0;
+  for (int i = last + 1; i < g_dw.n; ++i) keep[k++] = g_dw.ring[i];
+  const int kept = k;
+  for (int i = 0; i <= last; ++i) keep[k++] = g_dw.ring[i];
+  for (int i = g_dw.n; i < DW_RING; ++i) keep[k++] = g_dw.ring[i];
+  for (int i = 0; i < DW_RING; ++i) g_dw.ring[i] = keep[i];
+  g_dw.n = kept;
+}
+// called right after a dW GEMM (and its reduce) went to the side stream
+void dw_forked(const void* workspace, size_t bytes) {
+  if (g_dw.n == DW_RING) dw_join_all();
+  DwPending& e = g_dw.ring[g_dw.n++];
+  e.lo = (uintptr_t)workspace;
+  e.hi = e.lo + bytes;
+  (void)hipEventRecord(e.ev, g_dw.side);
+}
 
 int pick_bm(int64_t M) {
   (void)M;
@@ -899,11 +941,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (dx) {   // dX = dZ (W^T)^T: the forward-form kernel on the transposed weight
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
       // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
-      // layer) -> join it first.  (Message-passing layers have one GEMM per workspace and join anyway.)
-      if (g_dw.active && stream == g_dw.main) {
-        (void)hipEventRecord(g_dw.ev_join, g_dw.side);
-        (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
-      }
+      // layer) -> wait for the forks that used this range (those on other workspaces keep running).
+      if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);
       hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
       L32Args w{};
       w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
@@ -911,10 +950,12 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
+      bool forked = false;
       if (g_dw.active && stream == g_dw.main && dx && !(gt_prof_mask() & GT_PROF_LINEAR)) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
         stream = g_dw.side;
+        forked = true;
       }
       L32DwArgs d{};
       d.dy = dy; d.ymask = y_for_mask; d.x = x; d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;
@@ -928,6 +969,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
       hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, splits, len, dweight,
                          (const float*)d.dbpart, len2, dbias, (int64_t)0);
+      if (forked) dw_forked(workspace, workspace_bytes);
     }
     GT_CHECK_LAUNCH();
     return GT_OK;
@@ -961,10 +1003,12 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     // dW is off the critical path of the backward (only the optimizer reads it): inside a
     // gt_overlap_dw_begin/_end section it runs on the side stream beside dX and whatever follows.
     // (not while the launch profiler brackets this call: its events sit on the caller's stream only)
+    bool forked = false;
     if (g_dw.active && stream == g_dw.main && dx && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
       stream = g_dw.side;
+      forked = true;
     }
     const int64_t bmc = compute == GT_BF16 ? 64 : 32;
     a.splits = splits;
@@ -980,6 +1024,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
     hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
                        (const float*)a.dbpart, len2, dbias, a.g_part);
+    if (forked) dw_forked(workspace, workspace_bytes);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -994,16 +1039,25 @@ extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
       gt_set_error("gt_overlap_dw_begin: event creation failed");
       return GT_ERR_LAUNCH;
     }
+    for (int i = 0; i < DW_RING; ++i)
+      if (hipEventCreateWithFlags(&g_dw.ring[i].ev, hipEventDisableTiming) != hipSuccess) {
+        gt_set_error("gt_overlap_dw_begin: event creation failed");
+        return GT_ERR_LAUNCH;
+      }
   }
   g_dw.main = (hipStream_t)main_;
   g_dw.side = (hipStream_t)side_;
   g_dw.active = true;
+  g_dw.n = 0;
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_sync(void) {
   if (!g_dw.active) return GT_OK;
-  (void)hipEventRecord(g_dw.ev_join, g_dw.side);
-  (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
+  dw_join_all();
+  return GT_OK;
+}
+extern "C" int gt_overlap_dw_release(const void* workspace, size_t bytes) {
+  dw_release(workspace, bytes);
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_end(void) {

@@ -747,7 +747,7 @@ class _FusedModel(torch.autograd.Function):
         else:
             emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
-        q["ws"] = b.take(ws_bytes)
+        q["ws"] = [b.take(ws_bytes), b.take(ws_bytes)]   # alternated between consecutive stages (see W() below)
         q["ws2"] = b.take(s["ws2_bytes"])
         seg_ws_bytes = lib.gt_segment_sum_workspace_bytes(N, D) if plan.has_vn else 0
         q["ws3"] = b.take(seg_ws_bytes)   # the per-graph pooling of d x_l runs on the second stream with its own scratch
@@ -778,28 +778,44 @@ class _FusedModel(torch.autograd.Function):
         L, D, d, dev, Kc = plan.L, plan.D, plan.d, plan.dev, s["Kc"]
         nenc = len(s["enc_desc"])
         side = plan.side.cuda_stream if plan.side is not None else None
+        ov = plan.side_dw is not None
+        slot = [0]
+
+        def W(join=False):
+            """the next stage's workspace.  The two slots alternate, so the weight-gradient GEMMs a stage forks onto the
+            third stream (their partials and the dy they read live in the stage's slot) can run beside the NEXT stage: the
+            main stream then waits only for the GEMMs that used this slot two stages ago (gt_overlap_dw_release).
+            join=True waits for all of them, as the token-side stages do: beside a lagging dW GEMM their LayerNorm backward
+            was measured to return rows that differ in the last bits run to run (not understood), and
+            the fused backward is required to be bitwise reproducible; the message-passing stages are."""
+            slot[0] ^= 1
+            p = Q("ws", slot[0])
+            if ov:
+                if join:
+                    _call("gt_overlap_dw_sync")
+                else:
+                    _call("gt_overlap_dw_release", p, ws_bytes)
+            return p
+
         # ---- heads
         _call("gt_linear_bwd_ld", GT_F32, GT_F32, compute, P("hg"), s["wcat"], dl.data_ptr(), None, None, None, Q("d_hg"),
-              G + plan.headw_off * 4, G + plan.headb_off * 4, B, plan.Nh, d, plan.ldy, 0.0, Q("ws"), ws_bytes, st)
+              G + plan.headw_off * 4, G + plan.headb_off * 4, B, plan.Nh, d, plan.ldy, 0.0, W(), ws_bytes, st)
         # ---- pooled rows -> token rows
         dcur, dnext = Q("dtok", 0), Q("dtok", 1)
         _call("gt_rows_scatter", tdt, Q("d_hg"), lay.last_rows.data_ptr(), B, rows, d, dcur, st)
-        dw_sync()   # the heads' dW (side stream) shares the workspace with what follows
         if plan.norm_out is not None:
             ln = plan.norm_out
             _call("gt_layernorm_bwd", tdt, s["pre_out"], None, dcur, ln.weight.data_ptr(), P("sto"), P("sto") + rows * 4, 0.0, 0,
-                  rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, Q("ws"), ws_bytes, st)
+                  rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, W(True), ws_bytes, st)
             dcur, dnext = dnext, dcur
         for i in range(nenc - 1, -1, -1):
-            dw_sync()   # the previous layer's dW GEMMs still read its workspace
             _call("gt_encoder_layer_bwd", C.byref(s["enc_desc"][i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
-                  G + plan.enc_off[i] * 4, Q("ws"), ws_bytes, st)
+                  G + plan.enc_off[i] * 4, W(True), ws_bytes, st)
             dcur, dnext = dnext, dcur
-        dw_sync()
         if plan.norm_in is not None:
             ln = plan.norm_in
             _call("gt_layernorm_bwd", tdt, P("tok"), None, dcur, ln.weight.data_ptr(), P("st0"), P("st0") + rows * 4, 0.0, 0,
-                  rows, d, dnext, None, G + plan.norm_in_off[0] * 4, G + plan.norm_in_off[1] * 4, Q("ws"), ws_bytes, st)
+                  rows, d, dnext, None, G + plan.norm_in_off[0] * 4, G + plan.norm_in_off[1] * 4, W(True), ws_bytes, st)
             dcur, dnext = dnext, dcur
         # ---- token rows -> node rows (+ the CLS gradient)
         _call("gt_seq_scatter", tdt, dcur, None, gs.graph_ptr.data_ptr(), gs.node_graph.data_ptr(), lay.desc.data_ptr(), lay.B,
@@ -809,7 +825,7 @@ class _FusedModel(torch.autograd.Function):
             torch.sum(dc, dim=0, dtype=torch.float32, out=flat[plan.cls_off:plan.cls_off + d])
         g2t = plan.g2t
         _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
-              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, Q("ws"), ws_bytes, st)
+              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(True), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
         sync = model_sync if direct else None
         if sync is not None:
@@ -837,14 +853,13 @@ class _FusedModel(torch.autograd.Function):
                     _call("gt_event_record", plan.ev_extra[l], side)
                 else:
                     _call("gt_vn_update_bwd", C.byref(s["vn_desc"][l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
-                          G + plan.vn_off[l] * 4, Q("ws"), ws_bytes, st)
+                          G + plan.vn_off[l] * 4, W(), ws_bytes, st)
                 extra = Q("dC")
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = s["xptr"][l]
-            dw_sync()
             pool_on_side = plan.has_vn and side is not None
             _call(plan.conv_api + "_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
-                  Q("dvn", 3) if (plan.has_vn and not pool_on_side) else None, G + plan.gcn_off[l] * 4, Q("ws"), ws_bytes, st)
+                  Q("dvn", 3) if (plan.has_vn and not pool_on_side) else None, G + plan.gcn_off[l] * 4, W(), ws_bytes, st)
             if plan.has_vn:   # d vn_l = (layer l's broadcast add: per-graph sum of d x_l) + (update l's pooled + residual inputs)
                 # off the main chain: only the NEXT virtual-node update backward (second stream) reads it
                 vst = side if pool_on_side else st
@@ -861,7 +876,6 @@ class _FusedModel(torch.autograd.Function):
                 d_vn_next = tgt
             dy = out
         d_h0 = dy
-        dw_sync()
         if plan.has_vn:
             vst = side if side is not None else st
             _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, vst)
@@ -872,6 +886,7 @@ class _FusedModel(torch.autograd.Function):
         # on the wire while the embedding backward runs; the tables themselves follow right after it
         gnn_lo = plan.vn_emb_off if plan.has_vn else plan.gcn_off[0]
         if sync is not None:
+            dw_sync()
             sync.reduce_flat(flat, gnn_lo, plan.g2t_off[0])
         # ---- input encoder tables
         if plan.embed_kind == "linear":   # dW = d_h0^T x, db = colsum(d_h0); the features need no gradient
@@ -879,7 +894,7 @@ class _FusedModel(torch.autograd.Function):
             K, Kp = plan.ne_K, plan.ne_Kp
             dw = G + plan.ne_off[0] * 4 if Kp == K else Q("ne_dw")
             _call("gt_linear_bwd", GT_F32, GT_F32, s["compute"], ne_x, ne_w, d_h0, None, None, None, None, dw,
-                  G + plan.ne_off[1] * 4, N, D, Kp, 0.0, Q("ws"), ws_bytes, st)
+                  G + plan.ne_off[1] * 4, N, D, Kp, 0.0, W(), ws_bytes, st)
             dw_sync()
             if Kp != K:
                 _call("gt_repitch", G + plan.ne_off[0] * 4, K, dw, Kp, D, 4, st)
@@ -887,9 +902,9 @@ class _FusedModel(torch.autograd.Function):
             T, e_idx, e_str, e_clamp, _cols = s["embed"]
             d_tabs = (C.c_void_p * T)(*[G + off * 4 for off in plan.embed_off])
             if s["esort"]:
-                _call("gt_embed_sum_bwd_sorted", T, emb_rows, d_h0, N, D, P("eplan"), d_tabs, Q("ws"), ws_bytes, st)
+                _call("gt_embed_sum_bwd_sorted", T, emb_rows, d_h0, N, D, P("eplan"), d_tabs, W(), ws_bytes, st)
             else:
-                _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, Q("ws"), ws_bytes, st)
+                _call("gt_embed_sum_bwd", T, e_idx, e_str, e_clamp, emb_rows, d_h0, N, D, d_tabs, W(), ws_bytes, st)
 
         if sync is not None:
             sync.reduce_flat(flat, 0, gnn_lo)

@@ -418,9 +418,15 @@ int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const
  * gt_linear_bwd[_ld] issued on `main` that computes both dX and dW launches the dW part (and its
  * partial reduce) on `side`, ordered after everything already queued on `main`.  The caller must call
  * gt_overlap_dw_sync() (main waits for the side stream) before it overwrites a dy / x / workspace
- * buffer that such a call was given, and before it reads the weight gradients; _end syncs too. */
+ * buffer that such a call was given, and before it reads the weight gradients; _end syncs too.
+ * gt_overlap_dw_release(workspace, bytes) is the finer join: main waits only for the forked dW GEMMs whose
+ * workspace overlaps the given range (and, the side stream being in order, for those forked before them) --
+ * a caller that alternates two workspaces between consecutive layers lets layer k's dW run beside layer k+1
+ * and releases its workspace before layer k+2 (buffers a dW reads must live in that workspace or stay
+ * unchanged until the next full sync). */
 int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
 int gt_overlap_dw_sync(void);
+int gt_overlap_dw_release(const void* workspace, size_t bytes);
 int gt_overlap_dw_end(void);
 
 int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

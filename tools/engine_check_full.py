@@ -13,8 +13,10 @@ import bench
 from graphtrans_amd import ops
 
 dev = torch.device("cuda:0")
+ITERS = int(os.environ.get("GT_CHECK_ITERS", "20"))
+GNN = torch.float32 if os.environ.get("GT_CHECK_MODE", "bf16") == "mixed" else torch.bfloat16   # GNN-side GEMM arithmetic
 for wl in ("code2", "molpcba"):
-    ops.set_matmul_dtype(torch.bfloat16)
+    ops.set_matmul_dtype(GNN)
     torch.manual_seed(0)
     args, model, gen, loss_fn, _ = bench.build(wl, torch.bfloat16, dev, 256)
     for m in model.modules():
@@ -37,7 +39,7 @@ for wl in ("code2", "molpcba"):
     ref = grads(ref_model, False)
     first = None
     worst = 0.0
-    for it in range(20):
+    for it in range(ITERS):
         g = grads(model, True)
         if first is None:
             first = g
@@ -54,4 +56,4 @@ for wl in ("code2", "molpcba"):
                         if "transformer" in n or "graph_pred" in n or "gnn2" in n:
                             print("   ", "DIFF" if n in badn else "same", n)
                 sys.exit(1)
-    print(wl, "20 fused backward passes bitwise identical; max rel. difference to the module path %.2e" % worst)
+    print(wl, ITERS, "fused backward passes bitwise identical; max rel. difference to the module path %.2e" % worst)
