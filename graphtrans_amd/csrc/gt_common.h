@@ -66,6 +66,20 @@ __device__ __forceinline__ uint32_t gt_pack_bf16(float lo, float hi) {
   return r;
 }
 
+// ---- activations fused into GEMM epilogues / gradient loads ---------------------------------------------------------
+// GELU in torch's default (erf) form and its derivative (modules/transformer_encoder.py:17, masked_transformer_encoder.py:68)
+__device__ __forceinline__ void gt_gelu(float z, float& y, float& dydz) {
+  const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+  y = z * cdf;
+  dydz = cdf + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+// Gradient gate of a fused activation, applied while dY is loaded: `m` is the saved tensor's element.
+//   inv_keep > 0: m = forward output of relu(+dropout): dZ = dY * 1[m > 0] * inv_keep
+//   inv_keep == 0 (sentinel): m = saved multiplier d act / dz * dropout scale (GELU): dZ = dY * m
+__device__ __forceinline__ float gt_gate(float dy, float m, float inv_keep) {
+  return inv_keep == 0.f ? dy * m : (m > 0.f ? dy * inv_keep : 0.f);
+}
+
 struct gt_f4 {
   float x, y, z, w;
 };

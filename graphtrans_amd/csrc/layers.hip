@@ -33,7 +33,7 @@ size_t elt(int dtype) { return dtype == GT_BF16 ? 2 : 4; }
 
 // ---------------------------------------------------------------- encoder layer
 struct EncSaved {
-  void *qkv, *ctx, *a, *x1, *f1, *f2;
+  void *qkv, *ctx, *a, *x1, *f1, *f2, *g1;   // g1: gelu only, the FFN activation's gradient multiplier
   float *lse, *st1, *st2;
   size_t bytes;
 };
@@ -47,6 +47,7 @@ EncSaved enc_saved(const gt_encoder_layer* L, void* p) {
   s.x1 = b.take((size_t)L->rows * L->d_model * e);
   s.f1 = b.take((size_t)L->rows * L->ffn * e);
   s.f2 = b.take((size_t)L->rows * L->d_model * e);
+  s.g1 = b.take(L->act == 1 ? (size_t)L->rows * L->ffn * e : 0);
   s.lse = (float*)b.take((size_t)2 * L->nhead * L->rows * 4);
   s.st1 = (float*)b.take((size_t)2 * L->rows * 4);
   s.st2 = (float*)b.take((size_t)2 * L->rows * 4);
@@ -258,7 +259,10 @@ extern "C" int gt_encoder_layer_fwd(const gt_encoder_layer* L, const void* x, vo
   GT_TRY(gt_linear_fwd(t, t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, 0, 0.f, 0, st));
   GT_TRY(gt_layernorm_fwd(t, s.a, x, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, s.x1, s.st1,
                           s.st1 + R, st));
-  GT_TRY(gt_linear_fwd(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, R, F, d, 1, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
+  if (L->act == 1)   // f1 = drop(gelu(x1 W1^T + b1)), multiplier saved for the backward
+    GT_TRY(gt_linear_fwd_gelu(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, s.g1, R, F, d, d, F, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
+  else
+    GT_TRY(gt_linear_fwd(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, R, F, d, 1, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
   GT_TRY(gt_linear_fwd(t, t, c, s.f1, L->l2_w, L->l2_b, s.f2, R, d, F, 0, 0.f, 0, st));
   GT_TRY(gt_layernorm_fwd(t, s.f2, s.x1, L->n2_w, L->n2_b, L->ln_eps, p, L->seed ^ 0x14057B7EF767814FULL, R, d, y, s.st2,
                           s.st2 + R, st));
@@ -285,8 +289,12 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));
   // f1 = drop(relu(x1 W1^T + b1)) ; d_x1 += ...
-  GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, p, w.lin_ws,
-                       w.lin_ws_bytes, st));
+  if (L->act == 1)
+    GT_TRY(gt_linear_bwd_mul(t, t, c, s.x1, L->l1_w, w.d_f1, s.g1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, d, F, w.lin_ws,
+                             w.lin_ws_bytes, st));
+  else
+    GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, p, w.lin_ws,
+                         w.lin_ws_bytes, st));
   // x1 = LN1(x + drop(a))
   GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
                           g.n1_w, g.n1_b, w.ln_ws, w.ln_ws_bytes, st));

@@ -38,7 +38,8 @@ struct LinArgs {
   int64_t M, N, K;
   int64_t ldy;        // row stride (elements) of Y / dY / ymask; >= N
   int64_t ldx;        // row stride (elements) of X / dX / the dX addends; >= K
-  int act;            // 0 none, 1 relu
+  int act;            // 0 none, 1 relu, 2 gelu (erf)
+  void* gout;         // fwd, act == 2: [M][ldy] (storage type of Y) receives d act/dz * dropout scale, the backward's multiplier; or null
   float inv_keep;     // 1/(1-p)
   uint32_t thr, s0, s1;
   int splits;
@@ -138,7 +139,7 @@ struct Loader {
             }
           }
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) f[e] = y[e] > 0.f ? f[e] * inv_keep : 0.f;
+          for (int e = 0; e < EPC; ++e) f[e] = gt_gate(f[e], y[e], inv_keep);
         }
       }
       TC* dst = lds + r * LDS_LD + cc;
@@ -302,14 +303,24 @@ __global__ void __launch_bounds__(LT) k_linear_fwd(LinArgs a) {
       if (m < a.M && col < a.N) {
         float4 v = *reinterpret_cast<const float4*>(patch + r * PATCH_LD + c4);
         if (a.bias) v = gt_add4(v, bias_chunk(a.bias, col, a.N));
+        float4 gm = gt_zero4();
+        float* vv = reinterpret_cast<float*>(&v);
+        float* gg = reinterpret_cast<float*>(&gm);
         if (a.act == 1) v = gt_relu4(v);
-        if (a.thr) {
-          float* vv = reinterpret_cast<float*>(&v);
+        else if (a.act == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+          for (int e = 0; e < 4; ++e) gt_gelu(vv[e], vv[e], gg[e]);
+        }
+        if (a.thr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool keep = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr;
+            vv[e] = keep ? vv[e] * a.inv_keep : 0.f;
+            gg[e] = keep ? gg[e] * a.inv_keep : 0.f;
+          }
         }
         store_chunk<TY>(Y + m * a.ldy + col, v);
+        if (a.act == 2 && a.gout) store_chunk<TY>(reinterpret_cast<TY*>(a.gout) + m * a.ldy + col, gm);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -774,10 +785,31 @@ extern "C" int gt_linear_fwd_ld2(int x_dtype, int y_dtype, int compute, const vo
                                stream_);
 }
 
+static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias, void* y,
+                           void* gout, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups, int64_t x_group_stride,
+                           int64_t y_group_stride, int act, float dropout_p, uint64_t seed, gt_stream_t stream_);
+
 extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                                      const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
                                      int groups, int64_t x_group_stride, int64_t y_group_stride, int act, float dropout_p,
                                      uint64_t seed, gt_stream_t stream_) {
+  GT_CHECK_ARG(act == 0 || act == 1, "act must be 0 (none) or 1 (relu); gelu: gt_linear_fwd_gelu");
+  GT_CHECK_ARG(dropout_p == 0.f || act == 1, "fused dropout requires a fused activation");
+  return linear_fwd_impl(x_dtype, y_dtype, compute, x, weight, bias, y, nullptr, M, N, K, ldx, ldy, groups, x_group_stride,
+                         y_group_stride, act, dropout_p, seed, stream_);
+}
+
+// Y = dropout(gelu(X W^T + b)); gmul (nullable, storage type / pitch of Y) = gelu'(z) * dropout scale: the multiplier
+// gt_linear_bwd_mul takes in place of the ReLU path's forward output
+extern "C" int gt_linear_fwd_gelu(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                                  void* y, void* gmul, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
+                                  uint64_t seed, gt_stream_t stream_) {
+  return linear_fwd_impl(x_dtype, y_dtype, compute, x, weight, bias, y, gmul, M, N, K, ldx, ldy, 1, 0, 0, 2, dropout_p, seed, stream_);
+}
+
+static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias, void* y,
+                           void* gout, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups, int64_t x_group_stride,
+                           int64_t y_group_stride, int act, float dropout_p, uint64_t seed, gt_stream_t stream_) {
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
                                (N * K) % 4 == 0),
@@ -789,20 +821,18 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
   }
   if (rc) return rc;
   GT_CHECK_ARG(x && weight && y, "null buffer");
-  GT_CHECK_ARG(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
-  GT_CHECK_ARG(dropout_p == 0.f || act == 1, "fused dropout requires the fused relu (mask is recovered from Y > 0)");
   if (M == 0) return GT_OK;
   GtProfScope prof__(GT_PROF_LINEAR, "gt_linear_fwd", stream_, {M, N, K, x_dtype, y_dtype, compute});
   hipStream_t stream = (hipStream_t)stream_;
   LinArgs a{};
-  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act;
+  a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act; a.gout = gout;
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups)) {
     SmallArgs sa{};
     sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
-    sa.act = act; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
+    sa.act = act; sa.gout = (float*)gout; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
     const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(M, 16) * gt_cdiv(N, 32), 4);
     if (compute == GT_F32) hipLaunchKernelGGL(k_small_fwd<float>, dim3(blocks), dim3(256), 0, stream, sa);
     else hipLaunchKernelGGL(k_small_fwd<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
@@ -812,7 +842,7 @@ extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, cons
   if (w32_eligible(compute, x_dtype, M, groups)) {
     L32Args w{};
     w.a = x; w.w = weight; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
-    w.act = act; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;
+    w.act = act; w.gout = gout; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;
     w32_launch<false>(x_dtype, y_dtype, stream, w);
     GT_CHECK_LAUNCH();
     return GT_OK;
@@ -855,12 +885,28 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
                            K, ldy, dropout_p, workspace, workspace_bytes, stream_);
 }
 
+// y_for_mask of the gt_linear_bwd* call in flight on this thread is a MULTIPLIER (gt_linear_bwd_mul), not a forward output
+thread_local bool g_mul_mask = false;
+
 extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
                                  float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
                                  void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
                                ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+// backward of gt_linear_fwd_gelu: `gmul` is the multiplier that forward saved (dZ = dY * gmul); everything else as gt_linear_bwd_ld2
+extern "C" int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                 const void* gmul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                                 float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void* workspace,
+                                 size_t workspace_bytes, gt_stream_t stream_) {
+  GT_CHECK_ARG(gmul, "gt_linear_bwd_mul needs the multiplier");
+  g_mul_mask = true;
+  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, gmul, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
+                                       ldx, ldy, 1, 0, 0, 0.f, workspace, workspace_bytes, stream_);
+  g_mul_mask = false;
+  return rc;
 }
 
 extern "C" size_t gt_linear_bwd_grouped_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K, int groups) {
@@ -892,7 +938,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
   LinArgs a{};
   a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx;
   a.add1 = dx_add1; a.add2 = dx_add2;
-  a.inv_keep = 1.0f / (1.0f - dropout_p);
+  a.inv_keep = g_mul_mask ? 0.f : 1.0f / (1.0f - dropout_p);   // 0 = multiplier mode (gt_gate)
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   if (M == 0) {
     if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)groups * N * K * sizeof(float), stream);

@@ -25,6 +25,7 @@ struct L32Args {
   const void* add1;    // [M][ldo] storage type of out, or null
   const void* add2;
   void* out;           // [M][ldo]
+  void* gout;          // fwd, act == 2 (gelu): [M][ldo] multiplier for the backward, or null
   int64_t M, Nout, Kc;
   int64_t lda, ldw, ldo;
   int act;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) k_lin32(L32Args a) {
           float y[EA];
           chunk_to_f32<TA>(vm, y);
 #pragma unroll
-          for (int e = 0; e < EA; ++e) f[e] = y[e] > 0.f ? f[e] * a.inv_keep : 0.f;
+          for (int e = 0; e < EA; ++e) f[e] = gt_gate(f[e], y[e], a.inv_keep);
         }
       }
       float* dst = st + ar * LD + ac;
@@ -224,9 +225,22 @@ __global__ void __launch_bounds__(256) k_lin32(L32Args a) {
       if (ok[t]) {
         v[t] = *reinterpret_cast<const float4*>(patch + r * PLD + c4);
         if (a.bias) v[t] = gt_add4(v[t], *reinterpret_cast<const float4*>(sB + jb * 16 + c4));
+        float* vv = reinterpret_cast<float*>(&v[t]);
         if (a.act == 1) v[t] = gt_relu4(v[t]);
+        if constexpr (!MASK) {   // gelu only exists on the forward form
+          if (a.act == 2) {
+            float4 gm;
+            float* gg = reinterpret_cast<float*>(&gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              gt_gelu(vv[e], vv[e], gg[e]);
+              if (a.thr && lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) < a.thr) gg[e] = 0.f;
+              else if (a.thr) gg[e] *= a.inv_keep;
+            }
+            if (a.gout) gt_store4<TO>(reinterpret_cast<TO*>(a.gout) + m * a.ldo + col, gm);
+          }
+        }
         if (a.thr) {
-          float* vv = reinterpret_cast<float*>(&v[t]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
         }
@@ -363,7 +377,7 @@ __global__ void __launch_bounds__(256) k_lin32_dw(L32DwArgs a) {
             float y[EY];
             chunk_to_f32<TY>(vmk[i], y);
 #pragma unroll
-            for (int e = 0; e < EY; ++e) f[e] = y[e] > 0.f ? f[e] * a.inv_keep : 0.f;
+            for (int e = 0; e < EY; ++e) f[e] = gt_gate(f[e], y[e], a.inv_keep);
           }
         }
 #pragma unroll

@@ -22,6 +22,7 @@ struct SmallArgs {
   const float* add1;   // [M][ldx] or null (dX addends)
   const float* add2;
   float* out;          // fwd: Y [M][ldy]; dx: dX [M][ldx]; dw: dW [N][K]
+  float* gout;         // fwd, act == 2 (gelu): [M][ldy] multiplier for the backward, or null
   float* db;           // dw: [N] or null
   int64_t M, N, K, ldx, ldy;
   int act;
@@ -79,13 +80,24 @@ __global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
     if (col >= a.N) continue;
     float4 v = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
     if (a.bias) v = gt_add4(v, bias_chunk(a.bias, col, a.N));
+    float4 gm = gt_zero4();
+    float* vv = reinterpret_cast<float*>(&v);
+    float* gg = reinterpret_cast<float*>(&gm);
     if (a.act == 1) v = gt_relu4(v);
-    if (a.thr) {
-      float* vv = reinterpret_cast<float*>(&v);
+    else if (a.act == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vv[e] = lin_hash(a.s0, a.s1, (uint32_t)row, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+      for (int e = 0; e < 4; ++e) gt_gelu(vv[e], vv[e], gg[e]);
+    }
+    if (a.thr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool keep = lin_hash(a.s0, a.s1, (uint32_t)row, (uint32_t)(col + e)) >= a.thr;
+        vv[e] = keep ? vv[e] * a.inv_keep : 0.f;
+        gg[e] = keep ? gg[e] * a.inv_keep : 0.f;
+      }
     }
     *reinterpret_cast<float4*>(a.out + row * a.ldy + col) = v;
+    if (a.act == 2 && a.gout) *reinterpret_cast<float4*>(a.gout + row * a.ldy + col) = gm;
   }
 }
 
@@ -114,7 +126,7 @@ __global__ void __launch_bounds__(256) k_small_dx(SmallArgs a) {
     if (yr) {
       load8(yr + n0, rem, fy);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fz[e] = fy[e] > 0.f ? fz[e] * a.inv_keep : 0.f;
+      for (int e = 0; e < 8; ++e) fz[e] = gt_gate(fz[e], fy[e], a.inv_keep);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(256) k_small_dw(SmallArgs a) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float z = ok ? a.dy[mm * a.ldy + nc[q]] : 0.f;
-        if (a.ymask && ok) z = a.ymask[mm * a.ldy + nc[q]] > 0.f ? z * a.inv_keep : 0.f;
+        if (a.ymask && ok) z = gt_gate(z, a.ymask[mm * a.ldy + nc[q]], a.inv_keep);
         fz[q][e] = z;
         dbs[q] += z;
       }

@@ -159,6 +159,7 @@ class _Plan:
         self.norm_in = enc.norm_input
         self.norm_in_off = (seg(enc.norm_input.weight), seg(enc.norm_input.bias)) if enc.norm_input is not None else None
         self.enc_layers, self.enc_off = list(enc.transformer.layers), []
+        self.enc_act = layers.ENC_ACT[enc.activation]
         for mod in self.enc_layers:
             off = None
             for p in layers.encoder_layer_params(mod):
@@ -265,6 +266,7 @@ class _Plan:
                                 "n2_b"), layers.encoder_layer_params(mod)):
                 setattr(desc, name, p.data_ptr())
             desc.ln_eps = float(mod.norm1.eps)
+            desc.act = self.enc_act
 
     def small(self, B):
         c = self._cache.get(B)
@@ -409,7 +411,7 @@ def _eligible_static(model):
                 if not (len(m) == 6 and isinstance(m[0], torch.nn.Linear) and isinstance(m[1], BatchNorm1d)
                         and isinstance(m[3], torch.nn.Linear) and isinstance(m[4], BatchNorm1d)):
                     return False
-        if enc.activation != "relu" or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
+        if enc.activation not in layers.ENC_ACT or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
             return False
         for mod in enc.transformer.layers:
             if mod.linear1.weight.shape[0] % 8:

@@ -19,7 +19,8 @@ class EncoderLayerDesc(C.Structure):
     _fields_ = [("rows", C.c_int64), ("d_model", C.c_int64), ("ffn", C.c_int64),
                 ("nhead", C.c_int32), ("dtype", C.c_int32), ("compute", C.c_int32), ("training", C.c_int32),
                 ("seq_desc", _fp), ("num_seqs", C.c_int64), ("row_stride", C.c_int64), ("max_npos", C.c_int64),
-                ("work_items", _fp), ("num_work", C.c_int64), ("dropout_p", C.c_float), ("ln_eps", C.c_float), ("seed", C.c_uint64)] + \
+                ("work_items", _fp), ("num_work", C.c_int64), ("dropout_p", C.c_float), ("ln_eps", C.c_float),
+                ("act", C.c_int32), ("reserved_", C.c_int32), ("seed", C.c_uint64)] + \
                [(n, _fp) for n in ("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b",
                                    "n2_w", "n2_b")]
 
@@ -107,7 +108,7 @@ def encoder_layer_params(mod):
 
 class _EncoderLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lay, nhead, dropout_p, seed, training, ln_eps, *params):
+    def forward(ctx, x, lay, nhead, dropout_p, seed, training, ln_eps, act, *params):
         L = _bind()
         x = x.contiguous()
         rows, d = x.shape
@@ -121,6 +122,7 @@ class _EncoderLayer(torch.autograd.Function):
         desc.num_seqs, desc.row_stride, desc.max_npos = lay.B, lay.row_stride, lay.max_npos
         desc.work_items, desc.num_work = _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0)
         desc.dropout_p, desc.ln_eps, desc.seed = float(dropout_p), float(ln_eps), int(seed)
+        desc.act = ENC_ACT[act]
         for name, p in zip(("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w",
                             "n2_b"), params):
             setattr(desc, name, _ptr(_f32c(p)))
@@ -150,16 +152,19 @@ class _EncoderLayer(torch.autograd.Function):
             ws.zero_()
         _lib.check(L.gt_encoder_layer_bwd(C.byref(desc), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), _ptr(grads), _ptr(ws),
                                           ws_bytes, _stream()), "gt_encoder_layer_bwd")
-        return (dx, None, None, None, None, None, None, *_split(grads, params))
+        return (dx, None, None, None, None, None, None, None, *_split(grads, params))
+
+
+ENC_ACT = {"relu": 0, "gelu": 1}   # gt_encoder_layer.act
 
 
 def encoder_layer_eligible(mod, x, activation):
-    return (activation == "relu" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 8 == 0
+    return (activation in ENC_ACT and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 8 == 0
             and mod.linear1.weight.shape[0] % 8 == 0 and all(p.dtype == torch.float32 for p in mod.parameters()))
 
 
-def encoder_layer(x, mod, lay, nhead, dropout_p, seed, training):
-    return _EncoderLayer.apply(x, lay, nhead, dropout_p, seed, training, mod.norm1.eps, *encoder_layer_params(mod))
+def encoder_layer(x, mod, lay, nhead, dropout_p, seed, training, activation="relu"):
+    return _EncoderLayer.apply(x, lay, nhead, dropout_p, seed, training, mod.norm1.eps, activation, *encoder_layer_params(mod))
 
 
 # ------------------------------------------------------------------------------------------------

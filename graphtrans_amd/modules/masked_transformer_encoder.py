@@ -71,7 +71,7 @@ class Block(nn.Module):
 
     def _mlp(self, x):
         shape = x.shape
-        h = F.gelu(ops.linear_module(self.mlp[0], x.reshape(-1, shape[-1])))
+        h = ops.linear_module(self.mlp[0], x.reshape(-1, shape[-1]), act="gelu")   # GELU in the GEMM epilogue
         return self.mlp[3](ops.linear_module(self.mlp[2], h)).view(shape)
 
     def forward(self, x, attn_mask=None, valid_input_mask=None):

@@ -80,16 +80,13 @@ class TransformerNodeEncoder(nn.Module):
         sa = mod.self_attn
         p = self.dropout_p if self.training else 0.0
         if layers.encoder_layer_eligible(mod, x, self.activation):  # one composite op per layer
-            return layers.encoder_layer(x, mod, lay, self.nhead, p, seed, self.training)
+            return layers.encoder_layer(x, mod, lay, self.nhead, p, seed, self.training, self.activation)
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         ctx = ops.attention(qkv, lay, self.nhead, dropout_p=p, seed=seed)
         a = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias)
         x = self._ln(a, mod.norm1, resid=x, seed=seed ^ 0x5851F42D4C957F2D)
-        if self.activation == "relu":  # relu + dropout fused into linear1's epilogue
-            f = ops.linear(x, mod.linear1.weight, mod.linear1.bias, act="relu", dropout_p=p,
-                           seed=seed ^ 0x2545F4914F6CDD1D)
-        else:
-            f = self._drop(F.gelu(ops.linear(x, mod.linear1.weight, mod.linear1.bias)))
+        # activation (relu / gelu) + dropout fused into linear1's epilogue
+        f = ops.linear(x, mod.linear1.weight, mod.linear1.bias, act=self.activation, dropout_p=p, seed=seed ^ 0x2545F4914F6CDD1D)
         f = ops.linear(f, mod.linear2.weight, mod.linear2.bias)
         return self._ln(f, mod.norm2, resid=x, seed=seed ^ 0x14057B7EF767814F)
 

@@ -546,10 +546,18 @@ class _Linear(torch.autograd.Function):
         w32 = _f32(weight)
         b32 = _f32(bias)
         y = torch.empty((M, ldy), dtype=out_dtype, device=x2.device)
-        _lib.launch("gt_linear_fwd_ld", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
-                    M, N, K, ldy, act, float(dropout_p), int(seed), _stream())
+        if act == 2:   # gelu: the backward's multiplier gelu'(z) * dropout scale is written beside y
+            need = x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)
+            gmul = torch.empty_like(y) if need else None
+            _lib.launch("gt_linear_fwd_gelu", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
+                        _ptr(gmul), M, N, K, K, ldy, float(dropout_p), int(seed), _stream())
+            ctx.save_for_backward(x2, w32, gmul)
+        else:
+            _lib.launch("gt_linear_fwd_ld", _dtype_code(x2), _dtype_code(y), compute, _ptr(x2), _ptr(w32), _ptr(b32), _ptr(y),
+                        M, N, K, ldy, act, float(dropout_p), int(seed), _stream())
+            ctx.save_for_backward(x2, w32, y if act == 1 else None)
         fused = act == 1
-        ctx.save_for_backward(x2, w32, y if fused else None)
+        ctx.act = act
         ctx.cfg = (compute, dropout_p if fused else 0.0, x.shape, weight.dtype, None if bias is None else bias.dtype, ldy)
         if ldy != N:
             return y[:, :N]  # (M, N) view with row stride ldy
@@ -576,9 +584,13 @@ class _Linear(torch.autograd.Function):
         L = _lib.lib()
         ws_bytes = L.gt_linear_bwd_workspace_bytes(compute, M, N, K)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        _lib.launch("gt_linear_bwd_ld", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
-                    _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, ldy, float(dropout_p), _ptr(ws),
-                    ws_bytes, _stream())
+        if ctx.act == 2:
+            _lib.launch("gt_linear_bwd_mul", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
+                        _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, K, ldy, _ptr(ws), ws_bytes, _stream())
+        else:
+            _lib.launch("gt_linear_bwd_ld", _dtype_code(x2), _dtype_code(dy2), compute, _ptr(x2), _ptr(w32), _ptr(dy2),
+                        _ptr(ymask), None, None, _ptr(dx), _ptr(dw), _ptr(db), M, N, K, ldy, float(dropout_p), _ptr(ws),
+                        ws_bytes, _stream())
         return (None if dx is None else dx.view(xshape), None if not need_w else dw.to(wdt),
                 None if db is None else db.to(bdt), None, None, None, None, None, None)
 
@@ -604,7 +616,8 @@ def linear_supported(x, weight):
 
 
 def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None, ldy=None):
-    """act in {None, 'relu'}; dropout_p > 0 only together with relu (mask recovered from y > 0).
+    """act in {None, 'relu', 'gelu'}; dropout_p > 0 only together with an activation (relu: mask recovered from y > 0;
+    gelu (erf form): the forward writes the backward's multiplier gelu'(z) * dropout scale beside y).
     bf16-stored x always computes in bf16; fp32-stored x computes in get_matmul_dtype().
     ldy: row stride of the output buffer (multiple of 4 / 8 for fp32 / bf16) when N itself is not;
     the result is then the (M, N) column slice of an (M, ldy) buffer."""
@@ -616,11 +629,11 @@ def linear(x, weight, bias=None, act=None, dropout_p=0.0, seed=0, out_dtype=None
         out_dtype = x.dtype
     if compute == GT_F32 and out_dtype != torch.float32:
         raise ValueError("fp32 compute writes fp32")
-    a = 1 if act == "relu" else 0
-    if act not in (None, "relu"):
+    if act not in (None, "relu", "gelu"):
         raise ValueError(act)
+    a = {None: 0, "relu": 1, "gelu": 2}[act]
     if dropout_p > 0 and a == 0:
-        raise ValueError("fused dropout needs act='relu'")
+        raise ValueError("fused dropout needs a fused activation")
     return _Linear.apply(x, weight, bias, a, float(dropout_p), int(seed), compute, out_dtype, ldy)
 
 

@@ -413,6 +413,18 @@ int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const void* x, const
                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldy, float dropout_p, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
 
+/* GELU (erf form: transformer_activation=gelu modules/transformer_encoder.py:17; the Block MLP of
+ * masked_transformer_encoder.py:68) fused into the producing GEMM: Y = dropout(gelu(X W^T + b)).  `gmul` (nullable;
+ * storage type and pitch of Y) receives gelu'(z) * dropout scale; gt_linear_bwd_mul takes it where the ReLU path takes
+ * the forward output: dZ = dY * gmul, then dX / dW / db as gt_linear_bwd_ld2. */
+int gt_linear_fwd_gelu(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias,
+                       void* y, void* gmul, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
+                       uint64_t seed, gt_stream_t stream);
+int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                      const void* gmul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight, float* dbias,
+                      int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void* workspace, size_t workspace_bytes,
+                      gt_stream_t stream);
+
 /* Weight gradients are off the critical path of a backward pass (only the optimizer reads them).
  * Between gt_overlap_dw_begin(main, side) and gt_overlap_dw_end() on the same host thread, every
  * gt_linear_bwd[_ld] issued on `main` that computes both dX and dW launches the dW part (and its
@@ -485,7 +497,7 @@ int gt_bce_masked_bwd(const float* logits, const float* target, const float* out
  * gradient of the layer in the order of the descriptor's parameter fields (gt_*_grad_elems);
  * gradients are overwritten.  All parameters are fp32.
  */
-typedef struct gt_encoder_layer {  /* torch nn.TransformerEncoderLayer, post-norm, ReLU FFN */
+typedef struct gt_encoder_layer {  /* torch nn.TransformerEncoderLayer, post-norm, ReLU or GELU FFN */
   int64_t rows, d_model, ffn;
   int32_t nhead, dtype /* token storage */, compute /* fp32 storage only: GT_F32 | GT_BF16 */, training;
   const int32_t* seq_desc;
@@ -493,6 +505,7 @@ typedef struct gt_encoder_layer {  /* torch nn.TransformerEncoderLayer, post-nor
   const int32_t* work_items; /* optional attention tile list, see gt_attn_fwd */
   int64_t num_work;
   float dropout_p, ln_eps;
+  int32_t act /* 0 relu, 1 gelu (erf form) */, reserved_;
   uint64_t seed;
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
 } gt_encoder_layer;

@@ -35,7 +35,8 @@ def _run(model, batch, y, fused, seed):
 
 CASES = [dict(), dict(gnn_JK="last"), dict(gnn_virtual_node=False), dict(gnn_residual=True),
          dict(graph_pooling="last", transformer_norm_input=False), dict(max_seq_len=None), dict(gnn_virtual_node=False, gnn_JK="last"),
-         dict(compute_dtype=torch.bfloat16), dict(gnn_dropout=0.25), dict(gnn_dropout=0.25, gnn_residual=True, gnn_JK="last")]
+         dict(compute_dtype=torch.bfloat16), dict(gnn_dropout=0.25), dict(gnn_dropout=0.25, gnn_residual=True, gnn_JK="last"),
+         dict(transformer_activation="gelu"), dict(transformer_activation="gelu", compute_dtype=torch.bfloat16)]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in CASES])
@@ -104,7 +105,7 @@ def test_not_eligible_configurations_fall_back():
     from graphtrans_amd.encoders import ASTNodeEncoder
     from graphtrans_amd.models.gnn_transformer import GNNTransformer
     b = synth.code2_like(B=4, seed=2).to(DEV)
-    for kw in (dict(graph_pooling="mean"), dict(pos_encoder=True), dict(transformer_activation="gelu")):
+    for kw in (dict(graph_pooling="mean"), dict(pos_encoder=True)):
         model = GNNTransformer(50, ASTNodeEncoder(64, 98, 10030, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
         assert not engine.eligible(model, b, None), kw
         out = model(b)  # module path still runs
@@ -385,7 +386,7 @@ def test_device_built_token_layout_equals_the_host_built_one(max_input_len):
                 p.grad = None
             loss = losses.code2_loss(model(bb), y)
             loss.backward()
-            res.append((float(loss), [p.grad.detach().clone() for p in model.parameters()]))
+            res.append((float(loss.detach()), [p.grad.detach().clone() for p in model.parameters()]))
     for k in (1, 3):   # (fused, no sizes) vs (fused, sizes); (modules, no sizes) vs (modules, sizes)
         assert abs(res[k][0] - res[k - 1][0]) <= 1e-6 * max(1.0, abs(res[k - 1][0]))
         for a, c in zip(res[k][1], res[k - 1][1]):

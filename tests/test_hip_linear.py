@@ -16,7 +16,7 @@ SHAPES = [(31598, 300, 300), (31855, 384, 128), (31855, 512, 128), (31855, 128, 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("mode", ["fp32", "bf16c_fp32s", "bf16"])
-@pytest.mark.parametrize("act", [None, "relu"])
+@pytest.mark.parametrize("act", [None, "relu", "gelu"])
 def test_linear_fwd_bwd(M, N, K, mode, act):
     from graphtrans_amd import ops
 
@@ -33,7 +33,7 @@ def test_linear_fwd_bwd(M, N, K, mode, act):
         w_ref = w
     xr, wr, br = x.double().requires_grad_(True), w_ref.double().requires_grad_(True), b.double().requires_grad_(True)
     yr = F.linear(xr, wr, br)
-    yr = F.relu(yr) if act else yr
+    yr = F.relu(yr) if act == "relu" else (F.gelu(yr) if act == "gelu" else yr)   # F.gelu: the erf form, as in torch 1.7
     (yr * g.double()).sum().backward()
     ops.set_matmul_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
     try:
@@ -47,7 +47,7 @@ def test_linear_fwd_bwd(M, N, K, mode, act):
     tol = 1e-4 if mode == "fp32" else 3e-2
     y_ref, gx_ref, gw_ref, gb_ref = yr.detach(), xr.grad, wr.grad, br.grad
     gx, gw, gb = xd.grad.float().cpu(), wd.grad.cpu(), bd.grad.cpu()
-    if act:  # relu gate ties / near-zero pre-activations flip under different rounding: exclude them
+    if act == "relu":  # relu gate ties / near-zero pre-activations flip under different rounding: exclude them
         z = F.linear(x.double(), w_ref.double(), b.double())
         tie = z.abs() < (1e-4 if mode == "fp32" else 5e-2)
         if mode == "fp32":
@@ -69,6 +69,35 @@ def test_linear_fwd_bwd(M, N, K, mode, act):
     assert_close(gx, gx_ref, atol=tol, rtol=tol, what="dx")
     assert_close(gw, gw_ref, atol=tol, rtol=tol, what="dW")
     assert_close(gb, gb_ref, atol=tol, rtol=tol, what="db")
+
+
+def test_linear_gelu_fused_dropout():
+    """gelu + dropout in the epilogue; the backward multiplies by the saved gelu'(z) * mask / (1 - p)."""
+    from graphtrans_amd import ops
+
+    torch.manual_seed(2)
+    M, N, K, p = 3000, 512, 128, 0.3
+    for sdt in (torch.float32, torch.bfloat16):
+        x = torch.randn(M, K, device=DEV).to(sdt).requires_grad_(True)
+        w = (torch.randn(N, K, device=DEV) / K ** 0.5).requires_grad_(True)
+        b = (torch.randn(N, device=DEV) * 0.1).requires_grad_(True)
+        y = ops.linear(x, w, b, act="gelu", dropout_p=p, seed=11)
+        y0 = ops.linear(x, w, b, act="gelu")
+        keep = (y != 0) | (y0 == 0)
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+        assert torch.allclose(y[keep].float(), y0[keep].float() / (1 - p), rtol=2e-2 if sdt == torch.bfloat16 else 1e-5, atol=1e-6)
+        g = torch.randn(M, N, device=DEV)
+        (y.float() * g).sum().backward()
+        xr = x.detach().double().cpu().requires_grad_(True)
+        wr = (w.detach().bfloat16() if sdt == torch.bfloat16 else w.detach()).double().cpu().requires_grad_(True)
+        br = b.detach().double().cpu().requires_grad_(True)
+        yr = F.gelu(F.linear(xr, wr, br)) * keep.cpu().double() / (1 - p)
+        (yr * g.cpu().double()).sum().backward()
+        tol = 3e-2 if sdt == torch.bfloat16 else 1e-4
+        assert_close(x.grad.float().cpu(), xr.grad, atol=tol, rtol=tol, what="dx")
+        assert_close(w.grad.cpu(), wr.grad, atol=tol, rtol=tol, what="dW")
+        assert_close(b.grad.cpu(), br.grad, atol=tol, rtol=tol, what="db")
+        assert torch.equal(ops.linear(x, w, b, act="gelu", dropout_p=p, seed=11), y)
 
 
 def test_linear_fused_dropout():
