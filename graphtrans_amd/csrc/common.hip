@@ -95,6 +95,23 @@ extern "C" int gt_profile_get(int64_t i, char* name_out, int64_t name_cap, float
 }
 
 
+// ---- side streams of the fused path: created here so that they can carry a HIP priority ---------------------------
+// level: -1 = the highest priority the device offers, 0 = default, +1 = the lowest.  Returns the stream or NULL.
+extern "C" void* gt_stream_create(int level) {
+  int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const int prio = level < 0 ? greatest : (level > 0 ? least : 0);
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+  return st;
+}
+extern "C" void gt_stream_destroy(void* stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+extern "C" int gt_stream_priority_range(int* least, int* greatest) {
+  return hipDeviceGetStreamPriorityRange(least, greatest) == hipSuccess ? GT_OK : GT_ERR_LAUNCH;
+}
+
 // ---- events for cross-stream dependencies between entry points -------------------------------------
 extern "C" void* gt_event_create(void) {
   hipEvent_t ev = nullptr;

@@ -480,21 +480,31 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   const VnSaved s = vn_saved(L, const_cast<void*>(saved));
   const VnGrads g = vn_grads(L, grads);
   const int64_t B = L->B, D = L->D;
+  // with ev_dx_done: the dX chain first (d_x / d_vn are what the next layer's backward waits for), the event, then the two
+  // weight gradients; without it each GEMM's dW follows its dX directly
+  const bool defer = L->ev_dx_done != nullptr;
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, d_vn_out, L->bn2_w, L->bn2_b, s.st2, s.st2 + D, L->training, 1, B, D, w.d_z2, g.bn2_w,
                           g.bn2_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
-  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, B, D,
-                       2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, defer ? nullptr : g.w2,
+                       defer ? nullptr : g.b2, B, D, 2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, B, 2 * D, w.d_z1,
                           g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
   // d_t0 = d_z1 W1 ; d_vn = d_t0 (+ d_vn_out through the residual branch)
-  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, g.w1, g.b1, B,
-                       2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, defer ? nullptr : g.w1,
+                       defer ? nullptr : g.b1, B, 2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   // d_x[n] = d_t0[graph(n)] (+ d_x_add[n]: gradient reaching x from its other consumers)
   GT_TRY(gt_segment_bcast_add(GT_F32, d_x_add, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
   if (L->residual)
     GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
   else
     (void)hipMemcpyAsync(d_vn, w.d_t0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
+  if (defer) {
+    GT_TRY(gt_event_record(L->ev_dx_done, st));
+    GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, nullptr, g.w2, g.b2, B, D,
+                         2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+    GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, nullptr, g.w1, g.b1, B,
+                         2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  }
   return GT_OK;
 }
 

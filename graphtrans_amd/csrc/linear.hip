@@ -723,13 +723,13 @@ bool w32_eligible(int compute, int x_dtype, int64_t M, int groups) {
   return compute == GT_F32 && x_dtype == GT_F32 && groups == 1 && M >= W32_MIN_M;
 }
 
-template <typename TA, typename TO, bool MASK>
+template <typename TA, typename TO, bool MASK, bool GELU = false>
 void w32_launch_nt(int nt, dim3 grid, hipStream_t stream, const L32Args& a) {
   switch (nt) {
-    case 19: hipLaunchKernelGGL((k_lin32<TA, TO, 19, MASK>), grid, dim3(256), 0, stream, a); break;
-    case 16: hipLaunchKernelGGL((k_lin32<TA, TO, 16, MASK>), grid, dim3(256), 0, stream, a); break;
-    case 12: hipLaunchKernelGGL((k_lin32<TA, TO, 12, MASK>), grid, dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((k_lin32<TA, TO, 8, MASK>), grid, dim3(256), 0, stream, a); break;
+    case 19: hipLaunchKernelGGL((k_lin32<TA, TO, 19, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((k_lin32<TA, TO, 16, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((k_lin32<TA, TO, 12, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((k_lin32<TA, TO, 8, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
   }
 }
 
@@ -739,6 +739,12 @@ void w32_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   const int nt = w32_pick_nt(a.Nout);
   a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
   dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, W32_BM), 8) * 8 * a.ncb));
+  if constexpr (!MASK) {
+    if (a.act == 2) {   // gelu epilogue: fp32 rows in and out only (w32_eligible_fwd)
+      w32_launch_nt<float, float, false, true>(nt, grid, stream, a);
+      return;
+    }
+  }
   if (ta == GT_F32 && to == GT_F32) w32_launch_nt<float, float, MASK>(nt, grid, stream, a);
   else if (ta == GT_F32) w32_launch_nt<float, gt_bf16, MASK>(nt, grid, stream, a);
   else if (to == GT_F32) w32_launch_nt<gt_bf16, float, MASK>(nt, grid, stream, a);
@@ -839,7 +845,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
-  if (w32_eligible(compute, x_dtype, M, groups)) {
+  if (w32_eligible(compute, x_dtype, M, groups) && (act != 2 || (x_dtype == GT_F32 && y_dtype == GT_F32))) {
     L32Args w{};
     w.a = x; w.w = weight; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
     w.act = act; w.gout = gout; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;

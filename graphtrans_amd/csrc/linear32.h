@@ -53,8 +53,8 @@ __device__ __forceinline__ void chunk_to_f32(const uint4& v, float* f) {
   }
 }
 
-template <typename TA, typename TO, int NT, bool MASK>
-__global__ void __launch_bounds__(256) k_lin32(L32Args a) {
+template <typename TA, typename TO, int NT, bool MASK, bool GELU = false>   // GELU: its own instantiation (the erf epilogue
+__global__ void __launch_bounds__(256) k_lin32(L32Args a) {                  // would cost every other launch its occupancy)
   constexpr int BM = W32_BM, BK = W32_BK, LD = W32_LD;
   constexpr int EA = Chunk32<TA>::E;            // elements per 16-byte chunk of the row operand
   constexpr int ACH = BK / EA;                  // chunks per row of the A tile (4 fp32 / 2 bf16)
@@ -227,8 +227,8 @@ __global__ void __launch_bounds__(256) k_lin32(L32Args a) {
         if (a.bias) v[t] = gt_add4(v[t], *reinterpret_cast<const float4*>(sB + jb * 16 + c4));
         float* vv = reinterpret_cast<float*>(&v[t]);
         if (a.act == 1) v[t] = gt_relu4(v[t]);
-        if constexpr (!MASK) {   // gelu only exists on the forward form
-          if (a.act == 2) {
+        if constexpr (GELU) {
+          {
             float4 gm;
             float* gg = reinterpret_cast<float*>(&gm);
 #pragma unroll

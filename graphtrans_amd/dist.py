@@ -63,6 +63,11 @@ class GradSync:
         engine.state(model)["sync"] = self
         return self
 
+    @property
+    def active(self):
+        """reduce_flat() puts data on the wire (the fused backward joins its weight-gradient stream before it only then)"""
+        return self.world > 1 or self.always_reduce
+
     def reduce_flat(self, flat, lo, hi):
         """Average flat[lo:hi] over the ranks, asynchronously (called from the fused backward as soon as
         the kernels producing that range are enqueued).  finish() waits for it."""

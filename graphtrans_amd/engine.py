@@ -52,11 +52,27 @@ class _Bump:
 _SIDE_STREAMS = {}
 
 
+class _Stream:
+    """a HIP stream created by the library (gt_stream_create: carries a priority); lives as long as the process"""
+
+    def __init__(self, device, level):
+        with torch.cuda.device(device):
+            self.cuda_stream = _lib.lib().gt_stream_create(level)
+        if not self.cuda_stream:
+            raise RuntimeError("gt_stream_create failed")
+
+
+# priorities of the two side streams: the virtual-node chain is short and latency-bound and sits on the critical path of
+# the backward (highest); the weight-gradient GEMMs are long, chip-filling and nobody waits for them (lowest)
+VN_DEFER_DW = os.environ.get("GT_VN_DEFER_DW", "1") != "0"
+_SIDE_LEVEL = {"vn": int(os.environ.get("GT_PRIO_VN", "-1")), "dw": int(os.environ.get("GT_PRIO_DW", "1"))}
+
+
 def _side_stream(device, which):
     key = (torch.device(device).index or 0, which)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        st = _SIDE_STREAMS[key] = _Stream(device, _SIDE_LEVEL.get(which, 0))
     return st
 
 
@@ -199,9 +215,9 @@ class _Plan:
         self._fill_static()
         # the virtual-node update of layer l only feeds layer l+1: it runs on a second stream beside layer
         # l's conv (forward) / beside layer l's BatchNorm + aggregate backward (backward)
-        self.side = _side_stream(self.dev, 0) if (self.has_vn and OVERLAP_VN) else None
+        self.side = _side_stream(self.dev, "vn") if (self.has_vn and OVERLAP_VN) else None
         # weight-gradient GEMMs run on a third stream beside the dX chain (gt_overlap_dw_*)
-        self.side_dw = _side_stream(self.dev, 1) if OVERLAP_DW else None
+        self.side_dw = _side_stream(self.dev, "dw") if OVERLAP_DW else None
         lib = _lib.lib()
         nev = len(self.vn) if self.side is not None else 0
         self.ev_x = [lib.gt_event_create() for _ in range(nev)]      # x_l ready (main -> side)
@@ -492,6 +508,7 @@ class _FusedModel(torch.autograd.Function):
             desc.residual = 1 if model.gnn_node.residual else 0
             desc.training, desc.compute = training, compute
             desc.graph_ptr, desc.node_graph, desc.identity_graph = gs.graph_ptr.data_ptr(), gs.node_graph.data_ptr(), sm["ident"].data_ptr()
+            desc.ev_dx_done = plan.ev_extra[l] if (plan.side is not None and VN_DEFER_DW) else None   # recorded inside the backward composite, ahead of its dW GEMMs
         p_drop = float(enc.dropout_p) if model.training else 0.0
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if (model.training and enc.dropout_p > 0) else 0
         for i, desc in enumerate(plan.enc_desc):
@@ -829,7 +846,7 @@ class _FusedModel(torch.autograd.Function):
         _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
               Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(True), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
-        sync = model_sync if direct else None
+        sync = model_sync if (direct and model_sync is not None and (model_sync.active or os.environ.get('GT_DBG_KEEPJOIN'))) else None
         if sync is not None:
             dw_sync()
             sync.reduce_flat(flat, plan.g2t_off[0], plan.total)
@@ -851,8 +868,9 @@ class _FusedModel(torch.autograd.Function):
                     _call("gt_event_record", plan.ev_dvn[l], st)
                     _call("gt_stream_wait_event", side, plan.ev_dvn[l])
                     _call("gt_vn_update_bwd", C.byref(s["vn_desc"][l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
-                          G + plan.vn_off[l] * 4, Q("ws2"), s["ws2_bytes"], side)
-                    _call("gt_event_record", plan.ev_extra[l], side)
+                          G + plan.vn_off[l] * 4, Q("ws2"), s["ws2_bytes"], side)   # records ev_extra[l] itself (ev_dx_done) ...
+                    if not VN_DEFER_DW:
+                        _call("gt_event_record", plan.ev_extra[l], side)
                 else:
                     _call("gt_vn_update_bwd", C.byref(s["vn_desc"][l]), d_vn_next, P("vn_saved", l), extra, Q("dC"), Q("dvn", 2),
                           G + plan.vn_off[l] * 4, W(), ws_bytes, st)

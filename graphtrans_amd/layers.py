@@ -56,7 +56,7 @@ class VnUpdateDesc(C.Structure):
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
                [(n, _fp) for n in ("graph_ptr", "node_graph", "identity_graph", "w1", "b1", "bn1_w", "bn1_b", "w2", "b2",
                                    "bn2_w", "bn2_b", "bn1_rm", "bn1_rv", "bn2_rm", "bn2_rv", "bn1_nbt", "bn2_nbt")] + \
-               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32)]
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32), ("ev_dx_done", _fp)]
 
 
 def _any_sync(*bns):

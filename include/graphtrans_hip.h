@@ -52,6 +52,12 @@ const char* gt_last_error(void);
 /* Events for cross-stream dependencies between entry points (thin wrappers over hipEvent, timing
  * disabled): gt_event_record marks a point on `stream`, gt_stream_wait_event makes `stream` wait for it. */
 void* gt_event_create(void);
+/* Side streams of the fused path (non-blocking HIP streams).  level -1 / 0 / +1 = the device's highest / default / lowest
+ * stream priority: the weight-gradient GEMMs (nothing waits for them until the optimizer) run on a lowest-priority
+ * stream so that the critical-path kernels of the other streams get the compute units that free up first. */
+void* gt_stream_create(int level);
+void gt_stream_destroy(void* stream);
+int gt_stream_priority_range(int* least, int* greatest);
 void gt_event_destroy(void* event);
 int gt_event_record(void* event, gt_stream_t stream);
 int gt_stream_wait_event(gt_stream_t stream, void* event);
@@ -595,6 +601,8 @@ typedef struct gt_vn_update {  /* vn_out = drop(ReLU(BN(W2 ReLU(BN(W1 (pool(x) +
   uint64_t seed;     /* F.dropout on the MLP output (gnn_module.py:222), training only */
   float dropout_p;
   int32_t pad2_;
+  void* ev_dx_done;  /* optional gt_event: recorded by gt_vn_update_bwd once d_x and d_vn are enqueued -- BEFORE its two weight-
+                        gradient GEMMs, which nothing on the critical path waits for */
 } gt_vn_update;
 size_t gt_vn_update_saved_bytes(const gt_vn_update* layer);
 size_t gt_vn_update_workspace_bytes(const gt_vn_update* layer);

@@ -1,0 +1,45 @@
+"""Register / scratch budget of the GEMM kernels (hipcc -Rpass-analysis=kernel-resource-usage, no GPU needed).
+
+The wide-tile fp32 GEMM runs two blocks per CU only while it stays under ~168 VGPRs and does not spill: an epilogue
+feature compiled into the common instantiation (GELU, round 2) once pushed it to 194 VGPRs + 320 bytes of scratch per
+lane and cost the mixed mode 9 % end to end without failing any parity test.  This test pins the budget."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graphtrans_amd", "csrc")
+
+
+def _usage(src):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC).stderr
+    kernels, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    assert kernels, out[-2000:]
+    return kernels
+
+
+def test_gemm_kernels_keep_their_register_budget():
+    k = _usage("linear.hip")
+    spills = {n: v["ScratchSize"] for n, v in k.items() if v.get("ScratchSize", 0) > 0}
+    assert not spills, "GEMM kernels spilling to scratch: %s" % spills
+    wide = {n: v for n, v in k.items() if re.search(r"7k_lin32I", n)}
+    assert len(wide) >= 16
+    for n, v in wide.items():   # two blocks (8 waves) per CU: <= 512 / 2 registers per lane incl. accumulators
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
+    for n, v in k.items():
+        if re.search(r"12k_linear_(fwd|dx)I[ft][ft]tLi64E", n):   # the bf16-MFMA tiled kernels (encoder GEMMs), 64-row tiles
+            assert v["Occupancy"] >= 3, (n, v)
