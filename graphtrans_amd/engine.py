@@ -846,7 +846,7 @@ class _FusedModel(torch.autograd.Function):
         _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
               Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(True), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
-        sync = model_sync if (direct and model_sync is not None and (model_sync.active or os.environ.get('GT_DBG_KEEPJOIN'))) else None
+        sync = model_sync if (direct and model_sync is not None and model_sync.active) else None
         if sync is not None:
             dw_sync()
             sync.reduce_flat(flat, plan.g2t_off[0], plan.total)
