@@ -751,8 +751,13 @@ void w32_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   else w32_launch_nt<gt_bf16, gt_bf16, MASK>(nt, grid, stream, a);
 }
 
-int w32_dw_splits(int64_t M, int nkb, int nnb) {
-  int64_t s = 768 / ((int64_t)nkb * nnb);          // 3 blocks per CU = what the 48 KB LDS footprint admits (the dispatcher fills CUs greedily: 2 per CU leaves a third of them idle); every split costs N*K*4 bytes of partials twice
+// M-splits of the wide-tile dW GEMM.  Alone on the chip it wants ~768 blocks (3 per CU is what its 48 KB of LDS admits; the
+// dispatcher fills CUs greedily, 2 per CU leaves a third idle).  Forked onto the overlap stream (gt_overlap_dw_*) it shares
+// the chip with the critical path: one block per CU leaves every CU room for the other streams' kernels (the 5-25 us kernels
+// of the virtual-node chain ran 2-5 x longer beside an 800-block GEMM) and writes a third of the partials -- the GEMM
+// itself takes longer, but nothing waits for it (Code2 +1.7 %, Molpcba +2 % end to end).
+int w32_dw_splits(int64_t M, int nkb, int nnb, bool overlapped) {
+  int64_t s = (overlapped ? 256 : 768) / ((int64_t)nkb * nnb);   // every split costs N*K*4 bytes of partials twice
   const int64_t maxs = gt_cdiv(M, 16 * 8);          // at least 8 stages per split
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
@@ -866,7 +871,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
 extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K) {
   if (compute == GT_F32 && M >= W32_MIN_M) {   // wide-tile fp32 path: [dW / db partials | W^T for the dX GEMM]
     const int nt = w32_pick_nt(N);
-    const int splits = w32_dw_splits(M, (int)gt_cdiv(K, 64), (int)gt_cdiv(gt_cdiv(N, 16), nt));
+    const int splits = w32_dw_splits(M, (int)gt_cdiv(K, 64), (int)gt_cdiv(gt_cdiv(N, 16), nt), false);   // the larger of the two configurations
     return (size_t)splits * (size_t)(N * K + N) * sizeof(float) + (size_t)N * K * sizeof(float) + 512;
   }
   const size_t dw = (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float);
@@ -986,9 +991,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     }
     const int nt = w32_pick_nt(N);
     const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
-    const int splits = w32_dw_splits(M, nkb, nnb);
+    const bool will_fork = g_dw.active && stream == g_dw.main && dx && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
+    const int splits = w32_dw_splits(M, nkb, nnb, will_fork);
     float* part = reinterpret_cast<float*>(workspace);
-    float* wt = part + (size_t)splits * (size_t)(N * K + N) + 64;   // 256-byte offset keeps 16-byte alignment
+    float* wt = part + (size_t)w32_dw_splits(M, nkb, nnb, false) * (size_t)(N * K + N) + 64;   // behind the larger partial area
     wt = reinterpret_cast<float*>(((uintptr_t)wt + 255) & ~(uintptr_t)255);
     if (dx) {   // dX = dZ (W^T)^T: the forward-form kernel on the transposed weight
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
@@ -1002,12 +1008,11 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
-      bool forked = false;
-      if (g_dw.active && stream == g_dw.main && dx && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+      const bool forked = will_fork;
+      if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
         stream = g_dw.side;
-        forked = true;
       }
       L32DwArgs d{};
       d.dy = dy; d.ymask = y_for_mask; d.x = x; d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;

@@ -62,12 +62,13 @@ __global__ void __launch_bounds__(XT) k_xent_mean(const float* __restrict__ row_
                                                   int64_t tstride, int64_t B, int64_t L, int64_t C,
                                                   float* __restrict__ head_scale, float* __restrict__ loss) {
   __shared__ float red[4];
-  float total = 0.f;
+  float total = 0.f, bad = 0.f;
   for (int64_t l = 0; l < L; ++l) {
     float s = 0.f, n = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += XT) {
       const int64_t t = target[b * tstride + l];
       if (t != IGNORE && t >= 0 && t < C) { s += row_loss[b * L + l]; n += 1.f; }
+      else if (t != IGNORE) bad += 1.f;   // out of range and not ignore_index: torch raises a device-side assert
     }
     s = block_sum(s, red);
     n = block_sum(n, red);
@@ -75,7 +76,11 @@ __global__ void __launch_bounds__(XT) k_xent_mean(const float* __restrict__ row_
     if (threadIdx.x == 0) head_scale[l] = sc;
     total += n > 0.f ? s * sc : nanf("");  // torch: mean over zero rows is NaN
   }
-  if (threadIdx.x == 0) *loss = total;
+  bad = block_sum(bad, red);
+  if (threadIdx.x == 0) {
+    loss[0] = total;
+    loss[1] = bad;   // status word: number of out-of-range targets (treated as ignored above); the host raises on it when validating
+  }
 }
 
 __global__ void __launch_bounds__(XT) k_xent_bwd(const float* __restrict__ logits, const float* __restrict__ lse,

@@ -6,6 +6,8 @@ tensor or a missing library raises.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -786,6 +788,16 @@ def embed_sum(columns, tables, clamps=None):
 # ------------------------------------------------------------------------------------------------
 # softmax cross-entropy over the stacked prediction heads
 # ------------------------------------------------------------------------------------------------
+_VALIDATE = os.environ.get("GT_VALIDATE", "0") not in ("", "0")
+
+
+def set_validate(on):
+    """validate mode: index-like inputs of the losses are checked on the device and errors raised on the host (costs a
+    device -> host sync per call); off by default.  Also GT_VALIDATE=1."""
+    global _VALIDATE
+    _VALIDATE = bool(on)
+
+
 class _Xent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, stacked, target):
@@ -797,13 +809,17 @@ class _Xent(torch.autograd.Function):
         ld = stacked.stride(0) if B > 1 else L * C
         target = target.contiguous()
         dev = stacked.device
-        aux = torch.empty(2 * B * L + L + 1, dtype=torch.float32, device=dev)
+        aux = torch.empty(2 * B * L + L + 2, dtype=torch.float32, device=dev)   # ..., loss, status
         lse, row_loss, head_scale, loss = aux[:B * L], aux[B * L:2 * B * L], aux[2 * B * L:2 * B * L + L], aux[2 * B * L + L:]
         _lib.launch("gt_xent_fwd", _ptr(stacked), B, L, C, ld, _ptr(target), target.stride(0), _ptr(lse), _ptr(row_loss),
                     _ptr(head_scale), _ptr(loss), _stream())
         ctx.save_for_backward(stacked, target, lse, head_scale)
         ctx.ld = ld
-        return loss.reshape(())
+        if _VALIDATE:   # device -> host read of the status word (a sync): out-of-range class indices, like torch's assert
+            bad = int(loss[1].item())
+            if bad:
+                raise IndexError("softmax_xent: %d target(s) outside [0, %d) and not ignore_index (-100)" % (bad, C))
+        return loss[0].reshape(())
 
     @staticmethod
     def backward(ctx, g):

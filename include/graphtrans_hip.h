@@ -472,7 +472,9 @@ int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, 
  * target[b * target_stride + l] int64, ignore_index -100 as torch's default.
  *   fwd: lse [B*L], row_loss [B*L], head_scale [L] = 1 / (L * #live rows of head l), loss [1]
  *   bwd: dlogits [B][ld] = (softmax - onehot) * head_scale[l] * grad_loss[0]; columns L*C..ld zeroed
- */
+  * `loss` points to TWO floats: loss[0] = the loss, loss[1] = status = the number of targets that are neither ignore_index
+ * nor in [0, C) (they do not contribute; torch raises a device-side assert for them -- the host wrapper raises IndexError on a
+ * non-zero status in validate mode). */
 int gt_xent_fwd(const float* logits, int64_t B, int64_t L, int64_t C, int64_t ld, const int64_t* target,
                 int64_t target_stride, float* lse, float* row_loss, float* head_scale, float* loss,
                 gt_stream_t stream);

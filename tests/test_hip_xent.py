@@ -121,3 +121,23 @@ def test_tud_loss_is_the_one_head_cross_entropy(B, C, ld):
     assert (pred.grad.cpu() - ref.grad).abs().max().item() <= 1e-6
     with pytest.raises(RuntimeError):
         losses.tud_loss(ref, y)
+
+
+def test_xent_reports_out_of_range_targets_in_validate_mode():
+    """torch.nn.CrossEntropyLoss (dataset/code.py:42) asserts on a class index outside [0, C); the kernel counts such
+    targets into a status word and the wrapper raises when validating (off by default: the read is a device sync)."""
+    from graphtrans_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(6, 3, 11, device=DEV, requires_grad=True)
+    t = torch.randint(0, 11, (6, 3), device=DEV)
+    t[1, 2] = -100          # ignore_index: fine
+    ops.set_validate(True)
+    try:
+        ops.softmax_xent(x, t).backward()
+        t[4, 0] = 11
+        t[0, 1] = -3
+        with pytest.raises(IndexError, match="2 target"):
+            ops.softmax_xent(x, t)
+    finally:
+        ops.set_validate(False)
+    assert torch.isfinite(ops.softmax_xent(x, t))   # not validating: treated as ignored rows, as before
