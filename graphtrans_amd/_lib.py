@@ -83,9 +83,11 @@ SIGNATURES = {
     "gt_stream_create": (_p, [_i]),
     "gt_stream_destroy": (None, [_p]),
     "gt_stream_priority_range": (_i, [C.POINTER(_i), C.POINTER(_i)]),
+    "gt_linear_bwd_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_overlap_dw_begin": (_i, [_p, _p]),
     "gt_overlap_dw_sync": (_i, []),
     "gt_overlap_dw_release": (_i, [_p, _sz]),
+    "gt_overlap_dw_urgent": (_i, [_i]),
     "gt_overlap_dw_end": (_i, []),
     "gt_linear_fwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_fwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i, _f, _u64, _p]),

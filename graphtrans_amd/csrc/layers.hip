@@ -303,8 +303,11 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
                        w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_attn_bwd(t, s.qkv, s.ctx, w.d_ctx, s.lse, w.delta, w.d_qkv, R, d, L->nhead, L->seq_desc, L->num_seqs,
                      L->row_stride, L->max_npos, L->work_items, L->num_work, nullptr, nullptr, 0.f, scale, p, L->seed, st));
-  // qkv = x Win^T + bin ; dx += ...
-  GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, g.in_w, g.in_b, R, 3 * d, d, 0.f, w.lin_ws,
+  // qkv = x Win^T + bin ; dx += ...   The weight gradient first: forked onto the overlap stream it starts beside this layer's own
+  // dX GEMM, not together with the next stage's first kernel (a LayerNorm backward)
+  GT_TRY(gt_linear_bwd_dw_forked(t, t, c, x, L->in_w, w.d_qkv, nullptr, g.in_w, g.in_b, R, 3 * d, d, d, 3 * d, 0.f, w.lin_ws,
+                                 w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, nullptr, nullptr, R, 3 * d, d, 0.f, w.lin_ws,
                        w.lin_ws_bytes, st));
   return GT_OK;
 }

@@ -665,6 +665,7 @@ struct DwOverlap {
   bool active = false;
   hipStream_t main = nullptr, side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool urgent = false;       // the forks from here on are the last of the backward: the optimizer waits for them
   DwPending ring[DW_RING];   // forks since the last full join, oldest first (the side stream runs them in this order)
   int n = 0;
 };
@@ -898,6 +899,8 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
 
 // y_for_mask of the gt_linear_bwd* call in flight on this thread is a MULTIPLIER (gt_linear_bwd_mul), not a forward output
 thread_local bool g_mul_mask = false;
+// the gt_linear_bwd* call in flight computes dW only and may still go to the overlap stream (gt_linear_bwd_dw_forked)
+thread_local bool g_fork_dw_only = false;
 
 extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
@@ -905,6 +908,20 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
                                  void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
                                ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+// dW / db only (dx == NULL), and inside a gt_overlap_dw section still on the overlap stream, ordered behind everything queued on
+// `stream` so far: lets a caller start the weight gradient of a GEMM BEFORE its dX GEMM (the encoder layer's in_proj: a dW GEMM
+// that starts together with the next layer's first kernel is what the fused backward avoids)
+extern "C" int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                       const void* y_for_mask, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K,
+                                       int64_t ldx, int64_t ldy, float dropout_p, void* workspace, size_t workspace_bytes,
+                                       gt_stream_t stream_) {
+  g_fork_dw_only = true;
+  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, nullptr, nullptr, nullptr, dweight, dbias,
+                                       M, N, K, ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+  g_fork_dw_only = false;
+  return rc;
 }
 
 // backward of gt_linear_fwd_gelu: `gmul` is the multiplier that forward saved (dZ = dY * gmul); everything else as gt_linear_bwd_ld2
@@ -971,7 +988,11 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       else hipLaunchKernelGGL(k_small_dx<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
     }
     if (dweight) {
-      if (g_dw.active && stream == g_dw.main && dx && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+      // forked only with a workspace to book it under: the kernel itself needs none, but gt_overlap_dw_release(range) is how the
+      // caller learns when the dy / mask this GEMM reads (they live in the caller's workspace) may be overwritten
+      const bool forked = g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && workspace && workspace_bytes &&
+                          !(gt_prof_mask() & GT_PROF_LINEAR);
+      if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
         stream = g_dw.side;
@@ -980,6 +1001,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(N, 32) * gt_cdiv(K, 16), 4);
       if (compute == GT_F32) hipLaunchKernelGGL(k_small_dw<float>, dim3(blocks), dim3(256), 0, stream, sa);
       else hipLaunchKernelGGL(k_small_dw<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+      if (forked) dw_forked(workspace, workspace_bytes);
     }
     GT_CHECK_LAUNCH();
     return GT_OK;
@@ -991,8 +1013,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     }
     const int nt = w32_pick_nt(N);
     const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
-    const bool will_fork = g_dw.active && stream == g_dw.main && dx && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
-    const int splits = w32_dw_splits(M, nkb, nnb, will_fork);
+    const bool will_fork = g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
+    const int splits = w32_dw_splits(M, nkb, nnb, will_fork && !g_dw.urgent);
     float* part = reinterpret_cast<float*>(workspace);
     float* wt = part + (size_t)w32_dw_splits(M, nkb, nnb, false) * (size_t)(N * K + N) + 64;   // behind the larger partial area
     wt = reinterpret_cast<float*>(((uintptr_t)wt + 255) & ~(uintptr_t)255);
@@ -1061,7 +1083,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     // gt_overlap_dw_begin/_end section it runs on the side stream beside dX and whatever follows.
     // (not while the launch profiler brackets this call: its events sit on the caller's stream only)
     bool forked = false;
-    if (g_dw.active && stream == g_dw.main && dx && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+    if (g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
       stream = g_dw.side;
@@ -1105,12 +1127,17 @@ extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
   g_dw.main = (hipStream_t)main_;
   g_dw.side = (hipStream_t)side_;
   g_dw.active = true;
+  g_dw.urgent = false;
   g_dw.n = 0;
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_sync(void) {
   if (!g_dw.active) return GT_OK;
   dw_join_all();
+  return GT_OK;
+}
+extern "C" int gt_overlap_dw_urgent(int on) {
+  g_dw.urgent = on != 0;
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_release(const void* workspace, size_t bytes) {

@@ -804,9 +804,10 @@ class _FusedModel(torch.autograd.Function):
             """the next stage's workspace.  The two slots alternate, so the weight-gradient GEMMs a stage forks onto the
             third stream (their partials and the dy they read live in the stage's slot) can run beside the NEXT stage: the
             main stream then waits only for the GEMMs that used this slot two stages ago (gt_overlap_dw_release).
-            join=True waits for all of them, as the token-side stages do: beside a lagging dW GEMM their LayerNorm backward
-            was measured to return rows that differ in the last bits run to run (not understood), and
-            the fused backward is required to be bitwise reproducible; the message-passing stages are."""
+            join=True waits for all of them.  One schedule is avoided ("not understood"): a LayerNorm
+            backward that STARTS together with a dW GEMM returned, in 5-20 % of the passes, one token row that differs in
+            the last bits -- so the encoder composite forks its last dW (in_proj) ahead of its dX GEMM instead of behind
+            it, and the stage after the heads (whose dW starts microseconds before a LayerNorm backward) joins."""
             slot[0] ^= 1
             p = Q("ws", slot[0])
             if ov:
@@ -829,12 +830,12 @@ class _FusedModel(torch.autograd.Function):
             dcur, dnext = dnext, dcur
         for i in range(nenc - 1, -1, -1):
             _call("gt_encoder_layer_bwd", C.byref(s["enc_desc"][i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
-                  G + plan.enc_off[i] * 4, W(True), ws_bytes, st)
+                  G + plan.enc_off[i] * 4, W(), ws_bytes, st)
             dcur, dnext = dnext, dcur
         if plan.norm_in is not None:
             ln = plan.norm_in
             _call("gt_layernorm_bwd", tdt, P("tok"), None, dcur, ln.weight.data_ptr(), P("st0"), P("st0") + rows * 4, 0.0, 0,
-                  rows, d, dnext, None, G + plan.norm_in_off[0] * 4, G + plan.norm_in_off[1] * 4, W(True), ws_bytes, st)
+                  rows, d, dnext, None, G + plan.norm_in_off[0] * 4, G + plan.norm_in_off[1] * 4, W(), ws_bytes, st)
             dcur, dnext = dnext, dcur
         # ---- token rows -> node rows (+ the CLS gradient)
         _call("gt_seq_scatter", tdt, dcur, None, gs.graph_ptr.data_ptr(), gs.node_graph.data_ptr(), lay.desc.data_ptr(), lay.B,
@@ -844,7 +845,7 @@ class _FusedModel(torch.autograd.Function):
             torch.sum(dc, dim=0, dtype=torch.float32, out=flat[plan.cls_off:plan.cls_off + d])
         g2t = plan.g2t
         _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
-              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(True), ws_bytes, st)
+              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
         sync = model_sync if (direct and model_sync is not None and model_sync.active) else None
         if sync is not None:
@@ -877,6 +878,8 @@ class _FusedModel(torch.autograd.Function):
                 extra = Q("dC")
             out = Q("dB") if dy == Q("dA") else Q("dA")
             xin = s["xptr"][l]
+            if l == 0 and ov:
+                _call("gt_overlap_dw_urgent", 1)   # layer 0's weight gradients are the last: nothing left to overlap them with
             pool_on_side = plan.has_vn and side is not None
             _call(plan.conv_api + "_bwd", C.byref(s["gcn_desc"][l]), xin, dy, extra, P("gcn_saved", l), out,
                   Q("dvn", 3) if (plan.has_vn and not pool_on_side) else None, G + plan.gcn_off[l] * 4, W(), ws_bytes, st)

@@ -443,8 +443,16 @@ int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, cons
  * and releases its workspace before layer k+2 (buffers a dW reads must live in that workspace or stay
  * unchanged until the next full sync). */
 int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
+/* dW / db only; inside an overlap section it still runs on the overlap stream (ordered behind what `stream` holds so far):
+ * a caller can start a GEMM's weight gradient ahead of its dX GEMM. */
+int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                            const void* y_for_mask, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                            int64_t ldy, float dropout_p, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 int gt_overlap_dw_sync(void);
 int gt_overlap_dw_release(const void* workspace, size_t bytes);
+/* the weight-gradient GEMMs forked from now on are the last work of the backward (the optimizer waits for them): they get the
+ * chip-filling launch configuration instead of the one-block-per-CU configuration of an overlapped GEMM; reset by _begin */
+int gt_overlap_dw_urgent(int on);
 int gt_overlap_dw_end(void);
 
 int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

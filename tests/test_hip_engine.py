@@ -311,18 +311,20 @@ def test_freeze_gnn_leaves_the_fused_path():
     assert not engine.eligible(model2, b, None)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "mixed"])
 @pytest.mark.parametrize("workload", ["code2", "molpcba"])
-def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload):
-    """BASELINE configs[1] / [2] at full size (b256), three streams in play (main, virtual node, dW): ten fused
+def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload, mode):
+    """BASELINE configs[1] / [2] at full size (b256), three streams in play (main, virtual node, dW): thirty fused
     backward passes must agree bit for bit -- stream-ordering mistakes do not show at the small sizes of the other
-    tests because the GPU drains each kernel before the next one is enqueued."""
+    tests because the GPU drains each kernel before the next one is enqueued.  (A LayerNorm backward that STARTS together
+    with a weight-gradient GEMM of the overlap stream fails this test in 5-20 % of the passes: DESIGN.md section 8.)"""
     import importlib.util
     import os
     from graphtrans_amd import ops
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    ops.set_matmul_dtype(torch.bfloat16)
+    ops.set_matmul_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
     try:
         torch.manual_seed(0)
         args, model, gen, loss_fn, _ = bench.build(workload, torch.bfloat16, torch.device(DEV), 256)
@@ -333,7 +335,7 @@ def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload):
         model.train()
         b = bench.attach_sizes(gen(0)).to(DEV)
         first = None
-        for it in range(10):
+        for it in range(30):
             for p in model.parameters():
                 p.grad = None
             b.__dict__.pop("_gt_structure", None)
@@ -389,5 +391,5 @@ def test_device_built_token_layout_equals_the_host_built_one(max_input_len):
             res.append((float(loss.detach()), [p.grad.detach().clone() for p in model.parameters()]))
     for k in (1, 3):   # (fused, no sizes) vs (fused, sizes); (modules, no sizes) vs (modules, sizes)
         assert abs(res[k][0] - res[k - 1][0]) <= 1e-6 * max(1.0, abs(res[k - 1][0]))
-        for a, c in zip(res[k][1], res[k - 1][1]):
-            assert torch.allclose(a, c, rtol=1e-5, atol=1e-7), float((a - c).abs().max())
+        for (n, _), a, c in zip(model.named_parameters(), res[k][1], res[k - 1][1]):
+            assert torch.allclose(a, c, rtol=1e-5, atol=1e-7), (k, n, float((a - c).abs().max()))
