@@ -64,6 +64,7 @@ class _Stream:
 
 # priorities of the two side streams: the virtual-node chain is short and latency-bound and sits on the critical path of
 # the backward (highest); the weight-gradient GEMMs are long, chip-filling and nobody waits for them (lowest)
+DW_OVERLAP_MIN_ELEMS = 1 << 20   # nodes x emb_dim of the batch
 VN_DEFER_DW = os.environ.get("GT_VN_DEFER_DW", "1") != "0"
 _SIDE_LEVEL = {"vn": int(os.environ.get("GT_PRIO_VN", "-1")), "dw": int(os.environ.get("GT_PRIO_DW", "1"))}
 
@@ -778,7 +779,10 @@ class _FusedModel(torch.autograd.Function):
         def Q(key, i=None):
             return bb + (q[key] if i is None else q[key][i])
 
-        ov = plan.side_dw is not None
+        # the overlap stream pays for itself only when the kernels are long enough to hide its extra stream operations
+        # (~4 per GEMM): on NCI1-sized batches (1 k nodes) the step is host-bound and it cost 40 %
+        ov = plan.side_dw is not None and N * D >= DW_OVERLAP_MIN_ELEMS
+        s["ov"] = ov
         dw_sync = (lambda: _call("gt_overlap_dw_sync")) if ov else (lambda: None)
         if ov:
             _call("gt_overlap_dw_begin", st, plan.side_dw.cuda_stream)
@@ -797,7 +801,7 @@ class _FusedModel(torch.autograd.Function):
         L, D, d, dev, Kc = plan.L, plan.D, plan.d, plan.dev, s["Kc"]
         nenc = len(s["enc_desc"])
         side = plan.side.cuda_stream if plan.side is not None else None
-        ov = plan.side_dw is not None
+        ov = s["ov"]
         slot = [0]
 
         def W(join=False):

@@ -93,3 +93,17 @@ def quantile_err(a, b, q=0.98):
         return float(e.max())
     k = min(e.numel(), max(1, int(round(q * e.numel()))))
     return float(e.kthvalue(k).values)
+
+
+@pytest.fixture(autouse=True)
+def _exercise_dw_overlap_at_test_sizes(request):
+    """The fused backward forks its weight-gradient GEMMs onto a third stream only for batches above
+    engine.DW_OVERLAP_MIN_ELEMS (small steps are host-bound); the GPU tests run tiny batches and must cover that path."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from graphtrans_amd import engine
+    old = engine.DW_OVERLAP_MIN_ELEMS
+    engine.DW_OVERLAP_MIN_ELEMS = 0
+    yield
+    engine.DW_OVERLAP_MIN_ELEMS = old
