@@ -526,7 +526,9 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
         res = {
             "value": round(total_graphs / elapsed, 1), "ms_per_step": round(1e3 * elapsed / opt.steps, 4),
             "ms_per_step_median_device": round(step_ms[len(step_ms) // 2], 4) if step_ms else None,
-            "scaling": scaling, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+            "scaling": scaling,
+            # arithmetic of the GEMMs: message-passing side + heads / encoder layers (accumulators, statistics, softmax are fp32)
+            "dtype": {"mixed": "fp32+bf16", "bf16": "bf16", "fp32": "fp32"}[mode],
             "config": {"workload": wl_name, "mode": mode, "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",

@@ -908,7 +908,8 @@ class _FusedModel(torch.autograd.Function):
             _call("gt_segment_sum", GT_F32, d_vn_next, None, sm["ptr01"].data_ptr(), B, 1, D, G + plan.vn_emb_off * 4, vst)
             if side is not None:
                 _call("gt_event_record", plan.ev_vnemb[0], side)
-                _call("gt_stream_wait_event", st, plan.ev_vnemb[0])
+                if sync is not None:   # the gradient range below goes on the wire now
+                    _call("gt_stream_wait_event", st, plan.ev_vnemb[0])
         # the message-passing gradients (everything between the embedding tables and gnn2transformer) are final:
         # on the wire while the embedding backward runs; the tables themselves follow right after it
         gnn_lo = plan.vn_emb_off if plan.has_vn else plan.gcn_off[0]
@@ -935,6 +936,8 @@ class _FusedModel(torch.autograd.Function):
 
         if sync is not None:
             sync.reduce_flat(flat, 0, gnn_lo)
+        elif plan.has_vn and side is not None:
+            _call("gt_stream_wait_event", st, plan.ev_vnemb[0])   # joined only here: the embedding backward ran beside the tail of the virtual-node chain
         # ---- hand the gradients to the parameters
         if direct:
             for p, v in zip(plan.plist, plan.views):
