@@ -440,8 +440,8 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
                           L->table_rows, nullptr, w.d_lin, g.root, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
   // d_x = d_lin W (+ grads reaching x from its other consumers) (+ dy through the residual branch)
   if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
-  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, x, L->lin_w, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr, d_h_in,
-                       g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd_wt(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_wt, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr,
+                          d_h_in, g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   if (L->has_vn && d_vn)
     GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
@@ -565,12 +565,12 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
   const int64_t N = L->N, D = L->D;
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, dy, L->bn_w, L->bn_b, s.st, s.st + D, L->training, L->relu, N, D, w.d_z2, g.bn_w, g.bn_b,
                           L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
-  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, N, D,
-                       2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd_wt(GT_F32, GT_F32, L->compute, s.a1, L->w2, L->w2_t, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, g.w2, g.b2, N, D,
+                          2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, N, 2 * D, w.d_z1,
                           g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
-  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.agg, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_agg, g.w1, g.b1, N,
-                       2 * D, D, 0.f, w.lin_ws1, w.lin_ws_bytes, st));
+  GT_TRY(gt_linear_bwd_wt(GT_F32, GT_F32, L->compute, s.agg, L->w1, L->w1_t, w.d_z1, nullptr, nullptr, nullptr, w.d_agg, g.w1, g.b1, N,
+                          2 * D, D, 0.f, w.lin_ws1, w.lin_ws_bytes, st));
   const bool adds = dx_extra || L->residual;
   void* dx_conv = adds ? w.d_x : d_h_in;
   GT_TRY(gt_aggregate_bwd(GT_CONV_GIN, L->edge_mode, GT_F32, x, w.d_agg, N, L->E, D, L->out_ptr, L->out_dst, L->out_eid, nullptr,

@@ -901,6 +901,9 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
 thread_local bool g_mul_mask = false;
 // the gt_linear_bwd* call in flight computes dW only and may still go to the overlap stream (gt_linear_bwd_dw_forked)
 thread_local bool g_fork_dw_only = false;
+// W^T [K][N] prepared by the caller for the gt_linear_bwd* call in flight (gt_linear_bwd_wt): the wide fp32 dX GEMM then
+// skips its own transpose launch
+thread_local const float* g_weight_t = nullptr;
 
 extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
@@ -908,6 +911,27 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
                                  void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
                                ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+// gt_linear_bwd with the transposed weight W^T [K][N] supplied by the caller (weights do not change during a backward pass: one
+// gt_transpose per weight, off the critical path, replaces a transpose launch in front of every wide fp32 dX GEMM); NULL = as
+// gt_linear_bwd.  Paths that do not need W^T ignore it.
+extern "C" int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* weight_t,
+                                const void* dy, const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx,
+                                float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
+                                size_t workspace_bytes, gt_stream_t stream_) {
+  g_weight_t = weight_t;
+  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N,
+                                       K, K, N, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+  g_weight_t = nullptr;
+  return rc;
+}
+// out [K][N] = in [N][K]^T (fp32)
+extern "C" int gt_transpose(const float* in, float* out, int64_t N, int64_t K, gt_stream_t stream_) {
+  GT_CHECK_ARG(in && out && N > 0 && K > 0, "bad arguments");
+  hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, (hipStream_t)stream_, in, out, N, K);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
 }
 
 // dW / db only (dx == NULL), and inside a gt_overlap_dw section still on the overlap stream, ordered behind everything queued on
@@ -1022,8 +1046,12 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
       // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
       // layer) -> wait for the forks that used this range (those on other workspaces keep running).
-      if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);
-      hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
+      if (g_weight_t) {
+        wt = const_cast<float*>(g_weight_t);   // read only
+      } else {
+        if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);
+        hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
+      }
       L32Args w{};
       w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
       w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldw = N; w.ldo = ldx; w.inv_keep = a.inv_keep;

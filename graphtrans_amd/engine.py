@@ -229,6 +229,7 @@ class _Plan:
         self.ev_vnemb = [lib.gt_event_create()] if self.side is not None else []                        # d vn_0 reduced (side -> main)
         # the node-id sort for the embedding backward runs beside the forward on the dW stream
         self.ev_sort = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []
+        self.ev_wt = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []   # transposed weights ready
         self.embed_sorted = bool(self.embed) and max(int(t.shape[0]) for t in self.embed) <= 16384
         # x_0 = h_0 + vn_0[batch] with vn_0 = the ONE row of virtualnode_embedding for every graph (gnn_module.py:195):
         # the embedding-sum kernel takes it as one more table whose index column is a stride-0 zero
@@ -238,7 +239,7 @@ class _Plan:
     def __del__(self):
         try:
             lib = _lib.lib()
-            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra + self.ev_sort + self.ev_pool + self.ev_vnemb:
+            for ev in self.ev_x + self.ev_vn + self.ev_dvn + self.ev_extra + self.ev_sort + self.ev_wt + self.ev_pool + self.ev_vnemb:
                 lib.gt_event_destroy(ev)
         except Exception:
             pass
@@ -567,6 +568,12 @@ class _FusedModel(torch.autograd.Function):
         o["ws"] = b.take(ws_bytes)
         ws2_bytes = max([lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
         o["ws2"] = b.take(ws2_bytes)   # the side stream's workspace
+        # transposed copies of the message-passing weights for the backward's exact-fp32 dX GEMMs (they run the forward-form
+        # kernel on W^T): written once, beside the forward, instead of one transpose launch in front of every dX GEMM
+        want_wt = will_bwd and compute == GT_F32 and N >= 1024
+        if want_wt:
+            o["wt"] = [b.take((2 if plan.kind == "gin" else 1) * 2 * D * D * 4) for _ in range(L)]
+            o["g2t_wt"] = b.take(d * Kc * 4)
         # a device-built token layout only has an upper bound on the row count: zero-filled buffers keep the rows past the
         # true count finite (they contribute exactly 0 to every weight gradient)
         arena = (torch.empty if lay.exact else torch.zeros)(b.off, dtype=torch.uint8, device=dev)
@@ -576,6 +583,30 @@ class _FusedModel(torch.autograd.Function):
         def P(key, i=None):
             return base + (o[key] if i is None else o[key][i])
 
+        for dsc in plan.gcn_desc:
+            if plan.kind == "gin":
+                dsc.w1_t, dsc.w2_t = None, None
+            else:
+                dsc.lin_wt = None
+        g2t_wt = None
+        if want_wt:
+            tst = st
+            if plan.side_dw is not None:
+                tst = plan.side_dw.cuda_stream
+                _call("gt_event_record", plan.ev_wt[0], st)       # the weights are as the optimizer left them on the main stream
+                _call("gt_stream_wait_event", tst, plan.ev_wt[0])
+            for l, dsc in enumerate(plan.gcn_desc):
+                if plan.kind == "gin":   # w1 [2D][D], w2 [D][2D]
+                    dsc.w1_t, dsc.w2_t = P("wt", l), P("wt", l) + 2 * D * D * 4
+                    _call("gt_transpose", dsc.w1, dsc.w1_t, 2 * D, D, tst)
+                    _call("gt_transpose", dsc.w2, dsc.w2_t, D, 2 * D, tst)
+                else:
+                    dsc.lin_wt = P("wt", l)
+                    _call("gt_transpose", dsc.lin_w, dsc.lin_wt, D, D, tst)
+            g2t_wt = P("g2t_wt")
+            _call("gt_transpose", plan.g2t.weight.data_ptr(), g2t_wt, d, Kc, tst)
+            if plan.side_dw is not None:
+                _call("gt_event_record", plan.ev_wt[1], tst)
         if tab_rows_total:   # every layer's bond tables stacked by one copy: layer l reads its [rows_l][D] slice
             tv = arena[o["etab"]:o["etab"] + tab_rows_total * D * 4].view(torch.float32).view(tab_rows_total, D)
             torch.cat([t.detach() for tl in plan.tables for t in tl], out=tv)
@@ -713,7 +744,7 @@ class _FusedModel(torch.autograd.Function):
         # the plan's descriptors are rewritten by the next forward: the backward gets its own copies
         snap = lambda ds: [type(x_).from_buffer_copy(x_) for x_ in ds]
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
-                         ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
+                         ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, g2t_wt=g2t_wt, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
                          dims=(N, E, B, rows), sync=state(model).get("sync"))
         ctx.set_materialize_grads(False)
@@ -848,7 +879,9 @@ class _FusedModel(torch.autograd.Function):
             dc = barena[q["d_cls"]:q["d_cls"] + B * d * tsz].view(torch.bfloat16 if tdt == GT_BF16 else torch.float32).view(B, d)
             torch.sum(dc, dim=0, dtype=torch.float32, out=flat[plan.cls_off:plan.cls_off + d])
         g2t = plan.g2t
-        _call("gt_linear_bwd", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), Q("d_hn"), None, None, None,
+        if s["g2t_wt"] is not None and plan.ev_wt:
+            _call("gt_stream_wait_event", st, plan.ev_wt[1])   # the transposed weights were written on the overlap stream beside the forward
+        _call("gt_linear_bwd_wt", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), s["g2t_wt"], Q("d_hn"), None, None, None,
               Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
         sync = model_sync if (direct and model_sync is not None and model_sync.active) else None

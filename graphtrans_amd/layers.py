@@ -34,7 +34,8 @@ class GcnLayerDesc(C.Structure):
                [(n, _fp) for n in ("graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid",
                                    "deg", "dis", "edge_attr", "lin_w", "lin_b", "root", "edge_w", "edge_b", "bn_w", "bn_b",
                                    "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")] + \
-               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp)]
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp),
+                ("lin_wt", _fp)]
 
 
 class GinLayerDesc(C.Structure):
@@ -47,7 +48,8 @@ class GinLayerDesc(C.Structure):
                                    "edge_attr", "eps", "edge_w", "edge_b", "w1", "b1", "bn1_w", "bn1_b", "w2", "b2", "bn_w",
                                    "bn_b", "bn1_rm", "bn1_rv", "bn_rm", "bn_rv", "bn1_nbt", "bn_nbt", "ev_x_ready",
                                    "ev_dx_wait")] + \
-               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp)]
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp),
+                ("w1_t", _fp), ("w2_t", _fp)]
 
 
 class VnUpdateDesc(C.Structure):

@@ -443,6 +443,13 @@ int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, cons
  * and releases its workspace before layer k+2 (buffers a dW reads must live in that workspace or stay
  * unchanged until the next full sync). */
 int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
+/* gt_linear_bwd with W^T [K][N] (fp32, gt_transpose) supplied by the caller, NULL = none: the exact-fp32 dX GEMM runs on the
+ * transposed weight and otherwise transposes it in front of every call. */
+int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* weight_t,
+                     const void* dy, const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx,
+                     float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
+                     size_t workspace_bytes, gt_stream_t stream);
+int gt_transpose(const float* in /* [N][K] */, float* out /* [K][N] */, int64_t N, int64_t K, gt_stream_t stream);
 /* dW / db only; inside an overlap section it still runs on the overlap stream (ordered behind what `stream` holds so far):
  * a caller can start a GEMM's weight gradient ahead of its dX GEMM. */
 int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
@@ -556,6 +563,7 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
    * layer's x); ev_vn_next: optional gt_event recorded by the stream that produces vn_next, waited for before that pass */
   const void* vn_next;
   void* ev_vn_next;
+  const float* lin_wt; /* optional: lin_w transposed [D][D] (gt_transpose), for the backward's dX GEMM */
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
@@ -590,6 +598,7 @@ typedef struct gt_gin_layer {  /* x = h_in [+ vn[batch]]; y = drop(BN(GINConv(x)
    * layer's x); ev_vn_next: optional gt_event recorded by the stream that produces vn_next, waited for before that pass */
   const void* vn_next;
   void* ev_vn_next;
+  const float *w1_t, *w2_t; /* optional: w1 / w2 transposed (gt_transpose), for the backward's dX GEMMs */
 } gt_gin_layer;
 size_t gt_gin_layer_saved_bytes(const gt_gin_layer* layer);
 size_t gt_gin_layer_workspace_bytes(const gt_gin_layer* layer);
