@@ -74,7 +74,7 @@ struct AttnArgs {
   float scale_log2;   // scale * log2(e)
   float scale;
   float inv_keep;     // 1/(1-p)
-  uint32_t drop_thr;  // keep iff hash >= thr ; 0 -> no dropout
+  uint32_t drop_thr;  // keep iff the key's 16-bit half of its pair's hash >= thr ; 0 -> no dropout
   uint32_t seed0, seed1;
 };
 
@@ -279,9 +279,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     if (a.drop_thr) {
       const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8; i += 2) {   // one hash decides a PAIR of adjacent keys (16 bits each)
         const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)i * RNG_CK);
-        p[i] = h >= a.drop_thr ? p[i] * a.inv_keep : 0.f;
+        p[i] = (h & 0xffffu) >= a.drop_thr ? p[i] * a.inv_keep : 0.f;
+        p[i + 1] = (h >> 16) >= a.drop_thr ? p[i + 1] * a.inv_keep : 0.f;
       }
     }
     const Frag<T> bp = frag_from_f32<T>(p);
@@ -406,9 +407,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         const bool filled = dense && qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
         const float p = kvalid ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
         float dpi = dp[r];
-        if (a.drop_thr) {
-          const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)i * RNG_CK);
-          dpi = h >= a.drop_thr ? dpi * a.inv_keep : 0.f;
+        if (a.drop_thr) {   // the pair's hash (even key of the pair), this key's 16-bit half: the compiler shares it between r, r + 1
+          const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)(i & ~1) * RNG_CK);
+          dpi = ((i & 1) ? (h >> 16) : (h & 0xffffu)) >= a.drop_thr ? dpi * a.inv_keep : 0.f;
         }
         ds[i] = filled ? 0.f : p * (dpi - delta);  // masked_fill: no gradient through a filled score
       }
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
-  const uint32_t kpart = rng_kpart(a.seed0, (uint32_t)kp);
+  const uint32_t kpart = rng_kpart(a.seed0, (uint32_t)(kp & ~1));   // dropout decisions come in pairs of adjacent keys
   const uint32_t hb = bh * RNG_CH + a.seed1;
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         float pdrop = p;
         if (a.drop_thr) {
           const uint32_t h = rng_mix((qmul0 + (uint32_t)i * RNG_CQ) ^ hb, kpart);  // == rng_qpart(seed1, bh, qpos)
-          const bool keep = h >= a.drop_thr;
+          const bool keep = ((kp & 1) ? (h >> 16) : (h & 0xffffu)) >= a.drop_thr;
           dpi = keep ? dpi * a.inv_keep : 0.f;
           pdrop = keep ? p * a.inv_keep : 0.f;
         }
@@ -590,8 +591,8 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
   a.rows = rows; a.d_model = d_model; a.row_stride = row_stride; a.nhead = nhead;
   a.scale = scale; a.scale_log2 = scale * LOG2E;
   a.inv_keep = 1.0f / (1.0f - dropout_p);
-  double thr = (double)dropout_p * 4294967296.0;
-  a.drop_thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
+  double thr = (double)dropout_p * 65536.0 + 0.5;   // 16-bit decisions: two keys per hash; p is resolved to 1.5e-5
+  a.drop_thr = dropout_p > 0.f ? (uint32_t)(thr > 65535.0 ? 65535.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
   a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
   return a;
 }
