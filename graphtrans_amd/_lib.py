@@ -86,6 +86,7 @@ SIGNATURES = {
     "gt_linear_bwd_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
+    "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),
     "gt_overlap_dw_begin": (_i, [_p, _p]),
     "gt_overlap_dw_sync": (_i, []),
     "gt_overlap_dw_release": (_i, [_p, _sz]),

@@ -131,6 +131,49 @@ extern "C" int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx,
   return GT_OK;
 }
 
+// ---- stand-alone dropout (F.dropout / nn.Dropout where no producing kernel can carry it: the residual dropouts of the masked
+// encoder, masked_transformer_encoder.py:54,75; PNANodeEmbedding, pna/pna_module.py:78): y = keep ? x / (1 - p) : 0 with the
+// counter hash of the fused dropouts (element index, seed); the backward replays the same mask on the gradient ---------------
+namespace {
+__device__ __forceinline__ uint32_t drop_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
+  uint32_t x = (idx * 0x9E3779B1u) ^ s0;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x ^ s1;
+}
+template <typename T>
+__global__ void __launch_bounds__(UT) k_dropout(const T* __restrict__ x, T* __restrict__ y, int64_t n4, uint32_t thr, float inv_keep,
+                                                uint32_t s0, uint32_t s1) {
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * UT) {
+    float4 v = gt_load4<T>(x + i * 4);
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = drop_hash(s0, s1, (uint32_t)(i * 4 + e)) >= thr ? f[e] * inv_keep : 0.f;
+    gt_store4<T>(y + i * 4, v);
+  }
+}
+}  // namespace
+
+extern "C" int gt_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, gt_stream_t stream_) {
+  GT_CHECK_ARG(x && y && n >= 0 && n % 4 == 0 && n < (int64_t)1 << 32, "n must be a multiple of 4 below 2^32");
+  GT_CHECK_ARG(p >= 0.f && p < 1.f, "p must be in [0,1)");
+  GT_CHECK_ARG(dtype == GT_F32 || dtype == GT_BF16, "bad dtype");
+  if (n == 0) return GT_OK;
+  const double t = (double)p * 4294967296.0;
+  const uint32_t thr = p > 0.f ? (uint32_t)(t > 4294967295.0 ? 4294967295.0 : (t < 1.0 ? 1.0 : t)) : 0u;
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)(gt_cdiv(n4, UT) < 4096 ? gt_cdiv(n4, UT) : 4096);
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_dropout<float>, dim3(grid), dim3(UT), 0, (hipStream_t)stream_, (const float*)x, (float*)y, n4, thr,
+                       1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32));
+  else
+    hipLaunchKernelGGL(k_dropout<gt_bf16>, dim3(grid), dim3(UT), 0, (hipStream_t)stream_, (const gt_bf16*)x, (gt_bf16*)y, n4, thr,
+                       1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32));
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
 extern "C" int gt_add3(const float* a, const float* b, const float* c, int64_t n, float* out, gt_stream_t stream_) {
   GT_CHECK_ARG(n >= 0 && n % 4 == 0, "element count must be a multiple of 4");
   if (n == 0) return GT_OK;

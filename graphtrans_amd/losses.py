@@ -1,25 +1,29 @@
 """The trainers' calc_loss functions (define the backward seed of the fwd+bwd metric)."""
 import torch
-import torch.nn.functional as F
 
 
 def code2_loss(pred_list, y_arr):
-    """dataset/code.py:39-45: mean over the max_seq_len heads of CrossEntropy(pred_i, y_arr[:, i])."""
+    """dataset/code.py:39-45: mean over the max_seq_len heads of CrossEntropy(pred_i, y_arr[:, i]) on gt_xent_* (the heads of
+    the HIP path come out of one GEMM as one (B, L, C) tensor; separate (B, C) heads go through the same kernels one by one)."""
+    from . import ops
     stacked = getattr(pred_list, "stacked", None)
     if stacked is not None:  # heads computed as one GEMM: equal-size means -> one cross-entropy over B*L rows
         B, L, C = stacked.shape
-        if stacked.is_cuda and stacked.dtype == torch.float32 and stacked.stride(2) == 1 and stacked.stride(1) == C:
-            from . import ops
-            return ops.softmax_xent(stacked, y_arr)
-        return F.cross_entropy(stacked.to(torch.float32).reshape(B * L, C), y_arr[:, :L].reshape(B * L))
+        if not stacked.is_cuda:
+            raise RuntimeError("graphtrans_amd.losses.code2_loss runs on the GPU only (no CPU fallback); "
+                               "the CPU statement is oracle/reference_math.py:code2_loss")
+        if stacked.dtype != torch.float32 or stacked.stride(2) != 1 or stacked.stride(1) != C:
+            stacked = stacked.to(torch.float32).contiguous()
+        return ops.softmax_xent(stacked, y_arr)
     loss = 0
-    for i, pred in enumerate(pred_list):   # separate heads (the module path without stacked heads): gt_xent_* per head
+    for i, pred in enumerate(pred_list):
+        if not pred.is_cuda:
+            raise RuntimeError("graphtrans_amd.losses.code2_loss runs on the GPU only (no CPU fallback); "
+                               "the CPU statement is oracle/reference_math.py:code2_loss")
         p32 = pred.to(torch.float32)
-        if p32.is_cuda and p32.stride(-1) == 1:
-            from . import ops
-            loss = loss + ops.softmax_xent(p32.unsqueeze(1), y_arr[:, i:i + 1])
-        else:
-            loss = loss + F.cross_entropy(p32, y_arr[:, i])
+        if p32.stride(-1) != 1:
+            p32 = p32.contiguous()
+        loss = loss + ops.softmax_xent(p32.unsqueeze(1), y_arr[:, i:i + 1])
     return loss / len(pred_list)
 
 

@@ -14,7 +14,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 
@@ -51,7 +50,7 @@ class CausalSelfAttention(nn.Module):
         y = ops.attention(qkv, _BatchLayout(B, T, x.device), self.n_head, dropout_p=p, seed=seed,
                           scale=1.0 / math.sqrt(C // self.n_head), dense_mask=attn_mask, key_valid=valid_input_mask,
                           mask_value=mask_value)
-        return self.resid_drop(ops.linear_module(self.proj, y)).view(B, T, C)
+        return ops.dropout(ops.linear_module(self.proj, y), self.resid_drop.p, self.training).view(B, T, C)   # resid_drop (:54)
 
 
 class Block(nn.Module):
@@ -72,7 +71,7 @@ class Block(nn.Module):
     def _mlp(self, x):
         shape = x.shape
         h = ops.linear_module(self.mlp[0], x.reshape(-1, shape[-1]), act="gelu")   # GELU in the GEMM epilogue
-        return self.mlp[3](ops.linear_module(self.mlp[2], h)).view(shape)
+        return ops.dropout(ops.linear_module(self.mlp[2], h), self.mlp[3].p, self.training).view(shape)   # mlp[3] = nn.Dropout (:75)
 
     def forward(self, x, attn_mask=None, valid_input_mask=None):
         if self.prenorm:

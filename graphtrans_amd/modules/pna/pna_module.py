@@ -15,7 +15,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import ops
 from ..gnn_module import batch_structure
@@ -218,5 +217,5 @@ class PNANodeEmbedding(nn.Module):
                 x = h + x
             else:  # the reference leaves x unchanged without the residual (h is dropped, :73-76)
                 x = x
-            x = F.dropout(x, self.drop_ratio, training=self.training)
+            x = ops.dropout(x, self.drop_ratio, training=self.training)   # F.dropout (:78)
         return x

@@ -9,7 +9,6 @@ Two entry points:
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import layers, ops
 
@@ -72,9 +71,6 @@ class TransformerNodeEncoder(nn.Module):
         """LN(resid + dropout(x)) in one kernel (gt_layernorm_fwd); plain LN when resid is None."""
         p = self.dropout_p if (self.training and resid is not None) else 0.0
         return ops.layer_norm(x, ln.weight, ln.bias, ln.eps, resid=resid, dropout_p=p, seed=seed)
-
-    def _drop(self, x):
-        return F.dropout(x, self.dropout_p, self.training) if (self.training and self.dropout_p > 0) else x
 
     def _layer(self, x, mod, lay, seed):
         sa = mod.self_attn

@@ -788,6 +788,34 @@ def embed_sum(columns, tables, clamps=None):
 # ------------------------------------------------------------------------------------------------
 # softmax cross-entropy over the stacked prediction heads
 # ------------------------------------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _dev(x.contiguous(), "x")
+        if x.dtype not in (torch.float32, torch.bfloat16) or x.numel() % 4:
+            raise TypeError("dropout: fp32 / bf16 tensor with a multiple of 4 elements expected")
+        y = torch.empty_like(x)
+        _lib.launch("gt_dropout", _dtype_code(x), _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream())
+        ctx.cfg = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g.contiguous(), "grad")
+        out = torch.empty_like(g)
+        _lib.launch("gt_dropout", _dtype_code(g), _ptr(g), _ptr(out), g.numel(), ctx.cfg[0], ctx.cfg[1], _stream())
+        return out, None, None
+
+
+def dropout(x, p, training=True, seed=None):
+    """F.dropout(x, p, training) on gt_dropout (counter-hash mask, replayed by the backward); identity when not training."""
+    if not training or p <= 0.0:
+        return x
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    return _Dropout.apply(x, p, seed)
+
+
 _VALIDATE = os.environ.get("GT_VALIDATE", "0") not in ("", "0")
 
 

@@ -632,6 +632,11 @@ int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, v
 int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, const void* d_x_add, void* d_x,
                      void* d_vn, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
+/* Stand-alone dropout (F.dropout / nn.Dropout with no producing kernel to carry it: masked_transformer_encoder.py:54,75,
+ * pna/pna_module.py:78): y[i] = keep(i, seed) ? x[i] / (1 - p) : 0 over n elements (n % 4 == 0; x == y allowed).  The same
+ * call on the gradient is the backward (the mask is a function of (i, seed) only). */
+int gt_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, gt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Data movement of the fused model path (graphtrans_amd/engine.py).
  * gt_copy2d: dst[r][0..width) = src[r][0..width) with byte pitches (all multiples of 16): the two

@@ -141,3 +141,21 @@ def test_xent_reports_out_of_range_targets_in_validate_mode():
     finally:
         ops.set_validate(False)
     assert torch.isfinite(ops.softmax_xent(x, t))   # not validating: treated as ignored rows, as before
+
+
+def test_standalone_dropout_replays_its_mask():
+    """gt_dropout (nn.Dropout of the masked encoder / F.dropout of PNANodeEmbedding): keep rate, scaling, and the backward
+    applying the same mask."""
+    from graphtrans_amd import ops
+    torch.manual_seed(0)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(4096, 64, device=DEV).to(dt).requires_grad_(True)
+        y = ops.dropout(x, 0.25, True, seed=77)
+        keep = y != 0
+        assert abs(keep.float().mean().item() - 0.75) < 0.01
+        assert torch.allclose(y[keep].float(), x.detach()[keep].float() / 0.75, rtol=1e-2 if dt == torch.bfloat16 else 1e-6)
+        g = torch.randn_like(y)
+        y.backward(g)
+        assert torch.equal(x.grad != 0, keep & (g != 0))
+        assert torch.allclose(x.grad[keep].float(), g[keep].float() / 0.75, rtol=1e-2 if dt == torch.bfloat16 else 1e-6)
+        assert torch.equal(ops.dropout(x, 0.25, True, seed=77), y) and ops.dropout(x, 0.25, False) is x
