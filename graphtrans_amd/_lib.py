@@ -87,6 +87,10 @@ SIGNATURES = {
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
     "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),
+    "gt_linear_bwd_bnstats_ok": (_i, [_i, _i, _i, _i64]),
+    "gt_linear_bwd_bnstats_rows": (_i64, [_i64]),
+    "gt_linear_bwd_bnstats": (_i, [_p, _i64, _p, _p, _p, _p, _i, _p]),
+    "gt_batchnorm_bwd_parts": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "gt_overlap_dw_begin": (_i, [_p, _p]),
     "gt_overlap_dw_sync": (_i, []),
     "gt_overlap_dw_release": (_i, [_p, _sz]),

@@ -433,13 +433,22 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
   if (L->N == 0) return GT_OK;
   const GcnSaved s = gcn_saved(L, const_cast<void*>(saved));
   const GcnGrads g = gcn_grads(L, grads);
-  GT_TRY(gt_batchnorm_bwd(GT_F32, s.agg, dy, L->bn_w, L->bn_b, s.stats, s.stats + L->D, L->training, L->relu, L->N, L->D,
-                          w.d_agg, g.bn_w, g.bn_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
+  if (L->bn_part_in && L->bn_nparts_in > 0 && L->dropout_p == 0.f)   // statistics already summed in the dX epilogue that produced dy
+    GT_TRY(gt_batchnorm_bwd_parts(GT_F32, s.agg, dy, L->bn_w, L->bn_b, s.stats, s.stats + L->D, L->training, L->relu, L->N, L->D,
+                                  w.d_agg, g.bn_w, g.bn_b, L->bn_part_in, L->bn_nparts_in, st));
+  else
+    GT_TRY(gt_batchnorm_bwd(GT_F32, s.agg, dy, L->bn_w, L->bn_b, s.stats, s.stats + L->D, L->training, L->relu, L->N, L->D,
+                            w.d_agg, g.bn_w, g.bn_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
   GT_TRY(gt_aggregate_bwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, w.d_agg, L->N, L->E, L->D, L->out_ptr, L->out_dst,
                           L->out_eid, L->deg, L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off,
                           L->table_rows, nullptr, w.d_lin, g.root, g.edge_w, g.edge_b, nullptr, w.agg_ws, w.agg_ws_bytes, st));
   // d_x = d_lin W (+ grads reaching x from its other consumers) (+ dy through the residual branch)
   if (L->ev_dx_wait) GT_TRY(gt_stream_wait_event(st, L->ev_dx_wait));
+  if (L->prev_saved && L->prev_bn_part) {   // d_h_in is the dy of the previous layer's BatchNorm: its statistics ride in this epilogue
+    const GcnSaved ps = gcn_saved(L, const_cast<void*>(L->prev_saved));
+    GT_TRY(gt_linear_bwd_bnstats((const float*)ps.agg, L->D, ps.stats, ps.stats + L->D, L->prev_bn_w, L->prev_bn_b, L->prev_relu,
+                                 L->prev_bn_part));
+  }
   GT_TRY(gt_linear_bwd_wt(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_wt, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr,
                           d_h_in, g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   if (L->has_vn && d_vn)

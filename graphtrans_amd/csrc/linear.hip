@@ -724,13 +724,13 @@ bool w32_eligible(int compute, int x_dtype, int64_t M, int groups) {
   return compute == GT_F32 && x_dtype == GT_F32 && groups == 1 && M >= W32_MIN_M;
 }
 
-template <typename TA, typename TO, bool MASK, bool GELU = false>
+template <typename TA, typename TO, bool MASK, bool GELU = false, bool BNS = false>
 void w32_launch_nt(int nt, dim3 grid, hipStream_t stream, const L32Args& a) {
   switch (nt) {
-    case 19: hipLaunchKernelGGL((k_lin32<TA, TO, 19, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
-    case 16: hipLaunchKernelGGL((k_lin32<TA, TO, 16, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
-    case 12: hipLaunchKernelGGL((k_lin32<TA, TO, 12, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((k_lin32<TA, TO, 8, MASK, GELU>), grid, dim3(256), 0, stream, a); break;
+    case 19: hipLaunchKernelGGL((k_lin32<TA, TO, 19, MASK, GELU, BNS>), grid, dim3(256), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((k_lin32<TA, TO, 16, MASK, GELU, BNS>), grid, dim3(256), 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((k_lin32<TA, TO, 12, MASK, GELU, BNS>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((k_lin32<TA, TO, 8, MASK, GELU, BNS>), grid, dim3(256), 0, stream, a); break;
   }
 }
 
@@ -743,6 +743,11 @@ void w32_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   if constexpr (!MASK) {
     if (a.act == 2) {   // gelu epilogue: fp32 rows in and out only (w32_eligible_fwd)
       w32_launch_nt<float, float, false, true>(nt, grid, stream, a);
+      return;
+    }
+  } else {
+    if (a.bn_part) {    // BatchNorm-backward statistics in the dX epilogue: fp32 rows only (gt_linear_bwd_bnstats_ok)
+      w32_launch_nt<float, float, true, false, true>(nt, grid, stream, a);
       return;
     }
   }
@@ -904,6 +909,14 @@ thread_local bool g_fork_dw_only = false;
 // W^T [K][N] prepared by the caller for the gt_linear_bwd* call in flight (gt_linear_bwd_wt): the wide fp32 dX GEMM then
 // skips its own transpose launch
 thread_local const float* g_weight_t = nullptr;
+// BatchNorm-backward statistics to accumulate in the epilogue of the gt_linear_bwd* call in flight (gt_linear_bwd_bnstats)
+struct BnStatsReq {
+  const float *x = nullptr, *mean = nullptr, *rstd = nullptr, *w = nullptr, *b = nullptr;
+  float* part = nullptr;
+  int64_t ldx = 0;
+  int relu = 0;
+};
+thread_local BnStatsReq g_bns;
 
 extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
@@ -911,6 +924,21 @@ extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const vo
                                  void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
   return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
                                ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
+}
+
+// The dX of the NEXT gt_linear_bwd* call on this thread is the dy of a BatchNorm (input bn_x [M][ldx], saved mean / rstd, affine
+// w / b, ReLU behind it or not): its epilogue also writes the row-tile partial sums part[ceil(M/64)][2][K] of that BatchNorm's
+// backward (sum dy', sum dy' * xhat) -- what k_bn_bwd_partial would compute from a second pass over dy and bn_x.  Only the
+// exact-fp32 wide-tile path does this: ask gt_linear_bwd_bnstats_ok first; the request is dropped after the next call.
+extern "C" int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, int64_t M) {
+  return (w32_eligible(compute, x_dtype, M, 1) && x_dtype == GT_F32 && y_dtype == GT_F32) ? 1 : 0;
+}
+extern "C" int64_t gt_linear_bwd_bnstats_rows(int64_t M) { return gt_cdiv(M, W32_BM); }
+extern "C" int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w,
+                                     const float* b, int relu, float* part) {
+  GT_CHECK_ARG(bn_x && mean && rstd && w && b && part && ldx > 0, "null buffer");
+  g_bns.x = bn_x; g_bns.ldx = ldx; g_bns.mean = mean; g_bns.rstd = rstd; g_bns.w = w; g_bns.b = b; g_bns.relu = relu; g_bns.part = part;
+  return GT_OK;
 }
 
 // gt_linear_bwd with the transposed weight W^T [K][N] supplied by the caller (weights do not change during a backward pass: one
@@ -970,6 +998,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
+  struct BnsDrop { ~BnsDrop() { g_bns = BnStatsReq{}; } } bns_drop__;   // a gt_linear_bwd_bnstats request lives for one call
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
                                (N * K) % 4 == 0),
@@ -1055,6 +1084,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       L32Args w{};
       w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
       w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldw = N; w.ldo = ldx; w.inv_keep = a.inv_keep;
+      if (g_bns.part && x_dtype == GT_F32 && y_dtype == GT_F32) {
+        w.bn_x = g_bns.x; w.bn_ldx = g_bns.ldx; w.bn_mean = g_bns.mean; w.bn_rstd = g_bns.rstd; w.bn_w = g_bns.w; w.bn_b = g_bns.b;
+        w.bn_relu = g_bns.relu; w.bn_part = g_bns.part;
+      }
       w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {

@@ -26,6 +26,14 @@ struct L32Args {
   const void* add2;
   void* out;           // [M][ldo]
   void* gout;          // fwd, act == 2 (gelu): [M][ldo] multiplier for the backward, or null
+  // BNS (dX form): `out` is the dy of a BatchNorm further down the backward pass; its two column statistics are summed here
+  //   bn_part[row tile][0][Nout] = sum_rows dy', [1][Nout] = sum_rows dy' * xhat,  dy' = dy * 1[xhat * w + b > 0] if bn_relu
+  // (the row-tile partials k_bn_bwd_partial would produce from a second pass over dy and the BatchNorm input bn_x)
+  const float* bn_x;   // [M][bn_ldx] the BatchNorm's input rows
+  const float *bn_mean, *bn_rstd, *bn_w, *bn_b;   // [Nout]
+  float* bn_part;
+  int64_t bn_ldx;
+  int bn_relu;
   int64_t M, Nout, Kc;
   int64_t lda, ldw, ldo;
   int act;
@@ -53,15 +61,15 @@ __device__ __forceinline__ void chunk_to_f32(const uint4& v, float* f) {
   }
 }
 
-template <typename TA, typename TO, int NT, bool MASK, bool GELU = false>   // GELU: its own instantiation (the erf epilogue
-__global__ void __launch_bounds__(256) k_lin32(L32Args a) {                  // would cost every other launch its occupancy)
+template <typename TA, typename TO, int NT, bool MASK, bool GELU = false, bool BNS = false>   // GELU / BNS: their own instantiations
+__global__ void __launch_bounds__(256) k_lin32(L32Args a) {   // (an epilogue compiled into the common one costs every launch its occupancy)
   constexpr int BM = W32_BM, BK = W32_BK, LD = W32_LD;
   constexpr int EA = Chunk32<TA>::E;            // elements per 16-byte chunk of the row operand
   constexpr int ACH = BK / EA;                  // chunks per row of the A tile (4 fp32 / 2 bf16)
   constexpr int WROWS = NT * 16;
   constexpr int WIT = (WROWS * 4 + 255) / 256;  // W-tile chunks per thread
   constexpr int STAGE = (BM + WROWS) * LD;
-  constexpr int EPI = 4 * 16 * (128 + 4) + WROWS;   // epilogue: four per-wave patches + the bias row
+  constexpr int EPI = 4 * 16 * (128 + 4) + WROWS + (BNS ? 8 * WROWS : 0);   // epilogue: four per-wave patches + the bias row (+ BNS: [4 waves][2][WROWS])
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE > EPI ? 2 * STAGE : EPI];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -245,6 +253,7 @@ __global__ void __launch_bounds__(256) k_lin32(L32Args a) {                  // 
           for (int e = 0; e < 4; ++e) vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
         }
         v[t] = gt_add4(gt_add4(v[t], e1[t]), e2[t]);
+        if constexpr (BNS) *reinterpret_cast<float4*>(patch + r * PLD + c4) = v[t];   // the final dy, for the column pass below
       }
     }
 #pragma unroll
@@ -255,6 +264,49 @@ __global__ void __launch_bounds__(256) k_lin32(L32Args a) {                  // 
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (BNS) {
+      // column pass: lane = column (two per lane), the wave's 16 rows top to bottom -> per-wave sums, fixed order
+      float* red = smem + 4 * 16 * PLD + WROWS + wid * 2 * WROWS;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int colp = half * 64 + lane;            // column inside this batch of nj n-tiles
+        const int64_t col = n0 + jb * 16 + colp;
+        if (colp < nj * 16) {
+          float s1 = 0.f, s2 = 0.f;
+          if (col < a.Nout) {
+            const float mu = a.bn_mean[col], rs = a.bn_rstd[col], ww = a.bn_w[col], bb = a.bn_b[col];
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = mrow0 + r < a.M ? a.bn_x[(mrow0 + r) * a.bn_ldx + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (mrow0 + r < a.M) {
+                const float xh = (xv[r] - mu) * rs;
+                float dyv = patch[r * PLD + colp];
+                if (a.bn_relu && !(xh * ww + bb > 0.f)) dyv = 0.f;
+                s1 += dyv;
+                s2 = fmaf(dyv, xh, s2);
+              }
+            }
+          }
+          red[jb * 16 + colp] = s1;
+          red[WROWS + jb * 16 + colp] = s2;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if constexpr (BNS) {   // the four waves' sums -> this row tile's partial row
+    __syncthreads();
+    const float* red = smem + 4 * 16 * PLD + WROWS;
+    for (int c = tid; c < 2 * WROWS; c += 256) {
+      const int which = c / WROWS, cc = c % WROWS;
+      if (n0 + cc < a.Nout) {
+        const float t = (red[c] + red[2 * WROWS + c]) + (red[4 * WROWS + c] + red[6 * WROWS + c]);
+        a.bn_part[(mt * 2 + which) * a.Nout + n0 + cc] = t;
+      }
+    }
   }
 }
 

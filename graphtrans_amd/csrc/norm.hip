@@ -316,31 +316,33 @@ __device__ __forceinline__ void st1(T* p, float v) {
   if constexpr (sizeof(T) == 4) *reinterpret_cast<float*>(p) = v;
   else *reinterpret_cast<gt_bf16*>(p) = gt_f32_to_bf16(v);
 }
+constexpr int SM_COLS = 8;    // columns per block: 256-thread blocks find a slot on a busy chip at once (the virtual-node chain runs beside
+                              // chip-filling kernels; 1024-thread blocks waited up to 70 us for a CU with 16 free wave slots)
 constexpr int SM_LANES = 32;  // row lanes per column: 8 rows per thread at B = 256, 4 loads in flight
 // sum over the SM_LANES row lanes of a column, valid in row lane 0
 __device__ __forceinline__ float lanes_sum(float v, float* sm) {
-  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
-  sm[p * FIN_COLS + cl] = v;
+  const int cl = threadIdx.x % SM_COLS, p = threadIdx.x / SM_COLS;
+  sm[p * SM_COLS + cl] = v;
   __syncthreads();
   float t = 0.f;
   if (p == 0) {
 #pragma unroll
-    for (int q = 0; q < SM_LANES; ++q) t += sm[q * FIN_COLS + cl];
+    for (int q = 0; q < SM_LANES; ++q) t += sm[q * SM_COLS + cl];
   }
   __syncthreads();
   return t;
 }
 
 template <typename T>
-__global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_fwd(
+__global__ void __launch_bounds__(SM_COLS * SM_LANES) k_bn_small_fwd(
     const T* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
     const float* __restrict__ b, const T* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
     float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
     int64_t* __restrict__ num_batches_tracked, T* __restrict__ y, const T* __restrict__ bcast, const int32_t* __restrict__ bidx) {
-  __shared__ float sm[SM_LANES * FIN_COLS];
-  __shared__ float s_mu[FIN_COLS], s_rs[FIN_COLS];
-  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
-  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
+  __shared__ float sm[SM_LANES * SM_COLS];
+  __shared__ float s_mu[SM_COLS], s_rs[SM_COLS];
+  const int cl = threadIdx.x % SM_COLS, p = threadIdx.x / SM_COLS;
+  const int64_t c = (int64_t)blockIdx.x * SM_COLS + cl;
   const bool act = c < D;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
   const float piv = act ? ld1<T>(x + c) : 0.f;  // shifted sums: no cancellation for large means
@@ -390,14 +392,14 @@ __global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_fwd(
 }
 
 template <typename T>
-__global__ void __launch_bounds__(FIN_COLS * SM_LANES) k_bn_small_bwd(
+__global__ void __launch_bounds__(SM_COLS * SM_LANES) k_bn_small_bwd(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ b, int relu, int training, BnDrop drop, int64_t N, int64_t D,
     float* __restrict__ dbias, float* __restrict__ dweight, T* __restrict__ dx) {
-  __shared__ float sm[SM_LANES * FIN_COLS];
-  __shared__ float s_db[FIN_COLS], s_dw[FIN_COLS];
-  const int cl = threadIdx.x % FIN_COLS, p = threadIdx.x / FIN_COLS;
-  const int64_t c = (int64_t)blockIdx.x * FIN_COLS + cl;
+  __shared__ float sm[SM_LANES * SM_COLS];
+  __shared__ float s_db[SM_COLS], s_dw[SM_COLS];
+  const int cl = threadIdx.x % SM_COLS, p = threadIdx.x / SM_COLS;
+  const int64_t c = (int64_t)blockIdx.x * SM_COLS + cl;
   const bool act = c < D;
   const float mu = act ? mean[c] : 0.f, rs = act ? rstd[c] : 0.f, ww = act ? w[c] : 0.f, bb = act ? b[c] : 0.f;
   auto grad_at = [&](int64_t r, float& xh) {
@@ -793,11 +795,11 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
         if (rc) return rc;
       }
       if (dtype == GT_F32)
-        hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const float*)x, rows, dim,
+        hipLaunchKernelGGL(k_bn_small_fwd<float>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const float*)x, rows, dim,
                            eps, momentum, weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean,
                            running_var, num_batches_tracked, (float*)y, (const float*)bcast, bcast_index);
       else
-        hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const gt_bf16*)x, rows,
+        hipLaunchKernelGGL(k_bn_small_fwd<gt_bf16>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const gt_bf16*)x, rows,
                            dim, eps, momentum, weight, bias, (const gt_bf16*)resid, relu, drop, save_mean, save_rstd,
                            running_mean, running_var, num_batches_tracked, (gt_bf16*)y, (const gt_bf16*)bcast, bcast_index);
       GT_CHECK_LAUNCH();
@@ -860,11 +862,11 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const int g = flat_blocks(rows * (dim / 4));
   if (rows <= SMALL_ROWS) {
     if (dtype == GT_F32)
-      hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const float*)x,
+      hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const float*)x,
                          (const float*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias, dweight,
                          (float*)dx);
     else
-      hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * SM_LANES), 0, stream, (const gt_bf16*)x,
+      hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const gt_bf16*)x,
                          (const gt_bf16*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias,
                          dweight, (gt_bf16*)dx);
     GT_CHECK_LAUNCH();
@@ -883,6 +885,33 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
                        save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx);
   }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+// gt_batchnorm_bwd with the pass-1 partial sums supplied by the caller: part[nparts][2][dim] (sum dy', sum dy' * xhat over any
+// partition of the rows, e.g. the 64-row tiles of the GEMM whose dX epilogue produced them: gt_linear_bwd_bnstats).  Runs the
+// fixed-order finish and the apply pass only.  dropout_p must be 0 (the producers do not replay the dropout mask).
+extern "C" int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
+                                      const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
+                                      int64_t dim, void* dx, float* dweight, float* dbias, const float* part, int64_t nparts,
+                                      gt_stream_t stream_) {
+  int rc = check_norm("gt_batchnorm_bwd_parts", dtype, rows, dim);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && dy && weight && bias && save_mean && save_rstd && dx && dweight && dbias && part, "null buffer");
+  GT_CHECK_ARG(nparts >= 1 && nparts <= 0x7fffffff, "bad partial count");
+  if (rows == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const BnDrop drop = make_bn_drop(0.f, 0);
+  const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
+  const int g = flat_blocks(rows * (dim / 4));
+  hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, (int)nparts, dim, dbias, dweight);
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy, save_mean, save_rstd,
+                       weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, save_mean,
+                       save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -798,6 +798,16 @@ class _FusedModel(torch.autograd.Function):
         else:
             emb_ws = lib.gt_embed_sum_bwd_workspace_bytes(len(plan.embed), emb_rows, D)
         ws_bytes = max(s["ws_bytes"], enc_ws, ln_ws, lin_ws, emb_ws)
+        # BatchNorm-backward statistics summed in the dX epilogue of the layer above (GCN, exact-fp32 GEMMs, no GNN dropout):
+        # per-64-row-tile partial rows, one buffer per BatchNorm that is fed by a conv's dX (all but the last layer's)
+        d0 = s["gcn_desc"][0]
+        # (with a virtual node the main stream waits for the virtual-node chain between two dX GEMMs anyway: measured 0.4 %
+        # slower there -- the longer dX epilogue delays that chain -- so only models without one take it)
+        fuse_bn = (not plan.has_vn and plan.kind == "gcn" and bool(d0.training) and d0.dropout_p == 0.0 and
+                   bool(lib.gt_linear_bwd_bnstats_ok(compute, GT_F32, GT_F32, N)))
+        s["fuse_bn"] = fuse_bn
+        s["bn_rows"] = int(lib.gt_linear_bwd_bnstats_rows(N)) if fuse_bn else 0
+        q["bnpart"] = [b.take(s["bn_rows"] * 2 * D * 4 if fuse_bn else 0) for _ in range(max(L - 1, 0))]
         q["ws"] = [b.take(ws_bytes), b.take(ws_bytes)]   # alternated between consecutive stages (see W() below)
         q["ws2"] = b.take(s["ws2_bytes"])
         seg_ws_bytes = lib.gt_segment_sum_workspace_bytes(N, D) if plan.has_vn else 0
@@ -897,6 +907,14 @@ class _FusedModel(torch.autograd.Function):
             dy = Q("dA")
         else:
             dy = Q("d_rep")
+        if s["fuse_bn"]:
+            for l in range(1, L):
+                up, dn = s["gcn_desc"][l], s["gcn_desc"][l - 1]
+                up.prev_saved = P("gcn_saved", l - 1)
+                up.prev_bn_w, up.prev_bn_b = dn.bn_w, dn.bn_b
+                up.prev_relu = dn.relu
+                up.prev_bn_part = Q("bnpart", l - 1)
+                dn.bn_part_in, dn.bn_nparts_in = Q("bnpart", l - 1), s["bn_rows"]
         d_vn_next = None   # total gradient of vn_{l+1}
         for l in range(L - 1, -1, -1):
             extra = Q("dJ") if (l == 0 and plan.jk_cat) else None

@@ -35,7 +35,8 @@ class GcnLayerDesc(C.Structure):
                                    "deg", "dis", "edge_attr", "lin_w", "lin_b", "root", "edge_w", "edge_b", "bn_w", "bn_b",
                                    "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")] + \
                [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp),
-                ("lin_wt", _fp)]
+                ("lin_wt", _fp), ("prev_saved", _fp), ("prev_bn_w", _fp), ("prev_bn_b", _fp), ("prev_bn_part", _fp),
+                ("bn_part_in", _fp), ("prev_relu", C.c_int32), ("bn_nparts_in", C.c_int32)]
 
 
 class GinLayerDesc(C.Structure):

@@ -350,6 +350,12 @@ int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weig
                      const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows,
                      int64_t dim, void* dx, float* dweight, float* dbias, float dropout_p, uint64_t seed, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
+/* gt_batchnorm_bwd with its first pass done elsewhere: part[nparts][2][dim] = partial sums of dy' and dy' * xhat over any
+ * partition of the rows (gt_linear_bwd_bnstats writes them from the dX epilogue of the GEMM that produces dy); fixed-order
+ * finish + apply only.  For layers without dropout behind the BatchNorm. */
+int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
+                           const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows, int64_t dim,
+                           void* dx, float* dweight, float* dbias, const float* part, int64_t nparts, gt_stream_t stream);
 /* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
  * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
  * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */
@@ -443,6 +449,15 @@ int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, cons
  * and releases its workspace before layer k+2 (buffers a dW reads must live in that workspace or stay
  * unchanged until the next full sync). */
 int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
+/* BatchNorm-backward statistics in a dX epilogue.  When the dX of a GEMM is the dy of a BatchNorm further down the backward
+ * pass (x_l = relu(BN(agg_{l-1})) feeds conv_l: gnn_module.py:199-212), gt_linear_bwd_bnstats(...) before the
+ * gt_linear_bwd* call makes its epilogue also write part[gt_linear_bwd_bnstats_rows(M)][2][K]: per 64-row tile the sums of
+ * dy' and dy' * xhat (dy' = dy gated by the ReLU behind that BatchNorm) -- gt_batchnorm_bwd_parts then skips its own pass
+ * over dy and the BatchNorm input.  Only where gt_linear_bwd_bnstats_ok(...) says so (exact-fp32 path, fp32 rows, M >= 1024). */
+int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, int64_t M);
+int64_t gt_linear_bwd_bnstats_rows(int64_t M);
+int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w, const float* b,
+                          int relu, float* part);
 /* gt_linear_bwd with W^T [K][N] (fp32, gt_transpose) supplied by the caller, NULL = none: the exact-fp32 dX GEMM runs on the
  * transposed weight and otherwise transposes it in front of every call. */
 int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* weight_t,
@@ -564,6 +579,16 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
   const void* vn_next;
   void* ev_vn_next;
   const float* lin_wt; /* optional: lin_w transposed [D][D] (gt_transpose), for the backward's dX GEMM */
+  /* backward only, both optional.  This layer's d_h_in IS the dy of the previous layer's BatchNorm: with prev_saved (that
+   * layer's `saved` block: same N and D), its affine parameters and ReLU flag, the dX GEMM's epilogue writes the BatchNorm-
+   * backward partial sums into prev_bn_part[gt_linear_bwd_bnstats_rows(N)][2][D] (gt_linear_bwd_bnstats; the caller checks
+   * gt_linear_bwd_bnstats_ok and that no dropout follows that BatchNorm).  The previous layer's backward then gets the same
+   * buffer as bn_part_in / bn_nparts_in and skips its own statistics pass (gt_batchnorm_bwd_parts). */
+  const void* prev_saved;
+  const float *prev_bn_w, *prev_bn_b;
+  float* prev_bn_part;
+  const float* bn_part_in;
+  int32_t prev_relu, bn_nparts_in;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);

@@ -393,3 +393,31 @@ def test_device_built_token_layout_equals_the_host_built_one(max_input_len):
         assert abs(res[k][0] - res[k - 1][0]) <= 1e-6 * max(1.0, abs(res[k - 1][0]))
         for (n, _), a, c in zip(model.named_parameters(), res[k][1], res[k - 1][1]):
             assert torch.allclose(a, c, rtol=1e-5, atol=1e-7), (k, n, float((a - c).abs().max()))
+
+
+def test_batchnorm_backward_statistics_from_the_dx_epilogue():
+    """GCN without a virtual node at >= 1024 nodes in fp32 arithmetic: the previous layer's BatchNorm-backward column sums
+    come out of the dX GEMM's epilogue (gt_linear_bwd_bnstats / gt_batchnorm_bwd_parts) -- same gradients as the module
+    path, which runs the separate statistics pass."""
+    from graphtrans_amd import engine, losses, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    for kw in (dict(), dict(gnn_residual=True), dict(gnn_JK="last")):
+        args = _args(gnn_virtual_node=False, **kw)
+        torch.manual_seed(0)
+        model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV).train()
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+        b = synth.code2_like(B=24, seed=3, num_nodeattributes=300).to(DEV)
+        assert b.num_nodes >= 1024
+        y = torch.randint(0, 50, (24, 5), device=DEV)
+        assert engine.eligible(model, b, None)
+        ref_model = copy.deepcopy(model)
+        l0, g0, _ = _run(ref_model, b, y, False, 7)
+        l1, g1, _ = _run(model, b, y, True, 7)
+        assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
+        for n in g0:
+            scale = max(1.0, float(g0[n].abs().max()))
+            assert torch.allclose(g0[n] / scale, g1[n] / scale, rtol=1e-4, atol=2e-6), (kw, n, float((g0[n] - g1[n]).abs().max()))
