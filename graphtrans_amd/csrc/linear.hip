@@ -902,21 +902,24 @@ extern "C" int gt_linear_bwd_ld(int x_dtype, int y_dtype, int compute, const voi
                            K, ldy, dropout_p, workspace, workspace_bytes, stream_);
 }
 
-// y_for_mask of the gt_linear_bwd* call in flight on this thread is a MULTIPLIER (gt_linear_bwd_mul), not a forward output
-thread_local bool g_mul_mask = false;
-// the gt_linear_bwd* call in flight computes dW only and may still go to the overlap stream (gt_linear_bwd_dw_forked)
-thread_local bool g_fork_dw_only = false;
-// W^T [K][N] prepared by the caller for the gt_linear_bwd* call in flight (gt_linear_bwd_wt): the wide fp32 dX GEMM then
-// skips its own transpose launch
-thread_local const float* g_weight_t = nullptr;
-// BatchNorm-backward statistics to accumulate in the epilogue of the gt_linear_bwd* call in flight (gt_linear_bwd_bnstats)
-struct BnStatsReq {
+// Options of ONE gt_linear_bwd* call that the plain entry points do not carry in their signatures: the variant entry points
+// below set them for the duration of their call to gt_linear_bwd_grouped (per host thread; cleared when that call returns).
+struct BnStatsReq {   // BatchNorm-backward statistics to accumulate in the dX epilogue (gt_linear_bwd_bnstats)
   const float *x = nullptr, *mean = nullptr, *rstd = nullptr, *w = nullptr, *b = nullptr;
   float* part = nullptr;
   int64_t ldx = 0;
   int relu = 0;
 };
-thread_local BnStatsReq g_bns;
+struct BwdCallOpts {
+  bool mul_mask = false;             // y_for_mask is a MULTIPLIER (gt_linear_bwd_mul), not a forward output
+  bool fork_dw_only = false;         // dW-only call that may still go to the overlap stream (gt_linear_bwd_dw_forked)
+  const float* weight_t = nullptr;   // W^T [K][N] prepared by the caller (gt_linear_bwd_wt): no transpose launch
+  BnStatsReq bns;                    // set by gt_linear_bwd_bnstats BEFORE the call it applies to
+};
+thread_local BwdCallOpts g_opt;
+struct BwdOptScope {   // whatever was set is dropped when the call it was meant for returns
+  ~BwdOptScope() { g_opt = BwdCallOpts{}; }
+};
 
 extern "C" int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
@@ -937,7 +940,8 @@ extern "C" int64_t gt_linear_bwd_bnstats_rows(int64_t M) { return gt_cdiv(M, W32
 extern "C" int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w,
                                      const float* b, int relu, float* part) {
   GT_CHECK_ARG(bn_x && mean && rstd && w && b && part && ldx > 0, "null buffer");
-  g_bns.x = bn_x; g_bns.ldx = ldx; g_bns.mean = mean; g_bns.rstd = rstd; g_bns.w = w; g_bns.b = b; g_bns.relu = relu; g_bns.part = part;
+  BnStatsReq& q = g_opt.bns;
+  q.x = bn_x; q.ldx = ldx; q.mean = mean; q.rstd = rstd; q.w = w; q.b = b; q.relu = relu; q.part = part;
   return GT_OK;
 }
 
@@ -948,11 +952,9 @@ extern "C" int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const voi
                                 const void* dy, const void* y_for_mask, const void* dx_add1, const void* dx_add2, void* dx,
                                 float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
                                 size_t workspace_bytes, gt_stream_t stream_) {
-  g_weight_t = weight_t;
-  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N,
-                                       K, K, N, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
-  g_weight_t = nullptr;
-  return rc;
+  g_opt.weight_t = weight_t;
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, dweight, dbias, M, N, K, K, N,
+                               1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
 }
 // out [K][N] = in [N][K]^T (fp32)
 extern "C" int gt_transpose(const float* in, float* out, int64_t N, int64_t K, gt_stream_t stream_) {
@@ -969,11 +971,9 @@ extern "C" int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, co
                                        const void* y_for_mask, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K,
                                        int64_t ldx, int64_t ldy, float dropout_p, void* workspace, size_t workspace_bytes,
                                        gt_stream_t stream_) {
-  g_fork_dw_only = true;
-  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, nullptr, nullptr, nullptr, dweight, dbias,
-                                       M, N, K, ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
-  g_fork_dw_only = false;
-  return rc;
+  g_opt.fork_dw_only = true;
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, nullptr, nullptr, nullptr, dweight, dbias, M, N, K,
+                               ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
 }
 
 // backward of gt_linear_fwd_gelu: `gmul` is the multiplier that forward saved (dZ = dY * gmul); everything else as gt_linear_bwd_ld2
@@ -982,11 +982,9 @@ extern "C" int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const vo
                                  float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void* workspace,
                                  size_t workspace_bytes, gt_stream_t stream_) {
   GT_CHECK_ARG(gmul, "gt_linear_bwd_mul needs the multiplier");
-  g_mul_mask = true;
-  const int rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, gmul, dx_add1, dx_add2, dx, dweight, dbias, M, N, K,
-                                       ldx, ldy, 1, 0, 0, 0.f, workspace, workspace_bytes, stream_);
-  g_mul_mask = false;
-  return rc;
+  g_opt.mul_mask = true;
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, gmul, dx_add1, dx_add2, dx, dweight, dbias, M, N, K, ldx, ldy,
+                               1, 0, 0, 0.f, workspace, workspace_bytes, stream_);
 }
 
 extern "C" size_t gt_linear_bwd_grouped_workspace_bytes(int compute, int64_t M, int64_t N, int64_t K, int groups) {
@@ -998,7 +996,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
-  struct BnsDrop { ~BnsDrop() { g_bns = BnStatsReq{}; } } bns_drop__;   // a gt_linear_bwd_bnstats request lives for one call
+  BwdOptScope opt_scope__;   // the per-call options live for exactly this call
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
                                (N * K) % 4 == 0),
@@ -1019,7 +1017,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
   LinArgs a{};
   a.w = weight; a.a = dy; a.ymask = y_for_mask; a.x = x; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx;
   a.add1 = dx_add1; a.add2 = dx_add2;
-  a.inv_keep = g_mul_mask ? 0.f : 1.0f / (1.0f - dropout_p);   // 0 = multiplier mode (gt_gate)
+  a.inv_keep = g_opt.mul_mask ? 0.f : 1.0f / (1.0f - dropout_p);   // 0 = multiplier mode (gt_gate)
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
   if (M == 0) {
     if (dweight) (void)hipMemsetAsync(dweight, 0, (size_t)groups * N * K * sizeof(float), stream);
@@ -1043,7 +1041,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (dweight) {
       // forked only with a workspace to book it under: the kernel itself needs none, but gt_overlap_dw_release(range) is how the
       // caller learns when the dy / mask this GEMM reads (they live in the caller's workspace) may be overwritten
-      const bool forked = g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && workspace && workspace_bytes &&
+      const bool forked = g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && workspace && workspace_bytes &&
                           !(gt_prof_mask() & GT_PROF_LINEAR);
       if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
@@ -1066,7 +1064,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     }
     const int nt = w32_pick_nt(N);
     const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
-    const bool will_fork = g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
+    const bool will_fork = g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
     const int splits = w32_dw_splits(M, nkb, nnb, will_fork && !g_dw.urgent);
     float* part = reinterpret_cast<float*>(workspace);
     float* wt = part + (size_t)w32_dw_splits(M, nkb, nnb, false) * (size_t)(N * K + N) + 64;   // behind the larger partial area
@@ -1075,8 +1073,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
       // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
       // layer) -> wait for the forks that used this range (those on other workspaces keep running).
-      if (g_weight_t) {
-        wt = const_cast<float*>(g_weight_t);   // read only
+      if (g_opt.weight_t) {
+        wt = const_cast<float*>(g_opt.weight_t);   // read only
       } else {
         if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);
         hipLaunchKernelGGL(k_transpose32, dim3((unsigned)gt_cdiv(K, 32), (unsigned)gt_cdiv(N, 32)), dim3(256), 0, stream, weight, wt, N, K);
@@ -1084,9 +1082,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       L32Args w{};
       w.a = dy; w.amask = y_for_mask; w.w = wt; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
       w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldw = N; w.ldo = ldx; w.inv_keep = a.inv_keep;
-      if (g_bns.part && x_dtype == GT_F32 && y_dtype == GT_F32) {
-        w.bn_x = g_bns.x; w.bn_ldx = g_bns.ldx; w.bn_mean = g_bns.mean; w.bn_rstd = g_bns.rstd; w.bn_w = g_bns.w; w.bn_b = g_bns.b;
-        w.bn_relu = g_bns.relu; w.bn_part = g_bns.part;
+      if (g_opt.bns.part && x_dtype == GT_F32 && y_dtype == GT_F32) {
+        const BnStatsReq& q = g_opt.bns;
+        w.bn_x = q.x; w.bn_ldx = q.ldx; w.bn_mean = q.mean; w.bn_rstd = q.rstd; w.bn_w = q.w; w.bn_b = q.b;
+        w.bn_relu = q.relu; w.bn_part = q.part;
       }
       w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
@@ -1144,7 +1143,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     // gt_overlap_dw_begin/_end section it runs on the side stream beside dX and whatever follows.
     // (not while the launch profiler brackets this call: its events sit on the caller's stream only)
     bool forked = false;
-    if (g_dw.active && stream == g_dw.main && (dx || g_fork_dw_only) && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+    if (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
       stream = g_dw.side;
