@@ -760,8 +760,12 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   r.partial = (const float*)workspace; r.nblocks = grid; r.nslots = nslots; r.D = D; r.conv = conv; r.edge = edge_mode;
   r.K = (int)K; r.table_rows = (int)table_rows; r.d_self = d_self; r.d_w = d_edge_w; r.d_b = d_edge_b;
   int ctiles = (int)gt_cdiv(D, 64);
-  hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(256), 0, stream, r);
-  if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, stream, d_self, ctiles);
+  // the block partials only hold parameter gradients (root / eps, edge-encoder weights): their reduce goes to the overlap stream
+  // when there is one -- the next kernel of the backward (the dX GEMM) does not wait for it
+  hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, GT_PROF_AGGREGATE);
+  hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(256), 0, rstream, r);
+  if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, rstream, d_self, ctiles);
+  if (rstream != stream) gt_overlap_dw_booked(workspace, workspace_bytes);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -55,7 +55,7 @@ EncSaved enc_saved(const gt_encoder_layer* L, void* p) {
   return s;
 }
 struct EncWork {
-  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctx, *d_qkv, *lin_ws, *ln_ws;
+  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctx, *d_qkv, *lin_ws, *ln_ws, *ln_ws1;
   float* delta;
   size_t lin_ws_bytes, ln_ws_bytes, bytes;
 };
@@ -82,6 +82,7 @@ EncWork enc_work(const gt_encoder_layer* L, void* p) {
   w.lin_ws = b.take(m);
   w.ln_ws_bytes = gt_layernorm_bwd_workspace_bytes(R, d);
   w.ln_ws = b.take(w.ln_ws_bytes);
+  w.ln_ws1 = b.take(w.ln_ws_bytes);   // norm1's own: norm2's column finish (overlap stream) may still read ln_ws
   w.bytes = b.off;
   return w;
 }
@@ -297,7 +298,7 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
                          w.lin_ws_bytes, st));
   // x1 = LN1(x + drop(a))
   GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
-                          g.n1_w, g.n1_b, w.ln_ws, w.ln_ws_bytes, st));
+                          g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
   // a = ctx Wo^T + bo
   GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));

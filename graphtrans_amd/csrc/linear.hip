@@ -660,7 +660,7 @@ struct DwPending {
   uintptr_t lo, hi;   // workspace range a forked dW GEMM (partials + its reduce) still uses
   hipEvent_t ev;      // recorded on the side stream behind it
 };
-constexpr int DW_RING = 8;
+constexpr int DW_RING = 32;   // an encoder stage books 6 launches (4 dW GEMMs, 2 LayerNorm finishes), two stages are in flight
 struct DwOverlap {
   bool active = false;
   hipStream_t main = nullptr, side = nullptr;
@@ -1195,6 +1195,20 @@ extern "C" int gt_overlap_dw_sync(void) {
   if (!g_dw.active) return GT_OK;
   dw_join_all();
   return GT_OK;
+}
+// For the other entry points whose LAST launch only produces parameter gradients (the column finish of a LayerNorm backward,
+// the partial reduce of an aggregate backward): inside an overlap section on the section's main stream, returns the overlap
+// stream after ordering it behind everything queued on `stream` so far; otherwise `stream` itself.  A launch that went to the
+// overlap stream is then booked with gt_overlap_dw_booked(workspace it reads, bytes) so that gt_overlap_dw_release covers it.
+extern "C" gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned prof_category) {
+  // (not while the launch profiler brackets the caller's category: its events sit on the caller's stream only)
+  if (!g_dw.active || (hipStream_t)stream != g_dw.main || (gt_prof_mask() & prof_category)) return stream;
+  (void)hipEventRecord(g_dw.ev_fork, g_dw.main);
+  (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+  return (gt_stream_t)g_dw.side;
+}
+extern "C" void gt_overlap_dw_booked(const void* workspace, size_t bytes) {
+  if (g_dw.active) dw_forked(workspace, bytes);
 }
 extern "C" int gt_overlap_dw_urgent(int on) {
   g_dw.urgent = on != 0;

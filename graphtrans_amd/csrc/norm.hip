@@ -1012,8 +1012,11 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
-  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)workspace, grid,
+  // d gamma / d beta are parameter gradients: nothing on the critical path reads them -> the overlap stream when there is one
+  hipStream_t fstream = (hipStream_t)gt_overlap_dw_fork(stream_, GT_PROF_NORM);
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, fstream, (const float*)workspace, grid,
                      dim, dweight, dbias);
+  if (fstream != stream) gt_overlap_dw_booked(workspace, workspace_bytes);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

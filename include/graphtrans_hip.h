@@ -475,6 +475,11 @@ int gt_overlap_dw_release(const void* workspace, size_t bytes);
 /* the weight-gradient GEMMs forked from now on are the last work of the backward (the optimizer waits for them): they get the
  * chip-filling launch configuration instead of the one-block-per-CU configuration of an overlapped GEMM; reset by _begin */
 int gt_overlap_dw_urgent(int on);
+/* used by the entry points whose last launch only produces parameter gradients (gt_layernorm_bwd's column finish,
+ * gt_aggregate_bwd's partial reduce): the overlap stream, ordered behind `stream`, when `stream` is the main stream of an open
+ * overlap section -- else `stream`; a launch sent there is booked under the workspace it reads (gt_overlap_dw_release). */
+gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned profiler_category /* GT_PROF_* of the caller, 0 = none */);
+void gt_overlap_dw_booked(const void* workspace, size_t bytes);
 int gt_overlap_dw_end(void);
 
 int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
