@@ -808,6 +808,8 @@ class _FusedModel(torch.autograd.Function):
         s["fuse_bn"] = fuse_bn
         s["bn_rows"] = int(lib.gt_linear_bwd_bnstats_rows(N)) if fuse_bn else 0
         q["bnpart"] = [b.take(s["bn_rows"] * 2 * D * 4 if fuse_bn else 0) for _ in range(max(L - 1, 0))]
+        s["heads_ws_bytes"] = int(lib.gt_linear_bwd_workspace_bytes(compute, B, plan.Nh, d))
+        q["heads_ws"] = b.take(s["heads_ws_bytes"])   # the heads' dW partials: their own buffer (see the heads stage below)
         q["ws"] = [b.take(ws_bytes), b.take(ws_bytes)]   # alternated between consecutive stages (see W() below)
         q["ws2"] = b.take(s["ws2_bytes"])
         seg_ws_bytes = lib.gt_segment_sum_workspace_bytes(N, D) if plan.has_vn else 0
@@ -863,15 +865,19 @@ class _FusedModel(torch.autograd.Function):
             return p
 
         # ---- heads
+        # the weight gradient first (256 x 25 010 x 128: 85 us): forked onto the overlap stream it runs beside the heads' own dX
+        # GEMM and the stages after it, in a buffer of its own -- the dX GEMM's split-N partials take the stage's workspace
+        _call("gt_linear_bwd_dw_forked", GT_F32, GT_F32, compute, P("hg"), s["wcat"], dl.data_ptr(), None, G + plan.headw_off * 4,
+              G + plan.headb_off * 4, B, plan.Nh, d, d, plan.ldy, 0.0, Q("heads_ws"), s["heads_ws_bytes"], st)
         _call("gt_linear_bwd_ld", GT_F32, GT_F32, compute, P("hg"), s["wcat"], dl.data_ptr(), None, None, None, Q("d_hg"),
-              G + plan.headw_off * 4, G + plan.headb_off * 4, B, plan.Nh, d, plan.ldy, 0.0, W(), ws_bytes, st)
+              None, None, B, plan.Nh, d, plan.ldy, 0.0, W(), ws_bytes, st)
         # ---- pooled rows -> token rows
         dcur, dnext = Q("dtok", 0), Q("dtok", 1)
         _call("gt_rows_scatter", tdt, Q("d_hg"), lay.last_rows.data_ptr(), B, rows, d, dcur, st)
         if plan.norm_out is not None:
             ln = plan.norm_out
             _call("gt_layernorm_bwd", tdt, s["pre_out"], None, dcur, ln.weight.data_ptr(), P("sto"), P("sto") + rows * 4, 0.0, 0,
-                  rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, W(True), ws_bytes, st)
+                  rows, d, dnext, None, G + plan.norm_out_off[0] * 4, G + plan.norm_out_off[1] * 4, W(), ws_bytes, st)
             dcur, dnext = dnext, dcur
         for i in range(nenc - 1, -1, -1):
             _call("gt_encoder_layer_bwd", C.byref(s["enc_desc"][i]), s["enc_in"][i], dcur, P("enc_saved", i), dnext,
