@@ -713,6 +713,12 @@ int pick_bm(int64_t M) {
 
 
 // ---- short-M path (linear_small.h): one wave per output tile pair, no LDS, no partials ---------------------------------------
+// forward and dW of a short-M GEMM with a WIDE output (the 5 x 5002-way prediction heads, models/gnn_transformer.py:120-126: 256 rows
+// x 25 010 columns): the one-wave-per-tile kernels have no limit on N (their work list just grows); only the dX form would walk N
+// as its contraction and stays on the tiled split-N kernel
+bool small_wide_ok(int x_dtype, int y_dtype, int64_t M, int64_t K, int64_t ldx, int64_t ldy, int groups) {
+  return groups == 1 && x_dtype == GT_F32 && y_dtype == GT_F32 && M > 0 && M <= 512 && K <= 2048 && ldx % 4 == 0 && ldy % 4 == 0;
+}
 bool small_eligible(int x_dtype, int y_dtype, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups) {
   return groups == 1 && x_dtype == GT_F32 && y_dtype == GT_F32 && M > 0 && M <= 512 && N <= 2048 && K <= 2048 && ldx % 4 == 0 && ldy % 4 == 0;
 }
@@ -846,7 +852,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act; a.gout = gout;
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
-  if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups)) {
+  if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) || small_wide_ok(x_dtype, y_dtype, M, K, ldx, ldy, groups)) {
     SmallArgs sa{};
     sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
     sa.act = act; sa.gout = (float*)gout; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
@@ -1132,6 +1138,25 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       hipLaunchKernelGGL(k_split_reduce, dim3(rg), dim3(256), 0, stream, (const float*)workspace, splits, len,
                          reinterpret_cast<float*>(dx), (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);
     }
+  }
+  if (dweight && small_wide_ok(x_dtype, y_dtype, M, K, ldx, ldy, groups)) {   // wide short-M GEMM: dW on the one-wave-per-tile kernel
+    const bool forked = g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && a.splits <= 1 && workspace && workspace_bytes &&
+                        !(gt_prof_mask() & GT_PROF_LINEAR);
+    if (forked) {
+      (void)hipEventRecord(g_dw.ev_fork, stream);
+      (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+      stream = g_dw.side;
+    }
+    SmallArgs sa{};
+    sa.x = (const float*)x; sa.w = weight; sa.dy = (const float*)dy; sa.ymask = (const float*)y_for_mask;
+    sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy; sa.inv_keep = a.inv_keep;
+    sa.out = dweight; sa.db = dbias;
+    const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(N, 32) * gt_cdiv(K, 16), 4);
+    if (compute == GT_F32) hipLaunchKernelGGL(k_small_dw<float>, dim3(blocks), dim3(256), 0, stream, sa);
+    else hipLaunchKernelGGL(k_small_dw<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    if (forked) dw_forked(workspace, workspace_bytes);
+    GT_CHECK_LAUNCH();
+    return GT_OK;
   }
   if (dweight) {
     const int splits = dw_splits(M, N, K, compute);

@@ -24,7 +24,7 @@ def timeit(fn, n=iters, warm=5):
     return s.elapsed_time(e) / n * 1e3
 
 
-for M, N, K in ((31598, 300, 300), (31598, 128, 600), (131072, 256, 256), (6651, 600, 300)):
+for M, N, K in ((31598, 300, 300), (31598, 128, 600), (131072, 256, 256), (6651, 600, 300), (256, 25012, 128), (256, 600, 300)):
     x, w, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV), torch.randn(N, device=DEV)
     g, y, dx = torch.randn(M, N, device=DEV), torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV)
     dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
