@@ -712,6 +712,26 @@ int pick_bm(int64_t M) {
 }
 
 
+// Short-M launches: a wave per tile pair when the tiles alone fill the chip, else the four waves of a block split the contraction
+// of one tile pair (see small_combine in linear_small.h).
+enum SmallKind { SMALL_FWD, SMALL_DX, SMALL_DW };
+static inline void small_launch(SmallKind kind, int compute, int64_t tiles, int64_t contraction, hipStream_t stream, const SmallArgs& sa) {
+  const bool sk = tiles <= 2048 && contraction >= 128;
+  const unsigned blocks = (unsigned)(sk ? tiles : gt_cdiv(tiles, 4));
+#define GT_SMALL_GO(KERNEL)                                                                                              \
+  do {                                                                                                                    \
+    if (compute == GT_F32) { if (sk) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(blocks), dim3(256), 0, stream, sa);      \
+                             else hipLaunchKernelGGL((KERNEL<float, 1>), dim3(blocks), dim3(256), 0, stream, sa); }       \
+    else { if (sk) hipLaunchKernelGGL((KERNEL<gt_bf16, 4>), dim3(blocks), dim3(256), 0, stream, sa);                      \
+           else hipLaunchKernelGGL((KERNEL<gt_bf16, 1>), dim3(blocks), dim3(256), 0, stream, sa); }                       \
+  } while (0)
+  if (kind == SMALL_FWD) GT_SMALL_GO(k_small_fwd);
+  else if (kind == SMALL_DX) GT_SMALL_GO(k_small_dx);
+  else GT_SMALL_GO(k_small_dw);
+#undef GT_SMALL_GO
+}
+
+
 // ---- short-M path (linear_small.h): one wave per output tile pair, no LDS, no partials ---------------------------------------
 // forward and dW of a short-M GEMM with a WIDE output (the 5 x 5002-way prediction heads, models/gnn_transformer.py:120-126: 256 rows
 // x 25 010 columns): the one-wave-per-tile kernels have no limit on N (their work list just grows); only the dX form would walk N
@@ -856,9 +876,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     SmallArgs sa{};
     sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
     sa.act = act; sa.gout = (float*)gout; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
-    const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(M, 16) * gt_cdiv(N, 32), 4);
-    if (compute == GT_F32) hipLaunchKernelGGL(k_small_fwd<float>, dim3(blocks), dim3(256), 0, stream, sa);
-    else hipLaunchKernelGGL(k_small_fwd<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    small_launch(SMALL_FWD, compute, gt_cdiv(M, 16) * gt_cdiv(N, 32), K, stream, sa);
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
@@ -1040,9 +1058,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     sa.inv_keep = a.inv_keep;
     if (dx) {
       sa.out = (float*)dx;
-      const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(M, 16) * gt_cdiv(K, 32), 4);
-      if (compute == GT_F32) hipLaunchKernelGGL(k_small_dx<float>, dim3(blocks), dim3(256), 0, stream, sa);
-      else hipLaunchKernelGGL(k_small_dx<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+      small_launch(SMALL_DX, compute, gt_cdiv(M, 16) * gt_cdiv(K, 32), N, stream, sa);
     }
     if (dweight) {
       // forked only with a workspace to book it under: the kernel itself needs none, but gt_overlap_dw_release(range) is how the
@@ -1055,9 +1071,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         stream = g_dw.side;
       }
       sa.out = dweight; sa.db = dbias;
-      const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(N, 32) * gt_cdiv(K, 16), 4);
-      if (compute == GT_F32) hipLaunchKernelGGL(k_small_dw<float>, dim3(blocks), dim3(256), 0, stream, sa);
-      else hipLaunchKernelGGL(k_small_dw<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+      small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
       if (forked) dw_forked(workspace, workspace_bytes);
     }
     GT_CHECK_LAUNCH();
@@ -1151,9 +1165,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     sa.x = (const float*)x; sa.w = weight; sa.dy = (const float*)dy; sa.ymask = (const float*)y_for_mask;
     sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy; sa.inv_keep = a.inv_keep;
     sa.out = dweight; sa.db = dbias;
-    const unsigned blocks = (unsigned)gt_cdiv(gt_cdiv(N, 32) * gt_cdiv(K, 16), 4);
-    if (compute == GT_F32) hipLaunchKernelGGL(k_small_dw<float>, dim3(blocks), dim3(256), 0, stream, sa);
-    else hipLaunchKernelGGL(k_small_dw<gt_bf16>, dim3(blocks), dim3(256), 0, stream, sa);
+    small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
     if (forked) dw_forked(workspace, workspace_bytes);
     GT_CHECK_LAUNCH();
     return GT_OK;
