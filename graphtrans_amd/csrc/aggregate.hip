@@ -19,12 +19,14 @@
 //   accumulated in registers (Linear) or per-wave LDS rows (embedding tables), reduced per block
 //   and finished by a second kernel in a fixed order.
 #include "gt_common.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
 constexpr int AGG_THREADS = 256;
 constexpr int AGG_WAVES = AGG_THREADS / GT_WAVE;
-constexpr int BWD_BLOCKS = 2048;  // upper bound (sizes the partial workspace); the launch takes ~16 nodes per wave-tile
+constexpr int BWD_BLOCKS = 2048;  // upper bound (sizes the partial workspace); the launch takes one round of resident blocks (bwd_grid)
 constexpr int MAX_K = 4;
 // internal edge mode: Linear edge encoder with K <= 2 (the Code2 case, dataset/code.py:117): half the
 // weight registers / accumulators of the generic K <= 4 variant -> higher occupancy
@@ -578,12 +580,82 @@ __global__ void k_eps_finish(float* d_self, int ntiles) {
   }
 }
 
+#include "aggregate_wide.h"
+
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
+// fp32 rows of 257..448 columns that split evenly over the lanes take the W-floats-per-lane kernels (aggregate_wide.h)
+template <typename T>
+__host__ inline int wide_w(int64_t D) {
+  if constexpr (!std::is_same<T, float>::value) return 0;
+#ifdef AGGW_DISABLE
+  return 0;
+#endif
+  if (D <= 256 || D > 448) return 0;
+  const int w = (int)gt_cdiv(D, 64);
+  return D % w == 0 ? w : 0;
+}
+
+// Persistent backward grid.  Every wave-tile walks N / tiles source nodes one after the other, so the launch takes as long as one
+// walk times the number of ROUNDS of resident blocks: the grid is the largest that is resident at once (registers / LDS of this
+// instantiation, asked of the runtime once), i.e. the shortest walks that still finish in one round -- 1.08 rounds cost two
+// (Molpcba: 555 blocks 51 us, 416 blocks 38 us).  Depends on (kernel, N) only: the partial sums stay reproducible.
+inline int bwd_grid(void (*kernel)(AggArgs), size_t lds_bytes, int64_t N, int npw) {
+  struct Seen { const void* k; size_t lds; int per_cu; };
+  static Seen seen[64];
+  static int nseen = 0, cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  int per_cu = 0;
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].k == (const void*)kernel && seen[i].lds == lds_bytes) per_cu = seen[i].per_cu;
+  if (!per_cu) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, AGG_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (nseen < 64) seen[nseen++] = Seen{(const void*)kernel, lds_bytes, per_cu};
+  }
+  int64_t cap = (int64_t)cus * per_cu;
+  if (cap > BWD_BLOCKS) cap = BWD_BLOCKS;
+  int64_t nodes = gt_cdiv(N > 0 ? N : 1, cap * AGG_WAVES * npw);   // per wave-tile
+  if (nodes < 2) nodes = 2;
+  if (const char* e = getenv("GT_AGG_BWD_NODES")) nodes = atoi(e);
+  return (int)gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw * nodes), AGG_WAVES);
+}
+
+template <int W, int EDGE, bool GCN, bool BWD>
+void launch_wide_conv(const AggArgs& a, size_t lds_bytes, int* grid_bwd, hipStream_t stream) {
+  if constexpr (BWD) {
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)(k_aggw_bwd<W, EDGE, GCN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    *grid_bwd = bwd_grid(k_aggw_bwd<W, EDGE, GCN>, lds_bytes, a.N, 1);
+    hipLaunchKernelGGL((k_aggw_bwd<W, EDGE, GCN>), dim3(*grid_bwd), dim3(AGG_THREADS), lds_bytes, stream, a);
+  } else {
+    const int64_t waves = gt_cdiv(a.N, a.chunk);
+    hipLaunchKernelGGL((k_aggw_fwd<W, EDGE, GCN>), dim3((unsigned)(gt_cdiv(gt_cdiv(waves, AGG_WAVES), 8) * 8)), dim3(AGG_THREADS),
+                       lds_bytes, stream, a);
+  }
+}
+
+template <int W, int EDGE, bool BWD>
+void launch_wide(const AggArgs& a0, size_t lds_bytes, int* grid_bwd, hipStream_t stream) {
+  AggArgs a = a0;
+  if (a.E == 0) a.nbr = a.eid = a.ptr;   // the index prefetch reads entry 0 unconditionally: any readable int32 will do
+  if (a.conv == GT_CONV_GCN) launch_wide_conv<W, EDGE, true, BWD>(a, lds_bytes, grid_bwd, stream);
+  else launch_wide_conv<W, EDGE, false, BWD>(a, lds_bytes, grid_bwd, stream);
+}
+
 template <typename T, int EDGE, bool BWD>
-int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t stream) {
+int launch_cfg(const AggArgs& a, size_t lds_bytes, int* grid_bwd, hipStream_t stream) {
   const int64_t D = a.D;
+  switch (wide_w<T>(D)) {
+    case 5: launch_wide<5, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
+    case 6: launch_wide<6, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
+    case 7: launch_wide<7, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
+    default: break;
+  }
 #define GT_AGG_LAUNCH(LPN, NCH)                                                                              \
   do {                                                                                                       \
     constexpr int NPW = 64 / (LPN);                                                                          \
@@ -591,7 +663,8 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
       if (lds_bytes > 48 * 1024)                                                                             \
         (void)hipFuncSetAttribute((const void*)(k_agg_bwd<T, LPN, NCH, EDGE>),                              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
-      hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(grid_bwd), dim3(AGG_THREADS), lds_bytes,      \
+      *grid_bwd = bwd_grid(k_agg_bwd<T, LPN, NCH, EDGE>, lds_bytes, a.N, NPW);                              \
+      hipLaunchKernelGGL((k_agg_bwd<T, LPN, NCH, EDGE>), dim3(*grid_bwd), dim3(AGG_THREADS), lds_bytes,     \
                          stream, a);                                                                         \
     } else {                                                                                                 \
       int64_t waves = gt_cdiv(a.N, NPW * a.chunk);                                                           \
@@ -610,7 +683,7 @@ int launch_cfg(const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t str
 }
 
 template <typename T, bool BWD>
-int launch_edge(int edge_mode, const AggArgs& a, size_t lds_bytes, int grid_bwd, hipStream_t stream) {
+int launch_edge(int edge_mode, const AggArgs& a, size_t lds_bytes, int* grid_bwd, hipStream_t stream) {
   switch (edge_mode) {
     case GT_EDGE_NONE: return launch_cfg<T, GT_EDGE_NONE, BWD>(a, lds_bytes, grid_bwd, stream);
     case GT_EDGE_LINEAR:
@@ -685,6 +758,7 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
     const int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
     int64_t c = N / (4096 * npw);
     a.chunk = (int)(c < 1 ? 1 : (c > FWD_CHUNK ? FWD_CHUNK : c));
+    if (const char* e = getenv("GT_AGG_FWD_CHUNK")) a.chunk = atoi(e);
   }
   // embedding-table edge encoders: the (few) table rows are parked in LDS per block when they fit
   size_t fwd_lds = 0;
@@ -692,8 +766,8 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
     a.table_rows = (int)table_rows;
     fwd_lds = (size_t)table_rows * D * 4;
   }
-  rc = dtype == GT_F32 ? launch_edge<float, false>(edge_mode, a, fwd_lds, 0, stream)
-                       : launch_edge<gt_bf16, false>(edge_mode, a, fwd_lds, 0, stream);
+  rc = dtype == GT_F32 ? launch_edge<float, false>(edge_mode, a, fwd_lds, nullptr, stream)
+                       : launch_edge<gt_bf16, false>(edge_mode, a, fwd_lds, nullptr, stream);
   if (rc != GT_OK) return rc;
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -736,15 +810,7 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   GtProfScope prof__(GT_PROF_AGGREGATE, "gt_aggregate_bwd", stream_, {N, E, D, dtype == GT_F32 ? 4 : 2,
                      edge_mode == GT_EDGE_LINEAR ? K * 4 : (edge_mode == GT_EDGE_TABLES ? K * 8 : 0), edge_mode});
   const int nslots = bwd_slots(edge_mode, K, table_rows);
-  // persistent grid: enough wave-tiles to cover N, capped at BWD_BLOCKS
-  int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
-  // ~16 source nodes per wave-tile: measured best on both the Code2 batch (31.6 k nodes: 512 blocks, 105 -> 97 us)
-  // and the 131 k-node stress batch (2048 blocks); fewer, longer walks lose parallelism, more blocks only add
-  // partial rows to reduce.
-  int64_t min_nodes = N / (2048 * npw);   // small batches: shorter walks, so that ~2048 wave-tiles still exist
-  min_nodes = min_nodes < 2 ? 2 : (min_nodes > 32 ? 32 : min_nodes);
-  int64_t want = gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw * min_nodes), AGG_WAVES);
-  int grid = (int)(want < BWD_BLOCKS ? want : BWD_BLOCKS);
+  int grid = 0;   // chosen per kernel instantiation (bwd_grid)
   AggArgs a{};
   a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.g = grad_out; a.ptr = out_ptr; a.nbr = out_dst;
   a.eid = out_eid; a.deg = deg; a.dis = dis; a.self_param = self_param; a.attr = edge_attr; a.w = edge_w;
@@ -753,8 +819,8 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   if (edge_mode == GT_EDGE_TABLES)
     for (int k = 0; k < K; ++k) a.tab_off[k] = tab_off_host[k];
   size_t lds = bwd_lds_bytes(edge_mode, D, table_rows);
-  rc = dtype == GT_F32 ? launch_edge<float, true>(edge_mode, a, lds, grid, stream)
-                       : launch_edge<gt_bf16, true>(edge_mode, a, lds, grid, stream);
+  rc = dtype == GT_F32 ? launch_edge<float, true>(edge_mode, a, lds, &grid, stream)
+                       : launch_edge<gt_bf16, true>(edge_mode, a, lds, &grid, stream);
   if (rc != GT_OK) return rc;
   ReduceArgs r{};
   r.partial = (const float*)workspace; r.nblocks = grid; r.nslots = nslots; r.D = D; r.conv = conv; r.edge = edge_mode;
