@@ -20,7 +20,6 @@
 //   and finished by a second kernel in a fixed order.
 #include "gt_common.h"
 #include <type_traits>
-#include <cstdlib>
 
 namespace {
 
@@ -621,7 +620,6 @@ inline int bwd_grid(void (*kernel)(AggArgs), size_t lds_bytes, int64_t N, int np
   if (cap > BWD_BLOCKS) cap = BWD_BLOCKS;
   int64_t nodes = gt_cdiv(N > 0 ? N : 1, cap * AGG_WAVES * npw);   // per wave-tile
   if (nodes < 2) nodes = 2;
-  if (const char* e = getenv("GT_AGG_BWD_NODES")) nodes = atoi(e);
   return (int)gt_cdiv(gt_cdiv(N > 0 ? N : 1, npw * nodes), AGG_WAVES);
 }
 
@@ -758,7 +756,6 @@ extern "C" int gt_aggregate_fwd(int conv, int edge_mode, int dtype, const void* 
     const int64_t npw = D <= 64 ? 4 : (D <= 128 ? 2 : 1);
     int64_t c = N / (4096 * npw);
     a.chunk = (int)(c < 1 ? 1 : (c > FWD_CHUNK ? FWD_CHUNK : c));
-    if (const char* e = getenv("GT_AGG_FWD_CHUNK")) a.chunk = atoi(e);
   }
   // embedding-table edge encoders: the (few) table rows are parked in LDS per block when they fit
   size_t fwd_lds = 0;

@@ -12,9 +12,6 @@
 #ifndef AGGW_U
 #define AGGW_U 2   // edges gathered per trip
 #endif
-#ifndef AGGW_WAVES
-#define AGGW_WAVES 1
-#endif
 
 template <int W>
 struct Row {
@@ -226,7 +223,7 @@ __global__ void __launch_bounds__(AGG_THREADS) k_aggw_fwd(AggArgs a) {
 
 // ---- backward ------------------------------------------------------------------------------------------------------------
 template <int W, int EDGE, bool GCN>
-__global__ void __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_waves_per_eu(AGGW_WAVES))) k_aggw_bwd(AggArgs a) {
+__global__ void __launch_bounds__(AGG_THREADS) k_aggw_bwd(AggArgs a) {
   constexpr int NREG = reg_slots<EDGE>();
   constexpr int UB = AGGW_U;
   extern __shared__ __attribute__((aligned(16))) float lds[];

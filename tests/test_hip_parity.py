@@ -114,7 +114,11 @@ def test_conv_golden(name):
     ("gcn", "linear", 300, torch.float32), ("gin", "linear", 300, torch.float32), ("gcn", "none", 128, torch.float32),
     ("gin", "bond", 300, torch.float32), ("gcn", "dense", 272, torch.float32), ("gcn", "linear", 1024, torch.float32),
     ("gcn", "linear", 300, torch.bfloat16), ("gin", "bond", 128, torch.bfloat16),
-    ("gcn", "linear", 256, torch.float32), ("gcn", "linear", 256, torch.bfloat16)])   # D = 256: the ER stress config (C5)
+    ("gcn", "linear", 256, torch.float32), ("gcn", "linear", 256, torch.bfloat16),   # D = 256: the ER stress config (C5)
+    # the W-floats-per-lane kernels (aggregate_wide.h): W = 5 (300, 320), 6 (384), 7 (448) x every edge mode / conv
+    ("gcn", "dense", 300, torch.float32), ("gin", "none", 300, torch.float32), ("gcn", "bond", 320, torch.float32),
+    ("gin", "linear", 384, torch.float32), ("gcn", "bond", 384, torch.float32), ("gin", "dense", 448, torch.float32),
+    ("gcn", "linear", 448, torch.float32), ("gcn", "none", 360, torch.float32)])
 def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     """Seeded Code2 / Molpcba-shaped batches at the real emb dims; checked against the CPU oracle
     (gcn_aggregate / gin_aggregate) incl. every parameter gradient."""
@@ -174,6 +178,34 @@ def test_aggregate_vs_oracle(conv_name, edge, D, dtype):
     if enc is not None:
         for k, p in enc_d.named_parameters():
             assert_close(p.grad.cpu(), ref_pg[k], atol=tol, rtol=tol, what=f"d {k}")
+
+
+@pytest.mark.parametrize("conv_name", ["gcn", "gin"])
+@pytest.mark.parametrize("D", [128, 300])
+def test_aggregate_without_edges(conv_name, D):
+    """A batch of isolated nodes (E = 0): only the self term is left, forward and backward."""
+    from graphtrans_amd import ops
+    from graphtrans_amd.graph import GraphStructure
+
+    torch.manual_seed(2)
+    N = 37
+    ei = torch.zeros(2, 0, dtype=torch.long, device=DEV)
+    batch = torch.arange(N, device=DEV) // 5
+    gs = GraphStructure.build(ei, batch, num_graphs=int(batch.max()) + 1)
+    h = torch.randn(N, D, device=DEV, requires_grad=True)
+    sp = (torch.randn(1, D, device=DEV) * 0.3 if conv_name == "gcn" else torch.tensor([0.3], device=DEV)).requires_grad_(True)
+    lin = torch.nn.Linear(2, D).to(DEV)
+    spec = ops.EdgeSpec("linear", attr=torch.zeros(0, 2, device=DEV), weight=lin.weight, bias=lin.bias)
+    w = torch.randn(N, D, device=DEV)
+    out = ops.aggregate(h, gs, conv_name, sp, spec)
+    (out * w).sum().backward()
+    h_ref = h.detach().clone().requires_grad_(True)
+    sp_ref = sp.detach().clone().requires_grad_(True)
+    ref = torch.relu(h_ref + sp_ref) if conv_name == "gcn" else (1 + sp_ref) * h_ref   # deg = 1 (the self loop), conv.py:63-65
+    (ref * w).sum().backward()
+    assert_close(out.detach().cpu(), ref.detach().cpu(), what="out")
+    assert_close(h.grad.cpu(), h_ref.grad.cpu(), what="dh")
+    assert_close(sp.grad.cpu(), sp_ref.grad.cpu(), what="d self_param")
 
 
 def test_aggregate_is_deterministic_and_edge_order_invariant():
