@@ -84,6 +84,7 @@ SIGNATURES = {
     "gt_stream_destroy": (None, [_p]),
     "gt_stream_priority_range": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "gt_linear_bwd_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
+    "gt_linear_bwd_mul_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
     "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),

@@ -522,8 +522,10 @@ struct ReduceArgs {
   float* d_b;
 };
 
-__global__ void __launch_bounds__(256) k_agg_reduce(ReduceArgs r) {
-  __shared__ float sm[4][64];
+constexpr int RED_WAVES = 8;    // the backward leaves ~1000 partial rows (one round of resident blocks): 8 waves x 8 loads in flight
+                                // keep the chain of dependent round trips at 16 (4 waves: 31, 43 us for a 20-block kernel; 1024-thread blocks wait for a CU with 16 free slots)
+__global__ void __launch_bounds__(RED_WAVES * 64) k_agg_reduce(ReduceArgs r) {
+  __shared__ float sm[RED_WAVES][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int slot = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -535,17 +537,19 @@ __global__ void __launch_bounds__(256) k_agg_reduce(ReduceArgs r) {
     const float* p = r.partial + (int64_t)slot * r.D + c;
     const int64_t stride = (int64_t)r.nslots * r.D;
     int b = wid;
-    for (; b + 28 < r.nblocks; b += 32) {
+    for (; b + 7 * RED_WAVES < r.nblocks; b += 8 * RED_WAVES) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(b + 4 * u) * stride];
+      for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(b + RED_WAVES * u) * stride];
     }
-    for (; b < r.nblocks; b += 4) acc[0] += p[(int64_t)b * stride];
+    for (; b < r.nblocks; b += RED_WAVES) acc[0] += p[(int64_t)b * stride];
     t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   sm[wid][lane] = t;
   __syncthreads();
   if (wid != 0) return;
-  t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+  t = 0.f;
+#pragma unroll
+  for (int w = 0; w < RED_WAVES; ++w) t += sm[w][lane];
   if (slot == 0) {
     if (r.conv == GT_CONV_GCN) {
       if (c < r.D && r.d_self) r.d_self[c] = t;
@@ -826,7 +830,7 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   // the block partials only hold parameter gradients (root / eps, edge-encoder weights): their reduce goes to the overlap stream
   // when there is one -- the next kernel of the backward (the dX GEMM) does not wait for it
   hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, GT_PROF_AGGREGATE);
-  hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(256), 0, rstream, r);
+  hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(RED_WAVES * 64), 0, rstream, r);
   if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, rstream, d_self, ctiles);
   if (rstream != stream) gt_overlap_dw_booked(workspace, workspace_bytes);
   GT_CHECK_LAUNCH();

@@ -1000,6 +1000,17 @@ extern "C" int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, co
                                ldx, ldy, 1, 0, 0, dropout_p, workspace, workspace_bytes, stream_);
 }
 
+// gt_linear_bwd_dw_forked for a layer whose forward saved a multiplier (gt_linear_fwd_gelu): dZ = dY * gmul
+extern "C" int gt_linear_bwd_mul_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                           const void* gmul, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K,
+                                           int64_t ldx, int64_t ldy, void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  GT_CHECK_ARG(gmul, "gt_linear_bwd_mul_dw_forked needs the multiplier");
+  g_opt.fork_dw_only = true;
+  g_opt.mul_mask = true;
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, gmul, nullptr, nullptr, nullptr, dweight, dbias, M, N, K, ldx,
+                               ldy, 1, 0, 0, 0.f, workspace, workspace_bytes, stream_);
+}
+
 // backward of gt_linear_fwd_gelu: `gmul` is the multiplier that forward saved (dZ = dY * gmul); everything else as gt_linear_bwd_ld2
 extern "C" int gt_linear_bwd_mul(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                  const void* gmul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,

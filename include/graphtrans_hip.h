@@ -470,6 +470,9 @@ int gt_transpose(const float* in /* [N][K] */, float* out /* [K][N] */, int64_t 
 int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                             const void* y_for_mask, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx,
                             int64_t ldy, float dropout_p, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+int gt_linear_bwd_mul_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                const void* gmul, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                int64_t ldy, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 int gt_overlap_dw_sync(void);
 int gt_overlap_dw_release(const void* workspace, size_t bytes);
 /* the weight-gradient GEMMs forked from now on are the last work of the backward (the optimizer waits for them): they get the
