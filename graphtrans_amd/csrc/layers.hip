@@ -55,9 +55,9 @@ EncSaved enc_saved(const gt_encoder_layer* L, void* p) {
   return s;
 }
 struct EncWork {
-  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctx, *d_qkv, *lin_ws, *lin_ws_in, *ln_ws, *ln_ws1;
+  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctx, *d_qkv, *lin_ws, *ln_ws, *ln_ws1;
   float* delta;
-  size_t lin_ws_bytes, lin_ws_in_bytes, ln_ws_bytes, bytes;
+  size_t lin_ws_bytes, ln_ws_bytes, bytes;
 };
 EncWork enc_work(const gt_encoder_layer* L, void* p) {
   Bump b(p);
@@ -80,9 +80,6 @@ EncWork enc_work(const gt_encoder_layer* L, void* p) {
   q = gt_linear_bwd_workspace_bytes(c, R, d, F); m = q > m ? q : m;
   w.lin_ws_bytes = m;
   w.lin_ws = b.take(m);
-  // in_proj's weight gradient runs on the caller's stream while the three forked ones may still own lin_ws: its own partials
-  w.lin_ws_in_bytes = gt_linear_bwd_workspace_bytes(c, R, 3 * d, d);
-  w.lin_ws_in = b.take(w.lin_ws_in_bytes);
   w.ln_ws_bytes = gt_layernorm_bwd_workspace_bytes(R, d);
   w.ln_ws = b.take(w.ln_ws_bytes);
   w.ln_ws1 = b.take(w.ln_ws_bytes);   // norm1's own: norm2's column finish (overlap stream) may still read ln_ws
@@ -286,45 +283,33 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   const int64_t R = L->rows, d = L->d_model, F = L->ffn;
   const float p = L->training ? L->dropout_p : 0.f;
   const float scale = 1.0f / sqrtf((float)(d / L->nhead));
-  // Where the weight-gradient GEMMs go.  Inside an overlap section a dW-ONLY call with gt_linear_bwd_dw_forked runs on the overlap
-  // stream, a plain dW-only call on `st`; and gt_layernorm_bwd waits for the overlap stream before its row pass (see there).  So a
-  // dW is forked only where the LayerNorm backwards leave it a long stretch of main-stream work to hide behind:
-  //   LN2 | dX(l2) dX(l1) | LN1 | fork dW(l2) dW(l1) dW(out) || dX(out) attention dX(in) dW(in) | the next stage's LN2 ...
-  // (in_proj's dW stays on `st`: forked it would be what that LN2 waits for -- measured 1.8 % slower on Code2, 3 % on Molpcba;
-  // deferring it behind that LN2 instead: 1.5 % / 2.7 % slower.)  Outside a section everything simply runs in this order on `st`.
   // x2 = LN2(x1 + drop(f2))
   GT_TRY(gt_layernorm_bwd(t, s.f2, s.x1, dy, L->n2_w, s.st2, s.st2 + R, p, L->seed ^ 0x14057B7EF767814FULL, R, d, w.d_f2,
                           w.d_x1, g.n2_w, g.n2_b, w.ln_ws, w.ln_ws_bytes, st));
   // f2 = f1 W2^T + b2
-  GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, nullptr, nullptr, R, d, F, 0.f,
+  GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));
   // f1 = drop(relu(x1 W1^T + b1)) ; d_x1 += ...
   if (L->act == 1)
-    GT_TRY(gt_linear_bwd_mul(t, t, c, s.x1, L->l1_w, w.d_f1, s.g1, w.d_x1, nullptr, w.d_x1, nullptr, nullptr, R, F, d, d, F, w.lin_ws,
+    GT_TRY(gt_linear_bwd_mul(t, t, c, s.x1, L->l1_w, w.d_f1, s.g1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, d, F, w.lin_ws,
                              w.lin_ws_bytes, st));
   else
-    GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, nullptr, nullptr, R, F, d, p, w.lin_ws,
+    GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, p, w.lin_ws,
                          w.lin_ws_bytes, st));
   // x1 = LN1(x + drop(a))
   GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
                           g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
-  GT_TRY(gt_linear_bwd_dw_forked(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, g.l2_w, g.l2_b, R, d, F, F, d, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-  if (L->act == 1)
-    GT_TRY(gt_linear_bwd_mul_dw_forked(t, t, c, s.x1, L->l1_w, w.d_f1, s.g1, g.l1_w, g.l1_b, R, F, d, d, F, w.lin_ws, w.lin_ws_bytes, st));
-  else
-    GT_TRY(gt_linear_bwd_dw_forked(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, g.l1_w, g.l1_b, R, F, d, d, F, p, w.lin_ws, w.lin_ws_bytes, st));
   // a = ctx Wo^T + bo
-  GT_TRY(gt_linear_bwd_dw_forked(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, g.out_w, g.out_b, R, d, d, d, d, 0.f, w.lin_ws,
-                                 w.lin_ws_bytes, st));
-  GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, nullptr, nullptr, R, d, d, 0.f,
+  GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_attn_bwd(t, s.qkv, s.ctx, w.d_ctx, s.lse, w.delta, w.d_qkv, R, d, L->nhead, L->seq_desc, L->num_seqs,
                      L->row_stride, L->max_npos, L->work_items, L->num_work, nullptr, nullptr, 0.f, scale, p, L->seed, st));
-  // qkv = x Win^T + bin ; dx += ...
+  // qkv = x Win^T + bin ; dx += ...   The weight gradient first: forked onto the overlap stream it starts beside this layer's own
+  // dX GEMM, not together with the next stage's first kernel (a LayerNorm backward)
+  GT_TRY(gt_linear_bwd_dw_forked(t, t, c, x, L->in_w, w.d_qkv, nullptr, g.in_w, g.in_b, R, 3 * d, d, d, 3 * d, 0.f, w.lin_ws,
+                                 w.lin_ws_bytes, st));
   GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, nullptr, nullptr, R, 3 * d, d, 0.f, w.lin_ws,
                        w.lin_ws_bytes, st));
-  GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, nullptr, nullptr, nullptr, g.in_w, g.in_b, R, 3 * d, d, 0.f, w.lin_ws_in,
-                       w.lin_ws_in_bytes, st));
   return GT_OK;
 }
 

@@ -1010,10 +1010,6 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   const int bwd_waves = dim <= 256 ? 16 : NT / 64;   // waves per block of the launch below
   int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), bwd_waves);
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
-  // Inside an overlap section the row pass runs alone: beside the encoder's weight-gradient GEMMs on the overlap stream it
-  // returned, once in a few hundred passes, ONE row whose mean(dy gamma xhat) was off ("not understood") --
-  // so the main stream first waits for whatever the overlap stream holds (the callers order their forks so that this is little).
-  (void)gt_overlap_dw_sync();
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
   // d gamma / d beta are parameter gradients: nothing on the critical path reads them -> the overlap stream when there is one

@@ -851,10 +851,9 @@ class _FusedModel(torch.autograd.Function):
             """the next stage's workspace.  The two slots alternate, so the weight-gradient GEMMs a stage forks onto the
             third stream (their partials and the dy they read live in the stage's slot) can run beside the NEXT stage: the
             main stream then waits only for the GEMMs that used this slot two stages ago (gt_overlap_dw_release).
-            join=True waits for all of them.  One schedule is avoided ("not understood"): a LayerNorm
-            backward that STARTS together with a dW GEMM returned, in 5-20 % of the passes, one token row that differs in
-            the last bits -- so the encoder composite forks its last dW (in_proj) ahead of its dX GEMM instead of behind
-            it, and the stage after the heads (whose dW starts microseconds before a LayerNorm backward) joins."""
+            join=True waits for all of them.  (The encoder composite forks its last dW (in_proj) ahead of its dX GEMM and the
+            heads fork theirs first: leftovers of the hunt for the irreproducible LayerNorm backward, DESIGN.md section 8 --
+            the cause was an inline-asm conversion, not the schedule; the order costs nothing and stays.)"""
             slot[0] ^= 1
             p = Q("ws", slot[0])
             if ov:

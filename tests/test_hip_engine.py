@@ -317,9 +317,9 @@ def test_fused_backward_is_bitwise_reproducible_at_benchmark_size(workload, mode
     """BASELINE configs[1] / [2] at full size (b256), three streams in play (main, virtual node, dW): thirty fused
     backward passes, enqueued back to back without a device synchronisation (as in training), must agree bit for bit --
     stream-ordering mistakes do not show at the small sizes of the other tests because the GPU drains each kernel before
-    the next one is enqueued.  (A LayerNorm backward that runs beside the encoder's weight-gradient GEMMs on the overlap
-    stream fails this once in a few hundred passes: gt_layernorm_bwd therefore waits for that stream, DESIGN.md section 8;
-    `GT_CHECK_NOSYNC=1 GT_CHECK_ITERS=800 python tools/engine_check_full.py` is the long version of this test.)"""
+    the next one is enqueued.  (This is the test that kept failing once in a few hundred passes while the bf16 packing was an
+    inline-asm instruction: DESIGN.md section 8; `GT_CHECK_NOSYNC=1 GT_CHECK_ITERS=30000 python tools/engine_check_full.py`
+    is its long version.)"""
     import importlib.util
     import os
     from graphtrans_amd import ops

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Debug harness for the run-to-run differences of the fused backward under stream overlap ("not understood").
+"""Debug harness for the run-to-run differences of the fused backward under stream overlap ("the irreproducible LayerNorm backward").
 
 Needs a DEBUG build of the library (not shipped; GT_LIB_PATH selects it) with two additions:
 
