@@ -217,3 +217,53 @@ def test_tower_linear_grouped(M, T, K, N, bias, mode):
             assert (got.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
     finally:
         ops.set_matmul_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("sdt", [torch.float32, torch.bfloat16])
+def test_weight_gradient_only_entry_points(sdt):
+    """gt_linear_bwd_dw_forked / gt_linear_bwd_mul_dw_forked (dW and db alone; outside an overlap section they run on the
+    caller's stream) give the bits of the full backward's dW / db -- ReLU-gated and multiplier (GELU) forms."""
+    import ctypes as C
+    from graphtrans_amd import _lib
+
+    lib = _lib.lib()
+    torch.manual_seed(4)
+    M, N, K = 2500, 384, 128
+    code = _lib.GT_BF16 if sdt == torch.bfloat16 else _lib.GT_F32
+    comp = _lib.GT_BF16 if sdt == torch.bfloat16 else _lib.GT_F32
+    x = torch.randn(M, K, device=DEV).to(sdt)
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV).to(sdt)
+    y = torch.relu(torch.randn(M, N, device=DEV)).to(sdt)          # forward output: gate = y > 0
+    gm = (torch.rand(M, N, device=DEV) * 1.5).to(sdt)               # saved multiplier
+    ws_bytes = int(lib.gt_linear_bwd_workspace_bytes(comp, M, N, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def P(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def run(fn, *args):
+        _lib.check(getattr(lib, fn)(*args), fn)
+
+    dx = torch.empty_like(x)
+    for mul in (False, True):
+        dw0, db0 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        dw1, db1 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        if mul:
+            run("gt_linear_bwd_mul", code, code, comp, P(x), P(w), P(dy), P(gm), None, None, P(dx), P(dw0), P(db0), M, N, K, K, N,
+                P(ws), ws_bytes, st)
+            run("gt_linear_bwd_mul_dw_forked", code, code, comp, P(x), P(w), P(dy), P(gm), P(dw1), P(db1), M, N, K, K, N, P(ws),
+                ws_bytes, st)
+            z = dy.float() * gm.float()
+        else:
+            run("gt_linear_bwd", code, code, comp, P(x), P(w), P(dy), P(y), None, None, P(dx), P(dw0), P(db0), M, N, K, 0.0,
+                P(ws), ws_bytes, st)
+            run("gt_linear_bwd_dw_forked", code, code, comp, P(x), P(w), P(dy), P(y), P(dw1), P(db1), M, N, K, K, N, 0.0, P(ws),
+                ws_bytes, st)
+            z = dy.float() * (y > 0).float()
+        torch.cuda.synchronize()
+        assert torch.equal(dw0, dw1) and torch.equal(db0, db1), ("mul" if mul else "relu")
+        tol = 3e-2 if sdt == torch.bfloat16 else 1e-4
+        assert_close(dw1.cpu(), (z.double().t() @ x.double()).float().cpu(), atol=tol, rtol=tol, what="dW")
+        assert_close(db1.cpu(), z.double().sum(0).float().cpu(), atol=tol, rtol=tol, what="db")
