@@ -3,7 +3,8 @@
 (dropout off) must be bitwise identical run after run and match the module path; repeated to shake out ordering bugs
 between the main, virtual-node and dW streams.
 GT_CHECK_ITERS (20), GT_CHECK_MODE (bf16 | mixed), GT_CHECK_WORKLOADS (code2,molpcba), GT_CHECK_NOSYNC=1: no device synchronisation
-between the passes (the host runs ahead as in training: consecutive passes overlap on the side streams)."""
+between the passes (the host runs ahead as in training: consecutive passes overlap on the side streams), GT_CHECK_DROPOUT=1: dropout
+stays at the configuration's rates and torch's generator (the source of the per-step dropout seeds) is re-seeded before every pass."""
 import copy
 import os
 import sys
@@ -18,14 +19,16 @@ dev = torch.device("cuda:0")
 ITERS = int(os.environ.get("GT_CHECK_ITERS", "20"))
 GNN = torch.float32 if os.environ.get("GT_CHECK_MODE", "bf16") == "mixed" else torch.bfloat16   # GNN-side GEMM arithmetic
 NOSYNC = os.environ.get("GT_CHECK_NOSYNC") == "1"
+DROPOUT = os.environ.get("GT_CHECK_DROPOUT") == "1"
 for wl in os.environ.get("GT_CHECK_WORKLOADS", "code2,molpcba").split(","):
     ops.set_matmul_dtype(GNN)
     torch.manual_seed(0)
     args, model, gen, loss_fn, _ = bench.build(wl, torch.bfloat16, dev, 256)
-    for m in model.modules():
-        if hasattr(m, "dropout_p"):
-            m.dropout_p = 0.0
-    model.gnn_node.drop_ratio = 0.0
+    if not DROPOUT:
+        for m in model.modules():
+            if hasattr(m, "dropout_p"):
+                m.dropout_p = 0.0
+        model.gnn_node.drop_ratio = 0.0
     model.train()
     b = bench.attach_sizes(gen(0)).to(dev)
 
@@ -34,6 +37,8 @@ for wl in os.environ.get("GT_CHECK_WORKLOADS", "code2,molpcba").split(","):
         for p in m.parameters():
             p.grad = None
         b.__dict__.pop("_gt_structure", None)
+        if DROPOUT:
+            torch.manual_seed(1234)
         loss_fn(m(b), b).backward()
         if not NOSYNC:
             torch.cuda.synchronize()
