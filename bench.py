@@ -157,6 +157,42 @@ def collate_report(workload, per_gpu, with_cpu):
     return rep
 
 
+def aggregate_stress_report(device):
+    """The aggregate kernels' bandwidth proof (on Code2 the re-gathers hit L2, so its fractions are cache numbers):
+    gt_aggregate_fwd / _bwd alone on one batch of BASELINE configs[4] (256 x G(512, 8/511): 131 k nodes, ~1.05 M edges, D = 256,
+    GCN with the Linear(2) edge encoder), 20 launches each timed by the C-side launch profiler (HIP events on the launch stream)."""
+    from graphtrans_amd import _lib, ops, synth
+    from graphtrans_amd.graph import GraphStructure
+    from graphtrans_amd.modules.conv import edge_spec
+
+    D = 256
+    b = synth.er_stress(B=256, seed=0).to(device)
+    gs = GraphStructure.build(b.edge_index, b.batch, num_graphs=b.num_graphs)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(2, D).to(device)
+    h = torch.randn(gs.N, D, device=device, requires_grad=True)
+    root = torch.randn(1, D, device=device, requires_grad=True)
+    g = torch.randn(gs.N, D, device=device)
+    spec = edge_spec(lin, b.edge_attr, D)
+    for it in range(25):
+        if it == 5:
+            _lib.profile_enable(1)
+        ops.aggregate(h, gs, "gcn", root, spec).backward(g)
+    rec = _lib.profile_records()
+    _lib.profile_enable(0)
+    meta = dict(N=gs.N, E=gs.E, D=D, elt=4, attr_bytes=8)
+    out = {"workload": "BASELINE configs[4] batch: 256 x G(512, 8/511)", "N": int(gs.N), "E": int(gs.E), "D": D, "dtype": "f32"}
+    for name, bwd in (("gt_aggregate_fwd", False), ("gt_aggregate_bwd", True)):
+        ms = [m for n, m, _ in rec if n == name]
+        if not ms:
+            continue
+        us = 1e3 * sum(ms) / len(ms)
+        by = agg_bytes(meta, bwd)
+        out[name] = {"bound": "hbm", "avg_us": round(us, 1), "calls": len(ms), "algorithmic_bytes": int(by),
+                     "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def attach_sizes(b):
     b._sizes = torch.bincount(b.batch, minlength=b.num_graphs).numpy()
     return b
@@ -680,6 +716,10 @@ def main():
         MODES_RESET = MODES[opt.mode]
         from graphtrans_amd import ops as gt_ops
         gt_ops.set_matmul_dtype(MODES_RESET[0])
+        try:
+            res["aggregate_stress"] = aggregate_stress_report(device)
+        except Exception as e:
+            res["aggregate_stress"] = {"error": repr(e)}
     if rank == 0:
         if opt.workload in RAW_GEN:
             res["collate"] = collate_report(opt.workload, per_gpu, with_cpu=(world == 1 and not opt.no_cpu_baseline))

@@ -588,14 +588,16 @@ __global__ void k_eps_finish(float* d_self, int ntiles) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-// fp32 rows of 257..448 columns that split evenly over the lanes take the W-floats-per-lane kernels (aggregate_wide.h)
+// fp32 rows of 193..448 columns that split evenly over the lanes take the W-floats-per-lane kernels (aggregate_wide.h): W = 5..7
+// for the widths the float4-chunk mapping wastes registers on (300, 384, ...), W = 4 (D = 256, the stress configuration) for
+// their branch-free gather phases
 template <typename T>
 __host__ inline int wide_w(int64_t D) {
   if constexpr (!std::is_same<T, float>::value) return 0;
 #ifdef AGGW_DISABLE
   return 0;
 #endif
-  if (D <= 256 || D > 448) return 0;
+  if (D <= 192 || D > 448) return 0;
   const int w = (int)gt_cdiv(D, 64);
   return D % w == 0 ? w : 0;
 }
@@ -653,6 +655,7 @@ template <typename T, int EDGE, bool BWD>
 int launch_cfg(const AggArgs& a, size_t lds_bytes, int* grid_bwd, hipStream_t stream) {
   const int64_t D = a.D;
   switch (wide_w<T>(D)) {
+    case 4: launch_wide<4, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
     case 5: launch_wide<5, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
     case 6: launch_wide<6, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
     case 7: launch_wide<7, EDGE, BWD>(a, lds_bytes, grid_bwd, stream); return GT_OK;
