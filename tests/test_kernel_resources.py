@@ -43,3 +43,20 @@ def test_gemm_kernels_keep_their_register_budget():
     for n, v in k.items():
         if re.search(r"12k_linear_(fwd|dx)I[ft][ft]tLi64E", n):   # the bf16-MFMA tiled kernels (encoder GEMMs), 64-row tiles
             assert v["Occupancy"] >= 3, (n, v)
+
+
+def test_aggregate_kernels_keep_their_register_budget():
+    """The W-floats-per-lane aggregate kernels are chains of dependent gathers: they run at the speed of the number of
+    waves in flight (aggregate_wide.h).  D = 300 (W = 5): forward >= 5 waves per SIMD, backward >= 4 (its grid is sized for
+    that many resident blocks), nothing spilled."""
+    k = _usage("aggregate.hip")
+    wide = {n: v for n, v in k.items() if "k_aggw_" in n}
+    assert len(wide) >= 32
+    spills = {n: v["ScratchSize"] for n, v in wide.items() if v.get("ScratchSize", 0) > 0}
+    assert not spills, "aggregate kernels spilling to scratch: %s" % spills
+    for n, v in wide.items():
+        hot = re.search(r"k_aggw_(fwd|bwd)ILi5ELi[24]E", n)   # the Code2 (Linear, K <= 2) and Molpcba (tables) instantiations
+        if re.search(r"k_aggw_fwdILi5E", n):
+            assert v["Occupancy"] >= (5 if hot else 4), (n, v)
+        if re.search(r"k_aggw_bwdILi5E", n):
+            assert v["Occupancy"] >= (4 if hot else 3), (n, v)
