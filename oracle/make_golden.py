@@ -25,10 +25,40 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 REF = "/root/reference"
 sys.path.insert(0, os.path.join(HERE, "stubs"))
-sys.path.insert(0, REF)     # `models` / `modules` / `dataset` must resolve to the REFERENCE here ...
-sys.path.append(REPO)       # ... not to the repository's top-level alias packages of the same names
 
-import models  # noqa: E402,F401  (must precede modules.transformer_encoder: circular import, main.py:21)
+
+def _bind_reference_package(name):
+    """Register /root/reference/<name> under the dotted name `<name>` BEFORE anything imports it.
+    The repository root carries alias packages of the same names (`models/`, `modules/`: the
+    drop-in boundary); the reference's `modules/` has no __init__.py, i.e. it is a namespace package,
+    and a regular package anywhere on sys.path beats a namespace package whatever the path order.
+    Binding by explicit file path makes the fixtures come from the REFERENCE's classes whatever
+    sys.path holds; `_assert_reference_bound` checks it after the imports."""
+    import types
+
+    path = os.path.join(REF, name)
+    init = os.path.join(path, "__init__.py")
+    if os.path.exists(init):
+        spec = importlib.util.spec_from_file_location(name, init, submodule_search_locations=[path])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    else:
+        mod = types.ModuleType(name)
+        mod.__path__ = [path]
+        sys.modules[name] = mod
+    return mod
+
+
+for _stale in [k for k in sys.modules if k.split(".")[0] in ("models", "modules", "dataset", "trainers")]:
+    del sys.modules[_stale]
+sys.path.insert(0, REF)     # the reference's flat imports (`import utils`, `from trainers import ...`)
+_bind_reference_package("modules")   # namespace package in the reference
+_bind_reference_package("models")    # (must precede modules.transformer_encoder: circular import, main.py:21)
+if REPO not in sys.path:
+    sys.path.append(REPO)   # graphtrans_amd.synth / oracle.* only; `models` / `modules` are already bound above
+
+import models  # noqa: E402,F401
 from models.gnn_transformer import GNNTransformer  # noqa: E402
 from modules.conv import GCNConv, GINConv  # noqa: E402
 from modules.gnn_module import GNNNodeEmbedding  # noqa: E402
@@ -36,6 +66,21 @@ from modules.masked_transformer_encoder import Block, CausalSelfAttention  # noq
 from modules.transformer_encoder import TransformerNodeEncoder  # noqa: E402
 from modules.utils import pad_batch, unpad_batch  # noqa: E402
 from ogb.graphproppred.mol_encoder import AtomEncoder, BondEncoder  # noqa: E402
+
+
+
+def _assert_reference_bound():
+    import inspect
+
+    for cls in (GNNTransformer, GCNConv, GINConv, GNNNodeEmbedding, Block, CausalSelfAttention, TransformerNodeEncoder):
+        f = os.path.realpath(inspect.getsourcefile(cls))
+        assert f.startswith(REF + os.sep), f"{cls.__name__} was imported from {f}, not from the reference"
+    for fn in (pad_batch, unpad_batch):
+        f = os.path.realpath(inspect.getsourcefile(fn))
+        assert f.startswith(REF + os.sep), f"{fn.__name__} was imported from {f}, not from the reference"
+
+
+_assert_reference_bound()
 
 _spec = importlib.util.spec_from_file_location("ref_dataset_utils", os.path.join(REF, "dataset/utils.py"))
 _du = importlib.util.module_from_spec(_spec)
@@ -581,8 +626,14 @@ def g11_collate():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    if len(sys.argv) > 1:   # regenerate selected groups only, e.g. `make_golden.py g11_collate`
-        for name in sys.argv[1:]:
+    argv = sys.argv[1:]
+    if "--out" in argv:     # write somewhere else (tests/test_golden_recipe.py regenerates into a tmp dir)
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
+        os.makedirs(OUT, exist_ok=True)
+    if argv:   # regenerate selected groups only, e.g. `make_golden.py g11_collate`
+        for name in argv:
             globals()[name]()
         sys.exit(0)
     g1_g2_convs()
