@@ -349,7 +349,7 @@ def _time_oracle(sd, args, b, fwd, loss_of, threads, budget_s, min_iters=1):
 CPU_SAMPLE = {"code2": 64, "code2-pna": 64, "molpcba": 256, "nci1": 256, "er": 16}
 
 
-def cpu_baseline(workload, model, args, budget_s=24.0):
+def cpu_baseline(workload, model, args, budget_s=24.0, full_graphs=256):
     """The oracle timed as a CPU port, bounded to ~budget_s of CPU work so that the default run
     stays within minutes: the best multi-thread point (32 threads: torch's CPU kernels get SLOWER with more on these
     many small ops -- 256 threads: 154 s per 64-graph step; tools/cpu_sweep.py, profiles/r02_cpu_sweep.json) and one
@@ -365,8 +365,16 @@ def cpu_baseline(workload, model, args, budget_s=24.0):
     t, n = _time_oracle(sd, oargs, b, fwd, loss_of, threads, 0.55 * budget_s)
     g1 = graphs
     t1, n1 = _time_oracle(sd, oargs, b, fwd, loss_of, 1, 0.45 * budget_s)
+    full = None
+    if graphs < full_graphs and not os.environ.get("GT_BENCH_NO_CPU_FULL"):
+        # the batch the GPU line is quoted on (the sample flatters the CPU -- the padded attention of the
+        # reference layout grows with the longest graph of the batch): ONE timed pass, no warm-up (34 s at 32 threads)
+        bf, fwd_f, loss_f, _ = _oracle_case(workload, full_graphs)
+        tf, nf = _time_oracle(sd, oargs, bf, fwd_f, loss_f, threads, 1.0)
+        full = dict(value=round(full_graphs / tf, 2), unit="graphs/s", cores=threads, graphs=full_graphs, iters=nf, s_per_step=round(tf, 3),
+                    note="the full batch of the GPU line, one timed pass without warm-up")
     torch.set_num_threads(threads)
-    return dict(value=round(graphs / t, 2), unit="graphs/s", cores=threads, kind="port",
+    return dict(value=round(graphs / t, 2), unit="graphs/s", cores=threads, kind="port", full_batch=full,
                 sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on a {graphs}-graph seed-0 {what} "
                        f"batch, median of {n} timed iteration(s) on {threads} threads; padded layout like the reference (S = max "
                        f"nodes of the sample); host has {cores} logical cores (more threads are slower: profiles/r02_cpu_sweep.json)",
@@ -410,15 +418,22 @@ def cpu_baseline_full(workload, model, args, graphs=256, iters=5, limit_s=900.0)
 MODES = {"mixed": (torch.float32, torch.bfloat16), "bf16": (torch.bfloat16, torch.bfloat16), "fp32": (torch.float32, torch.float32)}
 
 
-def precision_vs_oracle(workload, modes, device, graphs=24):
-    """Fused path in each mode vs the float64 oracle on a `graphs`-graph sample at the real dims, dropout 0 (train-mode
-    BatchNorm): relative loss error and the relative L2 error of every parameter gradient (worst / median over the
-    tensors whose exact gradient is not ~0).  Same metric as tests/test_hip_configs.py, which bounds it."""
-    from types import SimpleNamespace
+def precision_vs_oracle(workload, modes, device, graphs=None):
+    """Fused path in each mode vs the float64 oracle on a sample at the real dims, dropout 0 (train-mode BatchNorm):
+    relative loss error and the relative L2 error of every parameter gradient (worst / median over the tensors whose
+    exact gradient is not ~0).  For the reduced-precision modes each tensor's error is also divided by the ORACLE's own
+    response of that tensor to bf16-sized (2^-9 relative) perturbations of the GEMM weights the mode rounds
+    (oracle/noise.py): `worst_vs_oracle_noise` is the largest such ratio -- an ill-conditioned gradient (GINConv.eps) has a
+    large error AND a large noise floor, a wrong kernel a large ratio.  Same metric as tests/test_hip_configs.py, which
+    bounds the ratio by 8."""
     from graphtrans_amd import ops as gt_ops
-    if workload not in ("code2", "molpcba"):
+    from oracle import noise as on
+    from oracle import reference_math as rm
+    if workload not in ("code2", "molpcba", "er"):
         return None
-    out = {"sample": f"{graphs} graphs, dropout 0, vs oracle/reference_math.py in float64"}
+    graphs = graphs or {"er": 4}.get(workload, 24)
+    out = {"sample": f"{graphs} graphs, dropout 0, vs oracle/reference_math.py in float64; vs_oracle_noise = rel-L2 error / the "
+                     "oracle's own rel-L2 response to 2^-9 relative perturbations of the GEMM weights the mode rounds to bf16"}
     ref = None
     for mode in modes:
         matmul, tok = MODES[mode]
@@ -429,25 +444,31 @@ def precision_vs_oracle(workload, modes, device, graphs=24):
         model.gnn_node.drop_ratio = 0.0
         model.transformer_encoder.dropout_p = 0.0
         b = gen(5)
+        oargs = on.oracle_args(args)
+        loss_of = {"code2": lambda o_: rm.code2_loss(o_, b.y_arr), "molpcba": lambda o_: rm.mol_loss(o_, b.y),
+                   "er": lambda o_: rm.tud_loss(o_, b.y)}[workload]
         if ref is None:   # identical parameters in every mode (same seed): one oracle run
-            b64, fwd, loss_of, _ = _oracle_case(workload, graphs)
-            oargs = SimpleNamespace(**{k: v for k, v in vars(args).items() if k not in ("compute_dtype", "token_layout")})
             sd = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+            b64 = b
+            if getattr(b, "x", None) is not None and b.x.is_floating_point():
+                import copy
+                b64 = copy.copy(b)
+                b64.x = b.x.double()
+                if getattr(b, "edge_attr", None) is not None and b.edge_attr.is_floating_point():
+                    b64.edge_attr = b.edge_attr.double()
             torch.set_default_dtype(torch.float64)
             try:
-                from oracle import reference_math as rm
-                o = rm.gnn_transformer(sd, oargs, b, None, True)
-                l64 = rm.code2_loss(o, b.y_arr) if workload == "code2" else rm.mol_loss(o, b.y)
+                l64 = loss_of(rm.gnn_transformer(sd, oargs, b64, None, True))
                 l64.backward()
             finally:
                 torch.set_default_dtype(torch.float32)
-            ref = (float(l64), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None})
+            ref = (float(l64), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, sd, b64)
         model = model.to(device).train()
         bd = attach_sizes(b).to(device)
         loss = loss_fn(model(bd), bd)
         loss.backward()
         torch.cuda.synchronize()
-        l64v, g64 = ref
+        l64v, g64, sd64, b64 = ref
         rms = {k: float(r.norm()) / r.numel() ** 0.5 for k, r in g64.items()}
         top = max(rms.values())
         errs = {}
@@ -458,6 +479,13 @@ def precision_vs_oracle(workload, modes, device, graphs=24):
         vals = sorted(errs.values())
         out[mode] = dict(loss_rel_err=float(f"{abs(float(loss) - l64v) / abs(l64v):.3e}"), grad_rel_l2_worst=float(f"{errs[worst]:.3e}"),
                          grad_rel_l2_worst_param=worst, grad_rel_l2_median=float(f"{vals[len(vals) // 2]:.3e}"), tensors=len(errs))
+        if mode != "fp32":
+            floor = on.lowp_noise({k: v.detach() for k, v in sd64.items()}, oargs, b64, rm.gnn_transformer, loss_of, g64, mode, seeds=(11, 12))
+            ratio = {k: errs[k] / max(floor[k], 2.5e-4) for k in errs}
+            wr = max(ratio, key=ratio.get)
+            out[mode].update(worst_vs_oracle_noise=float(f"{ratio[wr]:.3g}"), worst_vs_oracle_noise_param=wr,
+                             oracle_noise_of_worst_err_param=float(f"{floor[worst]:.3e}"),
+                             median_vs_oracle_noise=float(f"{sorted(ratio.values())[len(ratio) // 2]:.3g}"))
         del model
     return out
 
@@ -699,7 +727,7 @@ def main():
             res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step")} | \
                 {"graphs_per_gpu": o["config"]["graphs_per_gpu"], "global_batch": o["config"]["global_batch"]}
     if extra and world == 1:
-        others = [m for m in ("mixed", "bf16") if m != opt.mode]
+        others = [m for m in ("mixed", "bf16", "fp32") if m != opt.mode]
         res["modes"] = {}
         for m in others:
             del model
@@ -731,7 +759,7 @@ def main():
                                            sample=f"oracle/reference_math.py fwd+loss+bwd fp32, full {full['graphs']}-graph batch, median of "
                                                   f"{b['timed_iterations']} after 2 warm-ups, best of the thread counts below", full=full)
             else:
-                res["cpu_baseline"] = cpu_baseline(opt.workload, model, args)
+                res["cpu_baseline"] = cpu_baseline(opt.workload, model, args, full_graphs=per_gpu)
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist

@@ -18,6 +18,7 @@
 //   t_k = w_k 1[h[u]+e_k>0] g[col_k];  dh[u] = sum_k t_k + self';  edge-parameter gradients are
 //   accumulated in registers (Linear) or per-wave LDS rows (embedding tables), reduced per block
 //   and finished by a second kernel in a fixed order.
+#include <mutex>
 #include "gt_common.h"
 #include <type_traits>
 
@@ -607,20 +608,31 @@ __host__ inline int wide_w(int64_t D) {
 // instantiation, asked of the runtime once), i.e. the shortest walks that still finish in one round -- 1.08 rounds cost two
 // (Molpcba: 555 blocks 51 us, 416 blocks 38 us).  Depends on (kernel, N) only: the partial sums stay reproducible.
 inline int bwd_grid(void (*kernel)(AggArgs), size_t lds_bytes, int64_t N, int npw) {
-  struct Seen { const void* k; size_t lds; int per_cu; };
-  static Seen seen[64];
-  static int nseen = 0, cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
-  int per_cu = 0;
-  for (int i = 0; i < nseen; ++i)
-    if (seen[i].k == (const void*)kernel && seen[i].lds == lds_bytes) per_cu = seen[i].per_cu;
-  if (!per_cu) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, AGG_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (nseen < 64) seen[nseen++] = Seen{(const void*)kernel, lds_bytes, per_cu};
+  // one-time queries, cached per (device, kernel, LDS bytes) under a mutex: the entry points are called from the caller's
+  // thread AND from autograd's worker thread (C-ABI contract: no unguarded mutable globals), and the occupancy of a
+  // kernel -- hence the partial-sum order -- belongs to the device that runs it, not to whichever device asked first
+  struct Seen { int dev; const void* k; size_t lds; int per_cu; };
+  constexpr int MAX_DEV = 16, MAX_SEEN = 256;
+  static std::mutex mu;
+  static Seen seen[MAX_SEEN];
+  static int nseen = 0;
+  static int cus_of[MAX_DEV] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int cus = 0, per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < MAX_DEV) cus = cus_of[dev];
+    if (!cus) {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      if (dev >= 0 && dev < MAX_DEV) cus_of[dev] = cus;
+    }
+    for (int i = 0; i < nseen; ++i)
+      if (seen[i].dev == dev && seen[i].k == (const void*)kernel && seen[i].lds == lds_bytes) per_cu = seen[i].per_cu;
+    if (!per_cu) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, AGG_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (nseen < MAX_SEEN) seen[nseen++] = Seen{dev, (const void*)kernel, lds_bytes, per_cu};
+    }
   }
   int64_t cap = (int64_t)cus * per_cu;
   if (cap > BWD_BLOCKS) cap = BWD_BLOCKS;

@@ -750,6 +750,11 @@ class _FusedModel(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
             _call("gt_stream_wait_event", st, plan.ev_sort[1])
+        elif want_wt and plan.side_dw is not None:
+            # the transposed weights were written into THIS arena on the overlap stream: join it here too (the sort's event
+            # above is recorded behind the transposes on the same in-order stream), so that an autograd graph dropped
+            # without a backward cannot hand the arena back to the allocator under pending side-stream writes
+            _call("gt_stream_wait_event", st, plan.ev_wt[1])
         out = logits[:, :plan.Nh] if plan.ldy != plan.Nh else logits
         return out
 
@@ -995,6 +1000,10 @@ class _FusedModel(torch.autograd.Function):
         elif plan.has_vn and side is not None:
             _call("gt_stream_wait_event", st, plan.ev_vnemb[0])   # joined only here: the embedding backward ran beside the tail of the virtual-node chain
         # ---- hand the gradients to the parameters
+        if not direct:
+            # accumulation reads `flat` on the main stream right here: every fork that still writes it (layer 0's urgent dW
+            # GEMMs, aggregate partial reduces, LayerNorm column finishes on the overlap stream) has to be joined first (the virtual-node stream was joined just above) -- the `finally` join of gt_overlap_dw_end comes too late
+            dw_sync()
         if direct:
             for p, v in zip(plan.plist, plan.views):
                 p.grad = v

@@ -461,7 +461,7 @@ class _SyncBatchNorm(torch.autograd.Function):
         ws_bytes = L.gt_batchnorm_workspace_bytes(rows, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         dx = torch.empty_like(x)
-        sums = torch.empty((2, D), dtype=torch.float32, device=dev)   # [sum dy' xhat, sum dy'] over the LOCAL rows
+        sums = torch.zeros((2, D), dtype=torch.float32, device=dev)   # [sum dy' xhat, sum dy'] over the LOCAL rows
         _lib.launch("gt_batchnorm_bwd", _dtype_code(x), _ptr(x), _ptr(dy), _ptr(w32), _ptr(b32), _ptr(stats[0]), _ptr(stats[1]), 1,
                     1 if relu else 0, rows, D, _ptr(dx), _ptr(sums[0]), _ptr(sums[1]), dropout_p, seed, _ptr(ws), ws_bytes, _stream())
         glob = _dist_reduce(sums.clone(), group, gather=False)

@@ -106,6 +106,9 @@ def fp32_noise(model, args, b, loss_of, ref64, eps=6e-8, seeds=(1, 2)):
     return noise
 
 
+TAIL_CAP = 5e-2
+
+
 def check_grads(grads, ref64, noise, base=1e-3, factor=10.0, what=""):
     """per parameter-gradient tensor: 98 % of the elements within max(base, factor x the fp32 oracle's own noise) of the
     float64 oracle, relative to the tensor's largest entry (conftest.quantile_err: isolated gate flips are not counted),
@@ -130,6 +133,10 @@ def check_grads(grads, ref64, noise, base=1e-3, factor=10.0, what=""):
         else:
             e, tol = quantile_err(g, r), max(base, factor * noise[k])
             assert rel_l2(g, r) <= 5e-2, (k, rel_l2(g, r))
+            # the 2 % tail the quantile leaves out is capped too: a gate flip moves an element by O(1e-2) of
+            # the tensor's largest entry, a wrong row / tile by O(1)
+            tail = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-300)
+            assert tail <= TAIL_CAP, (k, "excluded tail", tail)
         rows.append((e / tol, e, tol, k))
     rows.sort(reverse=True)
     msg = "; ".join(f"{k}: err {e:.1e} (tol {t:.1e})" for _, e, t, k in rows[:4])
@@ -177,6 +184,25 @@ def test_c5_er_model_fp32_vs_oracle(fused):
     from conftest import rel_l2
     print(f"\nlogits rel-L2 vs float64: HIP {rel_l2(outs[0], ref_out64.detach()):.1e}, fp32 oracle {rel_l2(ref_out.detach(), ref_out64.detach()):.1e}")
     check_grads(grads, ref_g64, noise, what="C5 fp32 " + ("engine" if fused else "modules"))
+
+
+@pytest.mark.parametrize("mode", ["mixed", "bf16"])
+def test_c5_er_model_reduced_precision_vs_oracle(mode):
+    """The modes bench.py's ER line reports (only the fp32 mode was checked end to end): fused path, 8 graphs of
+    512 nodes at the real dims, loss and logits at the mode's bound, every gradient tensor within LOWP_FACTOR x the
+    oracle's own bf16-noise for that tensor (check_lowp_grads)."""
+    from conftest import rel_l2
+
+    matmul, tokens = MODES[mode]
+    args = _args(**ER_ARGS, compute_dtype=tokens)
+    model, b, oloss, hloss = build("er", args, 8, 11)
+    ref_out64, ref_loss64, ref_g64 = oracle_run(model, args, b, oloss, torch.float64)
+    outs, loss, grads = hip_run(model, b, hloss, matmul)
+    rel = abs(float(loss) - float(ref_loss64)) / abs(float(ref_loss64))
+    print(f"\n[er {mode}] loss rel err {rel:.2e}, logits rel-L2 {rel_l2(outs[0], ref_out64.detach()):.2e}")
+    assert rel <= BOUNDS[mode]["loss"] * 4, rel
+    assert rel_l2(outs[0], ref_out64.detach()) <= (2e-2 if mode == "mixed" else 5e-2)
+    check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=f"er {mode}")
 
 
 def _encoder_oracle(enc_state, args, x, mask, w, dtype, perturb_seed=None, eps=1e-7):
@@ -312,3 +338,36 @@ def test_fused_precision_modes_vs_oracle(workload, graphs, mode):
     assert rep["grad_rel_l2_median"] <= bound["median"], rep
     if mode == "fp32":
         check_grads(grads, ref_g64, noise, what=f"{workload} fp32")
+    else:
+        check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=f"{workload} {mode}")
+
+
+LOWP_FACTOR, LOWP_FLOOR = 8.0, 2e-3
+
+
+def check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=""):
+    """Reduced-precision modes, tensor by tensor: the relative L2 error of every parameter gradient against the float64
+    oracle is bounded by LOWP_FACTOR x the ORACLE's own response of that tensor to bf16-sized perturbations of the GEMM
+    weights the mode rounds (oracle/noise.py: 2^-9 relative, weights only -- activation rounding adds about as much
+    again, hence the factor), never less than LOWP_FLOOR.  An ill-conditioned gradient (GINConv.eps: one scalar summed
+    from N x D products of both signs, modules/conv.py:21,28) gets a wide bound because the oracle itself moves that
+    much, every well-conditioned tensor a tight one -- instead of one blanket bound per mode."""
+    from conftest import rel_l2
+    from oracle import noise as on
+    from oracle import reference_math as rm
+
+    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    floor = on.lowp_noise(sd64, on.oracle_args(args), b, rm.gnn_transformer, oloss, ref_g64, mode)
+    rms = {k: float(r.norm()) / r.numel() ** 0.5 for k, r in ref_g64.items()}
+    top = max(rms.values())
+    rows = []
+    for k, r in ref_g64.items():
+        if rms[k] < 1e-3 * top:
+            continue   # exact gradient ~ 0 (a bias in front of a train-mode BatchNorm): covered by the fp32 mode's absolute bound
+        e = rel_l2(grads[k] if k in grads else torch.zeros_like(r), r)
+        tol = max(LOWP_FACTOR * floor[k], LOWP_FLOOR)
+        rows.append((e / tol, e, floor[k], k))
+    rows.sort(reverse=True)
+    msg = "; ".join(f"{k}: err {e:.1e} = {e / max(f, 1e-30):.1f} x oracle noise {f:.1e}" for _, e, f, k in rows[:5])
+    print(f"\n[{what}] gradients closest to their bound ({LOWP_FACTOR:g} x oracle bf16-noise, floor {LOWP_FLOOR:g}): {msg}")
+    assert rows[0][0] <= 1.0, msg

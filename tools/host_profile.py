@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 batch = sys.argv[1] if len(sys.argv) > 1 else "8"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 workload = sys.argv[3] if len(sys.argv) > 3 else "code2"
-sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--no-kernel-timing", "--batch", batch,
+sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--no-kernel-timing", "--no-extra", "--batch", batch,
             "--workload", workload]
 import bench
 pr = cProfile.Profile()
