@@ -563,15 +563,16 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
         L.gt_profile_enable(0)  # pool allocated, records cleared; recording toggled per step below
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(opt.steps + 1)]   # per-step device times (median)
 
+    cur = torch.cuda.current_stream(device.index)   # (without an index torch resolves the device through hipGetDeviceCount: 110 us per call)
     t0 = time.perf_counter()
     for i in range(opt.steps):
-        marks[i].record()
+        marks[i].record(cur)
         if sample(i):
             L.gt_profile_resume(1 | 2 | 4)
         loss = step(opt.warmup + i)
         if sample(i):
             L.gt_profile_resume(0)
-    marks[opt.steps].record()
+    marks[opt.steps].record(cur)
     t_enqueued = time.perf_counter() - t0  # host time to enqueue all steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0

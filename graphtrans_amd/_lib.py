@@ -87,6 +87,10 @@ SIGNATURES = {
     "gt_linear_bwd_mul_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
+    "gt_w3_image_bytes": (_sz, [_i64, _i64]),
+    "gt_w3_images": (_i, [_i, _p, _p, _p, _p, _p, _p]),
+    "gt_w3_bind": (_i, [_i, _p, _p, _p, _p, _p]),
+    "gt_w3_unbind": (_i, []),
     "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),
     "gt_linear_bwd_bnstats_ok": (_i, [_i, _i, _i, _i64]),
     "gt_linear_bwd_bnstats_rows": (_i64, [_i64]),

@@ -16,6 +16,8 @@
 // bf16; compute type bf16 (v_mfma_f32_16x16x32_bf16) or fp32 (v_mfma_f32_16x16x4_f32, exact).
 // Orientation: every lane owns an output ROW index as its MFMA column (n = lane & 15) and 4
 // consecutive output columns as accumulator registers -> 8/16-byte stores, float4 bias loads.
+#include <mutex>
+
 #include "gt_common.h"
 #include "mfma_frag.h"
 
@@ -200,6 +202,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 }
 
 #include "linear32.h"
+#include "linear3x.h"
 #include "linear_small.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -884,6 +887,11 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     L32Args w{};
     w.a = x; w.w = weight; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
     w.act = act; w.gout = gout; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;
+    // a prepared bf16x3 image of this weight (gt_w3_bind): the fp32-accurate GEMM on the bf16 matrix pipe (linear3x.h);
+    // bf16 rows need K % 8 (their 16-byte chunks are whole k-groups)
+    w.w3 = (x_dtype == GT_F32 || K % 8 == 0) ? w3_lookup(weight, N, K, false) : nullptr;
+    if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
+    else
     w32_launch<false>(x_dtype, y_dtype, stream, w);
     GT_CHECK_LAUNCH();
     return GT_OK;
@@ -1104,7 +1112,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
       // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
       // layer) -> wait for the forks that used this range (those on other workspaces keep running).
-      if (g_opt.weight_t) {
+      const void* w3t = (g_opt.bns.part || (y_dtype != GT_F32 && N % 8)) ? nullptr : w3_lookup(weight, N, K, true);
+      if (w3t) {
+        wt = nullptr;   // the bound image of W^T: k_lin3, no transpose
+      } else if (g_opt.weight_t) {
         wt = const_cast<float*>(g_opt.weight_t);   // read only
       } else {
         if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);
@@ -1118,6 +1129,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.bn_x = q.x; w.bn_ldx = q.ldx; w.bn_mean = q.mean; w.bn_rstd = q.rstd; w.bn_w = q.w; w.bn_b = q.b;
         w.bn_relu = q.relu; w.bn_part = q.part;
       }
+      w.w3 = w3t;
+      if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
+      else
       w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
@@ -1214,6 +1228,53 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (forked) dw_forked(workspace, workspace_bytes);
   }
   GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+// ---- bf16x3 weight images (linear3x.h) --------------------------------------------------------------------------------
+// bytes of the image of a weight used as [rows][contraction] (forward: rows = N, contraction = K; dX form: rows = K, contraction = N)
+extern "C" size_t gt_w3_image_bytes(int64_t rows, int64_t contraction) {
+  return rows > 0 && contraction > 0 ? w3_image_bytes(rows, contraction) : 0;
+}
+// Builds `n` images in as few launches as the kernel-argument table allows (24 jobs each).  Job i: weight[i] is the fp32 matrix
+// [N[i]][K[i]] (row pitch K[i]); transposed[i] == 0 -> image of W (rows N, contraction K) for the forward, != 0 -> image of W^T (rows K,
+// contraction N) for the dX GEMM; image[i] has gt_w3_image_bytes(rows, contraction) bytes, 1024-byte aligned.
+extern "C" int gt_w3_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,
+                            void* const* image, gt_stream_t stream_) {
+  GT_CHECK_ARG(n >= 0 && (n == 0 || (weight && N && K && transposed && image)), "bad arguments");
+  for (int i0 = 0; i0 < n; i0 += W3_MAX_JOBS) {
+    W3Jobs jobs{};
+    int blocks = 0;
+    const int cnt = n - i0 < W3_MAX_JOBS ? n - i0 : W3_MAX_JOBS;
+    for (int i = 0; i < cnt; ++i) {
+      const int s = i0 + i;
+      GT_CHECK_ARG(weight[s] && image[s] && N[s] > 0 && K[s] > 0 && ((uintptr_t)image[s] & 1023) == 0, "null / unaligned buffer");
+      W3Job& J = jobs.j[i];
+      const int64_t rows = transposed[s] ? K[s] : N[s], contr = transposed[s] ? N[s] : K[s];
+      J.w = weight[s]; J.img = (unsigned char*)image[s]; J.R = (int)rows; J.C = (int)contr; J.ldw = (int)K[s];
+      J.transposed = transposed[s] ? 1 : 0; J.ntp = (int)w3_ntp(rows); J.ksteps = (int)gt_cdiv(contr, 32); J.block0 = blocks;
+      blocks += J.ksteps * ((J.ntp + 3) / 4);
+    }
+    jobs.n = cnt;
+    hipLaunchKernelGGL(k_w3_image, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, jobs);
+  }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+// Binds prepared images to weight pointers for the calling HOST THREAD: until gt_w3_unbind(), every big-M exact-fp32 GEMM
+// (compute == GT_F32, M >= 1024, one group) of gt_linear_fwd* / gt_linear_bwd* whose weight (pointer, N, K) is in the table runs
+// the bf16x6 kernel on the image (forward: image_fwd[i], dX: image_t[i]; a NULL entry keeps the exact-fp32 MFMA kernel for that
+// direction).  The images must stay valid and current (rebuilt after every optimizer step) while bound.  At most 64 entries.
+extern "C" int gt_w3_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
+                          const void* const* image_t) {
+  GT_CHECK_ARG(n >= 0 && n <= W3_MAX_BOUND && (n == 0 || (weight && N && K)), "at most 64 bound weights");
+  for (int i = 0; i < n; ++i)
+    g_w3.e[i] = W3Bound{weight[i], N[i], K[i], image_fwd ? image_fwd[i] : nullptr, image_t ? image_t[i] : nullptr};
+  g_w3.n = n;
+  return GT_OK;
+}
+extern "C" int gt_w3_unbind(void) {
+  g_w3.n = 0;
   return GT_OK;
 }
 

@@ -40,6 +40,8 @@ struct L32Args {
   float inv_keep;
   uint32_t thr, s0, s1;
   int ncb;             // column blocks of NT n-tiles
+  const void* w3;      // linear3x.h: the bf16x3 image of the weight (k_lin3), w is unused then
+  int w3_ntp;          // its 16-row tiles per plane and k-step
 };
 
 // 16-byte chunk of TA -> up to 8 floats

@@ -1,0 +1,389 @@
+// linear3x.h — fp32-accurate GEMMs on the bf16 matrix pipe ("bf16x6": three-way bf16 split of both operands, six products)
+// for the big-M linears of the message-passing side.  Included by linear.hip inside its anonymous namespace, after linear32.h.
+//
+// Why: v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate; the exact-fp32 kernels of linear32.h are MFMA-bound at
+// 0.47-0.50 of THAT peak (75 us for 31.6 k x 300 x 300) and were 25 % of the Code2 step's kernel time, 39 % of Molpcba's.
+// An fp32 value splits EXACTLY into three bf16 values (8 + 8 + 8 significand bits, a = a1 + a2 + a3 with
+// a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): both differences are exact in fp32), and a product of two bf16 values is
+// exact in fp32.  Keeping the six products of order <= 2^-16 (a1 b1; a1 b2, a2 b1; a1 b3, a2 b2, a3 b1) drops terms of relative size
+// 2^-24 and below -- the rounding of ONE fp32 multiply -- so the result differs from an exact-fp32 GEMM by accumulation order
+// only (measured: relative L2 to float64 1.4e-7 against 3.1e-7 for torch's fp32 GEMM on 4096 x 300 x 300; tests/test_hip_linear3x.py
+// holds it to the same bar as the exact kernels).  Six v_mfma_f32_16x16x32_bf16 (6 x 16 cycles per 16x16x32 product block)
+// replace eight v_mfma_f32_16x16x4_f32 (8 x 32 cycles): 2.7 x the matrix-pipe ceiling at fp32 accuracy.
+// Non-finite inputs: inf - inf = NaN in the split, i.e. an inf activation yields NaN where the exact kernel yields inf.
+//
+// Weights are split ONCE per step into an "image" (k_w3_image, all weights of a model in one launch): bf16 planes laid out in
+// the order the LDS wants them -- [k-step of 32][plane][16-row tile][1 KB: row r, 16-byte chunk (c ^ (r >> 1 & 3))] -- so a
+// k-step's tiles reach the LDS by global_load_lds_dwordx4 (LDS-DMA, lane-linear, no staging registers, no ds_write) and the
+// fragment reads (ds_read_b128 at row n, chunk g ^ (n >> 1 & 3)) are bank-conflict free in all four 16-lane service groups.
+// The dX form runs the same kernel on the image of W^T (built by the same launch, transposed indexing): no transpose pass.
+// The activation rows are split while they are staged (3 v_cvt_pk_bf16_f32 + 4 v_sub_f32 per pair).
+//
+// Block = 64 rows x NT n-tiles (NT = 10 or 8: N = 300 -> two column blocks of 160), 4 waves as 2 x 2, wave = 32 rows x NT/2
+// n-tiles; W stage double-buffered (2 x 3 x NT KB), A stage single (12 KB): 72 KB -> two blocks per CU, one block's barriers and
+// DMA waits hide under the other's MFMAs.
+#pragma once
+
+constexpr int W3_BM = 64;
+
+static inline int w3_pick_nt(int64_t R) {   // n-tiles per column block: fewest padded tiles, ties -> 10
+  const int64_t tiles = gt_cdiv(R, 16);
+  const int64_t w10 = gt_cdiv(tiles, 10) * 10 - tiles, w8 = gt_cdiv(tiles, 8) * 8 - tiles;
+  return w8 < w10 ? 8 : 10;
+}
+static inline int64_t w3_ntp(int64_t R) {   // tiles per plane and k-step, padded to whole column blocks
+  const int nt = w3_pick_nt(R);
+  return gt_cdiv(gt_cdiv(R, 16), nt) * nt;
+}
+static inline size_t w3_image_bytes(int64_t R, int64_t C) { return (size_t)gt_cdiv(C, 32) * 3 * (size_t)w3_ntp(R) * 1024; }
+
+// ---- image builder -------------------------------------------------------------------------------------------------
+struct W3Job {
+  const float* w;   // fp32 weight [rows][ldw]
+  unsigned char* img;
+  int R, C;         // image rows (output columns of the GEMM) and contraction length
+  int ldw;
+  int transposed;   // 0: element (r, c) = w[r * ldw + c]; 1: = w[c * ldw + r]  (the dX form: image of W^T)
+  int ntp, ksteps;
+  int block0;       // first block of this job
+};
+constexpr int W3_MAX_JOBS = 24;
+struct W3Jobs {
+  W3Job j[W3_MAX_JOBS];
+  int n;
+};
+
+__device__ __forceinline__ void w3_split_pair(float lo, float hi, uint32_t& u1, uint32_t& u2, uint32_t& u3) {
+  u1 = gt_pack_bf16(lo, hi);
+  const float rl = lo - __uint_as_float(u1 << 16), rh = hi - __uint_as_float(u1 & 0xffff0000u);   // exact
+  u2 = gt_pack_bf16(rl, rh);
+  u3 = gt_pack_bf16(rl - __uint_as_float(u2 << 16), rh - __uint_as_float(u2 & 0xffff0000u));
+}
+
+__global__ void __launch_bounds__(256) k_w3_image(W3Jobs jobs) {
+  int ji = 0;
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
+  const W3Job& J = jobs.j[ji];
+  const int b = (int)blockIdx.x - J.block0;
+  const int tpb = (J.ntp + 3) / 4;                  // blocks per k-step (4 tiles each)
+  const int ks = b / tpb, jt = (b % tpb) * 4 + (threadIdx.x >> 6);
+  if (ks >= J.ksteps || jt >= J.ntp) return;
+  const int l = threadIdx.x & 63, r = l >> 2, c = l & 3;
+  const int row = jt * 16 + r;
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = ks * 32 + c * 8 + e;
+    f[e] = (row < J.R && k < J.C) ? (J.transposed ? J.w[(int64_t)k * J.ldw + row] : J.w[(int64_t)row * J.ldw + k]) : 0.f;
+  }
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w3_split_pair(f[2 * q], f[2 * q + 1], p1[q], p2[q], p3[q]);
+  const int64_t tile = ((int64_t)ks * 3) * J.ntp + jt;
+  unsigned char* dst = J.img + tile * 1024 + r * 64 + ((c ^ ((r >> 1) & 3)) << 4);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+  *reinterpret_cast<uint4*>(dst + (int64_t)J.ntp * 1024) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+  *reinterpret_cast<uint4*>(dst + (int64_t)J.ntp * 2048) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
+// ---- the GEMM ------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void w3_lds_void;
+typedef const __attribute__((address_space(1))) void w3_glb_void;
+
+// out[M][Nout] = epilogue(A[M][Kc] Wimg^T); L32Args: a / amask / bias / add1 / add2 / out / gout / M / Nout / Kc / lda / ldo /
+// act / inv_keep / thr / s0 / s1 / ncb as for k_lin32; w3 = the image, w3_ntp its tiles per plane
+template <typename TA, typename TO, int NT, bool MASK, bool GELU = false>
+__global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
+  constexpr int BM = W3_BM;
+  constexpr int NPA = (sizeof(TA) == 2 && !MASK) ? 1 : 3;   // planes of the row operand (bf16 rows ARE their first plane)
+  constexpr int HT = NT / 2;                                // n-tiles per wave
+  constexpr int WSTAGE = 3 * NT * 1024, APLANE = BM * 64;
+  constexpr int PLD = HT * 16 + 4;                          // epilogue patch pitch (floats)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
+  unsigned char* sA = smem3 + 2 * WSTAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform in an SGPR: the DMA piece loop branches on it
+  const int n = lane & 15, g = lane >> 4, wm = wid >> 1, wn = wid & 1;
+  int64_t mt;
+  int cb;
+  {  // XCD-aware order: the column blocks of a row tile get ids 8 apart (same XCD, same L2)
+    const int64_t b = blockIdx.x;
+    const int64_t group = b / (8 * a.ncb);
+    const int r = (int)(b % (8 * a.ncb));
+    cb = r / 8;
+    mt = group * 8 + r % 8;
+  }
+  const int64_t m0 = mt * BM;
+  if (m0 >= a.M) return;
+  const int64_t n0 = (int64_t)cb * NT * 16;
+  const TA* A = reinterpret_cast<const TA*>(a.a);
+  const TA* Am = reinterpret_cast<const TA*>(a.amask);
+  const bool has_mask = MASK && Am != nullptr;
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(a.w3) + (int64_t)cb * NT * 1024 + lane * 16;
+  const int64_t plane_stride = (int64_t)a.w3_ntp * 1024;    // bytes between the planes of one k-step
+
+  // ---- row-operand staging: thread = (row ar, 8-element group q); out-of-range rows clamp to a valid row (never stored) ----
+  const int ar = tid >> 2, q = tid & 3;
+  const int64_t a_row = m0 + ar < a.M ? m0 + ar : a.M - 1;
+  const TA* a_src = A + a_row * a.lda;
+  const TA* m_src = has_mask ? Am + a_row * a.lda : nullptr;
+  uint4 va0 = make_uint4(0, 0, 0, 0), va1 = va0, vm0 = va0, vm1 = va0;
+  bool z0 = false, z1 = false;
+  auto load = [&](int ks) {
+    const int64_t k = (int64_t)ks * 32 + q * 8;
+    if constexpr (sizeof(TA) == 4) {
+      z0 = k + 4 > a.Kc;
+      z1 = k + 8 > a.Kc;
+      const int64_t k0c = z0 ? a.Kc - 4 : k, k1c = z1 ? a.Kc - 4 : k + 4;
+      va0 = *reinterpret_cast<const uint4*>(a_src + k0c);
+      va1 = *reinterpret_cast<const uint4*>(a_src + k1c);
+      if constexpr (MASK) {
+        if (has_mask) {
+          vm0 = *reinterpret_cast<const uint4*>(m_src + k0c);
+          vm1 = *reinterpret_cast<const uint4*>(m_src + k1c);
+        }
+      }
+    } else {
+      z0 = k + 8 > a.Kc;
+      const int64_t kc = z0 ? a.Kc - 8 : k;
+      va0 = *reinterpret_cast<const uint4*>(a_src + kc);
+      if constexpr (MASK) {
+        if (has_mask) vm0 = *reinterpret_cast<const uint4*>(m_src + kc);
+      }
+    }
+  };
+  auto store = [&]() {
+    unsigned char* dst = sA + ar * 64 + ((q ^ ((ar >> 1) & 3)) << 4);
+    if constexpr (NPA == 1) {
+      *reinterpret_cast<uint4*>(dst) = z0 ? make_uint4(0, 0, 0, 0) : va0;
+    } else {
+      float f[8];
+      if constexpr (sizeof(TA) == 4) {
+        if (z0) va0 = make_uint4(0, 0, 0, 0);
+        if (z1) va1 = make_uint4(0, 0, 0, 0);
+        f[0] = __uint_as_float(va0.x); f[1] = __uint_as_float(va0.y); f[2] = __uint_as_float(va0.z); f[3] = __uint_as_float(va0.w);
+        f[4] = __uint_as_float(va1.x); f[5] = __uint_as_float(va1.y); f[6] = __uint_as_float(va1.z); f[7] = __uint_as_float(va1.w);
+      } else {
+        if (z0) va0 = make_uint4(0, 0, 0, 0);
+        chunk_to_f32<TA>(va0, f);
+      }
+      if constexpr (MASK) {
+        if (has_mask) {
+          float y[8];
+          if constexpr (sizeof(TA) == 4) {
+            y[0] = __uint_as_float(vm0.x); y[1] = __uint_as_float(vm0.y); y[2] = __uint_as_float(vm0.z); y[3] = __uint_as_float(vm0.w);
+            y[4] = __uint_as_float(vm1.x); y[5] = __uint_as_float(vm1.y); y[6] = __uint_as_float(vm1.z); y[7] = __uint_as_float(vm1.w);
+          } else {
+            chunk_to_f32<TA>(vm0, y);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = gt_gate(f[e], y[e], a.inv_keep);
+        }
+      }
+      uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w3_split_pair(f[2 * e], f[2 * e + 1], p1[e], p2[e], p3[e]);
+      *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+      *reinterpret_cast<uint4*>(dst + APLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+      *reinterpret_cast<uint4*>(dst + 2 * APLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+    }
+  };
+  // ---- weight tiles: LDS-DMA, piece i = plane i / NT, tile i % NT -> LDS offset i KB; the four waves take them round robin ----
+  auto dma = [&](int ks, int buf) {
+    const unsigned char* src = img + (int64_t)ks * 3 * plane_stride;
+    unsigned char* dstb = smem3 + buf * WSTAGE;
+#pragma unroll
+    for (int i0 = 0; i0 < 3 * NT; i0 += 4) {
+      const int i = i0 + wid;
+      if (i < 3 * NT) {
+        const int p = i / NT, j = i % NT;
+        __builtin_amdgcn_global_load_lds((w3_glb_void*)(src + p * plane_stride + (int64_t)j * 1024), (w3_lds_void*)(dstb + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[2][HT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nks = (int)((a.Kc + 31) / 32);
+  const int swz = ((g ^ (n >> 1)) & 3) << 4;
+  dma(0, 0);
+  load(0);
+  for (int ks = 0; ks < nks; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step ks have landed, its row chunk is in registers
+    __syncthreads();                                   // every wave is done with step ks - 1: the A stage and W buffer (ks+1)&1 are free
+    store();
+    __syncthreads();                                   // A(ks) and all of W(ks) are visible
+    if (ks + 1 < nks) {
+      dma(ks + 1, (ks + 1) & 1);
+      load(ks + 1);
+    }
+    const unsigned char* sW = smem3 + (ks & 1) * WSTAGE + n * 64 + swz;
+    const unsigned char* sAf = sA + (wm * 32 + n) * 64 + swz;
+    bf16x8_t fa[2][NPA];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < NPA; ++p) fa[i][p] = *reinterpret_cast<const bf16x8_t*>(sAf + p * APLANE + i * 16 * 64);
+#pragma unroll
+    for (int jp = 0; jp < HT; jp += 2) {
+      bf16x8_t fw[2][3];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (jp + jj < HT) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fw[jj][p] = *reinterpret_cast<const bf16x8_t*>(sW + (p * NT + wn * HT + jp + jj) * 1024);
+        }
+      // the six products, small terms first; each round touches 2 x 2 independent accumulators
+      constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (PA[t] < NPA) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            if (jp + jj < HT) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                acc[i][jp + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj][PW[t]], fa[i][PA[t] < NPA ? PA[t] : 0], acc[i][jp + jj], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();   // the stage buffers become the epilogue's patches
+
+  // ---- epilogue: acc[i][j][r] = C[row m0 + wm*32 + i*16 + n][column n0 + (wn*HT + j)*16 + g*4 + r] ------------------------
+  float* fs = reinterpret_cast<float*>(smem3);
+  float* sB = fs + 4 * 16 * PLD;
+  if (a.bias) {
+    for (int c = tid; c < NT * 16; c += 256) sB[c] = n0 + c < a.Nout ? a.bias[n0 + c] : 0.f;
+    __syncthreads();
+  }
+  float* patch = fs + wid * 16 * PLD;
+  constexpr int CPR = HT * 4;   // 16-byte chunks per patch row; 16 rows -> HT chunks per lane
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < HT; ++j)
+      *reinterpret_cast<float4*>(patch + n * PLD + j * 16 + g * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t mrow0 = m0 + wm * 32 + i * 16;
+    const int64_t ncol0 = n0 + (int64_t)wn * HT * 16;
+    float4 v[HT], e1[HT], e2[HT];
+    bool ok[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const int c = lane + t * 64;
+      const int r = c / CPR, c4 = (c % CPR) * 4;
+      const int64_t m = mrow0 + r, col = ncol0 + c4;
+      ok[t] = m < a.M && col < a.Nout;
+      if (ok[t]) {
+        e1[t] = a.add1 ? gt_load4<TO>(reinterpret_cast<const TO*>(a.add1) + m * a.ldo + col) : gt_zero4();
+        e2[t] = a.add2 ? gt_load4<TO>(reinterpret_cast<const TO*>(a.add2) + m * a.ldo + col) : gt_zero4();
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const int c = lane + t * 64;
+      const int r = c / CPR, c4 = (c % CPR) * 4;
+      const int64_t m = mrow0 + r, col = ncol0 + c4;
+      if (ok[t]) {
+        v[t] = *reinterpret_cast<const float4*>(patch + r * PLD + c4);
+        if (a.bias) v[t] = gt_add4(v[t], *reinterpret_cast<const float4*>(sB + wn * HT * 16 + c4));
+        float* vv = reinterpret_cast<float*>(&v[t]);
+        if (a.act == 1) v[t] = gt_relu4(v[t]);
+        if constexpr (GELU) {
+          float4 gm;
+          float* gg = reinterpret_cast<float*>(&gm);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            gt_gelu(vv[e], vv[e], gg[e]);
+            if (a.thr && lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) < a.thr) gg[e] = 0.f;
+            else if (a.thr) gg[e] *= a.inv_keep;
+          }
+          if (a.gout) gt_store4<TO>(reinterpret_cast<TO*>(a.gout) + m * a.ldo + col, gm);
+        }
+        if (a.thr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = lin_hash(a.s0, a.s1, (uint32_t)m, (uint32_t)(col + e)) >= a.thr ? vv[e] * a.inv_keep : 0.f;
+        }
+        v[t] = gt_add4(gt_add4(v[t], e1[t]), e2[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const int c = lane + t * 64;
+      const int r = c / CPR, c4 = (c % CPR) * 4;
+      if (ok[t]) gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + ncol0 + c4, v[t]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <typename TA, typename TO, int NT, bool MASK, bool GELU>
+void w3_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
+  constexpr int LDS = 2 * 3 * NT * 1024 + 3 * W3_BM * 64;
+  static std::mutex mu;   // per instantiation: the > 64 KB dynamic-LDS opt-in is set once per device (C-ABI: one-time queries guarded)
+  static bool done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+      (void)hipFuncSetAttribute((const void*)(k_lin3<TA, TO, NT, MASK, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((k_lin3<TA, TO, NT, MASK, GELU>), grid, dim3(256), LDS, stream, a);
+}
+
+template <bool MASK>
+void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
+  const int nt = w3_pick_nt(a.Nout);
+  a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
+  a.w3_ntp = (int)w3_ntp(a.Nout);
+  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, W3_BM), 8) * 8 * a.ncb));
+  if constexpr (!MASK) {
+    if (a.act == 2) {   // gelu epilogue: fp32 rows in and out only
+      if (nt == 10) w3_launch_one<float, float, 10, false, true>(grid, stream, a);
+      else w3_launch_one<float, float, 8, false, true>(grid, stream, a);
+      return;
+    }
+  }
+#define GT_W3_GO(TA_, TO_)                                                         \
+  do {                                                                             \
+    if (nt == 10) w3_launch_one<TA_, TO_, 10, MASK, false>(grid, stream, a);       \
+    else w3_launch_one<TA_, TO_, 8, MASK, false>(grid, stream, a);                 \
+  } while (0)
+  if (ta == GT_F32 && to == GT_F32) GT_W3_GO(float, float);
+  else if (ta == GT_F32) GT_W3_GO(float, gt_bf16);
+  else if (to == GT_F32) GT_W3_GO(gt_bf16, float);
+  else GT_W3_GO(gt_bf16, gt_bf16);
+#undef GT_W3_GO
+}
+
+// ---- per-thread table of prepared images (gt_w3_bind / gt_w3_unbind) -----------------------------------------------------
+struct W3Bound {
+  const float* w;
+  int64_t N, K;          // the weight is [N][K]
+  const void* img_fwd;   // image of W   (rows N, contraction K) or null
+  const void* img_t;     // image of W^T (rows K, contraction N) or null
+};
+constexpr int W3_MAX_BOUND = 64;
+struct W3Table {
+  W3Bound e[W3_MAX_BOUND];
+  int n = 0;
+};
+thread_local W3Table g_w3;
+
+static inline const void* w3_lookup(const float* w, int64_t N, int64_t K, bool transposed) {
+  for (int i = 0; i < g_w3.n; ++i)
+    if (g_w3.e[i].w == w && g_w3.e[i].N == N && g_w3.e[i].K == K) return transposed ? g_w3.e[i].img_t : g_w3.e[i].img_fwd;
+  return nullptr;
+}

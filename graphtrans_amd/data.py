@@ -9,6 +9,11 @@ import ctypes
 import torch
 
 
+def _stream():   # (graph.py imports this module's Batch lazily; keep data.py free of package imports at module level)
+    from .graph import _stream as f
+    return f()
+
+
 class Batch:
     def __init__(self, **kw):
         self.__dict__.update(kw)
@@ -87,7 +92,7 @@ class GraphStore:
             dflag = up(flag)
             self.attr_rank = torch.empty(flag.size + 1, dtype=torch.int64, device=dev)
             _lib.launch("gt_attr_rank", dflag.data_ptr(), flag.size, self.attr_rank.data_ptr(),
-                        torch.cuda.current_stream().cuda_stream)
+                        _stream())
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         self._desc = _StoreDesc(p(self.node_ptr), p(self.edge_ptr), p(self.x), p(self.node_depth), p(self.edge_src),
                                 p(self.edge_dst), p(self.edge_attr), p(self.attr_rank), p(self.y),
@@ -127,7 +132,7 @@ class GraphStore:
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         out = _CollateOut(p(x), p(depth), p(batch), None, p(edge_index), p(ea_f), p(ea_i), p(y))
         self._lib.launch("gt_collate", ctypes.byref(self._desc), p(d_ids), B, N, E, ctypes.byref(out), p(ws), ws_bytes,
-                         torch.cuda.current_stream().cuda_stream)
+                         _stream())
         b = Batch(x=x, edge_index=edge_index, batch=batch, edge_attr=ea_f if self.augment else ea_i)
         if depth is not None:
             b.node_depth = depth

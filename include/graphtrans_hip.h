@@ -465,6 +465,23 @@ int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const void* x, const
                      float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, float dropout_p, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
 int gt_transpose(const float* in /* [N][K] */, float* out /* [K][N] */, int64_t N, int64_t K, gt_stream_t stream);
+
+/* ---- fp32-accurate GEMMs on the bf16 matrix pipe ("bf16x6", csrc/linear3x.h) -------------------------------------------
+ * The reference's Linear layers are fp32 (torch.nn.Linear: modules/conv.py:44,51, modules/gnn_module.py:161-170,
+ * models/gnn_transformer.py:69-70).  An fp32 value is EXACTLY the sum of three bf16 values; keeping the six operand-plane
+ * products down to relative 2^-16 reproduces the fp32 GEMM to accumulation order at 2.7 x the fp32-MFMA ceiling.  A weight is
+ * split once per optimizer step into an "image" (bf16 planes in LDS order); bound images reroute the big-M exact-fp32 GEMMs of
+ * gt_linear_fwd* / gt_linear_bwd* (compute == GT_F32, M >= 1024, one group) to the bf16x6 kernel. */
+size_t gt_w3_image_bytes(int64_t rows, int64_t contraction);
+/* n images in one launch per 24 jobs: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (forward), != 0 -> image of
+ * W^T (dX form); image[i]: gt_w3_image_bytes(rows, contraction) bytes, 1024-byte aligned. */
+int gt_w3_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,
+                 void* const* image, gt_stream_t stream);
+/* per HOST THREAD, until gt_w3_unbind(): weight[i] (pointer, N[i], K[i]) -> image_fwd[i] / image_t[i] (either may be NULL =
+ * keep the exact-fp32 MFMA kernel for that direction); at most 64 entries; the images must stay valid and current while bound */
+int gt_w3_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
+               const void* const* image_t);
+int gt_w3_unbind(void);
 /* dW / db only; inside an overlap section it still runs on the overlap stream (ordered behind what `stream` holds so far):
  * a caller can start a GEMM's weight gradient ahead of its dX GEMM. */
 int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

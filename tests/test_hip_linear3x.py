@@ -1,0 +1,158 @@
+"""bf16x6 GEMMs (csrc/linear3x.h: fp32 operands split exactly into three bf16 planes, six bf16-MFMA products) against a float64
+evaluation, with torch's fp32 GEMM and the exact-fp32 MFMA kernels (linear32.h) as yardsticks.  Through the C ABI
+(gt_w3_images / gt_w3_bind + gt_linear_fwd_ld2 / gt_linear_bwd_ld2) at the shapes of the benchmarked configurations:
+Code2 (31.6 k x 300 x 300, gnn2transformer 600 -> 128), Molpcba GIN (6.7 k x 300 <-> 600), ER (256 x 256), PNA (272)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GT_F32, GT_BF16 = 0, 1
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def fwd(x, W, b, bound, act=0, p=0.0, seed=0, out_dtype=torch.float32):
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    code = lambda t: GT_BF16 if t.dtype == torch.bfloat16 else GT_F32
+    call = lambda: _lib.launch("gt_linear_fwd_ld2", code(x), code(y), GT_F32, _p(x), _p(W), _p(b), _p(y), M, N, K, K, N, act, p, seed, _stream())
+    if bound is not None:
+        with bound.bound():
+            call()
+    else:
+        call()
+    return y
+
+
+def dx_of(x_like, W, dy, ymask, add1, add2, bound, p=0.0, dx_dtype=torch.float32):
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=dx_dtype, device=dy.device)
+    code = lambda t: GT_BF16 if t.dtype == torch.bfloat16 else GT_F32
+    ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(GT_F32, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    call = lambda: _lib.launch("gt_linear_bwd_ld2", code(dx), code(dy), GT_F32, None, _p(W), _p(dy), _p(ymask), _p(add1), _p(add2), _p(dx), None, None,
+                               M, N, K, K, N, p, _p(ws), ws_bytes, _stream())
+    if bound is not None:
+        with bound.bound():
+            call()
+    else:
+        call()
+    return dx
+
+
+SHAPES = [(31598, 300, 300), (31598, 128, 600), (6700, 600, 300), (6700, 300, 600), (4100, 256, 256), (16001, 272, 272), (2048, 64, 36), (1024, 20, 132)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES, ids=[f"{m}x{n}x{k}" for m, n, k in SHAPES])
+def test_forward_and_dx_match_float64_like_an_fp32_gemm(M, N, K):
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV) * (1.0 + 3.0 * torch.rand(M, 1, device=DEV))
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    y3, y32 = fwd(x, W, b, imgs), fwd(x, W, b, None)
+    y64 = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    t32 = torch.nn.functional.linear(x, W, b)
+    e3, e32, et = rel(y3, y64), rel(y32, y64), rel(t32, y64)
+    print(f"\nfwd {M}x{N}x{K}: bf16x6 {e3:.2e}  exact-fp32 MFMA {e32:.2e}  torch fp32 {et:.2e}")
+    assert e3 <= max(3 * et, 1e-6), (e3, et)
+    assert float((y3 - y64).abs().max()) <= 1e-4 * max(1.0, float(y64.abs().max()))
+    # dX = dY W (+ addends), dZ = dY * 1[Y > 0] / keep
+    dy = torch.randn(M, N, device=DEV)
+    yf = torch.relu(torch.randn(M, N, device=DEV))
+    a1, a2 = torch.randn(M, K, device=DEV), torch.randn(M, K, device=DEV)
+    d3, d32 = dx_of(x, W, dy, yf, a1, a2, imgs, p=0.25), dx_of(x, W, dy, yf, a1, a2, None, p=0.25)
+    dz = (dy.double() * (yf > 0)) / 0.75
+    d64 = dz @ W.double() + a1.double() + a2.double()
+    dt = ((dy * (yf > 0)) / 0.75) @ W + a1 + a2
+    e3, e32, et = rel(d3, d64), rel(d32, d64), rel(dt, d64)
+    print(f"dX  {M}x{N}x{K}: bf16x6 {e3:.2e}  exact-fp32 MFMA {e32:.2e}  torch fp32 {et:.2e}")
+    assert e3 <= max(3 * et, 1e-6), (e3, et)
+    # plain dX (no mask, no addends)
+    d3 = dx_of(x, W, dy, None, None, None, imgs)
+    assert rel(d3, dy.double() @ W.double()) <= max(3 * rel(dy @ W, dy.double() @ W.double()), 1e-6)
+
+
+def test_epilogue_relu_dropout_is_the_exact_kernels_mask():
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(1)
+    M, N, K = 5000, 300, 300
+    x, W, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) / K ** 0.5, torch.randn(N, device=DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    y3 = fwd(x, W, b, imgs, act=1, p=0.3, seed=12345)
+    y32 = fwd(x, W, b, None, act=1, p=0.3, seed=12345)
+    # same counter hash -> the same elements are dropped; ReLU gates may differ only where the pre-activation is ~0
+    differ = (y3 == 0) != (y32 == 0)
+    assert int(differ.sum()) <= 20, int(differ.sum())
+    same = ~differ
+    assert float((y3[same] - y32[same]).abs().max()) <= 2e-5
+    keep = float((y3 != 0).float().mean())
+    assert 0.30 < keep < 0.40   # ~ 0.5 (relu) * 0.7 (keep)
+
+
+@pytest.mark.parametrize("xd,yd", [(torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+def test_bf16_row_storage(xd, yd):
+    """the gnn2transformer shapes of the mixed mode: fp32 node rows -> bf16 token rows (forward), bf16 d tokens -> fp32 d rows (dX)"""
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(2)
+    M, N, K = 20000, 128, 600
+    x = torch.randn(M, K, device=DEV).to(xd)
+    W, b = torch.randn(N, K, device=DEV) / K ** 0.5, torch.randn(N, device=DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    y3, y32 = fwd(x, W, b, imgs, out_dtype=yd), fwd(x, W, b, None, out_dtype=yd)
+    y64 = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    tol = 3e-3 if yd == torch.bfloat16 else 1e-6
+    assert rel(y3, y64) <= max(1.5 * rel(y32, y64), tol), (rel(y3, y64), rel(y32, y64))
+    dy = torch.randn(M, N, device=DEV).to(yd)
+    d3, d32 = dx_of(x, W, dy, None, None, None, imgs, dx_dtype=xd), dx_of(x, W, dy, None, None, None, None, dx_dtype=xd)
+    d64 = dy.double() @ W.double()
+    tol = 3e-3 if xd == torch.bfloat16 else 1e-6
+    assert rel(d3, d64) <= max(1.5 * rel(d32, d64), tol), (rel(d3, d64), rel(d32, d64))
+
+
+def test_unbound_and_small_calls_keep_the_exact_kernels():
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(3)
+    W = torch.randn(300, 300, device=DEV) / 17.0
+    other = torch.randn(300, 300, device=DEV) / 17.0
+    imgs = W3Images([W])
+    imgs.build()
+    x = torch.randn(4096, 300, device=DEV)
+    a = fwd(x, other, None, imgs)          # a weight that is not in the table
+    b = fwd(x, other, None, None)
+    assert torch.equal(a, b)
+    xs = torch.randn(256, 300, device=DEV)   # short-M GEMMs (the virtual-node MLPs) never take the image path
+    assert torch.equal(fwd(xs, W, None, imgs), fwd(xs, W, None, None))
+
+
+def test_special_values_and_ranges():
+    """tiny / huge magnitudes survive the three-way split (bf16 has fp32's exponent range)"""
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(4)
+    M, N, K = 2048, 128, 128
+    x = torch.randn(M, K, device=DEV) * torch.logspace(-18, 18, M, device=DEV).unsqueeze(1)
+    W = torch.randn(N, K, device=DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    y3 = fwd(x, W, None, imgs)
+    y64 = x.double() @ W.double().t()
+    row_err = (y3.double() - y64).norm(dim=1) / y64.norm(dim=1)
+    assert float(row_err.max()) <= 2e-6, float(row_err.max())
