@@ -24,7 +24,9 @@
 // DMA waits hide under the other's MFMAs.
 #pragma once
 
-constexpr int W3_BM = 64;
+#ifndef W3_ABL
+#define W3_ABL 0   // compile-time ablation mask of tools/gemm3_probe.hip (1 no DMA, 2 no row loads, 4 no MFMA, 8 no stores); 0 in the library
+#endif
 
 static inline int w3_pick_nt(int64_t R) {   // n-tiles per column block: fewest padded tiles, ties -> 10
   const int64_t tiles = gt_cdiv(R, 16);
@@ -93,15 +95,16 @@ typedef const __attribute__((address_space(1))) void w3_glb_void;
 
 // out[M][Nout] = epilogue(A[M][Kc] Wimg^T); L32Args: a / amask / bias / add1 / add2 / out / gout / M / Nout / Kc / lda / ldo /
 // act / inv_keep / thr / s0 / s1 / ncb as for k_lin32; w3 = the image, w3_ntp its tiles per plane
-template <typename TA, typename TO, int NT, bool MASK, bool GELU = false>
+template <typename TA, typename TO, int NT, int MT, int WBUF, bool MASK, bool GELU = false>
 __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
-  constexpr int BM = W3_BM;
+  constexpr int BM = 32 * MT;                               // 2 x 2 waves, MT m-tiles per wave: 64 (MT = 2) or 128 rows (MT = 4)
+  constexpr int AR = BM / 64;                               // rows per staging thread
   constexpr int NPA = (sizeof(TA) == 2 && !MASK) ? 1 : 3;   // planes of the row operand (bf16 rows ARE their first plane)
   constexpr int HT = NT / 2;                                // n-tiles per wave
   constexpr int WSTAGE = 3 * NT * 1024, APLANE = BM * 64;
   constexpr int PLD = HT * 16 + 4;                          // epilogue patch pitch (floats)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
-  unsigned char* sA = smem3 + 2 * WSTAGE;
+  unsigned char* sA = smem3 + WBUF * WSTAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform in an SGPR: the DMA piece loop branches on it
   const int n = lane & 15, g = lane >> 4, wm = wid >> 1, wn = wid & 1;
@@ -123,70 +126,89 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
   const unsigned char* img = reinterpret_cast<const unsigned char*>(a.w3) + (int64_t)cb * NT * 1024 + lane * 16;
   const int64_t plane_stride = (int64_t)a.w3_ntp * 1024;    // bytes between the planes of one k-step
 
-  // ---- row-operand staging: thread = (row ar, 8-element group q); out-of-range rows clamp to a valid row (never stored) ----
+  // ---- row-operand staging: thread = (rows ar + 64 r, 8-element group q); out-of-range rows clamp to a valid row (never stored) ----
   const int ar = tid >> 2, q = tid & 3;
-  const int64_t a_row = m0 + ar < a.M ? m0 + ar : a.M - 1;
-  const TA* a_src = A + a_row * a.lda;
-  const TA* m_src = has_mask ? Am + a_row * a.lda : nullptr;
-  uint4 va0 = make_uint4(0, 0, 0, 0), va1 = va0, vm0 = va0, vm1 = va0;
-  bool z0 = false, z1 = false;
-  auto load = [&](int ks) {
+  const TA* a_src[AR];
+  const TA* m_src[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int64_t a_row = m0 + ar + 64 * r < a.M ? m0 + ar + 64 * r : a.M - 1;
+    a_src[r] = A + a_row * a.lda;
+    m_src[r] = has_mask ? Am + a_row * a.lda : nullptr;
+  }
+  struct ARegs {
+    uint4 v0[AR], v1[AR], m0[AR], m1[AR];
+    bool z0, z1;
+  };
+  ARegs R0;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) R0.v0[r] = R0.v1[r] = R0.m0[r] = R0.m1[r] = make_uint4(0, 0, 0, 0);
+  R0.z0 = R0.z1 = false;
+  auto load = [&](ARegs& R, int ks) {
     const int64_t k = (int64_t)ks * 32 + q * 8;
     if constexpr (sizeof(TA) == 4) {
-      z0 = k + 4 > a.Kc;
-      z1 = k + 8 > a.Kc;
-      const int64_t k0c = z0 ? a.Kc - 4 : k, k1c = z1 ? a.Kc - 4 : k + 4;
-      va0 = *reinterpret_cast<const uint4*>(a_src + k0c);
-      va1 = *reinterpret_cast<const uint4*>(a_src + k1c);
-      if constexpr (MASK) {
-        if (has_mask) {
-          vm0 = *reinterpret_cast<const uint4*>(m_src + k0c);
-          vm1 = *reinterpret_cast<const uint4*>(m_src + k1c);
+      R.z0 = k + 4 > a.Kc;
+      R.z1 = k + 8 > a.Kc;
+      const int64_t k0c = R.z0 ? a.Kc - 4 : k, k1c = R.z1 ? a.Kc - 4 : k + 4;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        R.v0[r] = *reinterpret_cast<const uint4*>(a_src[r] + k0c);
+        R.v1[r] = *reinterpret_cast<const uint4*>(a_src[r] + k1c);
+        if constexpr (MASK) {
+          if (has_mask) {
+            R.m0[r] = *reinterpret_cast<const uint4*>(m_src[r] + k0c);
+            R.m1[r] = *reinterpret_cast<const uint4*>(m_src[r] + k1c);
+          }
         }
       }
     } else {
-      z0 = k + 8 > a.Kc;
-      const int64_t kc = z0 ? a.Kc - 8 : k;
-      va0 = *reinterpret_cast<const uint4*>(a_src + kc);
-      if constexpr (MASK) {
-        if (has_mask) vm0 = *reinterpret_cast<const uint4*>(m_src + kc);
+      R.z0 = k + 8 > a.Kc;
+      const int64_t kc = R.z0 ? a.Kc - 8 : k;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        R.v0[r] = *reinterpret_cast<const uint4*>(a_src[r] + kc);
+        if constexpr (MASK) {
+          if (has_mask) R.m0[r] = *reinterpret_cast<const uint4*>(m_src[r] + kc);
+        }
       }
     }
   };
-  auto store = [&]() {
-    unsigned char* dst = sA + ar * 64 + ((q ^ ((ar >> 1) & 3)) << 4);
-    if constexpr (NPA == 1) {
-      *reinterpret_cast<uint4*>(dst) = z0 ? make_uint4(0, 0, 0, 0) : va0;
-    } else {
-      float f[8];
-      if constexpr (sizeof(TA) == 4) {
-        if (z0) va0 = make_uint4(0, 0, 0, 0);
-        if (z1) va1 = make_uint4(0, 0, 0, 0);
-        f[0] = __uint_as_float(va0.x); f[1] = __uint_as_float(va0.y); f[2] = __uint_as_float(va0.z); f[3] = __uint_as_float(va0.w);
-        f[4] = __uint_as_float(va1.x); f[5] = __uint_as_float(va1.y); f[6] = __uint_as_float(va1.z); f[7] = __uint_as_float(va1.w);
+  auto store = [&](const ARegs& R) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const int row = ar + 64 * r;
+      unsigned char* dst = sA + row * 64 + ((q ^ ((row >> 1) & 3)) << 4);
+      if constexpr (NPA == 1) {
+        *reinterpret_cast<uint4*>(dst) = R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r];
       } else {
-        if (z0) va0 = make_uint4(0, 0, 0, 0);
-        chunk_to_f32<TA>(va0, f);
-      }
-      if constexpr (MASK) {
-        if (has_mask) {
-          float y[8];
-          if constexpr (sizeof(TA) == 4) {
-            y[0] = __uint_as_float(vm0.x); y[1] = __uint_as_float(vm0.y); y[2] = __uint_as_float(vm0.z); y[3] = __uint_as_float(vm0.w);
-            y[4] = __uint_as_float(vm1.x); y[5] = __uint_as_float(vm1.y); y[6] = __uint_as_float(vm1.z); y[7] = __uint_as_float(vm1.w);
-          } else {
-            chunk_to_f32<TA>(vm0, y);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = gt_gate(f[e], y[e], a.inv_keep);
+        float f[8];
+        if constexpr (sizeof(TA) == 4) {
+          const uint4 u0 = R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r], u1 = R.z1 ? make_uint4(0, 0, 0, 0) : R.v1[r];
+          f[0] = __uint_as_float(u0.x); f[1] = __uint_as_float(u0.y); f[2] = __uint_as_float(u0.z); f[3] = __uint_as_float(u0.w);
+          f[4] = __uint_as_float(u1.x); f[5] = __uint_as_float(u1.y); f[6] = __uint_as_float(u1.z); f[7] = __uint_as_float(u1.w);
+        } else {
+          chunk_to_f32<TA>(R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r], f);
         }
-      }
-      uint32_t p1[4], p2[4], p3[4];
+        if constexpr (MASK) {
+          if (has_mask) {
+            float y[8];
+            if constexpr (sizeof(TA) == 4) {
+              y[0] = __uint_as_float(R.m0[r].x); y[1] = __uint_as_float(R.m0[r].y); y[2] = __uint_as_float(R.m0[r].z); y[3] = __uint_as_float(R.m0[r].w);
+              y[4] = __uint_as_float(R.m1[r].x); y[5] = __uint_as_float(R.m1[r].y); y[6] = __uint_as_float(R.m1[r].z); y[7] = __uint_as_float(R.m1[r].w);
+            } else {
+              chunk_to_f32<TA>(R.m0[r], y);
+            }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w3_split_pair(f[2 * e], f[2 * e + 1], p1[e], p2[e], p3[e]);
-      *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-      *reinterpret_cast<uint4*>(dst + APLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-      *reinterpret_cast<uint4*>(dst + 2 * APLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+            for (int e = 0; e < 8; ++e) f[e] = gt_gate(f[e], y[e], a.inv_keep);
+          }
+        }
+        uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w3_split_pair(f[2 * e], f[2 * e + 1], p1[e], p2[e], p3[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(dst + APLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * APLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+      }
     }
   };
   // ---- weight tiles: LDS-DMA, piece i = plane i / NT, tile i % NT -> LDS offset i KB; the four waves take them round robin ----
@@ -203,32 +225,40 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
     }
   };
 
-  f32x4 acc[2][HT];
+  f32x4 acc[MT][HT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < HT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nks = (int)((a.Kc + 31) / 32);
   const int swz = ((g ^ (n >> 1)) & 3) << 4;
-  dma(0, 0);
-  load(0);
+  // One k-step ahead, on purpose no deeper: two register sets with counted s_waitcnt (row chunks two steps ahead, loads and DMA from
+  // inline asm so that hipcc's vmcnt(0) in front of every LDS access behind an LDS-DMA does not drain them) measured 52 us against
+  // 48 us for this form on 31.6 k x 300 x 300 -- the k-step is bound by issuing its 30 + 8 KB of vector-memory traffic beside 240
+  // MFMAs (no loads at all: 34 us; no MFMAs: 39 us; tools/gemm3_probe results in DESIGN.md), not by their latency.
+  if constexpr (!(W3_ABL & 1)) dma(0, 0);
+  if constexpr (!(W3_ABL & 2)) load(R0, 0);
   for (int ks = 0; ks < nks; ++ks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step ks have landed, its row chunk is in registers
-    __syncthreads();                                   // every wave is done with step ks - 1: the A stage and W buffer (ks+1)&1 are free
-    store();
-    __syncthreads();                                   // A(ks) and all of W(ks) are visible
+    ARegs& R = R0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step ks have landed, its row chunks are in registers
+    if constexpr (WBUF == 2 && !(W3_ABL & 16)) __syncthreads();   // every wave is done with step ks - 1: the A stage and W buffer (ks+1)&1 are free
+    if constexpr (!(W3_ABL & 32)) store(R);
+    if constexpr (!(W3_ABL & 16)) __syncthreads();     // A(ks) and all of W(ks) are visible
     if (ks + 1 < nks) {
-      dma(ks + 1, (ks + 1) & 1);
-      load(ks + 1);
+      if constexpr (WBUF == 2 && !(W3_ABL & 1)) dma(ks + 1, (ks + 1) & 1);
+      if constexpr (!(W3_ABL & 2)) load(R, ks + 1);
     }
-    const unsigned char* sW = smem3 + (ks & 1) * WSTAGE + n * 64 + swz;
-    const unsigned char* sAf = sA + (wm * 32 + n) * 64 + swz;
-    bf16x8_t fa[2][NPA];
+    const unsigned char* sW = smem3 + (WBUF == 2 ? (ks & 1) : 0) * WSTAGE + n * 64 + swz;
+    const unsigned char* sAf = sA + (wm * 16 * MT + n) * 64 + swz;
+    bf16x8_t fa[MT][NPA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < NPA; ++p) fa[i][p] = *reinterpret_cast<const bf16x8_t*>(sAf + p * APLANE + i * 16 * 64);
+      for (int p = 0; p < NPA; ++p) {
+        if constexpr (W3_ABL & 64) fa[i][p] = __builtin_bit_cast(bf16x8_t, make_uint4(ks + i, p, lane, 7));
+        else fa[i][p] = *reinterpret_cast<const bf16x8_t*>(sAf + p * APLANE + i * 16 * 64);
+      }
 #pragma unroll
     for (int jp = 0; jp < HT; jp += 2) {
       bf16x8_t fw[2][3];
@@ -236,9 +266,12 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
       for (int jj = 0; jj < 2; ++jj)
         if (jp + jj < HT) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) fw[jj][p] = *reinterpret_cast<const bf16x8_t*>(sW + (p * NT + wn * HT + jp + jj) * 1024);
+          for (int p = 0; p < 3; ++p) {
+            if constexpr (W3_ABL & 64) fw[jj][p] = __builtin_bit_cast(bf16x8_t, make_uint4(ks + jp, p + jj, lane, 9));
+            else fw[jj][p] = *reinterpret_cast<const bf16x8_t*>(sW + (p * NT + wn * HT + jp + jj) * 1024);
+          }
         }
-      // the six products, small terms first; each round touches 2 x 2 independent accumulators
+      // the six products, small terms first; each round touches 2 x MT independent accumulators
       constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
@@ -247,10 +280,18 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
           for (int jj = 0; jj < 2; ++jj)
             if (jp + jj < HT) {
 #pragma unroll
-              for (int i = 0; i < 2; ++i)
+              for (int i = 0; i < MT; ++i)
+                if constexpr (W3_ABL & 4) acc[i][jp + jj][0] += __builtin_bit_cast(f32x4, fw[jj][PW[t]])[0] * __builtin_bit_cast(f32x4, fa[i][PA[t] < NPA ? PA[t] : 0])[0];
+                else
                 acc[i][jp + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj][PW[t]], fa[i][PA[t] < NPA ? PA[t] : 0], acc[i][jp + jj], 0, 0, 0);
             }
         }
+      }
+    }
+    if constexpr (WBUF == 1) {   // one W buffer: the next k-step's tiles can only start once every wave has read this one's
+      if constexpr (!(W3_ABL & 16)) __syncthreads();
+      if (ks + 1 < nks) {
+        if constexpr (!(W3_ABL & 1)) dma(ks + 1, 0);
       }
     }
   }
@@ -266,13 +307,13 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
   float* patch = fs + wid * 16 * PLD;
   constexpr int CPR = HT * 4;   // 16-byte chunks per patch row; 16 rows -> HT chunks per lane
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < HT; ++j)
       *reinterpret_cast<float4*>(patch + n * PLD + j * 16 + g * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int64_t mrow0 = m0 + wm * 32 + i * 16;
+    const int64_t mrow0 = m0 + wm * 16 * MT + i * 16;
     const int64_t ncol0 = n0 + (int64_t)wn * HT * 16;
     float4 v[HT], e1[HT], e2[HT];
     bool ok[HT];
@@ -319,16 +360,16 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
     for (int t = 0; t < HT; ++t) {
       const int c = lane + t * 64;
       const int r = c / CPR, c4 = (c % CPR) * 4;
-      if (ok[t]) gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + ncol0 + c4, v[t]);
+      if (ok[t] && (!(W3_ABL & 8) || v[t].x == 12345.678f)) gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + ncol0 + c4, v[t]);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
-template <typename TA, typename TO, int NT, bool MASK, bool GELU>
+template <typename TA, typename TO, int NT, int MT, int WBUF, bool MASK, bool GELU>
 void w3_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
-  constexpr int LDS = 2 * 3 * NT * 1024 + 3 * W3_BM * 64;
+  constexpr int LDS = WBUF * 3 * NT * 1024 + 3 * 32 * MT * 64;
   static std::mutex mu;   // per instantiation: the > 64 KB dynamic-LDS opt-in is set once per device (C-ABI: one-time queries guarded)
   static bool done[16] = {false};
   int dev = 0;
@@ -336,11 +377,27 @@ void w3_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= 16 || !done[dev]) {
-      (void)hipFuncSetAttribute((const void*)(k_lin3<TA, TO, NT, MASK, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)(k_lin3<TA, TO, NT, MT, WBUF, MASK, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (dev >= 0 && dev < 16) done[dev] = true;
     }
   }
-  hipLaunchKernelGGL((k_lin3<TA, TO, NT, MASK, GELU>), grid, dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((k_lin3<TA, TO, NT, MT, WBUF, MASK, GELU>), grid, dim3(256), LDS, stream, a);
+}
+
+#ifndef W3_FORCE_MT
+#define W3_FORCE_MT 0   // tools/gemm3_probe.hip only
+#endif
+#ifndef W3_WB_MT4
+#define W3_WB_MT4 1     // W buffers of the 128-row / 64-row configurations (the probe builds the other combinations)
+#endif
+#ifndef W3_WB_MT2
+#define W3_WB_MT2 2
+#endif
+// rows per block: 128 (one W buffer, two blocks per CU: every W byte feeds twice the MFMAs -- at 64 rows the kernel asks the L2 for
+// 40 B / cycle / CU at the MFMA rate) when that still gives the chip >= 384 blocks, else 64 (two W buffers)
+static inline int w3_pick_mt(int64_t M, int ncb) {
+  if (W3_FORCE_MT) return W3_FORCE_MT;
+  return gt_cdiv(M, 128) * ncb >= 384 ? 4 : 2;
 }
 
 template <bool MASK>
@@ -348,24 +405,31 @@ void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   const int nt = w3_pick_nt(a.Nout);
   a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
   a.w3_ntp = (int)w3_ntp(a.Nout);
-  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, W3_BM), 8) * 8 * a.ncb));
+  const int mt = w3_pick_mt(a.M, a.ncb);
+  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, 32 * mt), 8) * 8 * a.ncb));
+#define GT_W3_MT(TA_, TO_, NT_, GELU_)                                                             \
+  do {                                                                                             \
+    if (mt == 4) w3_launch_one<TA_, TO_, NT_, 4, W3_WB_MT4, MASK, GELU_>(grid, stream, a);                 \
+    else w3_launch_one<TA_, TO_, NT_, 2, W3_WB_MT2, MASK, GELU_>(grid, stream, a);                         \
+  } while (0)
   if constexpr (!MASK) {
     if (a.act == 2) {   // gelu epilogue: fp32 rows in and out only
-      if (nt == 10) w3_launch_one<float, float, 10, false, true>(grid, stream, a);
-      else w3_launch_one<float, float, 8, false, true>(grid, stream, a);
+      if (nt == 10) GT_W3_MT(float, float, 10, true);
+      else GT_W3_MT(float, float, 8, true);
       return;
     }
   }
-#define GT_W3_GO(TA_, TO_)                                                         \
-  do {                                                                             \
-    if (nt == 10) w3_launch_one<TA_, TO_, 10, MASK, false>(grid, stream, a);       \
-    else w3_launch_one<TA_, TO_, 8, MASK, false>(grid, stream, a);                 \
+#define GT_W3_GO(TA_, TO_)                                       \
+  do {                                                           \
+    if (nt == 10) GT_W3_MT(TA_, TO_, 10, false);                 \
+    else GT_W3_MT(TA_, TO_, 8, false);                           \
   } while (0)
   if (ta == GT_F32 && to == GT_F32) GT_W3_GO(float, float);
   else if (ta == GT_F32) GT_W3_GO(float, gt_bf16);
   else if (to == GT_F32) GT_W3_GO(gt_bf16, float);
   else GT_W3_GO(gt_bf16, gt_bf16);
 #undef GT_W3_GO
+#undef GT_W3_MT
 }
 
 // ---- per-thread table of prepared images (gt_w3_bind / gt_w3_unbind) -----------------------------------------------------

@@ -231,6 +231,21 @@ class _Plan:
         self.ev_sort = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []
         self.ev_wt = [lib.gt_event_create(), lib.gt_event_create()] if self.side_dw is not None else []   # transposed weights ready
         self.embed_sorted = bool(self.embed) and max(int(t.shape[0]) for t in self.embed) <= 16384
+        # big-M fp32 GEMM weights that can run as bf16x6 on the bf16 matrix pipe (w3.py / csrc/linear3x.h): images built per step
+        self.w3_weights = []
+        for conv, _bn in self.gcn:
+            if self.kind == "gcn":
+                self.w3_weights.append(conv.linear.weight)
+            else:
+                m = list(conv.mlp)
+                self.w3_weights += [m[0].weight, m[3].weight]
+        self.w3_weights.append(g2t.weight)
+        if self.embed_kind == "linear" and self.ne_Kp == self.ne_K:
+            self.w3_weights.append(self.ne_lin.weight)
+        self.w3_enc_weights = []   # the encoder layers' GEMMs run in fp32 only in the fp32 mode (fp32 token rows)
+        for mod in self.enc_layers:
+            self.w3_enc_weights += [mod.self_attn.in_proj_weight, mod.self_attn.out_proj.weight, mod.linear1.weight, mod.linear2.weight]
+        self._w3 = {}   # with_encoder -> (W3Images, versions)
         # x_0 = h_0 + vn_0[batch] with vn_0 = the ONE row of virtualnode_embedding for every graph (gnn_module.py:195):
         # the embedding-sum kernel takes it as one more table whose index column is a stride-0 zero
         self.vn0_in_embed = self.has_vn and self.embed_kind != "linear" and len(self.embed) < 16
@@ -285,6 +300,19 @@ class _Plan:
                 setattr(desc, name, p.data_ptr())
             desc.ln_eps = float(mod.norm1.eps)
             desc.act = self.enc_act
+
+    def w3_images(self, with_encoder, stream):
+        """bf16x3 images of the GEMM weights, rebuilt (one launch) whenever a weight changed since they were built"""
+        from . import w3
+        ws = self.w3_weights + (self.w3_enc_weights if with_encoder else [])
+        ent = self._w3.get(with_encoder)
+        if ent is None or not ent[0].current():
+            ent = self._w3[with_encoder] = [w3.W3Images(ws), None]
+        vers = (w3.EPOCH,) + tuple(w._version for w in ws)
+        if ent[1] != vers:
+            ent[0].build(stream)
+            ent[1] = vers
+        return ent[0]
 
     def small(self, B):
         c = self._cache.get(B)
@@ -457,8 +485,23 @@ def _call(name, *args):
 class _FusedModel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trigger, model, batched_data, gs, lay):
-        from . import ops
+        from . import ops, w3
         plan = _plan(model)
+        # exact-fp32 GEMM mode: the big-M linears run as bf16x6 on the bf16 matrix pipe (fp32-accurate, csrc/linear3x.h) on images
+        # of their weights -- rebuilt here when a weight changed (one launch), bound for this host thread while the pass runs
+        imgs = None
+        if w3.ENABLED and ops.get_matmul_dtype() != torch.bfloat16 and gs.N >= 1024:
+            imgs = plan.w3_images(model.transformer_encoder.compute_dtype != torch.bfloat16, _stream())
+            imgs.bind()
+        try:
+            return _FusedModel._forward_body(ctx, model, batched_data, gs, lay, plan, imgs)
+        finally:
+            if imgs is not None:
+                imgs.unbind()
+
+    @staticmethod
+    def _forward_body(ctx, model, batched_data, gs, lay, plan, imgs):
+        from . import ops
         L, D, d, dev = plan.L, plan.D, plan.d, plan.dev
         N, E, B, rows = gs.N, gs.E, gs.B, lay.rows
         st = _stream()
@@ -570,7 +613,9 @@ class _FusedModel(torch.autograd.Function):
         o["ws2"] = b.take(ws2_bytes)   # the side stream's workspace
         # transposed copies of the message-passing weights for the backward's exact-fp32 dX GEMMs (they run the forward-form
         # kernel on W^T): written once, beside the forward, instead of one transpose launch in front of every dX GEMM
-        want_wt = will_bwd and compute == GT_F32 and N >= 1024
+        # (with bound images the dX GEMMs run on the image of W^T; only the BatchNorm-statistics epilogue of models without a
+        # virtual node still takes the exact-fp32 kernel and its W^T)
+        want_wt = will_bwd and compute == GT_F32 and N >= 1024 and (imgs is None or (not plan.has_vn and plan.kind == "gcn"))
         if want_wt:
             o["wt"] = [b.take((2 if plan.kind == "gin" else 1) * 2 * D * D * 4) for _ in range(L)]
             o["g2t_wt"] = b.take(d * Kc * 4)
@@ -746,7 +791,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, g2t_wt=g2t_wt, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
-                         dims=(N, E, B, rows), sync=state(model).get("sync"))
+                         dims=(N, E, B, rows), sync=state(model).get("sync"), w3=imgs)
         ctx.set_materialize_grads(False)
         if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
             _call("gt_stream_wait_event", st, plan.ev_sort[1])
@@ -834,12 +879,16 @@ class _FusedModel(torch.autograd.Function):
         dw_sync = (lambda: _call("gt_overlap_dw_sync")) if ov else (lambda: None)
         if ov:
             _call("gt_overlap_dw_begin", st, plan.side_dw.cuda_stream)
+        if s.get("w3") is not None:
+            s["w3"].bind()   # (autograd's worker thread: the table is per host thread)
         try:
             return _FusedModel._backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena,
                                               emb_rows, st)
         finally:
             if ov:
                 _lib.lib().gt_overlap_dw_end()
+            if s.get("w3") is not None:
+                s["w3"].unbind()
 
     @staticmethod
     def _backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena, emb_rows, st):

@@ -90,6 +90,8 @@ class FusedAdamW(torch.optim.Optimizer):
     step.hooked = True
 
     def _step(self, closure=None):
+        from . import w3
+        w3.weights_changed()   # the kernel writes the parameters through raw pointers: cached bf16x3 weight images are stale
         loss = None
         if closure is not None:
             with torch.enable_grad():

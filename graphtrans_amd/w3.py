@@ -20,6 +20,15 @@ from .graph import _stream
 # GT_F32_GEMM=exact keeps the exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32) everywhere: the parity yardstick
 ENABLED = os.environ.get("GT_F32_GEMM", "split") != "exact"
 
+# Images are a cache of the weights: torch's in-place ops bump a parameter's `_version`, kernels that write parameters through raw
+# pointers (optim.FusedAdamW) do not -- they call weights_changed() instead; holders compare (versions, EPOCH).
+EPOCH = 0
+
+
+def weights_changed():
+    global EPOCH
+    EPOCH += 1
+
 
 class W3Images:
     def __init__(self, weights, forward=True, transposed=True):

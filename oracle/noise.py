@@ -42,6 +42,12 @@ def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12), 
     fwd: oracle.reference_math.gnn_transformer / pna_transformer, loss_of(outputs) -> scalar."""
     keys = gemm_weight_keys(sd64, mode)
     noise = {k: 0.0 for k in ref_g64}
+    b64 = copy.copy(batch)   # dense float inputs (TU / ER node features, Linear edge attributes) in the oracle's float64
+    for name in ("x", "edge_attr"):
+        v = getattr(b64, name, None)
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(b64, name, v.double())
+    batch = b64
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:

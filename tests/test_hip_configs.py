@@ -342,21 +342,21 @@ def test_fused_precision_modes_vs_oracle(workload, graphs, mode):
         check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=f"{workload} {mode}")
 
 
-LOWP_FACTOR, LOWP_FLOOR = 8.0, 2e-3
+LOWP_FACTOR, LOWP_FLOOR = 10.0, 2.0 ** -8   # floor = one bf16 ulp: the token rows themselves are stored in bf16 (activation rounding is not in the weight-only noise model)
 
 
 def check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=""):
     """Reduced-precision modes, tensor by tensor: the relative L2 error of every parameter gradient against the float64
     oracle is bounded by LOWP_FACTOR x the ORACLE's own response of that tensor to bf16-sized perturbations of the GEMM
     weights the mode rounds (oracle/noise.py: 2^-9 relative, weights only -- activation rounding adds about as much
-    again, hence the factor), never less than LOWP_FLOOR.  An ill-conditioned gradient (GINConv.eps: one scalar summed
+    again, hence the factor), never less than LOWP_FLOOR (2^-8: the storage rounding of the bf16 token rows, which the weight-only noise model leaves out).  An ill-conditioned gradient (GINConv.eps: one scalar summed
     from N x D products of both signs, modules/conv.py:21,28) gets a wide bound because the oracle itself moves that
     much, every well-conditioned tensor a tight one -- instead of one blanket bound per mode."""
     from conftest import rel_l2
     from oracle import noise as on
     from oracle import reference_math as rm
 
-    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu().clone()) for k, v in model.state_dict().items()}   # (hip_run moved the model)
     floor = on.lowp_noise(sd64, on.oracle_args(args), b, rm.gnn_transformer, oloss, ref_g64, mode)
     rms = {k: float(r.norm()) / r.numel() ** 0.5 for k, r in ref_g64.items()}
     top = max(rms.values())

@@ -40,6 +40,10 @@ def test_gemm_kernels_keep_their_register_budget():
     assert len(wide) >= 16
     for n, v in wide.items():   # two blocks (8 waves) per CU: <= 512 / 2 registers per lane incl. accumulators
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
+    split = {n: v for n, v in k.items() if re.search(r"6k_lin3I", n)}   # bf16x6 (linear3x.h): two blocks per CU by LDS (72 / 54 KB) and registers
+    assert len(split) >= 32
+    for n, v in split.items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
     for n, v in k.items():
         if re.search(r"12k_linear_(fwd|dx)I[ft][ft]tLi64E", n):   # the bf16-MFMA tiled kernels (encoder GEMMs), 64-row tiles
             assert v["Occupancy"] >= 3, (n, v)
