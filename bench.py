@@ -45,9 +45,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+PROF_MASK = 1 | 2 | 32       # csrc/gt_common.h: aggregate + attention entry points, the GEMM KERNELS one by one on their launch streams
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA
+MFMA_BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32-accurate products on the bf16 pipe: six bf16 MFMAs each (csrc/linear3x.h)
 
 
 def model_args(workload, dtype):
@@ -189,7 +191,24 @@ def aggregate_stress_report(device):
         us = 1e3 * sum(ms) / len(ms)
         by = agg_bytes(meta, bwd)
         out[name] = {"bound": "hbm", "avg_us": round(us, 1), "calls": len(ms), "algorithmic_bytes": int(by),
-                     "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4)}
+                     "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4),
+                     "traffic": None}
+    # HBM-side bytes per launch from the PMC passes over tools/agg_stress.py (tools/pmc_round.sh), same-build files only
+    try:
+        bid = build_id()
+        pdir = os.path.join(REPO, "profiles")
+        for fn in sorted(os.listdir(pdir), reverse=True):
+            if fn.endswith("_aggregate_stress_pmc_traffic.json"):
+                d = json.load(open(os.path.join(pdir, fn)))
+                if d.get("build_id") == bid:
+                    for k, v in d.get("traffic", {}).items():
+                        if k in out:
+                            out[k]["traffic"] = v
+                            out[k]["traffic_frac_of_peak"] = round(v / (out[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    out["traffic_source"] = "profiles/%s (build %s)" % (fn, bid)
+                    break
+    except OSError:
+        pass
     return out
 
 
@@ -253,16 +272,19 @@ def pmc_traffic(workload, mode, per_gpu):
 
 
 def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
-    """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the launch stream,
-    recorded inside the timed region).  -> per entry point roofline dicts.  The GEMM entry points are split by
-    compute type: exact-fp32 MFMA GEMMs (64 flop/clk/SIMD = 157 TFLOP/s) are MFMA-bound on every shape of this path
-    (arithmetic intensity 75 flop/B against a ridge of 20), the bf16 ones are HBM-bound (ridge 312 flop/B)."""
+    """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the stream each launch goes to, recorded
+    inside the timed region, under the schedule the un-profiled steps run: the weight-gradient GEMMs are bracketed ON the
+    overlap stream).  -> per kernel roofline dicts, keyed like rocprofv3's kernel names so that every `frac` can be
+    recomputed from profiles/*_kernel_stats.csv: achieved = algorithmic flops | bytes / average duration.
+      k_lin3[fwd|dx]      fp32-accurate GEMM on the bf16 pipe, six bf16 MFMAs per product: peak = 2500 / 6 = 416.7 TFLOP/s
+      k_lin32[..], k_lin32_dw+reduce   exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): peak 157.3 TFLOP/s
+      k_linear_*          bf16 MFMA on skinny shapes (M ~ 3e4, K, N <= 600): HBM-bound, priced on algorithmic bytes
+      k_small_*           short-M GEMMs (one row per graph): latency-bound, reported against the fp32 MFMA peak for scale"""
     groups = {}
     for name, ms, dims in records:
-        if name.startswith("gt_linear"):
-            # one entry per compute type AND shape class: big-M (node / token rows) vs short-M (one row per graph: the
-            # virtual-node MLPs and the prediction heads), whose flop counts differ by 100x
-            name = name + ("[fp32" if dims[5] == 0 else "[bf16") + (",rows=graphs]" if dims[0] <= 1024 else "]")
+        if name.startswith("k_"):
+            tag = "" if name.startswith(("k_lin3", "k_lin32")) else ("[fp32" if dims[5] == 0 else "[bf16") + (",rows=graphs]" if dims[0] <= 1024 else "]")
+            name = name + tag
         groups.setdefault(name, []).append((ms, dims))
     rep = {}
     for name, items in groups.items():
@@ -282,19 +304,22 @@ def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
             peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
             rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 5),
                              algorithmic_flops=int(per), **base)
-        elif name.startswith("gt_linear"):
-            base_name = name.split("[")[0]
+        elif name.startswith("k_"):
+            kind = name.split("[")[0]
 
             def lin_bytes(d):
                 M, N, K, xd, yd, _ = d
                 ex, ey = (2 if xd == 1 else 4), (2 if yd == 1 else 4)
-                b = M * K * ex + M * N * ey + N * K * 4
-                return b + M * N * ey if base_name == "gt_linear_bwd" else b
+                return M * K * ex + M * N * ey + N * K * 4
             per = float(np.mean([lin_bytes(d) for _, d in items]))
             gbs = per / (avg_us * 1e-6) / 1e9
-            fl = float(np.mean([2.0 * d[0] * d[1] * d[2] * (2 if base_name == "gt_linear_bwd" else 1) for _, d in items]))
+            fl = float(np.mean([2.0 * d[0] * d[1] * d[2] for _, d in items]))
             tf = fl / (avg_us * 1e-6) / 1e12
-            if "[fp32" in name:
+            if kind.startswith("k_lin3") and not kind.startswith("k_lin32"):
+                rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=round(MFMA_BF16X6_PEAK_TF, 1), unit="TFLOP/s",
+                                 frac=round(tf / MFMA_BF16X6_PEAK_TF, 4), algorithmic_flops=int(fl), algorithmic_bytes=int(per), gbs=round(gbs, 1),
+                                 peak_note="dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per fp32-accurate product", **base)
+            elif kind.startswith("k_lin32") or "[fp32" in name:
                 rep[name] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                  frac=round(tf / MFMA_F32_PEAK_TF, 4), algorithmic_flops=int(fl), algorithmic_bytes=int(per),
                                  gbs=round(gbs, 1), **base)
@@ -559,7 +584,7 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     sample = (lambda i: i % 16 == off) if timing else (lambda i: False)
     L = _lib.lib()
     if timing:
-        _lib.profile_enable(1 | 2 | 4)
+        _lib.profile_enable(PROF_MASK)
         L.gt_profile_enable(0)  # pool allocated, records cleared; recording toggled per step below
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(opt.steps + 1)]   # per-step device times (median)
 
@@ -568,7 +593,7 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     for i in range(opt.steps):
         marks[i].record(cur)
         if sample(i):
-            L.gt_profile_resume(1 | 2 | 4)
+            L.gt_profile_resume(PROF_MASK)
         loss = step(opt.warmup + i)
         if sample(i):
             L.gt_profile_resume(0)
@@ -714,7 +739,10 @@ def main():
     head, model, args, per_gpu = measure(opt, opt.mode, opt.scaling, world, rank, device)
     res = None
     if rank == 0:
-        res = {"metric": "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}",
+        metric = "graphs/sec (fwd+bwd) OGBG-Code2 GCN-Virtual b256" if opt.workload == "code2" else f"graphs/sec (fwd+bwd) {opt.workload}"
+        if world > 1:   # which of the two scalings `value` is (the other one rides in the same line)
+            metric += f" [value: {opt.scaling} scaling, {head['config']['graphs_per_gpu']} graphs per GPU x {world} GPUs]"
+        res = {"metric": metric,
                "value": head["value"], "unit": "graphs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None,
                "dtype": head["dtype"], "data": "synthetic"}

@@ -844,7 +844,7 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   int ctiles = (int)gt_cdiv(D, 64);
   // the block partials only hold parameter gradients (root / eps, edge-encoder weights): their reduce goes to the overlap stream
   // when there is one -- the next kernel of the backward (the dX GEMM) does not wait for it
-  hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, GT_PROF_AGGREGATE);
+  hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, 0 /* forked while profiled too: the brackets then hold the gather kernel alone, under the schedule the step really runs */);
   hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(RED_WAVES * 64), 0, rstream, r);
   if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, rstream, d_self, ctiles);
   if (rstream != stream) gt_overlap_dw_booked(workspace, workspace_bytes);

@@ -31,7 +31,11 @@ void gt_set_error(const char* fmt, ...);
   } while (0)
 
 // opt-in launch profiler (common.hip): categories for gt_profile_enable's mask
-enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF_NORM = 8, GT_PROF_SEGMENT = 16 };
+enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF_NORM = 8, GT_PROF_SEGMENT = 16,
+       // the GEMM KERNELS one by one, on the stream each is launched on (the overlap stream included): unlike GT_PROF_LINEAR
+       // (whole entry points, which keeps the weight-gradient GEMMs on the caller's stream while it brackets them) this
+       // category times the schedule the un-profiled step runs -- bench.py's roofline uses it
+       GT_PROF_GEMM_KERNEL = 32 };
 unsigned gt_prof_mask();
 int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims);
 void gt_prof_end(int64_t id, hipStream_t stream);

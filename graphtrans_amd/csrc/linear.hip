@@ -879,7 +879,10 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     SmallArgs sa{};
     sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
     sa.act = act; sa.gout = (float*)gout; sa.inv_keep = a.inv_keep; sa.thr = a.thr; sa.s0 = a.s0; sa.s1 = a.s1;
-    small_launch(SMALL_FWD, compute, gt_cdiv(M, 16) * gt_cdiv(N, 32), K, stream, sa);
+    {
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_small_fwd", stream, {M, N, K, x_dtype, y_dtype, compute});
+      small_launch(SMALL_FWD, compute, gt_cdiv(M, 16) * gt_cdiv(N, 32), K, stream, sa);
+    }
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
@@ -890,9 +893,11 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     // a prepared bf16x3 image of this weight (gt_w3_bind): the fp32-accurate GEMM on the bf16 matrix pipe (linear3x.h);
     // bf16 rows need K % 8 (their 16-byte chunks are whole k-groups)
     w.w3 = (x_dtype == GT_F32 || K % 8 == 0) ? w3_lookup(weight, N, K, false) : nullptr;
-    if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
-    else
-    w32_launch<false>(x_dtype, y_dtype, stream, w);
+    {
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
+      if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
+      else w32_launch<false>(x_dtype, y_dtype, stream, w);
+    }
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
@@ -900,8 +905,11 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
   a.ntiles = (int)gt_cdiv(N, BN);
   dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups);
   const int t0 = x_dtype, t1 = y_dtype;
-  if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_fwd, 64, grid, a);
-  else GT_LIN_DISPATCH_BM(k_linear_fwd, 128, grid, a);
+  {
+    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_linear_fwd", stream, {M, N, K, x_dtype, y_dtype, compute});
+    if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_fwd, 64, grid, a);
+    else GT_LIN_DISPATCH_BM(k_linear_fwd, 128, grid, a);
+  }
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
@@ -1077,6 +1085,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     sa.inv_keep = a.inv_keep;
     if (dx) {
       sa.out = (float*)dx;
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_small_dx", stream, {M, N, K, x_dtype, y_dtype, compute});
       small_launch(SMALL_DX, compute, gt_cdiv(M, 16) * gt_cdiv(K, 32), N, stream, sa);
     }
     if (dweight) {
@@ -1090,7 +1099,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         stream = g_dw.side;
       }
       sa.out = dweight; sa.db = dbias;
-      small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_small_dw", stream, {M, N, K, x_dtype, y_dtype, compute});
+        small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
+      }
       if (forked) dw_forked(workspace, workspace_bytes);
     }
     GT_CHECK_LAUNCH();
@@ -1130,9 +1142,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.bn_relu = q.relu; w.bn_part = q.part;
       }
       w.w3 = w3t;
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, w3t ? "k_lin3[dx]" : "k_lin32[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
       if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
-      else
-      w32_launch<true>(y_dtype, x_dtype, stream, w);
+      else w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
       const bool forked = will_fork;
@@ -1147,12 +1159,15 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       d.splits = splits; d.nkb = nkb; d.nnb = nnb;
       d.m_per_split = gt_cdiv(gt_cdiv(M, splits), 16) * 16;
       dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * nkb * nnb));
-      if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
-      else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
-      const int64_t len = N * K, len2 = dbias ? N : 0;
-      int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-      hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, splits, len, dweight,
-                         (const float*)d.dbpart, len2, dbias, (int64_t)0);
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin32_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+        if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
+        else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
+        const int64_t len = N * K, len2 = dbias ? N : 0;
+        int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+        hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, splits, len, dweight,
+                           (const float*)d.dbpart, len2, dbias, (int64_t)0);
+      }
       if (forked) dw_forked(workspace, workspace_bytes);
     }
     GT_CHECK_LAUNCH();
@@ -1169,6 +1184,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     a.ntiles = (int)gt_cdiv(K, BN);
     dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups, (unsigned)splits);
     const int t0 = y_dtype, t1 = x_dtype;
+    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_linear_dx", stream, {M, N, K, x_dtype, y_dtype, compute});
     if (bm == 64) GT_LIN_DISPATCH_BM(k_linear_dx, 64, grid, a);
     else GT_LIN_DISPATCH_BM(k_linear_dx, 128, grid, a);
     if (splits > 1) {
@@ -1190,7 +1206,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     sa.x = (const float*)x; sa.w = weight; sa.dy = (const float*)dy; sa.ymask = (const float*)y_for_mask;
     sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy; sa.inv_keep = a.inv_keep;
     sa.out = dweight; sa.db = dbias;
-    small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
+    {
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_small_dw", stream, {M, N, K, x_dtype, y_dtype, compute});
+      small_launch(SMALL_DW, compute, gt_cdiv(N, 32) * gt_cdiv(K, 16), M, stream, sa);
+    }
     if (forked) dw_forked(workspace, workspace_bytes);
     GT_CHECK_LAUNCH();
     return GT_OK;
@@ -1220,11 +1239,14 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     a.ntiles = a.ntx * (int)gt_cdiv(K, BN);
     dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * a.ntiles), (unsigned)groups);
     const int t0 = y_dtype, t1 = x_dtype;
-    GT_LIN_DISPATCH(k_linear_dw, grid, a);
-    const int64_t len = N * K, len2 = dbias ? N : 0;
-    int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-    hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
-                       (const float*)a.dbpart, len2, dbias, a.g_part);
+    {
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_linear_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+      GT_LIN_DISPATCH(k_linear_dw, grid, a);
+      const int64_t len = N * K, len2 = dbias ? N : 0;
+      int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+      hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,
+                         (const float*)a.dbpart, len2, dbias, a.g_part);
+    }
     if (forked) dw_forked(workspace, workspace_bytes);
   }
   GT_CHECK_LAUNCH();

@@ -11,6 +11,8 @@
 // channels, profiles/r01a): column statistics here are one streaming pass (shifted sums: pivot =
 // row 0 of every column, so sum / sum-of-squares do not cancel), deterministic block partials, a
 // latency-hidden fixed-order finish, then one apply pass with ReLU fused.
+#include <stdlib.h>
+
 #include "gt_common.h"
 
 namespace {
@@ -444,8 +446,13 @@ __global__ void __launch_bounds__(SM_COLS * SM_LANES) k_bn_small_bwd(
 }
 
 int part_blocks(int64_t N) {
+  static const int max_part = [] {   // experiment knob (GT_BN_MAX_PART), read once
+    const char* e = getenv("GT_BN_MAX_PART");
+    const int v = e ? atoi(e) : 0;
+    return v >= 32 && v <= 4096 ? v : MAX_PART;
+  }();
   int64_t b = gt_cdiv(N, 32);
-  return (int)(b < 1 ? 1 : (b > MAX_PART ? MAX_PART : b));
+  return (int)(b < 1 ? 1 : (b > max_part ? max_part : b));
 }
 int flat_blocks(int64_t items) {
   int64_t g = gt_cdiv(items, NT * 2);

@@ -20,6 +20,12 @@ for w in code2 molpcba; do
     python tools/pmc_traffic.py $f $wr $w $m 256 gpurun_out/$tag/${tag}_${w}_${m} || true
   done
 done
+# HBM traffic of the aggregate kernels on the stress batch (BASELINE configs[4]: the bandwidth proof; on Code2 the re-gathers hit L2)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_aggstress_$c
+  timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_aggstress_$c -o res -- python tools/agg_stress.py > gpurun_out/$tag/pmc_aggstress_$c.log 2>&1 || true
+done
+python tools/agg_stress.py --pmc-json $(find /tmp/pmc_aggstress_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_aggstress_WRITE_SIZE -name "*.db" | head -1) gpurun_out/$tag/${tag}_aggregate_stress_pmc_traffic.json || true
 # MFMA / LDS issue counters of the GEMM and attention kernels (Code2 only; one SQ pass, 8 slots)
 for m in $modes; do
   rm -rf /tmp/pmc_mfma_$m

@@ -16,13 +16,19 @@ import sys
 # bf16 GEMM paths and is reported on its own.
 BF16 = r"unsigned short"
 ENTRY = {
-    "gt_linear_fwd[fp32]": ((r"k_lin32<.*, false>",), r"k_lin32<.*, false>"),
-    "gt_linear_bwd[fp32]": ((r"k_lin32<.*, true>", r"k_transpose32", r"k_lin32_dw<"), r"k_lin32_dw<"),
-    "gt_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
-    "gt_linear_bwd[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>", r"k_linear_dw<[^>]*" + BF16 + r">"), r"k_linear_dw<[^>]*" + BF16 + r">"),
+    # GEMM kernels one by one (bench.py kernel_report keys = the C-side kernel-level profiler names, GT_PROF_GEMM_KERNEL)
+    "k_lin3[fwd]": ((r"k_lin3<[^>]*, false, (?:false|true)>",), r"k_lin3<[^>]*, false, (?:false|true)>"),
+    "k_lin3[dx]": ((r"k_lin3<[^>]*, true, false>",), r"k_lin3<[^>]*, true, false>"),
+    "k_lin32[fwd]": ((r"k_lin32<[^>]*?, \d+, false,",), r"k_lin32<[^>]*?, \d+, false,"),
+    "k_lin32[dx]": ((r"k_lin32<[^>]*?, \d+, true,", r"k_transpose32"), r"k_lin32<[^>]*?, \d+, true,"),
+    "k_lin32_dw+reduce": ((r"k_lin32_dw<",), r"k_lin32_dw<"),   # (its k_split_reduce launches are shared with the bf16 path: reported on their own)
+    "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
+    "k_linear_dx[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>",), r"k_linear_dx<[^>]*" + BF16 + r", \d+>"),
+    "k_linear_dw+reduce[bf16]": ((r"k_linear_dw<[^>]*" + BF16 + r">",), r"k_linear_dw<[^>]*" + BF16 + r">"),
     "k_split_reduce": ((r"k_split_reduce",), r"k_split_reduce"),
-    "gt_aggregate_fwd": ((r"k_agg_fwd<",), r"k_agg_fwd<"),
-    "gt_aggregate_bwd": ((r"k_agg_bwd<", r"k_agg_reduce"), r"k_agg_bwd<"),
+    "gt_aggregate_fwd": ((r"k_aggw?_fwd<",), r"k_aggw?_fwd<"),
+    "gt_aggregate_bwd": ((r"k_aggw?_bwd<",), r"k_aggw?_bwd<"),   # (the gather kernel: its parameter-partials reduce, k_agg_reduce, runs on the overlap stream)
+    "k_agg_reduce": ((r"k_agg_reduce",), r"k_agg_reduce"),
     "gt_attn_fwd": ((r"k_attn_fwd<",), r"k_attn_fwd<"),
     "gt_attn_bwd": ((r"k_attn_bwd_dq<", r"k_attn_bwd_dkv<"), r"k_attn_bwd_dq<"),
 }
@@ -34,7 +40,7 @@ def per_kernel(db, counter):
     for n, c, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
         if c != counter:
             continue
-        full = re.sub(r"\(anonymous namespace\)::", "", n)[:90]
+        full = re.sub(r"\(anonymous namespace\)::", "", n)[:120]
         if not re.search(r"\bk_[a-z_0-9]+", full):
             continue
         a = agg.setdefault(full, [0, 0.0])
