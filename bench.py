@@ -535,6 +535,13 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     torch.manual_seed(1234)  # identical initial parameters on every rank
     args, model, gen, loss_fn, wl_name = build(opt.workload, dtype, device, per_gpu)
     model.train()
+    # strong scaling splits ONE global batch over the ranks: with per-rank BatchNorm statistics that is a different model from the
+    # reference's single-device b256 (modules/gnn_module.py:204) -- synchronised statistics restore it, on the fused path
+    # (dist.BnSyncHook: 2 D + 1 floats per BatchNorm and direction over RCCL)
+    sync_bn = world > 1 and scaling == "strong" and not opt.no_sync_bn
+    if sync_bn:
+        from graphtrans_amd.modules.norm import convert_sync_batchnorm
+        convert_sync_batchnorm(model)
     sync = GradSync(model.parameters(), world_size=world).attach(model)
     optim = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)  # torch.optim.AdamW semantics, one HIP launch
     torch.manual_seed(1234 + rank)  # per-rank dropout streams
@@ -626,7 +633,8 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                        "step": ("collate+" if store is not None else "") + "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
                        "gnn_dtype": "fp32 storage, %s MFMA GEMMs (message passing, VN MLP, gnn2transformer, heads)" % ("bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32"),
                        "transformer_dtype": "%s token rows, %s MFMA (encoder layers)" % (("bf16", "bf16") if dtype == torch.bfloat16 else ("fp32", "bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32")),
-                       "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout}},
+                       "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout},
+                       "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics"},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }
         if records:
@@ -685,6 +693,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="only the headline measurement (no other modes / scaling / precision report)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md section 3 in full (minutes of CPU time) instead of the bounded sample")
+    ap.add_argument("--no-sync-bn", action="store_true", help="strong scaling with per-rank BatchNorm statistics (default: synchronised)")
     ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dry-run", action="store_true",

@@ -87,6 +87,7 @@ SIGNATURES = {
     "gt_linear_bwd_mul_dw_forked": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
+    "gt_bn_sync_set": (_i, [_p, _p, _i]),
     "gt_w3_image_bytes": (_sz, [_i64, _i64]),
     "gt_w3_images": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "gt_w3_bind": (_i, [_i, _p, _p, _p, _p, _p]),
@@ -228,6 +229,10 @@ def launch(name, *args, meta=None):
     else:
         rc = fn(*args)
     check(rc, name)
+
+
+# gt_bn_sync_fn (include/graphtrans_hip.h): int fn(void* user, int kind, float* buf, int64_t n, gt_stream_t stream)
+BN_SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 def check(rc, what):

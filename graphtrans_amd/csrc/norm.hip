@@ -283,8 +283,9 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ dbias, const float* __restrict__ dweight,
                                                      int relu, float inv_n, BnDrop drop, int64_t N, int64_t D,
-                                                     T* __restrict__ dx) {
+                                                     T* __restrict__ dx, const float* __restrict__ count_dev) {
   const int64_t C = D / 4, total = N * C;   // inv_n: 1 / (rows the statistics were taken over) in training, 0 in eval
+  if (count_dev) inv_n = 1.0f / count_dev[0];   // synchronised statistics: the all-reduced row count of every rank
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t c = (i % C) * 4;
     float4 g = gt_load4<T>(dy + i * 4);
@@ -443,6 +444,80 @@ __global__ void __launch_bounds__(SM_COLS * SM_LANES) k_bn_small_bwd(
     const float g = grad_at(r, xh);
     st1<T>(dx + r * D + c, ww * rs * (g - db - xh * dw));
   }
+}
+
+// ---- synchronised statistics across data-parallel ranks (modules/gnn_module.py:204,164,167 normalise over the
+// single-device batch, which graph sharding splits).  The collective belongs to the caller (torch.distributed / RCCL): while a hook
+// is set for the calling HOST THREAD every training-mode BatchNorm of this library -- also the ones inside the composite layer
+// entry points -- hands its local statistics to the hook between its two passes:
+//   kind 0 (forward):  buf[0 .. n)           = {rows, mean[D], biased var[D]} of the local rows, n = 2 D + 1
+//                      buf[n .. n + world n) <- the hook all-gathers every rank's n floats here, in rank order
+//   kind 1 (backward): buf[0 .. 2 D)         = {sum dy', sum dy' xhat} over the local rows  <- the hook all-reduces (sum) in place
+// `stream` is the stream the BatchNorm runs on (the collective has to be ordered on it); the hook returns 0 or an error code.
+// Forward then merges the ranks' statistics in rank order (Chan et al.) -- identical on every rank -- and updates the running
+// statistics with the GLOBAL batch; backward applies with the global sums and the global row count.  Parameter gradients stay the
+// local sums (the gradient all-reduce averages them like every other parameter).
+constexpr int BN_SYNC_MAX_WORLD = 64;
+struct BnSync {
+  gt_bn_sync_fn fn = nullptr;
+  void* user = nullptr;
+  int world = 1;
+};
+thread_local BnSync g_bn_sync;
+
+__global__ void k_bn_sync_pack(const float* __restrict__ mean, const float* __restrict__ rstd, float rows, float eps, int64_t D,
+                               float* __restrict__ buf) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) buf[0] = rows;
+  if (c < D) {
+    const float rs = rstd[c];
+    const float var = 1.0f / (rs * rs) - eps;
+    buf[1 + c] = mean[c];
+    buf[1 + D + c] = var > 0.f ? var : 0.f;
+  }
+}
+// one thread per column: ranks merged in rank order, in double
+__global__ void k_bn_sync_merge(const float* __restrict__ gathered, int world, int64_t D, float eps, float momentum,
+                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = 2 * D + 1;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= D) return;
+  double cnt = 0.0, mu = 0.0, m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double nr = (double)gathered[r * n];
+    if (nr <= 0.0) continue;
+    const double mr = (double)gathered[r * n + 1 + c], vr = (double)gathered[r * n + 1 + D + c];
+    const double tot = cnt + nr, delta = mr - mu;
+    m2 += vr * nr + delta * delta * cnt * nr / tot;
+    mu += delta * nr / tot;
+    cnt = tot;
+  }
+  const double var = cnt > 0.0 ? m2 / cnt : 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = cnt > 1.0 ? var * (cnt / (cnt - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+__global__ void k_bn_sync_copy2(const float* __restrict__ a, const float* __restrict__ b, float rows, int64_t D, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) out[2 * D] = rows;
+  if (c < D) {
+    out[c] = a[c];
+    out[D + c] = b[c];
+  }
+}
+// the exchange area of a BatchNorm workspace: behind the column partials (gt_batchnorm_workspace_bytes)
+float* bn_sync_buf(void* workspace, int64_t rows, int64_t dim);
+
+int part_blocks(int64_t N);
+float* bn_sync_buf(void* workspace, int64_t rows, int64_t dim) {
+  uintptr_t p = (uintptr_t)workspace + (size_t)part_blocks(rows) * 2 * dim * sizeof(float);
+  return (float*)((p + 255) & ~(uintptr_t)255);
 }
 
 int part_blocks(int64_t N) {
@@ -764,7 +839,9 @@ static BnDrop make_bn_drop(float dropout_p, uint64_t seed) {
 }
 
 extern "C" size_t gt_batchnorm_workspace_bytes(int64_t rows, int64_t dim) {
-  return (size_t)part_blocks(rows) * 2 * dim * sizeof(float) + 256;
+  // + the exchange buffers of synchronised statistics (gt_bn_sync_set): packed local statistics, the all-gathered copies of up to
+  // BN_SYNC_MAX_WORLD ranks and the all-reduced gradient sums
+  return (size_t)part_blocks(rows) * 2 * dim * sizeof(float) + 256 + (size_t)(BN_SYNC_MAX_WORLD + 2) * (2 * dim + 4) * sizeof(float);
 }
 
 extern "C" int gt_batchnorm_fwd(int dtype, const void* x, const float* weight, const float* bias,
@@ -791,12 +868,13 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
   const BnDrop drop = make_bn_drop(training ? dropout_p : 0.f, seed);
   GT_CHECK_ARG(x && weight && bias && y && save_mean && save_rstd, "null buffer");
   GT_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  if (rows == 0) return GT_OK;
+  const bool sync = training && g_bn_sync.fn && g_bn_sync.world > 1;   // statistics over every rank's rows (gt_bn_sync_set)
+  if (rows == 0 && !sync) return GT_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   if (training) {
-    GT_CHECK_ARG(rows > 1, "BatchNorm in training mode needs more than 1 row");  // torch raises too
-    if (rows <= SMALL_ROWS) {
+    GT_CHECK_ARG(rows > 1 || sync, "BatchNorm in training mode needs more than 1 row");  // torch raises too
+    if (rows <= SMALL_ROWS && !sync) {
       if (bcast && ev_bcast_ready) {
         rc = gt_stream_wait_event(stream_, ev_bcast_ready);
         if (rc) return rc;
@@ -819,14 +897,33 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
     }
     float* part = (float*)workspace;
     size_t lds = rowlane_lds(dim, 2);
-    if (dtype == GT_F32) {
-      hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
-      hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)x, part, nb, rows,
-                         dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
-    } else {
-      hipLaunchKernelGGL(k_bn_stats_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, rows, dim, part);
-      hipLaunchKernelGGL(k_bn_stats_finish<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const gt_bf16*)x, part, nb,
-                         rows, dim, eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
+    // synchronised: the local pass leaves the running statistics alone -- the merge below updates them with the global batch
+    float* rm_l = sync ? nullptr : running_mean;
+    float* rv_l = sync ? nullptr : running_var;
+    int64_t* nbt_l = sync ? nullptr : num_batches_tracked;
+    if (rows > 0) {
+      if (dtype == GT_F32) {
+        hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
+        hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)x, part, nb, rows,
+                           dim, eps, momentum, save_mean, save_rstd, rm_l, rv_l, nbt_l);
+      } else {
+        hipLaunchKernelGGL(k_bn_stats_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, rows, dim, part);
+        hipLaunchKernelGGL(k_bn_stats_finish<gt_bf16>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const gt_bf16*)x, part, nb,
+                           rows, dim, eps, momentum, save_mean, save_rstd, rm_l, rv_l, nbt_l);
+      }
+    }
+    if (sync) {
+      float* sb = bn_sync_buf(workspace, rows, dim);
+      const int64_t n = 2 * dim + 1;
+      const unsigned cg = (unsigned)gt_cdiv(dim > 1 ? dim : 1, 256);
+      if (rows > 0) hipLaunchKernelGGL(k_bn_sync_pack, dim3(cg), dim3(256), 0, stream, save_mean, save_rstd, (float)rows, eps, dim, sb);
+      else (void)hipMemsetAsync(sb, 0, (size_t)n * sizeof(float), stream);
+      GT_CHECK_LAUNCH();
+      const int hrc = g_bn_sync.fn(g_bn_sync.user, 0, sb, n, stream_);
+      if (hrc) { gt_set_error("gt_batchnorm_fwd: the statistics hook failed (%d)", hrc); return GT_ERR_LAUNCH; }
+      hipLaunchKernelGGL(k_bn_sync_merge, dim3(cg), dim3(256), 0, stream, sb + n, g_bn_sync.world, dim, eps, momentum, save_mean, save_rstd,
+                         running_mean, running_var, num_batches_tracked);
+      if (rows == 0) { GT_CHECK_LAUNCH(); return GT_OK; }
     }
   } else {
     hipLaunchKernelGGL(k_bn_eval_stats, dim3(cgrid), dim3(256), 0, stream, running_mean, running_var, dim, eps, save_mean,
@@ -856,7 +953,8 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
   const BnDrop drop = make_bn_drop(training ? dropout_p : 0.f, seed);
   GT_CHECK_ARG(x && dy && weight && bias && save_mean && save_rstd && dx && dweight && dbias, "null buffer");
-  if (rows == 0) return GT_OK;
+  const bool sync = training && g_bn_sync.fn && g_bn_sync.world > 1;
+  if (rows == 0 && !sync) return GT_OK;
   if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
     gt_set_error("gt_batchnorm_bwd: workspace too small");
     return GT_ERR_WORKSPACE;
@@ -867,6 +965,37 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
   const size_t lds = rowlane_lds(dim, 2);
   const int cgrid = (int)gt_cdiv(dim, FIN_COLS);
   const int g = flat_blocks(rows * (dim / 4));
+  if (sync) {   // local sums -> all-reduce (sums and row count) -> apply with the global ones; dweight / dbias stay local
+    const unsigned cg = (unsigned)gt_cdiv(dim > 1 ? dim : 1, 256);
+    float* sb = bn_sync_buf(workspace, rows, dim);
+    if (rows > 0) {
+      if (dtype == GT_F32)
+        hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy, weight, bias,
+                           save_mean, save_rstd, relu, drop, rows, dim, part);
+      else
+        hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy, weight,
+                           bias, save_mean, save_rstd, relu, drop, rows, dim, part);
+      hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
+      hipLaunchKernelGGL(k_bn_sync_copy2, dim3(cg), dim3(256), 0, stream, dbias, dweight, (float)rows, dim, sb);
+    } else {
+      (void)hipMemsetAsync(dbias, 0, (size_t)dim * sizeof(float), stream);
+      (void)hipMemsetAsync(dweight, 0, (size_t)dim * sizeof(float), stream);
+      (void)hipMemsetAsync(sb, 0, (size_t)(2 * dim + 1) * sizeof(float), stream);
+    }
+    GT_CHECK_LAUNCH();
+    const int hrc = g_bn_sync.fn(g_bn_sync.user, 1, sb, 2 * dim + 1, stream_);
+    if (hrc) { gt_set_error("gt_batchnorm_bwd: the statistics hook failed (%d)", hrc); return GT_ERR_LAUNCH; }
+    if (rows > 0) {
+      if (dtype == GT_F32)
+        hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy, save_mean, save_rstd,
+                           weight, bias, sb, sb + dim, relu, 1.0f, drop, rows, dim, (float*)dx, (const float*)(sb + 2 * dim));
+      else
+        hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, save_mean,
+                           save_rstd, weight, bias, sb, sb + dim, relu, 1.0f, drop, rows, dim, (gt_bf16*)dx, (const float*)(sb + 2 * dim));
+    }
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (rows <= SMALL_ROWS) {
     if (dtype == GT_F32)
       hipLaunchKernelGGL(k_bn_small_bwd<float>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const float*)x,
@@ -884,13 +1013,13 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL(k_bn_bwd_partial<gt_bf16>, dim3(nb), dim3(NT), lds, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, nb, dim, dbias, dweight);
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy,
-                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx);
+                       save_mean, save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx, (const float*)nullptr);
   }
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -915,10 +1044,10 @@ extern "C" int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, 
   hipLaunchKernelGGL(k_bn_bwd_finish, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, part, (int)nparts, dim, dbias, dweight);
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy, save_mean, save_rstd,
-                       weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx);
+                       weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (float*)dx, (const float*)nullptr);
   else
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, save_mean,
-                       save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx);
+                       save_rstd, weight, bias, dbias, dweight, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, (gt_bf16*)dx, (const float*)nullptr);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }
@@ -962,11 +1091,21 @@ extern "C" int gt_batchnorm_bwd_apply(int dtype, const void* x, const void* dy, 
   const float inv_n = (float)(1.0 / count);
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(NT), 0, stream, (const float*)x, (const float*)dy, mean, rstd, weight,
-                       bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (float*)dx);
+                       bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (float*)dx, (const float*)nullptr);
   else
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, mean, rstd,
-                       weight, bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (gt_bf16*)dx);
+                       weight, bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (gt_bf16*)dx, (const float*)nullptr);
   GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+// Per host thread: every training-mode BatchNorm call of this thread exchanges its statistics through `fn` (contract above);
+// world = ranks in the exchange (2..64); fn == NULL or world <= 1 switches it off again.
+extern "C" int gt_bn_sync_set(gt_bn_sync_fn fn, void* user, int world) {
+  GT_CHECK_ARG(world >= 0 && world <= BN_SYNC_MAX_WORLD, "at most 64 ranks");
+  g_bn_sync.fn = (fn && world > 1) ? fn : nullptr;
+  g_bn_sync.user = user;
+  g_bn_sync.world = g_bn_sync.fn ? world : 1;
   return GT_OK;
 }
 

@@ -15,6 +15,9 @@ Fused model path (engine.py): all gradients already live in ONE flat buffer, so 
 and the reduction is issued from inside the backward: the transformer + heads half of the buffer goes
 on the wire while the message-passing backward is still running (`attach` / `reduce_flat`).
 """
+import contextlib
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -130,3 +133,94 @@ def balanced_shards(sizes, world, cost=None):
         out[r].append(int(i))
         load[r] += float(c[i])
     return [np.array(sorted(o), dtype=np.int64) for o in out]
+
+
+# ---- synchronised BatchNorm statistics for the library's BatchNorm calls (composite / fused paths) -----------------------
+class _DevView:
+    """n floats at a raw device pointer as a torch tensor (no copy): torch.as_tensor reads __cuda_array_interface__"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class BnSyncHook:
+    """The collective half of synchronised BatchNorm (include/graphtrans_hip.h: gt_bn_sync_set).  While installed for the
+    calling thread, every training-mode BatchNorm inside the C library -- the ones in gt_gcn_layer_* / gt_gin_layer_* /
+    gt_vn_update_* included, i.e. the FUSED model path -- exchanges (rows, mean, var) by all-gather in its forward and
+    (sum dy', sum dy' xhat, rows) by all-reduce in its backward, on the stream it runs on.  With graphs sharded over ranks
+    the model then is the reference's single-device-batch model (modules/gnn_module.py:204,164,167).
+
+        hook = BnSyncHook(group)            # once
+        with hook.installed(): ...          # per thread (autograd's backward thread installs it again)
+    RCCL ("nccl") moves device buffers on the BatchNorm's stream; other backends (gloo in the tests) go through the host."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        from . import _lib
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device_collectives = dist.get_backend(group) == "nccl"
+        self._streams = {}
+        self.calls = 0
+        self.error = None
+        self._cb = _lib.BN_SYNC_FN(self._hook)   # keep the ctypes thunk alive as long as the hook
+
+    def _stream(self, ptr, device):
+        """torch stream object of the raw stream the BatchNorm runs on.  NULL is torch's default stream: ExternalStream(0) is NOT
+        -- torch.cuda.Stream(stream_ptr=0) takes a fresh stream from torch's pool, and a copy issued there overtakes the
+        kernels on the NULL stream (found as stale statistics packets in one exchange out of ~10)."""
+        if not ptr:
+            return torch.cuda.default_stream(device)
+        st = self._streams.get(ptr)
+        if st is None:
+            st = self._streams[ptr] = torch.cuda.ExternalStream(int(ptr), device=device)
+        return st
+
+    def _hook(self, user, kind, buf, n, stream):
+        import torch.distributed as dist
+        try:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            n, w = int(n), self.world
+            with torch.cuda.stream(self._stream(stream, dev)):
+                if kind == 0:
+                    view = torch.as_tensor(_DevView(buf, n * (w + 1)), device=dev)
+                    local, gathered = view[:n], view[n:]
+                    if self.device_collectives:
+                        dist.all_gather_into_tensor(gathered, local, group=self.group)
+                    else:
+                        parts = [torch.empty(n, dtype=torch.float32) for _ in range(w)]
+                        dist.all_gather(parts, local.cpu(), group=self.group)
+                        gathered.copy_(torch.cat(parts))
+                else:
+                    view = torch.as_tensor(_DevView(buf, n), device=dev)
+                    if self.device_collectives:
+                        dist.all_reduce(view, group=self.group)
+                    else:
+                        host = view.cpu()
+                        dist.all_reduce(host, group=self.group)
+                        view.copy_(host)
+            self.calls += 1
+            return 0
+        except Exception as e:   # never unwind through the C frames
+            self.error = e
+            return -1
+
+    def install(self):
+        from . import _lib
+        _lib.check(_lib.lib().gt_bn_sync_set(C.cast(self._cb, C.c_void_p), None, self.world), "gt_bn_sync_set")
+
+    @staticmethod
+    def uninstall():
+        from . import _lib
+        _lib.lib().gt_bn_sync_set(None, None, 1)
+
+    @contextlib.contextmanager
+    def installed(self):
+        self.install()
+        try:
+            yield self
+        finally:
+            self.uninstall()
+            if self.error is not None:
+                e, self.error = self.error, None
+                raise e

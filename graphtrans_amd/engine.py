@@ -344,6 +344,25 @@ def invalidate(model):
         st.pop("plan", None)
         st.pop("eligible", None)
         st.pop("params", None)
+        st.pop("bn_sync", None)
+        st.pop("bn_hook", None)
+
+
+def _bn_sync_hook(model, plan):
+    """dist.BnSyncHook of a model whose BatchNorms are synchronised (modules/norm.py:convert_sync_batchnorm), else None"""
+    from .modules.norm import BatchNorm1d, any_sync
+    st = state(model)
+    if "bn_sync" not in st:
+        bns = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
+        st["bn_sync"] = bns[0].sync_group if (bns and any_sync(*bns)) else False
+    grp = st["bn_sync"]
+    if grp is False:
+        return None
+    hook = st.get("bn_hook")
+    if hook is None:
+        from .dist import BnSyncHook
+        hook = st["bn_hook"] = BnSyncHook(grp)
+    return hook
 
 
 def _plan(model):
@@ -464,9 +483,14 @@ def _eligible_static(model):
                 return False
         if model.gnn2transformer.weight.shape[1] % 4:
             return False
+        # (synchronised BatchNorm -- statistics over all data-parallel ranks -- runs on this path too: the library's BatchNorm calls
+        # exchange their statistics through dist.BnSyncHook, installed around the pass; all of the model's BatchNorms or none)
         from .modules.norm import any_sync
-        if any_sync(*[m for m in model.modules() if isinstance(m, BatchNorm1d)]):
-            return False   # synchronised BatchNorm (statistics over all ranks) runs module by module
+        bns = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
+        if any_sync(*bns) and not all(getattr(b, "sync", False) for b in bns):
+            return False
+        if any_sync(*bns) and len({id(getattr(b, "sync_group", None)) for b in bns}) != 1:
+            return False
         for p in model.parameters():
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad):
                 return False
@@ -493,14 +517,22 @@ class _FusedModel(torch.autograd.Function):
         if w3.ENABLED and ops.get_matmul_dtype() != torch.bfloat16 and gs.N >= 1024:
             imgs = plan.w3_images(model.transformer_encoder.compute_dtype != torch.bfloat16, _stream())
             imgs.bind()
+        hook = _bn_sync_hook(model, plan) if model.training else None
+        if hook is not None:
+            hook.install()
         try:
-            return _FusedModel._forward_body(ctx, model, batched_data, gs, lay, plan, imgs)
+            return _FusedModel._forward_body(ctx, model, batched_data, gs, lay, plan, imgs, hook)
         finally:
             if imgs is not None:
                 imgs.unbind()
+            if hook is not None:
+                hook.uninstall()
+                if hook.error is not None:
+                    e, hook.error = hook.error, None
+                    raise e
 
     @staticmethod
-    def _forward_body(ctx, model, batched_data, gs, lay, plan, imgs):
+    def _forward_body(ctx, model, batched_data, gs, lay, plan, imgs, hook=None):
         from . import ops
         L, D, d, dev = plan.L, plan.D, plan.d, plan.dev
         N, E, B, rows = gs.N, gs.E, gs.B, lay.rows
@@ -791,7 +823,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, g2t_wt=g2t_wt, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
-                         dims=(N, E, B, rows), sync=state(model).get("sync"), w3=imgs)
+                         dims=(N, E, B, rows), sync=state(model).get("sync"), w3=imgs, bn_hook=hook)
         ctx.set_materialize_grads(False)
         if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
             _call("gt_stream_wait_event", st, plan.ev_sort[1])
@@ -853,7 +885,7 @@ class _FusedModel(torch.autograd.Function):
         d0 = s["gcn_desc"][0]
         # (with a virtual node the main stream waits for the virtual-node chain between two dX GEMMs anyway: measured 0.4 %
         # slower there -- the longer dX epilogue delays that chain -- so only models without one take it)
-        fuse_bn = (not plan.has_vn and plan.kind == "gcn" and bool(d0.training) and d0.dropout_p == 0.0 and
+        fuse_bn = (s.get("bn_hook") is None and not plan.has_vn and plan.kind == "gcn" and bool(d0.training) and d0.dropout_p == 0.0 and
                    bool(lib.gt_linear_bwd_bnstats_ok(compute, GT_F32, GT_F32, N)))
         s["fuse_bn"] = fuse_bn
         s["bn_rows"] = int(lib.gt_linear_bwd_bnstats_rows(N)) if fuse_bn else 0
@@ -881,6 +913,8 @@ class _FusedModel(torch.autograd.Function):
             _call("gt_overlap_dw_begin", st, plan.side_dw.cuda_stream)
         if s.get("w3") is not None:
             s["w3"].bind()   # (autograd's worker thread: the table is per host thread)
+        if s.get("bn_hook") is not None:
+            s["bn_hook"].install()
         try:
             return _FusedModel._backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena,
                                               emb_rows, st)
@@ -889,6 +923,11 @@ class _FusedModel(torch.autograd.Function):
                 _lib.lib().gt_overlap_dw_end()
             if s.get("w3") is not None:
                 s["w3"].unbind()
+            if s.get("bn_hook") is not None:
+                s["bn_hook"].uninstall()
+                if s["bn_hook"].error is not None:
+                    e, s["bn_hook"].error = s["bn_hook"].error, None
+                    raise e
 
     @staticmethod
     def _backward_body(ctx, s, plan, o, q, P, Q, G, flat, dl, direct, model_sync, ws_bytes, dw_sync, barena, emb_rows, st):

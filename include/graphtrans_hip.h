@@ -356,6 +356,15 @@ int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const float* weig
 int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float* weight, const float* bias,
                            const float* save_mean, const float* save_rstd, int training, int relu, int64_t rows, int64_t dim,
                            void* dx, float* dweight, float* dbias, const float* part, int64_t nparts, gt_stream_t stream);
+/* Synchronised BatchNorm statistics across data-parallel ranks (the reference normalises over its single-device
+ * batch: modules/gnn_module.py:204,164,167, modules/conv.py:19).  While a hook is set for the calling host thread, every
+ * training-mode gt_batchnorm_fwd* / gt_batchnorm_bwd -- including the ones inside gt_gcn_layer_*, gt_gin_layer_*, gt_vn_update_* --
+ * calls it between its local pass and its apply pass:
+ *   kind 0: buf[0..n) = {rows, mean[D], biased var[D]} (n = 2D+1); the hook all-gathers the ranks' n floats to buf[n .. n+world*n)
+ *   kind 1: buf[0..n) = {sum dy'[D], sum dy' xhat[D], rows} (n = 2D+1); the hook all-reduces (sum) in place
+ * on `stream` (stream-ordered, no host sync required); returns 0 or an error.  The collective itself is the caller's. */
+typedef int (*gt_bn_sync_fn)(void* user, int kind, float* buf, int64_t n, gt_stream_t stream);
+int gt_bn_sync_set(gt_bn_sync_fn fn, void* user, int world);
 /* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
  * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
  * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */

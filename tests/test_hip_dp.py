@@ -94,7 +94,7 @@ def _global_batch(ids):
     return GraphStore(raw).collate(ids)
 
 
-def _sync_worker(rank, world, port, out, gnn_type):
+def _sync_worker(rank, world, port, out, gnn_type, fused=True):
     import numpy as np
 
     from graphtrans_amd import engine, losses
@@ -106,18 +106,25 @@ def _sync_worker(rank, world, port, out, gnn_type):
     model = convert_sync_batchnorm(_model(gnn_type))
     sync = GradSync(model.parameters(), world_size=world).attach(model)
     b = _global_batch(np.arange(6 * rank, 6 * rank + 6))
-    assert not engine.eligible(model, b, None)      # synchronised statistics: module by module
+    model.fused = fused
+    # synchronised statistics run on the FUSED path too (round 3): the library's BatchNorm calls exchange them through
+    # dist.BnSyncHook (gt_bn_sync_set), installed around the fused forward / backward
+    assert engine.eligible(model, b, None) == fused
     for p in model.parameters():
         p.grad = None
     losses.code2_loss(model(b), b.y_arr).backward()
     sync.finish()
+    if fused:
+        hook = engine.state(model).get("bn_hook")
+        assert hook is not None and hook.calls > 0, "the fused path did not exchange any BatchNorm statistics"
     out[rank] = ([p.grad.detach().float().cpu().clone() for p in model.parameters()],
                  {k: v.detach().float().cpu().clone() for k, v in model.named_buffers() if "running" in k})
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["engine", "modules"])
 @pytest.mark.parametrize("gnn_type", ["gcn", "gin"])
-def test_sync_batchnorm_shards_equal_the_single_device_batch(gnn_type):
+def test_sync_batchnorm_shards_equal_the_single_device_batch(gnn_type, fused):
     """with graphs sharded over ranks, per-rank BatchNorm statistics are a different model from the
     reference's single-device batch; convert_sync_batchnorm restores it.  Two ranks x 6 graphs with synchronised
     statistics + gradient averaging == one process on the 12-graph batch (gradients AND running statistics)."""
@@ -129,7 +136,7 @@ def test_sync_batchnorm_shards_equal_the_single_device_batch(gnn_type):
     port = s.getsockname()[1]
     s.close()
     out = mp.Manager().dict()
-    mp.spawn(_sync_worker, args=(2, port, out, gnn_type), nprocs=2, join=True)
+    mp.spawn(_sync_worker, args=(2, port, out, gnn_type, fused), nprocs=2, join=True)
     model = _model(gnn_type)
     b = _global_batch(np.arange(12))
     losses.code2_loss(model(b), b.y_arr).backward()
