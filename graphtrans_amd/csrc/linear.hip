@@ -835,6 +835,18 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
                            void* gout, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups, int64_t x_group_stride,
                            int64_t y_group_stride, int act, float dropout_p, uint64_t seed, gt_stream_t stream_);
 
+// The row operand / the dX of ONE call as two matrices side by side (the JK = "cat" concatenation without its copy): set by the
+// *_cat2 entry points for the duration of their call (per host thread), honoured by the bf16x6 path only.
+struct Cat2Req {
+  const void* x2 = nullptr;   // forward / dW: contraction columns [split, K) of X
+  void* dx2 = nullptr;        // dX: output columns [split, K)
+  int64_t split = 0, ld2 = 0;
+};
+thread_local Cat2Req g_cat2;
+struct Cat2Scope {
+  ~Cat2Scope() { g_cat2 = Cat2Req{}; }
+};
+
 extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                                      const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
                                      int groups, int64_t x_group_stride, int64_t y_group_stride, int act, float dropout_p,
@@ -861,7 +873,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
                                (N * K) % 4 == 0),
                "group strides must keep 16-byte alignment");
   int rc = check_lin("gt_linear_fwd", x_dtype, y_dtype, compute, M, N, K, ldy);
-  if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
+  if (rc == GT_OK && (ldx < (g_cat2.x2 ? g_cat2.split : K) || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {   // (cat2: the first matrix holds columns [0, split))
     gt_set_error("gt_linear_fwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
     rc = GT_ERR_UNSUPPORTED;
   }
@@ -893,6 +905,10 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     // a prepared bf16x3 image of this weight (gt_w3_bind): the fp32-accurate GEMM on the bf16 matrix pipe (linear3x.h);
     // bf16 rows need K % 8 (their 16-byte chunks are whole k-groups)
     w.w3 = (x_dtype == GT_F32 || K % 8 == 0) ? w3_lookup(weight, N, K, false) : nullptr;
+    if (g_cat2.x2) {
+      if (!w.w3 || x_dtype != GT_F32) { gt_set_error("gt_linear_fwd_cat2: needs a bound weight image and fp32 rows"); return GT_ERR_UNSUPPORTED; }
+      w.a2 = g_cat2.x2; w.a_split = g_cat2.split; w.lda2 = g_cat2.ld2;
+    }
     {
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
       if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
@@ -1053,7 +1069,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                (N * K) % 4 == 0),
                "group strides must keep 16-byte alignment");
   int rc = check_lin("gt_linear_bwd", x_dtype, y_dtype, compute, M, N, K, ldy);
-  if (rc == GT_OK && (ldx < K || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {
+  if (rc == GT_OK && (ldx < (g_cat2.x2 ? g_cat2.split : K) || ldx % (x_dtype == GT_BF16 ? 8 : 4))) {   // (cat2: the first matrix holds columns [0, split))
     gt_set_error("gt_linear_bwd: ldx (%lld) must be >= K and a multiple of 16 bytes", (long long)ldx);
     rc = GT_ERR_UNSUPPORTED;
   }
@@ -1142,6 +1158,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.bn_relu = q.relu; w.bn_part = q.part;
       }
       w.w3 = w3t;
+      if (g_cat2.dx2) {
+        if (!w3t || dx_add1 || dx_add2) { gt_set_error("gt_linear_bwd_cat2: needs a bound weight image and no addends"); return GT_ERR_UNSUPPORTED; }
+        w.out2 = g_cat2.dx2; w.out_split = g_cat2.split; w.ldo2 = g_cat2.ld2;
+      }
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w3t ? "k_lin3[dx]" : "k_lin32[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
       if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
       else w32_launch<true>(y_dtype, x_dtype, stream, w);
@@ -1154,8 +1174,34 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         stream = g_dw.side;
       }
       L32DwArgs d{};
-      d.dy = dy; d.ymask = y_for_mask; d.x = x; d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;
-      d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx; d.inv_keep = a.inv_keep;
+      d.dy = dy; d.ymask = y_for_mask; d.x = x; d.inv_keep = a.inv_keep;
+      d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx;
+      if (g_cat2.x2) { d.x2 = g_cat2.x2; d.x_split = g_cat2.split; d.ldx2 = g_cat2.ld2; }
+      // weights with bound images run the bf16x6 dW kernel too (160 x 160 output tiles, split over M; linear3x.h)
+      const bool split3 = x_dtype == GT_F32 && w3_lookup(weight, N, K, false) != nullptr && (y_dtype == GT_F32 || N % 8 == 0);
+      if (split3) {
+        const int nkb3 = (int)gt_cdiv(K, W3D_T), nnb3 = (int)gt_cdiv(N, W3D_T);
+        int s3 = w3_dw_splits(M, nkb3 * nnb3);
+        const int cap = w32_dw_splits(M, nkb, nnb, false);   // the workspace is sized for this many partial copies
+        if (s3 > cap) s3 = cap;
+        d.part = part; d.dbpart = dbias ? part + (size_t)s3 * N * K : nullptr;
+        d.splits = s3; d.nkb = nkb3; d.nnb = nnb3;
+        d.m_per_split = gt_cdiv(gt_cdiv(M, s3), 32) * 32;
+        dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3));
+        {
+          GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+          if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
+          else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
+          const int64_t len = N * K, len2 = dbias ? N : 0;
+          int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+          hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, s3, len, dweight,
+                             (const float*)d.dbpart, len2, dbias, (int64_t)0);
+        }
+        if (forked) dw_forked(workspace, workspace_bytes);
+        GT_CHECK_LAUNCH();
+        return GT_OK;
+      }
+      d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;
       d.splits = splits; d.nkb = nkb; d.nnb = nnb;
       d.m_per_split = gt_cdiv(gt_cdiv(M, splits), 16) * 16;
       dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * nkb * nnb));
@@ -1251,6 +1297,34 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
   }
   GT_CHECK_LAUNCH();
   return GT_OK;
+}
+
+// ---- JK = "cat" without the copy: X = [X1 | X2] (modules/gnn_module.py:104-105 feeding models/gnn_transformer.py:92) -------------
+// 1 when gt_linear_fwd_cat2 / gt_linear_bwd_cat2 can run this GEMM (big-M exact-fp32 compute on a weight whose images are bound)
+extern "C" int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, int64_t K1, int64_t K2) {
+  return (w32_eligible(compute, GT_F32, M, 1) && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0 && w3_lookup(weight, N, K1 + K2, false) &&
+          w3_lookup(weight, N, K1 + K2, true)) ? 1 : 0;
+}
+// Y[M][N] = [X1 | X2] W^T + b with X1 [M][K1] (pitch ldx1), X2 [M][K2] (pitch ldx2), W [N][K1 + K2]; fp32 rows, y_dtype fp32 / bf16
+extern "C" int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2,
+                                  int64_t ldx2, const float* weight, const float* bias, void* y, int64_t M, int64_t N, int64_t ldy,
+                                  gt_stream_t stream_) {
+  GT_CHECK_ARG(x1 && x2 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0 && ldx2 >= K2 && ldx2 % 4 == 0, "bad second operand");
+  Cat2Scope scope__;
+  g_cat2.x2 = x2; g_cat2.split = K1; g_cat2.ld2 = ldx2;
+  return linear_fwd_impl(GT_F32, y_dtype, compute, x1, weight, bias, y, nullptr, M, N, K1 + K2, ldx1, ldy, 1, 0, 0, 0, 0.f, 0, stream_);
+}
+// backward of the above: dX1 [M][K1] (pitch lddx1) and dX2 [M][K2] (pitch lddx2) from dY [M][N] (y_dtype, pitch ldy); dW [N][K1+K2], db
+extern "C" int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2,
+                                  int64_t ldx2, const float* weight, const void* dy, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2,
+                                  float* dweight, float* dbias, int64_t M, int64_t N, int64_t ldy, void* workspace,
+                                  size_t workspace_bytes, gt_stream_t stream_) {
+  GT_CHECK_ARG(x1 && x2 && dx1 && dx2 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0, "bad operands");
+  GT_CHECK_ARG(ldx1 == lddx1 && ldx2 == lddx2, "dX pitches must equal the X pitches");   // (one pitch per matrix in the kernel arguments)
+  Cat2Scope scope__;
+  g_cat2.x2 = x2; g_cat2.dx2 = dx2; g_cat2.split = K1; g_cat2.ld2 = ldx2;
+  return gt_linear_bwd_grouped(GT_F32, y_dtype, compute, x1, weight, dy, nullptr, nullptr, nullptr, dx1, dweight, dbias, M, N, K1 + K2,
+                               ldx1, ldy, 1, 0, 0, 0.f, workspace, workspace_bytes, stream_);
 }
 
 // ---- bf16x3 weight images (linear3x.h) --------------------------------------------------------------------------------

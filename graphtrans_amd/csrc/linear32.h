@@ -42,6 +42,11 @@ struct L32Args {
   int ncb;             // column blocks of NT n-tiles
   const void* w3;      // linear3x.h: the bf16x3 image of the weight (k_lin3), w is unused then
   int w3_ntp;          // its 16-row tiles per plane and k-step
+  // k_lin3 only -- the JK = "cat" concatenation without a copy (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105):
+  const void* a2;      // contraction columns [a_split, Kc) of the row operand come from this matrix (pitch lda2); null = none
+  int64_t a_split, lda2;
+  void* out2;          // output columns [out_split, Nout) go to this matrix (pitch ldo2); null = none (then no addends)
+  int64_t out_split, ldo2;
 };
 
 // 16-byte chunk of TA -> up to 8 floats
@@ -341,6 +346,8 @@ struct L32DwArgs {
   float inv_keep;
   int splits, nkb, nnb;   // k-blocks of 64 columns, n-blocks of NT n-tiles
   int64_t m_per_split;
+  const void* x2;      // columns [x_split, K) of X come from this matrix (pitch ldx2); null = none
+  int64_t x_split, ldx2;
 };
 
 template <typename TY, typename TX, int NT, bool MASK>
@@ -398,6 +405,11 @@ __global__ void __launch_bounds__(256) k_lin32_dw(L32DwArgs a) {
   const int xr = x_thr ? tid / XCH : 0, xc = (tid % XCH) * EX;
   const bool x_colok = x_thr && k0 + xc < a.K;
   const TX* x_src = X + (k0 + xc < a.K ? k0 + xc : 0);
+  int64_t x_ld = a.ldx;
+  if (a.x2 && k0 + xc >= a.x_split && k0 + xc < a.K) {   // this thread's chunk column lies in the second matrix (x_split % 4 == 0)
+    x_src = reinterpret_cast<const TX*>(a.x2) + (k0 + xc - a.x_split);
+    x_ld = a.ldx2;
+  }
   int64_t tail_rows = BMc;   // valid rows of the stage being staged
   auto load = [&](int64_t m0) {
     tail_rows = me - m0 < BMc ? me - m0 : BMc;
@@ -413,7 +425,7 @@ __global__ void __launch_bounds__(256) k_lin32_dw(L32DwArgs a) {
     }
     int64_t row = m0 + xr;
     row = row < me ? row : last;
-    vx = *reinterpret_cast<const uint4*>(x_src + row * a.ldx);
+    vx = *reinterpret_cast<const uint4*>(x_src + row * x_ld);
   };
   auto store = [&](float* st) {
     float* sZ = st;

@@ -129,11 +129,14 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
   // ---- row-operand staging: thread = (rows ar + 64 r, 8-element group q); out-of-range rows clamp to a valid row (never stored) ----
   const int ar = tid >> 2, q = tid & 3;
   const TA* a_src[AR];
+  const TA* a2_src[AR];   // second row operand (virtual concatenation), columns [a_split, Kc)
   const TA* m_src[AR];
+  const bool cat2 = a.a2 != nullptr;
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const int64_t a_row = m0 + ar + 64 * r < a.M ? m0 + ar + 64 * r : a.M - 1;
     a_src[r] = A + a_row * a.lda;
+    a2_src[r] = cat2 ? reinterpret_cast<const TA*>(a.a2) + a_row * a.lda2 - a.a_split : nullptr;
     m_src[r] = has_mask ? Am + a_row * a.lda : nullptr;
   }
   struct ARegs {
@@ -152,8 +155,8 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
       const int64_t k0c = R.z0 ? a.Kc - 4 : k, k1c = R.z1 ? a.Kc - 4 : k + 4;
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
-        R.v0[r] = *reinterpret_cast<const uint4*>(a_src[r] + k0c);
-        R.v1[r] = *reinterpret_cast<const uint4*>(a_src[r] + k1c);
+        R.v0[r] = *reinterpret_cast<const uint4*>((cat2 && k0c >= a.a_split ? a2_src[r] : a_src[r]) + k0c);
+        R.v1[r] = *reinterpret_cast<const uint4*>((cat2 && k1c >= a.a_split ? a2_src[r] : a_src[r]) + k1c);
         if constexpr (MASK) {
           if (has_mask) {
             R.m0[r] = *reinterpret_cast<const uint4*>(m_src[r] + k0c);
@@ -360,7 +363,11 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
     for (int t = 0; t < HT; ++t) {
       const int c = lane + t * 64;
       const int r = c / CPR, c4 = (c % CPR) * 4;
-      if (ok[t] && (!(W3_ABL & 8) || v[t].x == 12345.678f)) gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + ncol0 + c4, v[t]);
+      if (ok[t] && (!(W3_ABL & 8) || v[t].x == 12345.678f)) {
+        const int64_t col = ncol0 + c4;
+        if (a.out2 && col >= a.out_split) gt_store4<TO>(reinterpret_cast<TO*>(a.out2) + (mrow0 + r) * a.ldo2 + col - a.out_split, v[t]);
+        else gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + col, v[t]);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -430,6 +437,197 @@ void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   else GT_W3_GO(gt_bf16, gt_bf16);
 #undef GT_W3_GO
 #undef GT_W3_MT
+}
+
+// ---- dW[N][K] = dZ^T X, db = colsum(dZ): contraction over M on the bf16 pipe -----------------------------------------------------
+// Both operands are activations: they are split into bf16 planes while they are staged ([m][column] row-major per plane, 32 rows per
+// stage) and read TRANSPOSED by ds_read_b64_tr_b16 (the contraction index m becomes the fragments' k-slots).  Block = 160 x 160
+// outputs (N = K = 300: 2 x 2 tiles, 13 % padding instead of the 64 % of 128-wide tiles) x an M range; 4 waves as 2 x 2, wave =
+// 5 x 5 accumulator tiles; the wave keeps the 15 X fragments of a stage in registers and streams the dZ fragments past them.
+// Partials [split][N][K] + the fixed-order k_split_reduce as for the other dW kernels (bitwise reproducible).
+constexpr int W3D_T = 160, W3D_LD = W3D_T + 8, W3D_PLANE = 32 * W3D_LD;   // bf16 elements
+
+template <typename TS>
+__device__ __forceinline__ void w3d_load_chunks(const TS* src, int64_t ld, int64_t row0, int64_t rows_end, int64_t col0, int64_t cols_end,
+                                                uint4* v, const TS* msrc, uint4* vm, const TS* src2 = nullptr, int64_t split = 0,
+                                                int64_t ld2 = 0) {
+  // a [32][160] tile as 16-byte chunks, chunk c = tid + 256 i: row c / CH, column chunk c % CH; out-of-range chunks are clamped to a
+  // valid address (branch-free loads) and zeroed at store time
+  constexpr int E = 16 / sizeof(TS), CH = W3D_T / E, NIT = (32 * CH + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = threadIdx.x + i * 256;
+    const int r = c / CH, cc = (c % CH) * E;
+    int64_t row = row0 + r, col = col0 + cc;
+    row = row < rows_end ? row : rows_end - 1;
+    col = col < cols_end ? col : 0;
+    if (r < 32) {
+      if (src2 && col >= split) v[i] = *reinterpret_cast<const uint4*>(src2 + row * ld2 + (col - split));   // columns [split, ..) of a virtual concatenation
+      else v[i] = *reinterpret_cast<const uint4*>(src + row * ld + col);
+      if (msrc) vm[i] = *reinterpret_cast<const uint4*>(msrc + row * ld + col);
+    }
+  }
+}
+
+template <typename TS, bool MASK>
+__device__ __forceinline__ void w3d_store_chunks(gt_bf16* planes, int64_t row0, int64_t rows_end, int64_t col0, int64_t cols_end,
+                                                 const uint4* v, const uint4* vm, bool has_mask, float inv_keep) {
+  constexpr int E = 16 / sizeof(TS), CH = W3D_T / E, NIT = (32 * CH + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = threadIdx.x + i * 256;
+    const int r = c / CH, cc = (c % CH) * E;
+    if (r >= 32) continue;
+    const bool ok = row0 + r < rows_end && col0 + cc < cols_end;
+    float f[E];
+    chunk_to_f32<TS>(ok ? v[i] : make_uint4(0, 0, 0, 0), f);
+    if constexpr (MASK) {
+      if (has_mask) {
+        float y[E];
+        chunk_to_f32<TS>(vm[i], y);
+#pragma unroll
+        for (int e = 0; e < E; ++e) f[e] = ok ? gt_gate(f[e], y[e], inv_keep) : 0.f;
+      }
+    }
+    uint32_t p1[E / 2], p2[E / 2], p3[E / 2];
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) w3_split_pair(f[2 * e], f[2 * e + 1], p1[e], p2[e], p3[e]);
+    gt_bf16* dst = planes + r * W3D_LD + cc;
+    if constexpr (E == 4) {
+      *reinterpret_cast<uint2*>(dst) = make_uint2(p1[0], p1[1]);
+      *reinterpret_cast<uint2*>(dst + W3D_PLANE) = make_uint2(p2[0], p2[1]);
+      *reinterpret_cast<uint2*>(dst + 2 * W3D_PLANE) = make_uint2(p3[0], p3[1]);
+    } else {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+      *reinterpret_cast<uint4*>(dst + W3D_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+      *reinterpret_cast<uint4*>(dst + 2 * W3D_PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+    }
+  }
+}
+
+template <typename TY, typename TX, bool MASK>
+__global__ void __launch_bounds__(256, 1) k_lin3_dw(L32DwArgs a) {
+  constexpr int EY = 16 / sizeof(TY), EX = 16 / sizeof(TX);
+  constexpr int ZIT = (32 * (W3D_T / EY) + 255) / 256, XIT = (32 * (W3D_T / EX) + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3d[];
+  gt_bf16* sZ = reinterpret_cast<gt_bf16*>(smem3d);   // [3][32][W3D_LD]
+  gt_bf16* sX = sZ + 3 * W3D_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = lane & 15, g = lane >> 4, wn = wid & 1, wk = wid >> 1;
+  int64_t split_;
+  int tile_;
+  {  // XCD-aware: the tiles of one M-split read the same dZ / X rows -> ids 8 apart (same XCD, same L2)
+    const int nt = a.nkb * a.nnb;
+    const int64_t b = blockIdx.x;
+    const int64_t group = b / (8 * nt);
+    const int r = (int)(b % (8 * nt));
+    tile_ = r / 8;
+    split_ = group * 8 + r % 8;
+  }
+  if (split_ >= a.splits) return;
+  const int kb = tile_ % a.nkb, nb = tile_ / a.nkb;
+  const int64_t n0 = (int64_t)nb * W3D_T, k0 = (int64_t)kb * W3D_T;
+  const int64_t mb = split_ * a.m_per_split;
+  const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
+  const TY* dY = reinterpret_cast<const TY*>(a.dy);
+  const TY* Ym = reinterpret_cast<const TY*>(a.ymask);
+  const bool has_mask = MASK && Ym != nullptr;
+  const TX* X = reinterpret_cast<const TX*>(a.x);
+
+  f32x4 acc[5][5];   // [n tile j][k tile i]
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;   // kb == 0, tid < 160: column n0 + tid
+
+  uint4 vz[ZIT], vmk[MASK ? ZIT : 1], vx[XIT];
+  if (mb < me) {
+    w3d_load_chunks<TY>(dY, a.ldy, mb, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk);
+    w3d_load_chunks<TX>(X, a.ldx, mb, me, k0, a.K, vx, nullptr, nullptr, reinterpret_cast<const TX*>(a.x2), a.x_split, a.ldx2);
+  }
+  for (int64_t m0 = mb; m0 < me; m0 += 32) {
+    __syncthreads();   // every wave is done with the previous stage's planes
+    w3d_store_chunks<TY, MASK>(sZ, m0, me, n0, a.N, vz, vmk, has_mask, a.inv_keep);
+    w3d_store_chunks<TX, false>(sX, m0, me, k0, a.K, vx, nullptr, false, 1.f);
+    __syncthreads();
+    if (m0 + 32 < me) {
+      w3d_load_chunks<TY>(dY, a.ldy, m0 + 32, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk);
+      w3d_load_chunks<TX>(X, a.ldx, m0 + 32, me, k0, a.K, vx, nullptr, nullptr, reinterpret_cast<const TX*>(a.x2), a.x_split, a.ldx2);
+    }
+    if (kb == 0 && tid < W3D_T) {   // db: the three planes of a value add back to the value exactly
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) {
+        const gt_bf16* q = sZ + r * W3D_LD + tid;
+        dbacc += (gt_bf16_to_f32(q[0]) + gt_bf16_to_f32(q[W3D_PLANE])) + gt_bf16_to_f32(q[2 * W3D_PLANE]);
+      }
+    }
+    Frag<gt_bf16> fx[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fx[i][p] = frag_load_tr(sX + p * W3D_PLANE, W3D_LD, 0, wk * 80 + i * 16, n, g);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      Frag<gt_bf16> fz[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fz[p] = frag_load_tr(sZ + p * W3D_PLANE, W3D_LD, 0, wn * 80 + j * 16, n, g);
+      constexpr int PZ[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[j][i] = mma(fz[PZ[t]], fx[i][PX[t]], acc[j][i]);
+    }
+  }
+  __syncthreads();
+  // acc[j][i][r] = C[row n0 + wn*80 + j*16 + g*4 + r][column k0 + wk*80 + i*16 + n] -> per-wave patch [16 n rows][80 k columns]
+  constexpr int PLD = 80 + 4;
+  float* patch = reinterpret_cast<float*>(smem3d) + wid * 16 * PLD;
+  float* part = a.part + (int64_t)split_ * a.N * a.K;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(g * 4 + r) * PLD + i * 16 + n] = acc[j][i][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {   // 16 rows x 20 chunks = 320 chunks
+      const int c = lane + q * 64;
+      const int r = c / 20, c4 = (c % 20) * 4;
+      const int64_t row = n0 + wn * 80 + j * 16 + r, col = k0 + wk * 80 + c4;
+      if (row < a.N && col < a.K) *reinterpret_cast<float4*>(part + row * a.K + col) = *reinterpret_cast<const float4*>(patch + r * PLD + c4);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (kb == 0 && tid < W3D_T && n0 + tid < a.N && a.dbpart) a.dbpart[(int64_t)split_ * a.N + n0 + tid] = dbacc;
+}
+
+static inline int w3_dw_splits(int64_t M, int tiles) {
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);          // one block per CU: the kernel runs on the overlap stream beside the dX chain
+  const int64_t maxs = gt_cdiv(M, 32 * 8);           // at least 8 stages per split
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+template <typename TY, typename TX>
+void w3_launch_dw(dim3 grid, hipStream_t stream, const L32DwArgs& a) {
+  constexpr int LDS = 6 * W3D_PLANE * 2;
+  static std::mutex mu;
+  static bool done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+      (void)hipFuncSetAttribute((const void*)(k_lin3_dw<TY, TX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((k_lin3_dw<TY, TX, true>), grid, dim3(256), LDS, stream, a);
 }
 
 // ---- per-thread table of prepared images (gt_w3_bind / gt_w3_unbind) -----------------------------------------------------

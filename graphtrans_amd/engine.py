@@ -609,7 +609,10 @@ class _FusedModel(torch.autograd.Function):
         gcn_saved_bytes = [getattr(lib, plan.conv_api + "_saved_bytes")(C.byref(dsc)) for dsc in plan.gcn_desc]
         o["gcn_saved"] = [b.take(n) for n in gcn_saved_bytes]
         Kc = 2 * D if plan.jk_cat else D
-        if plan.jk_cat:
+        # JK = "cat" (modules/gnn_module.py:104-105): with bound weight images the gnn2transformer GEMM reads [h_list[0] | h_list[-1]]
+        # from the two matrices where they lie and its backward writes the two gradients where their consumers read them
+        cat2 = bool(plan.jk_cat and imgs is not None and lib.gt_linear_cat2_ok(compute, plan.g2t.weight.data_ptr(), N, d, D, D))
+        if plan.jk_cat and not cat2:
             o["cat"] = b.take(N * Kc * 4)
         o["hn"] = b.take(N * d * tsz)
         o["tok"] = b.take(rows * d * tsz)
@@ -768,17 +771,21 @@ class _FusedModel(torch.autograd.Function):
                 _call(plan.conv_api + "_fwd", C.byref(dsc), P("h", l), None, None, P("h", l + 1), P("gcn_saved", l), P("ws"),
                       ws_bytes, st)
         first = X(0)   # h_list[0] after the in-place virtual-node add
-        if plan.jk_cat:   # torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
-            _call("gt_copy2d", P("cat"), Kc * 4, first, D * 4, D * 4, N, st)
-            _call("gt_copy2d", P("cat") + D * 4, Kc * 4, P("h", L), D * 4, D * 4, N, st)
-            node_rep = P("cat")
-        else:
-            node_rep = P("h", L)
-
-        # ---- gnn2transformer + token rows + encoder   (models/gnn_transformer.py:92-114)
         g2t = plan.g2t
-        _call("gt_linear_fwd", GT_F32, tdt, compute, node_rep, g2t.weight.data_ptr(), g2t.bias.data_ptr(), P("hn"), N, d, Kc,
-              0, 0.0, 0, st)
+        if cat2:
+            node_rep = None
+            _call("gt_linear_fwd_cat2", tdt, compute, first, D, D, P("h", L), D, D, g2t.weight.data_ptr(), g2t.bias.data_ptr(), P("hn"),
+                  N, d, d, st)
+        else:
+            if plan.jk_cat:   # torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
+                _call("gt_copy2d", P("cat"), Kc * 4, first, D * 4, D * 4, N, st)
+                _call("gt_copy2d", P("cat") + D * 4, Kc * 4, P("h", L), D * 4, D * 4, N, st)
+                node_rep = P("cat")
+            else:
+                node_rep = P("h", L)
+            # ---- gnn2transformer + token rows + encoder   (models/gnn_transformer.py:92-114)
+            _call("gt_linear_fwd", GT_F32, tdt, compute, node_rep, g2t.weight.data_ptr(), g2t.bias.data_ptr(), P("hn"), N, d, Kc,
+                  0, 0.0, 0, st)
         cls_t = None
         if plan.cls is not None:
             cls_t = plan.cls.detach().reshape(-1)
@@ -823,7 +830,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.state = dict(gcn_desc=snap(plan.gcn_desc), vn_desc=snap(plan.vn_desc), enc_desc=snap(plan.enc_desc), plan=plan, arena=arena, o=o, base=base, gs=gs, lay=lay, sm=sm, compute=compute, tdt=tdt, tsz=tsz,
                          ws_bytes=ws_bytes, ws2_bytes=ws2_bytes, g2t_wt=g2t_wt, xptr=[X(l) for l in range(L)], enc_in=enc_in, pre_out=pre_out, first=first, node_rep=node_rep, Kc=Kc,
                          embed=(T, e_idx, e_str, e_clamp, cols), esort=esort, ne=(ne_x, ne_w), wcat=wcat, keep=(x, ea_f, cls_t, batched_data),
-                         dims=(N, E, B, rows), sync=state(model).get("sync"), w3=imgs, bn_hook=hook)
+                         dims=(N, E, B, rows), sync=state(model).get("sync"), w3=imgs, bn_hook=hook, cat2=cat2, h_last=P("h", L))
         ctx.set_materialize_grads(False)
         if esort and plan.side_dw is not None:   # long finished; joins the sort's stream before anything can free the arena
             _call("gt_stream_wait_event", st, plan.ev_sort[1])
@@ -989,8 +996,12 @@ class _FusedModel(torch.autograd.Function):
         g2t = plan.g2t
         if s["g2t_wt"] is not None and plan.ev_wt:
             _call("gt_stream_wait_event", st, plan.ev_wt[1])   # the transposed weights were written on the overlap stream beside the forward
-        _call("gt_linear_bwd_wt", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), s["g2t_wt"], Q("d_hn"), None, None, None,
-              Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(), ws_bytes, st)
+        if s["cat2"]:   # d h_list[0] -> dJ, d h_list[-1] -> dA straight from the GEMM (no d_rep, no copies)
+            _call("gt_linear_bwd_cat2", tdt, compute, s["first"], D, D, s["h_last"], D, D, g2t.weight.data_ptr(), Q("d_hn"), Q("dJ"), D,
+                  Q("dA"), D, G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, d, W(), ws_bytes, st)
+        else:
+            _call("gt_linear_bwd_wt", GT_F32, tdt, compute, s["node_rep"], g2t.weight.data_ptr(), s["g2t_wt"], Q("d_hn"), None, None, None,
+                  Q("d_rep"), G + plan.g2t_off[0] * 4, G + plan.g2t_off[1] * 4, N, d, Kc, 0.0, W(), ws_bytes, st)
         # every gradient from gnn2transformer onwards is final: put that half of the flat buffer on the wire
         sync = model_sync if (direct and model_sync is not None and model_sync.active) else None
         if sync is not None:
@@ -999,7 +1010,9 @@ class _FusedModel(torch.autograd.Function):
         # ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l (=
         # h_list[l] after the virtual-node add) from its consumers other than conv_l: the JK slab (l = 0)
         # and the virtual-node update's pooling (l < L-1).
-        if plan.jk_cat:
+        if s["cat2"]:
+            dy = Q("dA")
+        elif plan.jk_cat:
             _call("gt_copy2d", Q("dA"), D * 4, Q("d_rep") + D * 4, Kc * 4, D * 4, N, st)   # d h_list[-1]
             _call("gt_copy2d", Q("dJ"), D * 4, Q("d_rep"), Kc * 4, D * 4, N, st)           # d h_list[0]
             dy = Q("dA")

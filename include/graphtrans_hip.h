@@ -481,6 +481,15 @@ int gt_transpose(const float* in /* [N][K] */, float* out /* [K][N] */, int64_t 
  * products down to relative 2^-16 reproduces the fp32 GEMM to accumulation order at 2.7 x the fp32-MFMA ceiling.  A weight is
  * split once per optimizer step into an "image" (bf16 planes in LDS order); bound images reroute the big-M exact-fp32 GEMMs of
  * gt_linear_fwd* / gt_linear_bwd* (compute == GT_F32, M >= 1024, one group) to the bf16x6 kernel. */
+/* JK = "cat" without its copy (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105, feeding gnn2transformer,
+ * models/gnn_transformer.py:92): the GEMM reads its row operand from two matrices side by side and its backward writes the two
+ * gradients where their consumers read them.  Only on weights whose images are bound (ask gt_linear_cat2_ok first). */
+int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, int64_t K1, int64_t K2);
+int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
+                       const float* weight, const float* bias, void* y, int64_t M, int64_t N, int64_t ldy, gt_stream_t stream);
+int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
+                       const float* weight, const void* dy, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2, float* dweight,
+                       float* dbias, int64_t M, int64_t N, int64_t ldy, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 size_t gt_w3_image_bytes(int64_t rows, int64_t contraction);
 /* n images in one launch per 24 jobs: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (forward), != 0 -> image of
  * W^T (dX form); image[i]: gt_w3_image_bytes(rows, contraction) bytes, 1024-byte aligned. */

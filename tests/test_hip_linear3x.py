@@ -160,3 +160,102 @@ def test_special_values_and_ranges():
     y64 = x.double() @ W.double().t()
     row_err = (y3.double() - y64).norm(dim=1) / y64.norm(dim=1)
     assert float(row_err.max()) <= 2e-6, float(row_err.max())
+
+
+def bwd_all(x, W, dy, ymask, bound, p=0.0):
+    """dX, dW, db of one gt_linear_bwd_ld2 call"""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
+    dw = torch.empty(N, K, device=dy.device)
+    db = torch.empty(N, device=dy.device)
+    code = lambda t: GT_BF16 if t.dtype == torch.bfloat16 else GT_F32
+    ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(GT_F32, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    call = lambda: _lib.launch("gt_linear_bwd_ld2", code(x), code(dy), GT_F32, _p(x), _p(W), _p(dy), _p(ymask), None, None, _p(dx), _p(dw), _p(db),
+                               M, N, K, K, N, p, _p(ws), ws_bytes, _stream())
+    if bound is not None:
+        with bound.bound():
+            call()
+    else:
+        call()
+    return dx, dw, db
+
+
+DW_SHAPES = [(31598, 300, 300), (31598, 128, 600), (6700, 600, 300), (6700, 300, 600), (4100, 256, 256), (16001, 272, 272), (2048, 64, 36), (1500, 20, 132)]
+
+
+@pytest.mark.parametrize("M,N,K", DW_SHAPES, ids=[f"{m}x{n}x{k}" for m, n, k in DW_SHAPES])
+def test_weight_gradient_matches_float64_like_an_fp32_gemm(M, N, K):
+    """k_lin3_dw (both operands split into planes while staged, transposed fragment reads) + the fixed-order reduce"""
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, device=DEV) * (0.5 + torch.rand(M, 1, device=DEV))
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV)
+    yf = torch.relu(torch.randn(M, N, device=DEV))
+    imgs = W3Images([W])
+    imgs.build()
+    dz = (dy.double() * (yf > 0)) / 0.9
+    w64, b64 = dz.t() @ x.double(), dz.sum(0)
+    dzf = (dy * (yf > 0)) / 0.9
+    wt, bt = dzf.t() @ x, dzf.sum(0)
+    _, w3, b3 = bwd_all(x, W, dy, yf, imgs, p=0.1)
+    _, w32, b32 = bwd_all(x, W, dy, yf, None, p=0.1)
+    e3, e32, et = rel(w3, w64), rel(w32, w64), rel(wt, w64)
+    print(f"\ndW {M}x{N}x{K}: bf16x6 {e3:.2e}  exact-fp32 MFMA {e32:.2e}  torch fp32 {et:.2e};  db {rel(b3, b64):.2e} / {rel(b32, b64):.2e} / {rel(bt, b64):.2e}")
+    assert e3 <= max(3 * et, 1e-6), (e3, et)
+    assert rel(b3, b64) <= max(3 * rel(bt, b64), 1e-6)
+    # bitwise reproducible (fixed-order reduce)
+    _, w3b, b3b = bwd_all(x, W, dy, yf, imgs, p=0.1)
+    assert torch.equal(w3, w3b) and torch.equal(b3, b3b)
+
+
+def test_weight_gradient_from_bf16_rows():
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(9)
+    M, N, K = 20000, 128, 600
+    x = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    imgs = W3Images([W])
+    imgs.build()
+    _, w3, b3 = bwd_all(x, W, dy, None, imgs)
+    w64, b64 = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert rel(w3, w64) <= 1e-6 and rel(b3, b64) <= 1e-6, (rel(w3, w64), rel(b3, b64))
+
+
+def test_virtual_concatenation_equals_the_copied_one():
+    """gt_linear_fwd_cat2 / gt_linear_bwd_cat2: [X1 | X2] W^T without building [X1 | X2] (JK = 'cat' feeding gnn2transformer)"""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W3Images
+    torch.manual_seed(11)
+    M, D, N = 31598, 300, 128
+    x1, x2 = torch.randn(M, D, device=DEV), torch.randn(M, D, device=DEV)
+    W, b = torch.randn(N, 2 * D, device=DEV) / (2 * D) ** 0.5, torch.randn(N, device=DEV)
+    cat = torch.cat([x1, x2], 1).contiguous()
+    imgs = W3Images([W])
+    imgs.build()
+    L = _lib.lib()
+    for yd in (torch.float32, torch.bfloat16):
+        code = GT_BF16 if yd == torch.bfloat16 else GT_F32
+        y_ref = fwd(cat, W, b, imgs, out_dtype=yd)
+        y = torch.empty(M, N, dtype=yd, device=DEV)
+        dy = torch.randn(M, N, device=DEV).to(yd)
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        dw, db = torch.empty_like(W), torch.empty_like(b)
+        ws_bytes = L.gt_linear_bwd_workspace_bytes(GT_F32, M, N, 2 * D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        assert L.gt_linear_cat2_ok(GT_F32, _p(W), M, N, D, D) == 0   # nothing bound yet
+        with imgs.bound():
+            assert L.gt_linear_cat2_ok(GT_F32, _p(W), M, N, D, D) == 1
+            _lib.launch("gt_linear_fwd_cat2", code, GT_F32, _p(x1), D, D, _p(x2), D, D, _p(W), _p(b), _p(y), M, N, N, _stream())
+            _lib.launch("gt_linear_bwd_cat2", code, GT_F32, _p(x1), D, D, _p(x2), D, D, _p(W), _p(dy), _p(dx1), D, _p(dx2), D, _p(dw), _p(db),
+                        M, N, N, _p(ws), ws_bytes, _stream())
+        assert torch.equal(y, y_ref)
+        dxr, dwr, dbr = bwd_all(cat, W, dy, None, imgs)
+        assert torch.equal(torch.cat([dx1, dx2], 1), dxr)
+        assert torch.equal(dw, dwr) and torch.equal(db, dbr)

@@ -21,6 +21,7 @@ ENTRY = {
     "k_lin3[dx]": ((r"k_lin3<[^>]*, true, false>",), r"k_lin3<[^>]*, true, false>"),
     "k_lin32[fwd]": ((r"k_lin32<[^>]*?, \d+, false,",), r"k_lin32<[^>]*?, \d+, false,"),
     "k_lin32[dx]": ((r"k_lin32<[^>]*?, \d+, true,", r"k_transpose32"), r"k_lin32<[^>]*?, \d+, true,"),
+    "k_lin3_dw+reduce": ((r"k_lin3_dw<",), r"k_lin3_dw<"),     # (its k_split_reduce launches are shared with the other dW kernels: reported on their own)
     "k_lin32_dw+reduce": ((r"k_lin32_dw<",), r"k_lin32_dw<"),   # (its k_split_reduce launches are shared with the bf16 path: reported on their own)
     "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dx[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>",), r"k_linear_dx<[^>]*" + BF16 + r", \d+>"),
