@@ -760,10 +760,23 @@ def main():
     if extra and world > 1:   # the other scaling of the same step, same ranks
         other = "strong" if opt.scaling == "weak" else "weak"
         del model
-        o, model, _, _ = measure(opt, opt.mode, other, world, rank, device, want_kernels=False)
-        if rank == 0:
-            res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step")} | \
-                {"graphs_per_gpu": o["config"]["graphs_per_gpu"], "global_batch": o["config"]["global_batch"]}
+        try:   # the second measurement must not take the headline line down with it (every rank takes the same branch)
+            o, model, _, _ = measure(opt, opt.mode, other, world, rank, device, want_kernels=False)
+            if rank == 0:
+                res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step")} | \
+                    {"graphs_per_gpu": o["config"]["graphs_per_gpu"], "global_batch": o["config"]["global_batch"],
+                     "batchnorm": o["config"]["batchnorm"]}
+            if other == "strong" and not opt.no_sync_bn:   # and what the synchronised statistics cost: the same split with per-rank statistics
+                del model
+                opt.no_sync_bn = True
+                o2, model, _, _ = measure(opt, opt.mode, other, world, rank, device, want_kernels=False)
+                opt.no_sync_bn = False
+                if rank == 0:
+                    res[other + "_scaling"]["per_rank_batchnorm"] = {k: o2[k] for k in ("value", "ms_per_step")}
+        except Exception as e:
+            model = None
+            if rank == 0:
+                res[other + "_scaling"] = {"error": repr(e)[:500]}
     if extra and world == 1:
         others = [m for m in ("mixed", "bf16", "fp32") if m != opt.mode]
         res["modes"] = {}

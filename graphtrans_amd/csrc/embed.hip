@@ -585,8 +585,20 @@ extern "C" int gt_embed_sum_bwd_sorted(int num_tables, const int64_t* table_rows
   }
   hipStream_t stream = (hipStream_t)stream_;
   const SortLayout L = sort_layout(num_tables, table_rows_host, N);
-  for (int t = 0; t < num_tables; ++t)  // rows nobody indexes get zero
-    if (d_tables_host[t]) (void)hipMemsetAsync(d_tables_host[t], 0, (size_t)table_rows_host[t] * D * sizeof(float), stream);
+  // rows nobody indexes get zero: one memset per run of tables that lie back to back (the fused path's flat gradient buffer
+  // holds them contiguously: one launch instead of one per table)
+  for (int t = 0; t < num_tables;) {
+    if (!d_tables_host[t]) { ++t; continue; }
+    char* lo = (char*)d_tables_host[t];
+    char* hi = lo + (size_t)table_rows_host[t] * D * sizeof(float);
+    int u = t + 1;
+    while (u < num_tables && d_tables_host[u] && (char*)d_tables_host[u] >= hi && (char*)d_tables_host[u] - hi < 64) {
+      hi = (char*)d_tables_host[u] + (size_t)table_rows_host[u] * D * sizeof(float);   // (a gap is the 16-byte segment padding)
+      ++u;
+    }
+    (void)hipMemsetAsync(lo, 0, (size_t)(hi - lo), stream);
+    t = u;
+  }
   if (N == 0) return GT_OK;
   SegArgs a{};
   a.T = num_tables; a.N = N; a.D = D; a.nchunks = (int)gt_cdiv(N, SEG_CH); a.g = grad_out;

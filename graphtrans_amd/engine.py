@@ -203,6 +203,22 @@ class _Plan:
             self.params.append((h.bias, self.total))
             self.total += h.bias.numel()
         self.total = _c4(self.total)
+        # the max_seq_len prediction heads (models/gnn_transformer.py:120-126) run as ONE GEMM over their stacked weights: instead
+        # of stacking them by a 12.8 MB torch.cat per step (two launches on the critical path), the parameters' storage IS the
+        # stacked matrix -- each head's weight / bias becomes a view of it (same Parameter objects, same state_dict keys; an
+        # optimizer that caches data pointers, like optim.FusedAdamW, notices the move and rebuilds its tables)
+        self.head_w_flat = self.head_b_flat = None
+        if len(self.heads) > 1:
+            with torch.no_grad():
+                wf = torch.cat([h.weight.detach() for h in self.heads]).contiguous()
+                bf = torch.cat([h.bias.detach() for h in self.heads]).contiguous()
+                r0 = 0
+                for h in self.heads:
+                    n_ = h.weight.shape[0]
+                    h.weight.data = wf[r0:r0 + n_]
+                    h.bias.data = bf[r0:r0 + n_]
+                    r0 += n_
+            self.head_w_flat, self.head_b_flat = wf, bf
         # persistent flat gradient buffer and its per-parameter views
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in self.params]
@@ -639,8 +655,8 @@ class _FusedModel(torch.autograd.Function):
             o["ne_x"] = b.take(N * plan.ne_Kp * 4)
             o["ne_w"] = b.take(D * plan.ne_Kp * 4)
         o["hg"] = b.take(B * d * 4)
-        o["wcat"] = b.take(plan.Nh * d * 4)
-        o["bcat"] = b.take(plan.Nh * 4)
+        o["wcat"] = b.take(0 if plan.head_w_flat is not None else plan.Nh * d * 4)
+        o["bcat"] = b.take(0 if plan.head_w_flat is not None else plan.Nh * 4)
         ws_bytes = max([getattr(lib, plan.conv_api + "_workspace_bytes")(C.byref(dsc)) for dsc in plan.gcn_desc]
                        + [lib.gt_vn_update_workspace_bytes(C.byref(dsc)) for dsc in plan.vn_desc] + [256])
         o["ws"] = b.take(ws_bytes)
@@ -815,6 +831,8 @@ class _FusedModel(torch.autograd.Function):
         # ---- prediction heads as one GEMM over the stacked weights   (gnn_transformer.py:120-126)
         if len(plan.heads) == 1:
             wcat, bcat = plan.heads[0].weight.data_ptr(), plan.heads[0].bias.data_ptr()
+        elif plan.head_w_flat is not None:
+            wcat, bcat = plan.head_w_flat.data_ptr(), plan.head_b_flat.data_ptr()
         else:
             ww = arena[o["wcat"]:o["wcat"] + plan.Nh * d * 4].view(torch.float32).view(plan.Nh, d)
             wb = arena[o["bcat"]:o["bcat"] + plan.Nh * 4].view(torch.float32)
