@@ -166,3 +166,41 @@ def test_packed_equals_padded_encoder():
         out = enc.forward_tokens(tok, lay)
         outs[kind] = out.index_select(0, lay.last_rows)
     assert_close(outs["packed"].cpu(), outs["padded"].cpu(), what="cls rows packed vs padded")
+
+
+# ---- bf16 backward at more lengths / head dims, with dropout, and run-to-run reproducibility ------------------------------------
+@pytest.mark.parametrize("hd,nhead", [(32, 4), (16, 4), (8, 2)])
+@pytest.mark.parametrize("kind", ["packed", "padded"])
+def test_bf16_backward_vs_reference_more_shapes(hd, nhead, kind):
+    from graphtrans_amd import ops
+
+    torch.manual_seed(3)
+    d = nhead * hd
+    lens = [1, 7, 33, 64, 65, 130, 31, 32, 200, 256, 255, 129]
+    lay = make_layout(kind, lens)
+    qkv = torch.randn(lay.rows, 3 * d)
+    w = torch.randn(lay.rows, d)
+    qkv_q = qkv.to(torch.bfloat16).float()
+    ref_in = qkv_q.clone().requires_grad_(True)
+    ref = reference(ref_in, lay, nhead, hd ** -0.5)
+    (ref * w.double()).sum().backward()
+    x = qkv.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    out = ops.attention(x, lay, nhead)
+    (out.float() * w.to(DEV)).sum().backward()
+    assert_close(x.grad.float().cpu(), ref_in.grad, atol=2e-2, rtol=2e-2, what="d_qkv")
+
+
+def test_bf16_backward_with_dropout_is_bitwise_reproducible():
+    from graphtrans_amd import ops
+    torch.manual_seed(4)
+    nhead, hd = 4, 32
+    d = nhead * hd
+    lay = make_layout("packed", [300, 17, 256, 257, 64, 1000, 5, 128])
+    x = torch.randn(lay.rows, 3 * d).to(DEV).to(torch.bfloat16)
+    w = torch.randn(lay.rows, d, device=DEV)
+    grads = []
+    for _ in range(2):
+        xx = x.clone().requires_grad_(True)
+        (ops.attention(xx, lay, nhead, dropout_p=0.3, seed=991).float() * w).sum().backward()
+        grads.append(xx.grad.clone())
+    assert torch.equal(grads[0], grads[1])
