@@ -95,6 +95,12 @@ SIGNATURES = {
     "gt_w3_images": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "gt_w3_bind": (_i, [_i, _p, _p, _p, _p, _p]),
     "gt_w3_unbind": (_i, []),
+    "gt_w1_image_bytes": (_sz, [_i64, _i64]),
+    "gt_w1_images": (_i, [_i, _p, _p, _p, _p, _p, _p]),
+    "gt_w1_bind": (_i, [_i, _p, _p, _p, _p, _p]),
+    "gt_w1_unbind": (_i, []),
+    "gt_linear_bwd_gate_out_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
+    "gt_linear_bwd_gate_out": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),
     "gt_linear_bwd_bnstats_ok": (_i, [_i, _i, _i, _i64]),
     "gt_linear_bwd_bnstats_rows": (_i64, [_i64]),

@@ -203,6 +203,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 
 #include "linear32.h"
 #include "linear3x.h"
+#include "linear1.h"
 #include "linear_small.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -917,6 +918,21 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
+  // bf16 rows in and out with a bound fragment-order image of this weight (gt_w1_bind): the weight-stationary kernel (linear1.h)
+  if (x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && groups == 1 && act != 2 && M >= W1_MIN_M) {
+    if (const void* img = w1_lookup(weight, N, K, false)) {
+      L1Args l{};
+      l.a = (const gt_bf16*)x; l.img = (const unsigned char*)img; l.bias = bias; l.out = (gt_bf16*)y;
+      l.M = M; l.lda = ldx; l.ldo = ldy; l.N = (int)N; l.K = (int)K; l.act = act;
+      l.inv_keep = a.inv_keep; l.thr = a.thr; l.s0 = a.s0; l.s1 = a.s1;
+      bool ok;
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
+        ok = w1_launch(stream, l);
+      }
+      if (ok) { GT_CHECK_LAUNCH(); return GT_OK; }
+    }
+  }
   const int bm = pick_bm(M);
   a.ntiles = (int)gt_cdiv(N, BN);
   dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups);
@@ -971,6 +987,7 @@ struct BwdCallOpts {
   bool fork_dw_only = false;         // dW-only call that may still go to the overlap stream (gt_linear_bwd_dw_forked)
   const float* weight_t = nullptr;   // W^T [K][N] prepared by the caller (gt_linear_bwd_wt): no transpose launch
   BnStatsReq bns;                    // set by gt_linear_bwd_bnstats BEFORE the call it applies to
+  bool gate_out = false;             // y_for_mask [M][ldx] gates the dX OUTPUT (gt_linear_bwd_gate_out), dY is used as it is
 };
 thread_local BwdCallOpts g_opt;
 struct BwdOptScope {   // whatever was set is dropped when the call it was meant for returns
@@ -1219,7 +1236,27 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
-  if (dx) {
+  bool dx_done = false;
+  if (dx && x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && groups == 1 && M >= W1_MIN_M && (!y_for_mask || g_opt.gate_out)) {
+    // dX = dY W on the bound image of W^T (linear1.h); a gate here applies to the OUTPUT columns (gt_linear_bwd_gate_out)
+    if (const void* img = w1_lookup(weight, N, K, true)) {
+      L1Args l{};
+      l.a = (const gt_bf16*)dy; l.img = (const unsigned char*)img; l.out = (gt_bf16*)dx;
+      l.gate = g_opt.gate_out ? (const gt_bf16*)y_for_mask : nullptr; l.gate_inv_keep = a.inv_keep;
+      l.add1 = (const gt_bf16*)dx_add1; l.add2 = (const gt_bf16*)dx_add2;
+      l.M = M; l.lda = ldy; l.ldo = ldx; l.N = (int)K; l.K = (int)N;
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
+        dx_done = w1_launch(stream, l);
+      }
+    }
+  }
+  if (g_opt.gate_out) {
+    if (dx && !dx_done) { gt_set_error("gt_linear_bwd_gate_out: not covered (ask gt_linear_bwd_gate_out_ok)"); return GT_ERR_UNSUPPORTED; }
+    a.ymask = nullptr;   // the gate belongs to the dX output, not to dY: the weight gradient below reads dY as it is
+    y_for_mask = nullptr;
+  }
+  if (dx && !dx_done) {
     const int bm = pick_bm(M);
     // split-N partials are plain fp32 sums: only for fp32 dX without fused addends (and not for grouped launches)
     int splits = (x_dtype == GT_F32 && !dx_add1 && !dx_add2 && ldx == K && groups == 1) ? dx_splits(M, N, K, bm) : 1;
@@ -1372,6 +1409,69 @@ extern "C" int gt_w3_bind(int n, const float* const* weight, const int64_t* N, c
 extern "C" int gt_w3_unbind(void) {
   g_w3.n = 0;
   return GT_OK;
+}
+
+// ---- fragment-order bf16 images for the encoder layers' GEMMs (linear1.h) ------------------------------------------------
+// 0 when the (rows, contraction) GEMM is not covered by the weight-stationary kernel (rows % 64, contraction % 128, <= 1024)
+extern "C" size_t gt_w1_image_bytes(int64_t rows, int64_t contraction) {
+  return w1_pick_ntw(rows, contraction) ? w1_image_bytes(rows, contraction) : 0;
+}
+// Job i as gt_w3_images: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (rows N, contraction K), != 0 -> image of W^T;
+// image[i] has gt_w1_image_bytes(rows, contraction) bytes (non-zero), 16-byte aligned.
+extern "C" int gt_w1_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,
+                            void* const* image, gt_stream_t stream_) {
+  GT_CHECK_ARG(n >= 0 && (n == 0 || (weight && N && K && transposed && image)), "bad arguments");
+  for (int i0 = 0; i0 < n; i0 += W1_MAX_JOBS) {
+    W1Jobs jobs{};
+    int blocks = 0;
+    const int cnt = n - i0 < W1_MAX_JOBS ? n - i0 : W1_MAX_JOBS;
+    for (int i = 0; i < cnt; ++i) {
+      const int s = i0 + i;
+      GT_CHECK_ARG(weight[s] && image[s] && N[s] > 0 && K[s] > 0 && ((uintptr_t)image[s] & 15) == 0, "null / unaligned buffer");
+      const int64_t rows = transposed[s] ? K[s] : N[s], contr = transposed[s] ? N[s] : K[s];
+      GT_CHECK_ARG(w1_pick_ntw(rows, contr) != 0, "shape not covered (gt_w1_image_bytes == 0)");
+      W1Job& J = jobs.j[i];
+      J.w = weight[s]; J.img = (unsigned char*)image[s]; J.R = (int)rows; J.C = (int)contr; J.ldw = (int)K[s];
+      J.transposed = transposed[s] ? 1 : 0; J.block0 = blocks;
+      blocks += (int)gt_cdiv((rows / 16) * (contr / 32), 4);
+    }
+    jobs.n = cnt;
+    hipLaunchKernelGGL(k_w1_image, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, jobs);
+  }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+// Binds images for the calling HOST THREAD: until gt_w1_unbind(), gt_linear_fwd* / gt_linear_bwd* calls with bf16 rows in and out,
+// bf16 compute, one group, no GELU and a weight (pointer, N, K) in the table run the weight-stationary kernel (forward: image_fwd[i];
+// dX: image_t[i], when the call has no gate on dY; NULL keeps the tiled kernel for that direction).  Images must be current.
+extern "C" int gt_w1_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
+                          const void* const* image_t) {
+  GT_CHECK_ARG(n >= 0 && n <= W1_MAX_BOUND && (n == 0 || (weight && N && K)), "at most 64 bound weights");
+  for (int i = 0; i < n; ++i)
+    g_w1.e[i] = W1Bound{weight[i], N[i], K[i], image_fwd ? image_fwd[i] : nullptr, image_t ? image_t[i] : nullptr};
+  g_w1.n = n;
+  return GT_OK;
+}
+extern "C" int gt_w1_unbind(void) {
+  g_w1.n = 0;
+  return GT_OK;
+}
+// gt_linear_bwd_ld2 whose gate (`y_or_mul` [M][ldx]: the forward output of the layer BELOW when dropout_p >= 0 -- dZ = dX * 1[y > 0]
+// / (1 - p) -- or, with dropout_p < 0, a saved multiplier) applies to the dX OUTPUT of this call; dY is used as it is (also by the
+// weight gradient).  Only on the weight-stationary path: ask gt_linear_bwd_gate_out_ok first.
+extern "C" int gt_linear_bwd_gate_out_ok(int x_dtype, int y_dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
+  return (x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_lookup(weight, N, K, true) &&
+          w1_pick_ntw(K, N)) ? 1 : 0;
+}
+extern "C" int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                                      const void* y_or_mul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight,
+                                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p,
+                                      void* workspace, size_t workspace_bytes, gt_stream_t stream_) {
+  GT_CHECK_ARG(y_or_mul && dx, "gt_linear_bwd_gate_out needs the gate tensor and dx");
+  g_opt.gate_out = true;
+  g_opt.mul_mask = dropout_p < 0.f;
+  return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_or_mul, dx_add1, dx_add2, dx, dweight, dbias, M, N, K, ldx, ldy,
+                               1, 0, 0, dropout_p < 0.f ? 0.f : dropout_p, workspace, workspace_bytes, stream_);
 }
 
 // ---- overlap section -------------------------------------------------------------------------------

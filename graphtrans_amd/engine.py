@@ -330,6 +330,19 @@ class _Plan:
             ent[1] = vers
         return ent[0]
 
+    def w1_images(self, stream):
+        """fragment-order bf16 images of the encoder layers' weights (w3.W1Images / csrc/linear1.h), rebuilt when a weight changed"""
+        from . import w3
+        ws = self.w3_enc_weights
+        ent = self._w3.get("w1")
+        if ent is None or not ent[0].current():
+            ent = self._w3["w1"] = [w3.W1Images(ws), None]
+        vers = (w3.EPOCH,) + tuple(w._version for w in ws)
+        if ent[1] != vers:
+            ent[0].build(stream)
+            ent[1] = vers
+        return ent[0]
+
     def small(self, B):
         c = self._cache.get(B)
         if c is None:
@@ -533,6 +546,12 @@ class _FusedModel(torch.autograd.Function):
         if w3.ENABLED and ops.get_matmul_dtype() != torch.bfloat16 and gs.N >= 1024:
             imgs = plan.w3_images(model.transformer_encoder.compute_dtype != torch.bfloat16, _stream())
             imgs.bind()
+        # bf16 token rows: the encoder layers' GEMMs run with the weight stationary in registers on fragment-order images (linear1.h)
+        imgs1 = None
+        if w3.W1_ENABLED and model.transformer_encoder.compute_dtype == torch.bfloat16 and plan.w3_enc_weights:
+            imgs1 = plan.w1_images(_stream())
+            imgs1.bind()
+        ctx.w1 = imgs1
         hook = _bn_sync_hook(model, plan) if model.training else None
         if hook is not None:
             hook.install()
@@ -541,6 +560,8 @@ class _FusedModel(torch.autograd.Function):
         finally:
             if imgs is not None:
                 imgs.unbind()
+            if imgs1 is not None:
+                imgs1.unbind()
             if hook is not None:
                 hook.uninstall()
                 if hook.error is not None:
@@ -938,6 +959,9 @@ class _FusedModel(torch.autograd.Function):
             _call("gt_overlap_dw_begin", st, plan.side_dw.cuda_stream)
         if s.get("w3") is not None:
             s["w3"].bind()   # (autograd's worker thread: the table is per host thread)
+        w1 = getattr(ctx, "w1", None)
+        if w1 is not None:
+            w1.bind()
         if s.get("bn_hook") is not None:
             s["bn_hook"].install()
         try:
@@ -948,6 +972,8 @@ class _FusedModel(torch.autograd.Function):
                 _lib.lib().gt_overlap_dw_end()
             if s.get("w3") is not None:
                 s["w3"].unbind()
+            if w1 is not None:
+                w1.unbind()
             if s.get("bn_hook") is not None:
                 s["bn_hook"].uninstall()
                 if s["bn_hook"].error is not None:

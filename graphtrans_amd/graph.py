@@ -155,10 +155,25 @@ class SeqLayout:
         self.kept = kept
         self.desc_cpu = desc
         # attention tile list: (sequence, 64-position tile) for every tile that exists (ragged sizes)
+        # Longest sequences FIRST: a block walks all keys (queries) of its sequence tile by tile, so the longest sequence's
+        # blocks are a serial chain several times the typical one (Code2-like: 418 against 126 tokens) -- started last it
+        # was the tail of every attention launch.  The kernels give XCD x the x-th contiguous eighth of the list (one L2 per
+        # sequence) and dispatch each eighth front to back: sequences are dealt to the eighths by length rank, each eighth
+        # holds its own in descending length, padded with {-1, 0} entries (skipped) to equal size.
         tiles = (desc[:, 1].astype(np.int64) + 63) // 64
-        wseq = np.repeat(np.arange(B, dtype=np.int32), tiles)
-        wtile = (np.arange(int(tiles.sum()), dtype=np.int64) - np.repeat(np.cumsum(tiles) - tiles, tiles)).astype(np.int32)
-        work = np.stack([wseq, wtile], axis=1).astype(np.int32) if B else np.zeros((0, 2), np.int32)
+        if B:
+            order = np.argsort(-desc[:, 1].astype(np.int64), kind="stable")
+            parts = []
+            for x in range(8):
+                sq = order[x::8]
+                t = tiles[sq]
+                ws = np.repeat(sq.astype(np.int32), t)
+                wt = (np.arange(int(t.sum()), dtype=np.int64) - np.repeat(np.cumsum(t) - t, t)).astype(np.int32)
+                parts.append(np.stack([ws, wt], axis=1).astype(np.int32))
+            wpx = max(p.shape[0] for p in parts)
+            work = np.concatenate([np.concatenate([p, np.tile(np.array([[-1, 0]], np.int32), (wpx - p.shape[0], 1))], 0) for p in parts], 0)
+        else:
+            work = np.zeros((0, 2), np.int32)
         self.num_work = int(work.shape[0])
         # token row of the last position (CLS / last node) of every sequence: the pooled row
         last_row = desc[:, 0].astype(np.int64) + (desc[:, 1].astype(np.int64) - 1) * self.row_stride

@@ -31,6 +31,8 @@ def weights_changed():
 
 
 class W3Images:
+    _fn = ("gt_w3_image_bytes", "gt_w3_images", "gt_w3_bind", "gt_w3_unbind")
+
     def __init__(self, weights, forward=True, transposed=True):
         self.weights = [w for w in weights]
         if not self.weights:
@@ -44,11 +46,12 @@ class W3Images:
                 raise TypeError("W3Images: contiguous fp32 GPU matrices only")
             N, K = int(w.shape[0]), int(w.shape[1])
             fo = to = None
-            if forward:
-                fo, off = off, off + int(lib.gt_w3_image_bytes(N, K))
+            nbytes = getattr(lib, self._fn[0])
+            if forward and int(nbytes(N, K)):        # (0 bytes: a shape the kernel does not cover -- that direction stays unbound)
+                fo, off = off, off + (int(nbytes(N, K)) + 1023) // 1024 * 1024
                 jobs.append((w, N, K, 0, fo))
-            if transposed:
-                to, off = off, off + int(lib.gt_w3_image_bytes(K, N))
+            if transposed and int(nbytes(K, N)):
+                to, off = off, off + (int(nbytes(K, N)) + 1023) // 1024 * 1024
                 jobs.append((w, N, K, 1, to))
             self.fwd_off.append(fo)
             self.t_off.append(to)
@@ -74,15 +77,16 @@ class W3Images:
         return self.ptrs == tuple(w.data_ptr() for w in self.weights)
 
     def build(self, stream=None):
-        _lib.check(_lib.lib().gt_w3_images(self._n, self._w, self._N, self._K, self._T, self._img, _stream() if stream is None else stream),
-                   "gt_w3_images")
+        if self._n:
+            _lib.check(getattr(_lib.lib(), self._fn[1])(self._n, self._w, self._N, self._K, self._T, self._img,
+                                                        _stream() if stream is None else stream), self._fn[1])
 
     def bind(self):
-        _lib.check(_lib.lib().gt_w3_bind(len(self.weights), self._bw, self._bN, self._bK, self._bf, self._bt), "gt_w3_bind")
+        _lib.check(getattr(_lib.lib(), self._fn[2])(len(self.weights), self._bw, self._bN, self._bK, self._bf, self._bt), self._fn[2])
 
-    @staticmethod
-    def unbind():
-        _lib.lib().gt_w3_unbind()
+    @classmethod
+    def unbind(cls):
+        getattr(_lib.lib(), cls._fn[3])()
 
     @contextlib.contextmanager
     def bound(self):
@@ -91,3 +95,14 @@ class W3Images:
             yield self
         finally:
             self.unbind()
+
+
+# GT_BF16_GEMM=tiled keeps the tiled bf16 kernels for the encoder layers (A/B yardstick)
+W1_ENABLED = os.environ.get("GT_BF16_GEMM", "stationary") != "tiled"
+
+
+class W1Images(W3Images):
+    """bf16 images in MFMA fragment order for the encoder layers' GEMMs (csrc/linear1.h, "gt_w1_*"): nn.TransformerEncoderLayer's
+    in_proj / out_proj / linear1 / linear2 (modules/transformer_encoder.py:28-32) with bf16 token rows run with the weight stationary
+    in registers on a BOUND weight; same life cycle as W3Images (build after every optimizer step, bind per host thread)."""
+    _fn = ("gt_w1_image_bytes", "gt_w1_images", "gt_w1_bind", "gt_w1_unbind")

@@ -500,6 +500,30 @@ int gt_w3_images(int n, const float* const* weight, const int64_t* N, const int6
 int gt_w3_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
                const void* const* image_t);
 int gt_w3_unbind(void);
+
+/* ---- bf16 images in MFMA fragment order for the encoder layers' GEMMs (weight stationary in registers; csrc/linear1.h) --------
+ * Replaces, per GEMM of nn.TransformerEncoderLayer (modules/transformer_encoder.py:28-32; in_proj / out_proj / linear1 / linear2),
+ * the per-block re-staging of the fp32 master weight: the image is built once per optimizer step, all weights in one launch.
+ * gt_w1_image_bytes: bytes of the image of a (rows = output columns, contraction) matrix; 0 = shape not covered (rows % 64,
+ * contraction % 128, contraction <= 1024 and a fragment budget of 128 VGPRs per wave) -- such GEMMs keep the tiled kernels. */
+size_t gt_w1_image_bytes(int64_t rows, int64_t contraction);
+/* job i: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (forward), != 0 -> image of W^T (dX); 16-byte aligned */
+int gt_w1_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,
+                 void* const* image, gt_stream_t stream);
+/* per HOST THREAD, until gt_w1_unbind(): gt_linear_fwd* / gt_linear_bwd* calls with bf16 rows in and out, bf16 compute, one group,
+ * act in {none, relu} whose weight (pointer, N, K) is bound run the weight-stationary kernel (either image may be NULL) */
+int gt_w1_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
+               const void* const* image_t);
+int gt_w1_unbind(void);
+/* gt_linear_bwd_ld2 with the activation gate on the dX OUTPUT: dx = gate(dy W, y_or_mul) + add1 + add2, where y_or_mul [M][ldx] is
+ * the forward output of the layer below (dropout_p >= 0: * 1[y > 0] / (1 - p)) or a saved multiplier (dropout_p < 0).  dW / db use
+ * dy as it is.  The encoder layer's backward writes dZ1 = d(linear1 output) straight out of linear2's dX GEMM this way (the tensor
+ * both GEMMs of linear1's backward read).  Only with a bound W^T image: gt_linear_bwd_gate_out_ok says so. */
+int gt_linear_bwd_gate_out_ok(int x_dtype, int y_dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K);
+int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
+                           const void* y_or_mul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight, float* dbias,
+                           int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p, void* workspace,
+                           size_t workspace_bytes, gt_stream_t stream);
 /* dW / db only; inside an overlap section it still runs on the overlap stream (ordered behind what `stream` holds so far):
  * a caller can start a GEMM's weight gradient ahead of its dX GEMM. */
 int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

@@ -371,10 +371,19 @@ def test_device_built_token_layout_equals_the_host_built_one(max_input_len):
     lh, ld = g_host.layout("packed", max_input_len, True), g_dev.layout("packed", max_input_len, True)
     assert lh.exact and not ld.exact
     meta = ld.meta.cpu().numpy()
-    assert meta[0] == lh.rows and meta[1] == lh.num_work and meta[2] == lh.max_npos and meta[3] == lh.S
-    assert ld.rows >= lh.rows and ld.num_work >= lh.num_work and ld.max_npos >= lh.max_npos
+    # (the host-built work list is ordered longest sequence first per XCD eighth and padded with {-1, 0}: same SET of tiles)
+    real = lambda w: sorted(map(tuple, w.cpu().numpy()[w.cpu().numpy()[:, 0] >= 0].tolist()))
+    n_real = len(real(lh.work))
+    assert meta[0] == lh.rows and meta[1] == n_real and meta[2] == lh.max_npos and meta[3] == lh.S
+    assert ld.rows >= lh.rows and ld.num_work >= n_real and ld.max_npos >= lh.max_npos
     assert torch.equal(ld.desc, lh.desc) and torch.equal(ld.last_rows, lh.last_rows)
-    assert torch.equal(ld.work[:lh.num_work], lh.work) and bool((ld.work[lh.num_work:] == -1).all())
+    assert real(ld.work) == real(lh.work) and bool((ld.work[n_real:] == -1).all())
+    hw = lh.work.cpu().numpy()
+    wpx = lh.num_work // 8
+    for x in range(8):   # every eighth: its sequences in descending length, padding at the end
+        sq = hw[x * wpx:(x + 1) * wpx, 0]
+        lens = [int(lh.desc_cpu[s_, 1]) for s_ in sq if s_ >= 0]
+        assert lens == sorted(lens, reverse=True) and bool((sq[len(lens):] == -1).all())
     # the model on both
     args = _args(max_input_len=max_input_len, transformer_dropout=0.0)
     torch.manual_seed(0)

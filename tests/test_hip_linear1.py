@@ -1,0 +1,151 @@
+"""Weight-stationary bf16 GEMMs of the encoder layers (csrc/linear1.h) through the C ABI (gt_w1_images / gt_w1_bind +
+gt_linear_fwd_ld2 / gt_linear_bwd_ld2 / gt_linear_bwd_gate_out) against a float64 evaluation of the SAME bf16 operands, with the tiled
+bf16 kernels (unbound weight) as the yardstick, at the encoder shapes of the benchmarked configurations: d_model 128 / ffn 512
+(Code2, Molpcba, PNA), ffn 256 (NCI1), d_model 256 / ffn 1024 (ER), ragged and tiny M."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GT_F32, GT_BF16 = 0, 1
+BF = torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def fwd(x, W, b, bound, act=0, p=0.0, seed=0):
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=BF, device=x.device)
+    call = lambda: _lib.launch("gt_linear_fwd_ld2", GT_BF16, GT_BF16, GT_BF16, _p(x), _p(W), _p(b), _p(y), M, N, K, K, N, act, p, seed, _stream())
+    if bound is not None:
+        with bound.bound():
+            call()
+    else:
+        call()
+    return y
+
+
+def bwd(x, W, dy, ymask, add1, add2, bound, p=0.0, gate_out=False, want_dw=False):
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=BF, device=dy.device)
+    dw = torch.zeros(N, K, device=dy.device) if want_dw else None
+    db = torch.zeros(N, device=dy.device) if want_dw else None
+    ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(GT_BF16, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    name = "gt_linear_bwd_gate_out" if gate_out else "gt_linear_bwd_ld2"
+    call = lambda: _lib.launch(name, GT_BF16, GT_BF16, GT_BF16, _p(x), _p(W), _p(dy), _p(ymask), _p(add1), _p(add2), _p(dx), _p(dw), _p(db),
+                               M, N, K, K, N, p, _p(ws), ws_bytes, _stream())
+    if bound is not None:
+        with bound.bound():
+            call()
+    else:
+        call()
+    return (dx, dw, db) if want_dw else dx
+
+
+# (M, N, K): forward shapes; their dX runs the (K, N) image
+SHAPES = [(31598, 384, 128), (31598, 128, 128), (31598, 512, 128), (31598, 128, 512),   # Code2 / Molpcba / PNA encoder
+          (1153, 256, 128), (1153, 128, 256),                                         # NCI1 ffn 256
+          (20011, 256, 256), (20011, 512, 256), (20011, 256, 512),   # d_model 256
+          (63, 384, 128), (64, 128, 512), (1, 512, 128), (4099, 128, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES, ids=[f"{m}x{n}x{k}" for m, n, k in SHAPES])
+def test_forward_and_dx_match_float64_of_the_same_bf16_operands(M, N, K):
+    from graphtrans_amd import _lib
+    from graphtrans_amd.w3 import W1Images
+    lib = _lib.lib()
+    assert lib.gt_w1_image_bytes(N, K) > 0 and lib.gt_w1_image_bytes(K, N) > 0
+    torch.manual_seed(M + N + K)
+    x = (torch.randn(M, K, device=DEV) * (1.0 + 3.0 * torch.rand(M, 1, device=DEV))).to(BF)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    imgs = W1Images([W])
+    imgs.build()
+    y1, y0 = fwd(x, W, b, imgs), fwd(x, W, b, None)
+    Wb = W.to(BF).double()
+    y64 = x.double() @ Wb.t() + b.double()
+    e1, e0 = rel(y1, y64), rel(y0, y64)
+    print(f"\nfwd {M}x{N}x{K}: stationary {e1:.2e}  tiled {e0:.2e}")
+    assert e1 <= 1.05 * e0 + 1e-5 and e1 < 4e-3      # one bf16 rounding of the output: ~2^-9 / sqrt(3)
+    assert rel(y1, y0) < 4e-3
+    # relu + dropout: the SAME mask as the tiled kernel (the hash is a function of (seed, row, column) only)
+    r1, r0 = fwd(x, W, b, imgs, act=1, p=0.3, seed=1234567), fwd(x, W, b, None, act=1, p=0.3, seed=1234567)
+    assert bool(((r1 == 0) == (r0 == 0)).all()) or float(((r1 == 0) != (r0 == 0)).float().mean()) < 1e-4   # (values within rounding of 0 may flip)
+    ref = torch.relu(y64) / 0.7 * (r0 != 0)
+    assert rel(r1, ref) <= 1.05 * rel(r0, ref) + 1e-5
+    # dX = dY W + add1 + add2
+    dy = torch.randn(M, N, device=DEV).to(BF)
+    a1, a2 = torch.randn(M, K, device=DEV).to(BF), torch.randn(M, K, device=DEV).to(BF)
+    d1, d0 = bwd(x, W, dy, None, a1, a2, imgs), bwd(x, W, dy, None, a1, a2, None)
+    d64 = dy.double() @ Wb + a1.double() + a2.double()
+    e1, e0 = rel(d1, d64), rel(d0, d64)
+    print(f"dx  {M}x{N}x{K}: stationary {e1:.2e}  tiled {e0:.2e}")
+    assert e1 <= 1.05 * e0 + 1e-5 and e1 < 4e-3
+    d1n = bwd(x, W, dy, None, None, None, imgs)
+    assert rel(d1n, dy.double() @ Wb) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(31598, 128, 512), (4099, 128, 256), (20011, 256, 1024)], ids=["code2-l2", "nci1-l2", "er-l2"])
+def test_gate_on_the_dx_output_is_the_gated_gradient_both_gemms_of_linear1_read(M, N, K):
+    """linear2's backward (x = f1 [M][K], W2 [N][K], dy = dF2 [M][N]) with the ReLU / dropout gate of f1 on its dX OUTPUT:
+    dZ1 = (dF2 W2) * 1[f1 > 0] / keep; dW2 / db2 from the un-gated dy.  And the multiplier form (dropout_p < 0)."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.w3 import W1Images
+    lib = _lib.lib()
+    torch.manual_seed(N + K)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    f1 = (torch.relu(torch.randn(M, K, device=DEV)) * (torch.rand(M, K, device=DEV) > 0.3)).to(BF)
+    dy = torch.randn(M, N, device=DEV).to(BF)
+    imgs = W1Images([W])
+    imgs.build()
+    with imgs.bound():
+        assert lib.gt_linear_bwd_gate_out_ok(GT_BF16, GT_BF16, GT_BF16, W.data_ptr(), M, N, K) == 1
+    assert lib.gt_linear_bwd_gate_out_ok(GT_BF16, GT_BF16, GT_BF16, W.data_ptr(), M, N, K) == 0   # unbound
+    dz, dw, db = bwd(f1, W, dy, f1, None, None, imgs, p=0.3, gate_out=True, want_dw=True)
+    Wb = W.to(BF).double()
+    ref = (dy.double() @ Wb) * (f1 > 0) / 0.7
+    assert rel(dz, ref) < 4e-3
+    assert bool((dz[f1 <= 0] == 0).all())
+    dw64, db64 = dy.double().t() @ f1.double(), dy.double().sum(0)
+    assert rel(dw, dw64) < 2e-3 and rel(db, db64) < 1e-4
+    # the tiled path gates dY of the NEXT call instead: same tensor within one extra bf16 rounding
+    mul = torch.rand(M, K, device=DEV).to(BF)
+    dzm = bwd(f1, W, dy, mul, None, None, imgs, p=-1.0, gate_out=True)
+    assert rel(dzm, (dy.double() @ Wb) * mul.double()) < 4e-3
+    # unbound: the call reports that it is not covered instead of mis-gating
+    from graphtrans_amd.graph import _stream
+    dx = torch.empty(M, K, dtype=BF, device=DEV)
+    ws_bytes = lib.gt_linear_bwd_workspace_bytes(GT_BF16, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    rc = lib.gt_linear_bwd_gate_out(GT_BF16, GT_BF16, GT_BF16, None, _p(W), _p(dy), _p(f1), None, None, _p(dx), None, None, M, N, K, K, N, 0.3,
+                                    _p(ws), ws_bytes, _stream())
+    assert rc != 0
+
+
+def test_uncovered_shapes_keep_the_tiled_kernels():
+    from graphtrans_amd import _lib
+    from graphtrans_amd.w3 import W1Images
+    lib = _lib.lib()
+    assert lib.gt_w1_image_bytes(300, 128) == 0 and lib.gt_w1_image_bytes(128, 96) == 0 and lib.gt_w1_image_bytes(128, 2048) == 0
+    torch.manual_seed(0)
+    M, N, K = 5000, 128, 96     # forward not covered (K % 128), dX (image of W^T: rows 96) not covered either
+    x = torch.randn(M, K, device=DEV).to(BF)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    imgs = W1Images([W])
+    imgs.build()
+    y1, y0 = fwd(x, W, None, imgs), fwd(x, W, None, None)
+    assert torch.equal(y1, y0)

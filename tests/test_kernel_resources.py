@@ -44,6 +44,10 @@ def test_gemm_kernels_keep_their_register_budget():
     assert len(split) >= 32
     for n, v in split.items():
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
+    stat = {n: v for n, v in k.items() if re.search(r"6k_lin1I", n)}   # weight-stationary bf16 (linear1.h): one 8-wave block per CU
+    assert len(stat) >= 9
+    for n, v in stat.items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
     for n, v in k.items():
         if re.search(r"12k_linear_(fwd|dx)I[ft][ft]tLi64E", n):   # the bf16-MFMA tiled kernels (encoder GEMMs), 64-row tiles
             assert v["Occupancy"] >= 3, (n, v)
