@@ -45,7 +45,7 @@ def test_gemm_kernels_keep_their_register_budget():
     for n, v in split.items():
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
     stat = {n: v for n, v in k.items() if re.search(r"6k_lin1I", n)}   # weight-stationary bf16 (linear1.h): one 8-wave block per CU
-    assert len(stat) >= 9
+    assert len(stat) >= 7
     for n, v in stat.items():
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
     for n, v in k.items():
