@@ -257,16 +257,26 @@ extern "C" int gt_encoder_layer_fwd(const gt_encoder_layer* L, const void* x, vo
   GT_TRY(gt_linear_fwd(t, t, c, x, L->in_w, L->in_b, s.qkv, R, 3 * d, d, 0, 0.f, 0, st));
   GT_TRY(gt_attn_fwd(t, s.qkv, s.ctx, s.lse, R, d, L->nhead, L->seq_desc, L->num_seqs, L->row_stride, L->max_npos,
                      L->work_items, L->num_work, nullptr, nullptr, 0.f, scale, p, L->seed, st));
-  GT_TRY(gt_linear_fwd(t, t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, 0, 0.f, 0, st));
-  GT_TRY(gt_layernorm_fwd(t, s.a, x, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, s.x1, s.st1,
-                          s.st1 + R, st));
+  if (gt_linear_layernorm_fwd_ok(t, c, L->out_w, R, d, d)) {   // out_proj + residual + dropout + norm1 as one launch (linear1.h)
+    GT_TRY(gt_linear_layernorm_fwd(t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, x, L->n1_w, L->n1_b, L->ln_eps, p,
+                                   L->seed ^ 0x5851F42D4C957F2DULL, s.x1, s.st1, s.st1 + R, st));
+  } else {
+    GT_TRY(gt_linear_fwd(t, t, c, s.ctx, L->out_w, L->out_b, s.a, R, d, d, 0, 0.f, 0, st));
+    GT_TRY(gt_layernorm_fwd(t, s.a, x, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, s.x1, s.st1,
+                            s.st1 + R, st));
+  }
   if (L->act == 1)   // f1 = drop(gelu(x1 W1^T + b1)), multiplier saved for the backward
     GT_TRY(gt_linear_fwd_gelu(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, s.g1, R, F, d, d, F, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
   else
     GT_TRY(gt_linear_fwd(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, R, F, d, 1, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
-  GT_TRY(gt_linear_fwd(t, t, c, s.f1, L->l2_w, L->l2_b, s.f2, R, d, F, 0, 0.f, 0, st));
-  GT_TRY(gt_layernorm_fwd(t, s.f2, s.x1, L->n2_w, L->n2_b, L->ln_eps, p, L->seed ^ 0x14057B7EF767814FULL, R, d, y, s.st2,
-                          s.st2 + R, st));
+  if (gt_linear_layernorm_fwd_ok(t, c, L->l2_w, R, d, F)) {    // linear2 + residual + dropout + norm2
+    GT_TRY(gt_linear_layernorm_fwd(t, c, s.f1, L->l2_w, L->l2_b, s.f2, R, d, F, s.x1, L->n2_w, L->n2_b, L->ln_eps, p,
+                                   L->seed ^ 0x14057B7EF767814FULL, y, s.st2, s.st2 + R, st));
+  } else {
+    GT_TRY(gt_linear_fwd(t, t, c, s.f1, L->l2_w, L->l2_b, s.f2, R, d, F, 0, 0.f, 0, st));
+    GT_TRY(gt_layernorm_fwd(t, s.f2, s.x1, L->n2_w, L->n2_b, L->ln_eps, p, L->seed ^ 0x14057B7EF767814FULL, R, d, y, s.st2,
+                            s.st2 + R, st));
+  }
   return GT_OK;
 }
 

@@ -1474,6 +1474,43 @@ extern "C" int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, con
                                1, 0, 0, dropout_p < 0.f ? 0.f : dropout_p, workspace, workspace_bytes, stream_);
 }
 
+// y = LayerNorm(resid + dropout(a)) * ln_w + ln_b with a = x W^T + b, as ONE launch: the GEMM's epilogue holds whole rows (N = the
+// LayerNorm dim in one column block), saves a (the LayerNorm backward re-reads it), mean and rstd exactly as gt_linear_fwd followed by
+// gt_layernorm_fwd(a, resid, ...) would (post-norm nn.TransformerEncoderLayer: x = norm1(x + dropout1(sa)), x = norm2(x + dropout2(ff));
+// modules/transformer_encoder.py:28-32).  Only on the weight-stationary path: gt_linear_layernorm_fwd_ok says so (callers fall back to
+// the two calls).
+extern "C" int gt_linear_layernorm_fwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
+  return (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_ln_covered(N, K) && w1_lookup(weight, N, K, false)) ? 1 : 0;
+}
+extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, const float* weight, const float* bias, void* a_out,
+                                       int64_t M, int64_t N, int64_t K, const void* resid, const float* ln_weight, const float* ln_bias,
+                                       float eps, float dropout_p, uint64_t seed, void* y, float* save_mean, float* save_rstd,
+                                       gt_stream_t stream_) {
+  GT_CHECK_ARG(x && weight && a_out && ln_weight && ln_bias && y && save_mean && save_rstd, "null buffer");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  if (!gt_linear_layernorm_fwd_ok(dtype, compute, weight, M, N, K)) {
+    gt_set_error("gt_linear_layernorm_fwd: not covered (ask gt_linear_layernorm_fwd_ok)");
+    return GT_ERR_UNSUPPORTED;
+  }
+  if (M == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  LinArgs d{};
+  fill_drop(d, dropout_p, seed);
+  L1Args l{};
+  l.a = (const gt_bf16*)x; l.img = (const unsigned char*)w1_lookup(weight, N, K, false); l.bias = bias; l.out = (gt_bf16*)a_out;
+  l.M = M; l.lda = K; l.ldo = N; l.N = (int)N; l.K = (int)K;
+  l.ln_resid = (const gt_bf16*)resid; l.ln_w = ln_weight; l.ln_b = ln_bias; l.ln_out = (gt_bf16*)y; l.ln_mean = save_mean; l.ln_rstd = save_rstd;
+  l.ln_eps = eps; l.ln_inv_keep = d.inv_keep; l.ln_thr = d.thr; l.ln_s0 = d.s0; l.ln_s1 = d.s1;
+  bool ok;
+  {
+    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[fwd+ln]", stream, {M, N, K, dtype, dtype, compute});
+    ok = w1_launch(stream, l);
+  }
+  if (!ok) { gt_set_error("gt_linear_layernorm_fwd: launch set-up failed"); return GT_ERR_LAUNCH; }
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
 // ---- overlap section -------------------------------------------------------------------------------
 extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
   GT_CHECK_ARG(side_ && main_ != side_, "need a distinct side stream");

@@ -67,6 +67,16 @@ struct L1Args {
   float inv_keep;             // forward dropout behind the activation
   uint32_t thr, s0, s1;
   float gate_inv_keep;
+  // LN instantiations (one column block = the whole row): out = a = bf16(acc + bias) is SAVED (the LayerNorm backward re-reads it),
+  // ln_out = LayerNorm(ln_resid + dropout(a)) * ln_w + ln_b, ln_mean / ln_rstd = the row statistics it saves
+  const gt_bf16* ln_resid;    // [M][ldo] or null
+  const float* ln_w;
+  const float* ln_b;
+  gt_bf16* ln_out;            // [M][ldo]
+  float* ln_mean;
+  float* ln_rstd;
+  float ln_eps, ln_inv_keep;
+  uint32_t ln_thr, ln_s0, ln_s1;
   int ncb;                    // column blocks of 64 * NTW columns
   int sgroups;                // row-tile groups in flight: grid = 8 * ncb * sgroups
   int row_tiles;              // ceil(M / 64)
@@ -80,10 +90,17 @@ constexpr int64_t W1_MIN_M = 1;
 template <int NTW>
 constexpr int w1_patch_ld() { return NTW * 16 + 4; }
 template <int NTW>
-constexpr size_t w1_lds_bytes() { return 2 * W1_STAGE + 8 * 16 * w1_patch_ld<NTW>() * sizeof(float); }
+constexpr size_t w1_lds_bytes() { return 2 * W1_STAGE + 8 * 16 * w1_patch_ld<NTW>() * sizeof(float) + 64 * 4 * 2 * sizeof(float); }
+
+// Chan's merge of two (mean, M2) partials over EQUAL counts n each
+__device__ __forceinline__ void w1_merge(float& mean, float& m2, float mean_b, float m2_b, float n) {
+  const float dlt = mean_b - mean;
+  mean += 0.5f * dlt;
+  m2 += m2_b + dlt * dlt * (0.5f * n);
+}
 
 // KS = K / 32 k-steps (K % 128 == 0), NTW = n-tiles per wave (column block = 4 * NTW * 16 columns)
-template <int KS, int NTW>
+template <int KS, int NTW, bool LN = false>
 __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   constexpr int KCH = KS / 4;                 // 128-deep chunks per row tile
   constexpr int PLD = w1_patch_ld<NTW>();
@@ -92,6 +109,7 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, g = lane >> 4, wm = wid >> 2, wn = wid & 3;
   float* patch = reinterpret_cast<float*>(smem1 + 2 * W1_STAGE) + wid * 16 * PLD;
+  float2* rowstat = reinterpret_cast<float2*>(smem1 + 2 * W1_STAGE + 8 * 16 * PLD * sizeof(float));   // LN: [64 rows][4 column waves] (mean, M2)
   // block -> (XCD, column block, row-tile group): the ncb column blocks of a row tile share an XCD (one L2) and run together
   const int xcd = blockIdx.x & 7, cb = (blockIdx.x >> 3) % a.ncb, sg = (blockIdx.x >> 3) / a.ncb;
   const int col0 = (cb * 4 + wn) * NTW * 16;   // first output column of this wave
@@ -168,6 +186,110 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
     if (kc == KCH - 1) {
       // ---- epilogue of this row tile: per wave, 2 m-tiles x (NTW x 16) columns through the wave's patch
       const int tile = first_tile + t * tile_stride;
+      if constexpr (LN) {
+        // ---- LayerNorm epilogue: phase A per wave (a = bf16(acc + bias) stored; z = resid + dropout(a) kept in registers; the wave's
+        // (mean, M2) over its NTW x 16 columns of every row -> LDS), block barrier, phase B (merge the 4 column waves, normalise, store)
+        constexpr int CPR = NTW * 2, NCH = 16 * CPR, NQ = NCH / 64;
+        static_assert(NCH % 64 == 0, "LN epilogue: whole waves of chunks");
+        float z[2][NQ][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            *reinterpret_cast<float4*>(patch + n * PLD + j * 16 + g * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ch = lane + q * 64;
+            const int r = ch / CPR, c8 = (ch % CPR) * 8;
+            int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
+            const bool live = m < a.M;
+            if (!live) m = a.M - 1;   // (tail rows compute on a valid row and store nothing)
+            const int col = col0 + c8;
+            float v[8];
+            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(patch + r * PLD + c8);
+            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(patch + r * PLD + c8 + 4);
+            if (a.bias) {
+              const float4 b0 = *reinterpret_cast<const float4*>(a.bias + col), b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            const int64_t o = m * a.ldo + col;
+            const uint4 packed = make_uint4(gt_pack_bf16(v[0], v[1]), gt_pack_bf16(v[2], v[3]), gt_pack_bf16(v[4], v[5]), gt_pack_bf16(v[6], v[7]));
+            if (live) *reinterpret_cast<uint4*>(a.out + o) = packed;
+            // the LayerNorm sees the SAVED (bf16) sub-layer output, as the stand-alone kernel and the backward do
+            const uint32_t u[4] = {packed.x, packed.y, packed.z, packed.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] = __uint_as_float(u[e] << 16);
+              v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+            }
+            if (a.ln_thr) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = lin_hash(a.ln_s0, a.ln_s1, (uint32_t)m, (uint32_t)(col + e)) >= a.ln_thr ? v[e] * a.ln_inv_keep : 0.f;
+            }
+            if (a.ln_resid) {
+              const uint4 ad = *reinterpret_cast<const uint4*>(a.ln_resid + o);
+              const uint32_t w[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] += __uint_as_float(w[e] << 16);
+                v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+              }
+            }
+            float mean = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            mean *= 0.125f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              z[i][q][e] = v[e];
+              m2 = fmaf(v[e] - mean, v[e] - mean, m2);
+            }
+            float cnt = 8.f;
+#pragma unroll
+            for (int sh = 1; sh < CPR; sh <<= 1, cnt *= 2.f)   // the CPR adjacent lanes of a row
+              w1_merge(mean, m2, __shfl_xor(mean, sh, 64), __shfl_xor(m2, sh, 64), cnt);
+            if ((ch % CPR) == 0) rowstat[(wm * 32 + i * 16 + r) * 4 + wn] = make_float2(mean, m2);
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ch = lane + q * 64;
+            const int r = ch / CPR, c8 = (ch % CPR) * 8;
+            const int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
+            const float2* rsp = rowstat + (wm * 32 + i * 16 + r) * 4;
+            const float2 p0 = rsp[0], p1 = rsp[1], p2 = rsp[2], p3 = rsp[3];
+            float mean = p0.x, m2 = p0.y, mean_b = p2.x, m2_b = p2.y;
+            w1_merge(mean, m2, p1.x, p1.y, (float)(NTW * 16));
+            w1_merge(mean_b, m2_b, p3.x, p3.y, (float)(NTW * 16));
+            w1_merge(mean, m2, mean_b, m2_b, (float)(NTW * 32));
+            const float rs = 1.0f / sqrtf(m2 * (1.0f / (float)(NTW * 64)) + a.ln_eps);
+            if (m < a.M) {
+              const int col = col0 + c8;
+              const float4 w0 = *reinterpret_cast<const float4*>(a.ln_w + col), w1 = *reinterpret_cast<const float4*>(a.ln_w + col + 4);
+              const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + col), b1 = *reinterpret_cast<const float4*>(a.ln_b + col + 4);
+              const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, gb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+              float y[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = (z[i][q][e] - mean) * rs * gw[e] + gb[e];
+              *reinterpret_cast<uint4*>(a.ln_out + m * a.ldo + col) =
+                  make_uint4(gt_pack_bf16(y[0], y[1]), gt_pack_bf16(y[2], y[3]), gt_pack_bf16(y[4], y[5]), gt_pack_bf16(y[6], y[7]));
+              if (wn == 0 && (ch % CPR) == 0) {
+                a.ln_mean[m] = mean;
+                a.ln_rstd[m] = rs;
+              }
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -237,6 +359,7 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      }
     }
     __syncthreads();
     }
@@ -260,7 +383,7 @@ static inline int w1_pick_ntw(int64_t R, int64_t C) {
   return 0;
 }
 
-template <int KS, int NTW>
+template <int KS, int NTW, bool LN = false>
 static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a) {
   static std::mutex mu;
   static bool set[64] = {};
@@ -270,15 +393,19 @@ static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a)
   if (dev >= 0 && dev < 64) {
     std::lock_guard<std::mutex> lk(mu);
     if (!set[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
       set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((k_lin1<KS, NTW>), grid, dim3(W1_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((k_lin1<KS, NTW, LN>), grid, dim3(W1_THREADS), lds, stream, a);
   return true;
 }
 
 // out[M][N] = epilogue(A[M][K] image^T); false = shape not covered / launch set-up failed
+static inline bool w1_ln_covered(int64_t N, int64_t K) {
+  const int ntw = w1_pick_ntw(N, K), ks = (int)(K / 32);
+  return ntw && N == 64 * ntw && ((ntw == 2 && (ks == 4 || ks == 8 || ks == 16)) || (ntw == 4 && ks == 8));
+}
 static inline bool w1_launch(hipStream_t stream, L1Args& a) {
   const int ntw = w1_pick_ntw(a.N, a.K);
   if (!ntw || a.M <= 0) return false;
@@ -291,6 +418,13 @@ static inline bool w1_launch(hipStream_t stream, L1Args& a) {
   a.sgroups = sgroups;
   const dim3 grid((unsigned)(8 * a.ncb * sgroups));
   const int ks = a.K / 32;
+  if (a.ln_out) {   // LayerNorm epilogue: the row must lie in ONE column block
+    if (a.ncb != 1) return false;
+#define GT_W1_LN_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_, true>(grid, stream, a)
+    GT_W1_LN_CASE(4, 2); GT_W1_LN_CASE(8, 2); GT_W1_LN_CASE(16, 2); GT_W1_LN_CASE(8, 4);
+#undef GT_W1_LN_CASE
+    return false;
+  }
 #define GT_W1_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_>(grid, stream, a)
   GT_W1_CASE(4, 6); GT_W1_CASE(4, 4); GT_W1_CASE(4, 2);
   GT_W1_CASE(8, 4); GT_W1_CASE(8, 2);

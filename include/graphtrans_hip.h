@@ -515,6 +515,13 @@ int gt_w1_images(int n, const float* const* weight, const int64_t* N, const int6
 int gt_w1_bind(int n, const float* const* weight, const int64_t* N, const int64_t* K, const void* const* image_fwd,
                const void* const* image_t);
 int gt_w1_unbind(void);
+/* a = x W^T + b and y = LayerNorm(resid + dropout(a)) * ln_w + ln_b in ONE launch (post-norm encoder layer: out_proj + norm1,
+ * linear2 + norm2; modules/transformer_encoder.py:28-32): a_out, save_mean, save_rstd as gt_linear_fwd + gt_layernorm_fwd write them.
+ * Only with a bound image and N = the LayerNorm dim in one column block: gt_linear_layernorm_fwd_ok; otherwise make the two calls. */
+int gt_linear_layernorm_fwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K);
+int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, const float* weight, const float* bias, void* a_out, int64_t M,
+                            int64_t N, int64_t K, const void* resid, const float* ln_weight, const float* ln_bias, float eps,
+                            float dropout_p, uint64_t seed, void* y, float* save_mean, float* save_rstd, gt_stream_t stream);
 /* gt_linear_bwd_ld2 with the activation gate on the dX OUTPUT: dx = gate(dy W, y_or_mul) + add1 + add2, where y_or_mul [M][ldx] is
  * the forward output of the layer below (dropout_p >= 0: * 1[y > 0] / (1 - p)) or a saved multiplier (dropout_p < 0).  dW / db use
  * dy as it is.  The encoder layer's backward writes dZ1 = d(linear1 output) straight out of linear2's dX GEMM this way (the tensor

@@ -149,3 +149,48 @@ def test_uncovered_shapes_keep_the_tiled_kernels():
     imgs.build()
     y1, y0 = fwd(x, W, None, imgs), fwd(x, W, None, None)
     assert torch.equal(y1, y0)
+
+
+@pytest.mark.parametrize("M,N,K,p", [(31598, 128, 128, 0.3), (31598, 128, 512, 0.3), (4099, 128, 256, 0.0), (20011, 256, 256, 0.1), (61, 128, 128, 0.3)],
+                         ids=["out_proj", "linear2", "nci1-l2", "d256", "tiny"])
+def test_gemm_with_layernorm_epilogue_equals_the_two_kernels(M, N, K, p):
+    """gt_linear_layernorm_fwd (a = x W^T + b saved; y = LayerNorm(resid + dropout(a)); mean / rstd saved) against gt_linear_fwd
+    (tiled kernel) + gt_layernorm_fwd, and against float64 of the same bf16 operands with the SAME dropout mask."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W1Images
+    lib = _lib.lib()
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV).to(BF)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    resid = (2.0 * torch.randn(M, N, device=DEV)).to(BF)
+    g, be = 1.0 + 0.1 * torch.randn(N, device=DEV), 0.1 * torch.randn(N, device=DEV)
+    imgs = W1Images([W])
+    imgs.build()
+    a1, y1 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, N, dtype=BF, device=DEV)
+    mu1, rs1 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    seed = 0x1234567890ABCDEF
+    assert lib.gt_linear_layernorm_fwd_ok(GT_BF16, GT_BF16, _p(W), M, N, K) == 0   # unbound
+    with imgs.bound():
+        assert lib.gt_linear_layernorm_fwd_ok(GT_BF16, GT_BF16, _p(W), M, N, K) == 1
+        _lib.launch("gt_linear_layernorm_fwd", GT_BF16, GT_BF16, _p(x), _p(W), _p(b), _p(a1), M, N, K, _p(resid), _p(g), _p(be), 1e-5, p, seed,
+                    _p(y1), _p(mu1), _p(rs1), _stream())
+    a0 = fwd(x, W, b, None)
+    y0 = torch.empty(M, N, dtype=BF, device=DEV)
+    mu0, rs0 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    _lib.launch("gt_layernorm_fwd", GT_BF16, _p(a0), _p(resid), _p(g), _p(be), 1e-5, p, seed, M, N, _p(y0), _p(mu0), _p(rs0), _stream())
+    assert rel(a1, a0) < 4e-3
+    # the LayerNorm of the fused kernel on ITS saved a, by the stand-alone kernel: same rows up to the reduction order
+    y2 = torch.empty(M, N, dtype=BF, device=DEV)
+    mu2, rs2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    _lib.launch("gt_layernorm_fwd", GT_BF16, _p(a1), _p(resid), _p(g), _p(be), 1e-5, p, seed, M, N, _p(y2), _p(mu2), _p(rs2), _stream())
+    assert float((mu1 - mu2).abs().max()) < 1e-5 * max(1.0, float(mu2.abs().max())) and rel(rs1, rs2) < 1e-5
+    assert float((y1.float() - y2.float()).abs().max()) <= 2 ** -7 * float(y2.float().abs().max()) and rel(y1, y2) < 1e-3   # <= one bf16 ulp apart
+    assert rel(y1, y0) < 1e-2
+    # float64 with the mask the kernels used (recovered from the stand-alone kernel at weight 1 / bias 0 is overkill: p = 0 case only)
+    if p == 0.0:
+        z = resid.double() + a1.double()
+        ref = torch.nn.functional.layer_norm(z, (N,), g.double(), be.double(), 1e-5)
+        assert rel(y1, ref) < 4e-3
+        assert rel(mu1, z.mean(1)) < 1e-5 and rel(rs1, 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)) < 1e-5
