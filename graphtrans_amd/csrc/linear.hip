@@ -1480,7 +1480,8 @@ extern "C" int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, con
 // modules/transformer_encoder.py:28-32).  Only on the weight-stationary path: gt_linear_layernorm_fwd_ok says so (callers fall back to
 // the two calls).
 extern "C" int gt_linear_layernorm_fwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
-  return (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_ln_covered(N, K) && w1_lookup(weight, N, K, false)) ? 1 : 0;
+  static const bool on = [] { const char* e = getenv("GT_W1_LN"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return !on ? 0 : (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_ln_covered(N, K) && w1_lookup(weight, N, K, false)) ? 1 : 0;
 }
 extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, const float* weight, const float* bias, void* a_out,
                                        int64_t M, int64_t N, int64_t K, const void* resid, const float* ln_weight, const float* ln_bias,
