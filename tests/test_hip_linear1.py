@@ -194,3 +194,19 @@ def test_gemm_with_layernorm_epilogue_equals_the_two_kernels(M, N, K, p):
         ref = torch.nn.functional.layer_norm(z, (N,), g.double(), be.double(), 1e-5)
         assert rel(y1, ref) < 4e-3
         assert rel(mu1, z.mean(1)) < 1e-5 and rel(rs1, 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(31598, 384, 128), (31598, 128, 128), (31598, 512, 128), (31598, 128, 512), (20011, 1024, 256), (5003, 72, 200), (1024, 136, 8),
+                                    (1025, 128, 128)], ids=lambda v: str(v))
+def test_bf16_weight_gradient(M, N, K):
+    """dW = dY^T X, db = colsum(dY) for bf16 rows (M-splits + fixed-order reduce) against float64 of the same bf16 operands, at the
+    encoder shapes and at ragged ones; twice the same bits (no atomics)."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV).to(BF)
+    dy = (torch.randn(M, N, device=DEV) * (0.5 + torch.rand(M, 1, device=DEV))).to(BF)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    _, dw, db = bwd(x, W, dy, None, None, None, None, want_dw=True)
+    dw64, db64 = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert rel(dw, dw64) < 2e-6 and rel(db, db64) < 2e-6      # exact bf16 products, fp32 accumulation
+    _, dw2, db2 = bwd(x, W, dy, None, None, None, None, want_dw=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)

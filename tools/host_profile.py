@@ -1,19 +1,14 @@
-#!/usr/bin/env python
-"""cProfile of the host side of bench.py's step (where does Python/launch time go?).
-With --batch 8 the GPU is never the bottleneck, so the times are pure host enqueue cost."""
-import cProfile, pstats, sys, os, io
+"""Where the HOST spends a step (cProfile around bench.py's step loop): python tools/host_profile.py [workload] [steps]"""
+import cProfile, pstats, sys, io, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-batch = sys.argv[1] if len(sys.argv) > 1 else "8"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-workload = sys.argv[3] if len(sys.argv) > 3 else "code2"
-sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--no-kernel-timing", "--no-extra", "--batch", batch,
-            "--workload", workload]
+sys.argv = ["bench.py", "--workload", sys.argv[1] if len(sys.argv) > 1 else "code2", "--steps", sys.argv[2] if len(sys.argv) > 2 else "60", "--warmup", "10",
+            "--no-kernel-timing", "--no-cpu-baseline", "--no-extra"]
 import bench
 pr = cProfile.Profile()
 pr.enable()
 bench.main()
 pr.disable()
-for key, n in (("tottime", 45), ("cumulative", 70)):
+for key in ("tottime", "cumulative"):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(n)
-    print(s.getvalue()[:12000])
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    print(s.getvalue()[:9000])
