@@ -431,6 +431,7 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
   }
   if (L->has_vn && L->ev_x_ready) GT_TRY(gt_event_record(L->ev_x_ready, st));   // x (with its virtual-node add) is complete
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_b, s.lin, L->N, L->D, L->D, 0, 0.f, 0, st));
+  if (L->ev_graph_ready) GT_TRY(gt_stream_wait_event(st, L->ev_graph_ready));   // gt_graph_prep ran beside everything up to here
   GT_TRY(gt_aggregate_fwd(GT_CONV_GCN, L->edge_mode, GT_F32, s.lin, L->N, L->E, L->D, L->in_ptr, L->in_src, L->in_eid, L->deg,
                           L->dis, L->root, L->edge_attr, L->edge_cols, L->edge_w, L->edge_b, L->tab_off, L->table_rows, nullptr, s.agg, st));
   // h = batch_norm(h) [relu] [+ h_list[layer]]   (gnn_module.py:204-212; dropout p = 0 or eval here)

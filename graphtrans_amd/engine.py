@@ -77,6 +77,50 @@ def _side_stream(device, which):
     return st
 
 
+# ---- step preamble beside the first kernels -------------------------------------------------------------------------------
+# gt_graph_prep (8 short launches: degree count, scans, fill, per-node sorts) and the encoder's weight images do not depend on
+# anything the step computes, and nothing needs them before the first aggregate / the first encoder layer: they run on a side
+# stream that starts where the main stream stands when the batch arrives (so memory the allocator hands out for them is no
+# longer in use) while the main stream does its zero-fills, the bf16x3 images, the input embedding and layer 0's GEMM.
+PREP_OVERLAP = os.environ.get("GT_PREP_OVERLAP", "1") != "0"
+_PREPS = {}
+
+
+class Prep:
+    def __init__(self, device):
+        lib = _lib.lib()
+        self.device = torch.device(device)
+        self.stream = _side_stream(device, "prep").cuda_stream
+        self.ev_begin, self.ev_graph, self.ev_w1 = lib.gt_event_create(), lib.gt_event_create(), lib.gt_event_create()
+        self.active = False
+
+    def begin(self):
+        """the side stream continues from the main stream's current position"""
+        main = _stream()
+        _call("gt_event_record", self.ev_begin, main)
+        _call("gt_stream_wait_event", self.stream, self.ev_begin)
+        self.active = True
+
+    def graph_done(self):
+        _call("gt_event_record", self.ev_graph, self.stream)
+        return self.ev_graph
+
+    def w1_done(self):
+        _call("gt_event_record", self.ev_w1, self.stream)
+        self.active = False
+        return self.ev_w1
+
+
+def prep_for(device):
+    if not PREP_OVERLAP or torch.device(device).type != "cuda":
+        return None
+    key = torch.device(device).index or 0
+    p = _PREPS.get(key)
+    if p is None:
+        p = _PREPS[key] = Prep(device)
+    return p
+
+
 # ---------------------------------------------------------------------------------------------------
 # plan: parameter order, gradient layout, persistent descriptors (built once per model)
 # ---------------------------------------------------------------------------------------------------
@@ -548,10 +592,17 @@ class _FusedModel(torch.autograd.Function):
             imgs.bind()
         # bf16 token rows: the encoder layers' GEMMs run with the weight stationary in registers on fragment-order images (linear1.h)
         imgs1 = None
+        ev_w1 = None
         if w3.W1_ENABLED and model.transformer_encoder.compute_dtype == torch.bfloat16 and plan.w3_enc_weights:
-            imgs1 = plan.w1_images(_stream())
+            prep = _PREPS.get(plan.dev.index or 0)
+            if prep is not None and prep.active:   # this step's structure is being built on the side stream: the images follow it there
+                imgs1 = plan.w1_images(prep.stream)
+                ev_w1 = prep.w1_done()
+            else:
+                imgs1 = plan.w1_images(_stream())
             imgs1.bind()
         ctx.w1 = imgs1
+        ctx.ev_w1 = ev_w1
         hook = _bn_sync_hook(model, plan) if model.training else None
         if hook is not None:
             hook.install()
@@ -773,6 +824,17 @@ class _FusedModel(torch.autograd.Function):
                 if plan.side_dw is not None:
                     _call("gt_event_record", plan.ev_sort[1], sst)
 
+        # ---- the graph structure may still be in the making on the side stream (Prep): GCN layer 0 waits between its GEMM and its
+        # aggregate (descriptor), the virtual-node stream before its first segment sum; every other configuration right here
+        ev_graph, gs.ready_event = getattr(gs, "ready_event", None), None
+        late_wait = ev_graph is not None and plan.kind == "gcn" and (not plan.has_vn or plan.vn0_in_embed)
+        if plan.kind == "gcn":
+            plan.gcn_desc[0].ev_graph_ready = ev_graph if late_wait else None
+        if ev_graph is not None:
+            if not late_wait:
+                _call("gt_stream_wait_event", st, ev_graph)
+            elif side is not None:
+                _call("gt_stream_wait_event", side, ev_graph)
         # ---- message passing   (modules/gnn_module.py:181-224)
         # x_l (= h_list[l] after its in-place virtual-node add): layer 0's comes from the embedding kernel (or a broadcast
         # add for Linear node encoders), layer l+1's is written by layer l's BatchNorm apply pass (vn_next)
@@ -809,6 +871,9 @@ class _FusedModel(torch.autograd.Function):
                       ws_bytes, st)
         first = X(0)   # h_list[0] after the in-place virtual-node add
         g2t = plan.g2t
+        if getattr(ctx, "ev_w1", None) is not None:   # the encoder's weight images were built on the side stream (Prep)
+            _call("gt_stream_wait_event", st, ctx.ev_w1)
+            ctx.ev_w1 = None
         if cat2:
             node_rep = None
             _call("gt_linear_fwd_cat2", tdt, compute, first, D, D, P("h", L), D, D, g2t.weight.data_ptr(), g2t.bias.data_ptr(), P("hn"),

@@ -26,10 +26,10 @@ class GraphStructure:
     """graph_ptr, node_graph, CSR by destination (in_*), CSC by source (out_*), deg, dis."""
 
     __slots__ = ("N", "E", "B", "device", "graph_ptr", "node_graph", "in_ptr", "in_src", "in_eid", "out_ptr",
-                 "out_dst", "out_eid", "deg", "dis", "status", "_sizes", "_layouts", "_pna_scales")
+                 "out_dst", "out_eid", "deg", "dis", "status", "_sizes", "_layouts", "_pna_scales", "_ws", "ready_event")
 
     @staticmethod
-    def build(edge_index, batch, num_graphs=None, sizes=None):
+    def build(edge_index, batch, num_graphs=None, sizes=None, stream=None):
         """edge_index (2,E) int64, batch (N,) int64 sorted; both on the GPU.  `num_graphs` / `sizes`
         (host values, e.g. PyG Batch.num_graphs / the collater's per-graph node counts) avoid the
         device sync the reference performs at modules/gnn_module.py:195."""
@@ -61,7 +61,9 @@ class GraphStructure:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.launch("gt_graph_prep", _ptr(edge_index), _ptr(batch), N, E, B, _ptr(gs.graph_ptr), _ptr(gs.node_graph),
                     _ptr(gs.in_ptr), _ptr(gs.in_src), _ptr(gs.in_eid), _ptr(gs.out_ptr), _ptr(gs.out_dst),
-                    _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes, _stream())
+                    _ptr(gs.out_eid), _ptr(gs.deg), _ptr(gs.dis), _ptr(gs.status), _ptr(ws), ws_bytes, _stream() if stream is None else stream)
+        gs._ws = ws   # (with a caller's stream the workspace must outlive this call's allocator scope)
+        gs.ready_event = None   # set by a caller that built on a side stream: consumers wait for it once (engine.prep_*)
         gs._sizes = None if sizes is None else np.asarray(sizes, dtype=np.int64)
         gs._layouts = {}
         gs._pna_scales = None

@@ -9,8 +9,9 @@ from .conv import GCNConv, GINConv, edge_spec
 from .norm import BatchNorm1d, mlp_bn_relu
 
 
-def batch_structure(batched_data):
-    """GraphStructure of a collated batch, built once and cached on the batch object."""
+def batch_structure(batched_data, prep=None):
+    """GraphStructure of a collated batch, built once and cached on the batch object.  prep: engine.Prep -- build on its side
+    stream (the caller's kernels wait for gs.ready_event before they read the structure)."""
     gs = getattr(batched_data, "_gt_structure", None)
     if gs is None:
         sizes = getattr(batched_data, "_sizes", None)
@@ -20,7 +21,12 @@ def batch_structure(batched_data):
                 ng = batched_data.num_graphs
             except Exception:
                 ng = None
-        gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes)
+        if prep is not None and sizes is not None:   # (without host-side sizes the token layout is built on the device from this structure)
+            prep.begin()
+            gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes, stream=prep.stream)
+            gs.ready_event = prep.graph_done()
+        else:
+            gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes)
         try:
             batched_data._gt_structure = gs
         except Exception:

@@ -663,6 +663,10 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
   float* prev_bn_part;
   const float* bn_part_in;
   int32_t prev_relu, bn_nparts_in;
+  /* forward only, optional gt_event: the graph structure (in_ptr / in_src / in_eid / deg / dis of this descriptor) is being built on
+   * another stream (gt_graph_prep beside the input embedding and this layer's GEMM); the forward waits for it between its linear
+   * and its aggregate.  NULL = the arrays are ready on `stream`. */
+  void* ev_graph_ready;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);
