@@ -154,19 +154,27 @@ struct TilePair {
   Frag<T> fa, fb;
   int r, col;
   bool has;
-  __device__ __forceinline__ void init() {
+  const T* pa;   // this thread's chunk of the tile at position 0 of the sequence
+  const T* pb;
+  int64_t sa, sb;   // elements per position (wave-uniform)
+  __device__ __forceinline__ void init(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride) {
     const int c = threadIdx.x;
     has = c < TILE * CH;
     r = c / CH;
     col = (c % CH) * 8;
+    pa = srcA + (row0 + (int64_t)r * row_stride) * ldA + col;
+    pb = srcB + (row0 + (int64_t)r * row_stride) * ldB + col;
+    sa = row_stride * ldA;
+    sb = row_stride * ldB;
   }
-  __device__ __forceinline__ void load(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride,
-                                       int pos0, int lo, int hi) {
+  // The tile at positions [pos0, pos0 + TILE): the per-thread row address is base + pos0 * (row_stride * ld) -- pos0 and the
+  // stride are wave-uniform, so the 64-bit product is scalar work and the vector side is one 64-bit add per operand (the
+  // per-lane (row0 + pos * row_stride) * ld of the first version was five quarter-rate multiplies per operand and step)
+  __device__ __forceinline__ void load(int pos0, int lo, int hi) {
     const int pos = pos0 + r;
     const bool ok = has && pos >= lo && pos < hi;
-    const int64_t row = row0 + (int64_t)pos * row_stride;
-    fa = ok ? frag_load(srcA + row * ldA + col) : frag_zero<T>();
-    fb = ok ? frag_load(srcB + row * ldB + col) : frag_zero<T>();
+    fa = ok ? frag_load(pa + (int64_t)pos0 * sa) : frag_zero<T>();
+    fb = ok ? frag_load(pb + (int64_t)pos0 * sb) : frag_zero<T>();
   }
   __device__ __forceinline__ void store(T* sA, T* sB) const {
     if (has) {
@@ -219,18 +227,18 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
   constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   TilePair<T, HD> stg;
-  stg.init();
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
+  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();   // the zero fill above and the first store touch the same rows
-  stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k_first, kv_off, kv_end);
+  stg.load(k_first, kv_off, kv_end);
   stg.store(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
   for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
     const bool more = k0 + TILE < kv_end;
-    if (more) stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k0 + TILE, kv_off, kv_end);
+    if (more) stg.load(k0 + TILE, kv_off, kv_end);
     const T* sK = sKb[cur];
     const T* sV = sVb[cur];
     // S^T: two 16-key tiles; row m of tile t <-> key (m>>2)*8 + t*4 + (m&3)
@@ -374,18 +382,18 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
   TilePair<T, HD> stg;
-  stg.init();
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
+  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();
-  stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k_first, kv_off, kv_end);
+  stg.load(k_first, kv_off, kv_end);
   stg.store(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
   for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
     const bool more = k0 + TILE < kv_end;
-    if (more) stg.load(srcK, ld3, srcV, ld3, row0, a.row_stride, k0 + TILE, kv_off, kv_end);
+    if (more) stg.load(k0 + TILE, kv_off, kv_end);
     const T* sK = sKb[cur];
     const T* sV = sVb[cur];
     float ds[8];
@@ -481,9 +489,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
   TilePair<T, HD> stg;
-  stg.init();
   const T* srcQ = qkv + head * HD;
   const T* srcDO = dctx + head * HD;
+  stg.init(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride);
   // threads 0..95 also carry one statistic of one query of the tile (0: running max, 1: log2(sum), 2: delta)
   const int aux_r = threadIdx.x & (TILE - 1), aux_which = threadIdx.x / TILE;
   const float* aux_src = aux_which == 0 ? a.lse : (aux_which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   };
   if (HD < 32) __syncthreads();
   if (any_valid) {
-    stg.load(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride, 0, 0, npos);
+    stg.load(0, 0, npos);
     load_aux(0);
     stg.store(sQb[0], sDOb[0]);
     if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
@@ -504,7 +512,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   for (int q0 = 0; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
     const bool more = q0 + TILE < npos;
     if (more) {
-      stg.load(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride, q0 + TILE, 0, npos);
+      stg.load(q0 + TILE, 0, npos);
       load_aux(q0 + TILE);
     }
     const T* sQ = sQb[cur];

@@ -496,10 +496,39 @@ def eligible(model, batched_data, perturb):
     return True
 
 
+def has_grad_hooks(model):
+    """Tensor hooks on parameters (register_hook / register_post_accumulate_grad_hook): the fused node assigns `.grad` itself and
+    would never fire them."""
+    for p in model.parameters():
+        if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return True
+    return False
+
+
+def wrapped_in_ddp(model):
+    """True when `model` is the `.module` of a torch DistributedDataParallel instance.  DDP reduces gradients from hooks on the
+    parameters' AccumulateGrad nodes (C++ side, invisible from here), which a node that assigns `.grad` directly never reaches:
+    such a model runs the module-by-module path (autograd accumulates as usual), or -- the supported way -- uses
+    graphtrans_amd.dist.GradSync, whose all-reduce the fused backward issues itself.  Found through the wrapper that holds the
+    model (wrapper.__dict__['_modules']['module'] is model)."""
+    import gc
+    from torch.nn.parallel import DistributedDataParallel
+    for mods in gc.get_referrers(model):
+        if not isinstance(mods, dict) or mods.get("module") is not model:
+            continue
+        for wd in gc.get_referrers(mods):
+            if isinstance(wd, dict) and wd.get("_modules") is mods:
+                if any(isinstance(o, DistributedDataParallel) for o in gc.get_referrers(wd)):
+                    return True
+    return False
+
+
 def _eligible_static(model):
     from . import ops
     from .modules.conv import GCNConv
     from .modules.norm import BatchNorm1d
+    if has_grad_hooks(model) or wrapped_in_ddp(model):   # (ADVICE r2: the fused node bypasses autograd's per-parameter machinery)
+        return False
     gnn, enc = model.gnn_node, model.transformer_encoder
     try:
         if not model._use_packed() or gnn.JK not in ("last", "cat"):

@@ -206,3 +206,38 @@ def test_bench_self_spawns_its_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["max_over_ranks"] == 2.0
+
+
+def _ddp_probe(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphtrans_amd import engine
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4))
+    res = [engine.wrapped_in_ddp(m), engine.has_grad_hooks(m)]
+    wrapper = torch.nn.parallel.DistributedDataParallel(m)
+    res.append(engine.wrapped_in_ddp(m))
+    holder = torch.nn.ModuleDict({"module": torch.nn.Linear(2, 2)})   # a plain container with a child called "module" is not DDP
+    res.append(engine.wrapped_in_ddp(holder["module"]))
+    m2 = torch.nn.Linear(3, 3)
+    m2.weight.register_hook(lambda g: g)
+    m3 = torch.nn.Linear(3, 3)
+    m3.bias.register_post_accumulate_grad_hook(lambda p: None)
+    res += [engine.has_grad_hooks(m2), engine.has_grad_hooks(m3)]
+    out.put(res)
+    del wrapper
+    dist.destroy_process_group()
+
+
+def test_fused_path_declines_models_under_ddp_or_with_gradient_hooks():
+    """The fused autograd node assigns `.grad` itself: DistributedDataParallel's reducer hooks and user tensor hooks would never
+    fire, so engine.eligible sends such models through the module-by-module path."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_ddp_probe, args=(0, 1, port, out))
+    p.start()
+    res = out.get(timeout=120)
+    p.join(60)
+    assert res == [False, False, True, False, True, True]
