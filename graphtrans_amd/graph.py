@@ -94,6 +94,37 @@ class GraphStructure:
         return self._layouts[key]
 
 
+class _StageRing:
+    """ONE pinned host allocation cut into slots (pinning costs ~1 ms per allocation), handed out round robin; a slot is reused
+    only after the H2D copy that last read it has completed (waited for if the host is more than a ring ahead of the device)."""
+    SLOTS, SLOT_BYTES = 64, 1 << 16
+
+    def __init__(self):
+        self.buf = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def take(self, nbytes):
+        if nbytes > self.SLOT_BYTES:
+            return None, None
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        if self.events[i] is None:
+            self.events[i] = torch.cuda.Event()
+        else:
+            self.events[i].synchronize()
+        return self.buf[i * self.SLOT_BYTES:(i + 1) * self.SLOT_BYTES], self.events[i]
+
+
+_RING = []
+
+
+def _staging(nbytes):
+    if not _RING:
+        _RING.append(_StageRing())
+    return _RING[0].take(nbytes)
+
+
 class SeqLayout:
     """seq_desc[B][4] = {row0, npos, kv_off, kv_len} (see include/graphtrans_hip.h).
 
@@ -165,26 +196,52 @@ class SeqLayout:
         tiles = (desc[:, 1].astype(np.int64) + 63) // 64
         if B:
             order = np.argsort(-desc[:, 1].astype(np.int64), kind="stable")
-            parts = []
-            for x in range(8):
-                sq = order[x::8]
-                t = tiles[sq]
-                ws = np.repeat(sq.astype(np.int32), t)
-                wt = (np.arange(int(t.sum()), dtype=np.int64) - np.repeat(np.cumsum(t) - t, t)).astype(np.int32)
-                parts.append(np.stack([ws, wt], axis=1).astype(np.int32))
-            wpx = max(p.shape[0] for p in parts)
-            work = np.concatenate([np.concatenate([p, np.tile(np.array([[-1, 0]], np.int32), (wpx - p.shape[0], 1))], 0) for p in parts], 0)
+            xcd = np.arange(B) % 8                              # eighth of the sequence of length rank r
+            perm = order[np.argsort(xcd, kind="stable")]        # = concat(order[x::8] for x in 0..7)
+            xs = np.sort(xcd)                                   # eighth of perm[i]
+            t = tiles[perm]
+            cnt = np.bincount(xs, weights=t, minlength=8).astype(np.int64)   # tiles per eighth
+            wpx = int(cnt.max())
+            tot = int(t.sum())
+            ws = np.repeat(perm, t)
+            first = np.cumsum(t) - t                            # first work item of every sequence
+            wt = np.arange(tot, dtype=np.int64) - np.repeat(first, t)
+            seg0 = np.cumsum(cnt) - cnt                         # first work item of every eighth
+            wx = np.repeat(xs, t)
+            dest = wx * wpx + (np.arange(tot, dtype=np.int64) - seg0[wx])
+            work = np.empty((8 * wpx, 2), np.int32)
+            work[:, 0] = -1
+            work[:, 1] = 0
+            work[dest, 0] = ws
+            work[dest, 1] = wt
         else:
             work = np.zeros((0, 2), np.int32)
         self.num_work = int(work.shape[0])
         # token row of the last position (CLS / last node) of every sequence: the pooled row
         last_row = desc[:, 0].astype(np.int64) + (desc[:, 1].astype(np.int64) - 1) * self.row_stride
         if torch.device(gs.device).type == "cuda":
-            # pinned staging + non_blocking: a pageable H2D copy blocks the host until everything
-            # already queued on the stream has drained (it showed up as a 10 ms/step stall)
-            self.desc = torch.from_numpy(desc).pin_memory().to(gs.device, non_blocking=True)
-            self.last_rows = torch.from_numpy(last_row).pin_memory().to(gs.device, non_blocking=True)
-            self.work = torch.from_numpy(work).pin_memory().to(gs.device, non_blocking=True) if self.num_work else None
+            # ONE pinned staging buffer from a ring (pin_memory() per array cost ~30 us each) and ONE non_blocking H2D copy: a pageable
+            # copy would block the host until everything already queued on the stream has drained (a 10 ms/step stall once)
+            nd, nl, nw = desc.size * 4, last_row.size * 8, work.size * 4
+            o_l = (nd + 15) // 16 * 16
+            o_w = (o_l + nl + 15) // 16 * 16
+            nbytes = max(o_w + nw, 16)
+            pinned, event = _staging(nbytes)
+            if pinned is None:   # (larger than a ring slot: its own pinned buffer)
+                pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            hb = pinned.numpy()
+            hb[:nd].view(np.int32)[:] = desc.reshape(-1)
+            hb[o_l:o_l + nl].view(np.int64)[:] = last_row
+            if nw:
+                hb[o_w:o_w + nw].view(np.int32)[:] = work.reshape(-1)
+            db = torch.empty(nbytes, dtype=torch.uint8, device=gs.device)
+            db.copy_(pinned[:nbytes], non_blocking=True)
+            if event is not None:
+                event.record()
+            self._dev = db
+            self.desc = db[:nd].view(torch.int32).view(B, 4)
+            self.last_rows = db[o_l:o_l + nl].view(torch.int64)
+            self.work = db[o_w:o_w + nw].view(torch.int32).view(-1, 2) if self.num_work else None
         else:
             self.work = torch.from_numpy(work)
             self.desc = torch.from_numpy(desc)

@@ -104,13 +104,19 @@ class FusedAdamW(torch.optim.Optimizer):
             plan = self._plan(gi, group)
             params = plan["params"]
             grads = [p.grad for p in params]
-            for t, g in enumerate(grads):
-                if g is None:
-                    continue
-                if g.dtype != torch.float32 or not g.is_cuda or g.is_sparse:
-                    raise RuntimeError("FusedAdamW: dense fp32 GPU gradients only")
-                if not g.is_contiguous():
-                    grads[t] = g.contiguous()
+            fast = plan.get("fast")
+            # the SAME gradient tensors as last step (the fused model path hands out persistent views of its flat buffer): they were
+            # validated then -- 4 attribute reads per tensor less, ~0.1 ms of host time per step on a 128-tensor model
+            same = fast is not None and len(fast["refs"]) == len(grads) and all(r() is g for r, g in zip(fast["refs"], grads))
+            plan["same"] = same
+            if not same:
+                for t, g in enumerate(grads):
+                    if g is None:
+                        continue
+                    if g.dtype != torch.float32 or not g.is_cuda or g.is_sparse:
+                        raise RuntimeError("FusedAdamW: dense fp32 GPU gradients only")
+                    if not g.is_contiguous():
+                        grads[t] = g.contiguous()
             work.append((group, plan, grads))
         scale_ptr = None
         if self.max_grad_norm is not None and work:
@@ -138,8 +144,7 @@ class FusedAdamW(torch.optim.Optimizer):
             # gradient tensors are the SAME objects as last step (the fused model path hands out persistent views of its flat
             # buffer) -> the ctypes pointer arrays of the last step are reused; building them cost 0.2 ms of host time per step
             fast = plan.get("fast")
-            if fast is not None and len(fast["refs"]) == len(grads) and all(r() is g for r, g in zip(fast["refs"], grads)) \
-                    and fast["uniform"]:
+            if plan.get("same") and fast["uniform"]:
                 step = steps[0] + 1
                 for t in range(len(steps)):
                     steps[t] = step
