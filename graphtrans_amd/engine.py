@@ -622,9 +622,12 @@ class _FusedModel(torch.autograd.Function):
         # bf16 token rows: the encoder layers' GEMMs run with the weight stationary in registers on fragment-order images (linear1.h)
         imgs1 = None
         ev_w1 = None
+        prep = _PREPS.get(plan.dev.index or 0)
+        prep_active = prep is not None and prep.active and getattr(gs, "ready_event", None) is not None   # begun for THIS call's structure
+        if prep is not None:
+            prep.active = False   # (consumed here whether or not anything follows the structure onto the side stream)
         if w3.W1_ENABLED and model.transformer_encoder.compute_dtype == torch.bfloat16 and plan.w3_enc_weights:
-            prep = _PREPS.get(plan.dev.index or 0)
-            if prep is not None and prep.active:   # this step's structure is being built on the side stream: the images follow it there
+            if prep_active:   # this step's structure is being built on the side stream: the images follow it there
                 imgs1 = plan.w1_images(prep.stream)
                 ev_w1 = prep.w1_done()
             else:

@@ -22,8 +22,8 @@ ENTRY = {
     "k_lin32[fwd]": ((r"k_lin32<[^>]*?, \d+, false,",), r"k_lin32<[^>]*?, \d+, false,"),
     "k_lin32[dx]": ((r"k_lin32<[^>]*?, \d+, true,", r"k_transpose32"), r"k_lin32<[^>]*?, \d+, true,"),
     # weight-stationary encoder GEMMs: forward and dX share instantiations (k_lin1<KS, NTW, LN>), so the plain ones are pooled
-    "k_lin1[fwd+ln]": ((r"k_lin1<\d+, \d+, (?:true|1)>",), r"k_lin1<\d+, \d+, (?:true|1)>"),
-    "k_lin1[fwd|dx]": ((r"k_lin1<\d+, \d+, (?:false|0)>",), r"k_lin1<\d+, \d+, (?:false|0)>"),
+    "k_lin1[fwd+ln][bf16]": ((r"k_lin1<\d+, \d+, (?:true|1)>",), r"k_lin1<\d+, \d+, (?:true|1)>"),
+    "k_lin1[fwd|dx][bf16]": ((r"k_lin1<\d+, \d+, (?:false|0)>",), r"k_lin1<\d+, \d+, (?:false|0)>"),
     "k_lin3_dw+reduce": ((r"k_lin3_dw<",), r"k_lin3_dw<"),     # (its k_split_reduce launches are shared with the other dW kernels: reported on their own)
     "k_lin32_dw+reduce": ((r"k_lin32_dw<",), r"k_lin32_dw<"),   # (its k_split_reduce launches are shared with the bf16 path: reported on their own)
     "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
