@@ -777,6 +777,117 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd(LnArgs a) {
   }
 }
 
+// LayerNorm backward for bf16 rows of EXACTLY 128 columns (the encoder layers' d_model): 16 lanes per row, 8 columns per lane in one
+// 16-byte load per operand -- four rows per wave and trip instead of two, half the trips and half the dependent shuffle steps of the
+// generic kernel (19 us for 40 MB at Code2's 32 k token rows: a chain of round trips, not bandwidth).  Same arithmetic, same dropout
+// hash, same partial layout ([block][2][D]) for k_ln_bwd_finish.
+template <int NTB>
+__global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [waves][2][128]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane >> 4, sl = lane & 15, col = sl * 8;
+  const gt_bf16* dy = reinterpret_cast<const gt_bf16*>(a.dy);
+  const gt_bf16* xin = reinterpret_cast<const gt_bf16*>(a.x);
+  const gt_bf16* rin = reinterpret_cast<const gt_bf16*>(a.resid);
+  float gw[8], aw[8], ab[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gw[e] = a.w[col + e]; aw[e] = 0.f; ab[e] = 0.f; }
+  const int64_t stride = (int64_t)gridDim.x * (NTB / 64) * 4;
+  int64_t row = ((int64_t)blockIdx.x * (NTB / 64) + wid) * 4 + sub;
+  // the next trip's operands are in flight while this trip is reduced
+  uint4 cx, cr, cd, nx, nr, nd;
+  float cmu, crs, nmu, nrs;
+  auto clampr = [&](int64_t r) { return r < a.rows ? r : a.rows - 1; };
+  {
+    const int64_t q = clampr(row) * 128 + col;
+    cx = *reinterpret_cast<const uint4*>(xin + q);
+    cr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
+    cd = *reinterpret_cast<const uint4*>(dy + q);
+    cmu = a.mean[clampr(row)];
+    crs = a.rstd[clampr(row)];
+  }
+  for (; row - sub < a.rows; row += stride) {   // (uniform per wave: its four rows start at row - sub)
+    {
+      const int64_t rn = clampr(row + stride), q = rn * 128 + col;
+      nx = *reinterpret_cast<const uint4*>(xin + q);
+      nr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
+      nd = *reinterpret_cast<const uint4*>(dy + q);
+      nmu = a.mean[rn];
+      nrs = a.rstd[rn];
+    }
+    const bool live = row < a.rows;
+    const float cnt = live ? 1.f : 0.f;
+    float d[8], x[8], r[8];
+    {
+      const uint32_t ud[4] = {cd.x, cd.y, cd.z, cd.w}, ux[4] = {cx.x, cx.y, cx.z, cx.w}, ur[4] = {cr.x, cr.y, cr.z, cr.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[2 * e] = __uint_as_float(ud[e] << 16); d[2 * e + 1] = __uint_as_float(ud[e] & 0xffff0000u);
+        x[2 * e] = __uint_as_float(ux[e] << 16); x[2 * e + 1] = __uint_as_float(ux[e] & 0xffff0000u);
+        r[2 * e] = __uint_as_float(ur[e] << 16); r[2 * e + 1] = __uint_as_float(ur[e] & 0xffff0000u);
+      }
+    }
+    bool keep[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      keep[e] = true;
+      if (a.thr) {
+        keep[e] = ln_hash(a.s0, a.s1, (uint32_t)(live ? row : a.rows - 1), (uint32_t)(col + e)) >= a.thr;
+        x[e] = keep[e] ? x[e] * a.inv_keep : 0.f;
+      }
+    }
+    float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float z = rin ? x[e] + r[e] : x[e];
+      xh[e] = (z - cmu) * crs;
+      g[e] = d[e] * gw[e];
+      ab[e] = fmaf(d[e], cnt, ab[e]);
+      aw[e] = fmaf(d[e] * cnt, xh[e], aw[e]);
+    }
+    s1 = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+    s2 = ((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) + ((g[4] * xh[4] + g[5] * xh[5]) + (g[6] * xh[6] + g[7] * xh[7]));
+    const float m1 = group_sum<16>(s1) * (1.0f / 128.0f), m2 = group_sum<16>(s2) * (1.0f / 128.0f);
+    float dz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[e] = crs * (g[e] - m1 - xh[e] * m2);
+    if (live) {
+      if (a.dresid)
+        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dresid) + row * 128 + col) =
+            make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+      if (a.dx) {
+        if (a.thr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dz[e] = keep[e] ? dz[e] * a.inv_keep : 0.f;
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dx) + row * 128 + col) =
+            make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+      }
+    }
+    cx = nx; cr = nr; cd = nd; cmu = nmu; crs = nrs;
+  }
+  // the four row groups of a wave -> the waves of the block -> one partial row per block
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    aw[e] += __shfl_xor(aw[e], 16, 64); aw[e] += __shfl_xor(aw[e], 32, 64);
+    ab[e] += __shfl_xor(ab[e], 16, 64); ab[e] += __shfl_xor(ab[e], 32, 64);
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      lds[(wid * 2 + 0) * 128 + col + e] = aw[e];
+      lds[(wid * 2 + 1) * 128 + col + e] = ab[e];
+    }
+  }
+  __syncthreads();
+  float* part = a.part + (int64_t)blockIdx.x * 256;
+  for (int i = threadIdx.x; i < 256; i += NTB) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NTB / 64; ++w) t += lds[w * 256 + i];
+    part[i] = t;   // [0][128] = dweight partial, [1][128] = dbias partial
+  }
+}
 __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dweight,
                                 float* __restrict__ dbias) {
   __shared__ float sm[FINK_LANES * FIN_COLS];
@@ -788,11 +899,18 @@ __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_
   dbias[c] = s2;
 }
 
-constexpr int LN_BWD_BLOCKS = 256;
+constexpr int LN_BWD_BLOCKS = 256;   // (512 blocks for the d = 128 kernel -- one trip per wave -- measured 1.2 % slower end to end)
 
 template <typename T, bool BWD>
 void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
   const int64_t D = a.D;
+  if constexpr (BWD && sizeof(T) == 2) {
+    static const bool d128 = [] { const char* e = getenv("GT_LN_BWD_D128"); return !e || atoi(e) != 0; }();   // (A/B knob)
+    if (D == 128 && d128) {
+      hipLaunchKernelGGL((k_ln_bwd_d128<1024>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
+      return;
+    }
+  }
 #define GT_LN(LPN, NCH)                                                                                      \
   do {                                                                                                       \
     if constexpr (BWD) {                                                                                     \
@@ -1152,7 +1270,8 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   a.x = x; a.resid = resid; a.w = weight; a.dy = dy; a.dx = dx; a.dresid = dresid; a.mean = const_cast<float*>(save_mean);
   a.rstd = const_cast<float*>(save_rstd); a.rows = rows; a.D = dim; a.part = (float*)workspace;
   fill_drop(a, dropout_p, seed);
-  const int64_t npw = dim <= 64 ? 4 : (dim <= 128 ? 2 : 1);
+  const bool d128 = dtype == GT_BF16 && dim == 128;   // k_ln_bwd_d128: four rows per wave and trip
+  const int64_t npw = d128 ? 4 : (dim <= 64 ? 4 : (dim <= 128 ? 2 : 1));
   const int bwd_waves = dim <= 256 ? 16 : NT / 64;   // waves per block of the launch below
   int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), bwd_waves);
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
