@@ -205,6 +205,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 #include "linear3x.h"
 #include "linear1.h"
 #include "linear_small.h"
+#include "linear_dw16.h"
 
 // ------------------------------------------------------------------------------------------------
 // forward: Y = act(X W^T + b) [dropout]
@@ -1312,6 +1313,27 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
       stream = g_dw.side;
       forked = true;
+    }
+    if (dw16_ok(x_dtype, y_dtype, compute, x, dy, a.ymask, M, N, K, ldx, ldy, groups)) {   // bf16 token rows: the LDS-DMA ring kernel (linear_dw16.h)
+      Dw16Args d{};
+      d.dy = (const gt_bf16*)dy; d.x = (const gt_bf16*)x; d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx;
+      d.splits = dw16_splits(M, N, K, splits);
+      d.m_per_split = gt_cdiv(gt_cdiv(M, d.splits), D16_ROWS) * D16_ROWS;
+      d.part = reinterpret_cast<float*>(workspace);
+      d.dbpart = dbias ? d.part + (size_t)d.splits * N * K : nullptr;
+      d.ntx = (int)(N / D16_T);
+      d.ntiles = d.ntx * (int)(K / D16_T);
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_dw16+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+        hipLaunchKernelGGL(k_dw16, dim3((unsigned)(gt_cdiv(d.splits, 8) * 8 * d.ntiles)), dim3(256), 0, stream, d);
+        const int64_t len = N * K, len2 = dbias ? N : 0;
+        int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+        hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)d.part, d.splits, len, dweight,
+                           (const float*)d.dbpart, len2, dbias, (int64_t)0);
+      }
+      if (forked) dw_forked(workspace, workspace_bytes);
+      GT_CHECK_LAUNCH();
+      return GT_OK;
     }
     const int64_t bmc = compute == GT_BF16 ? 64 : 32;
     a.splits = splits;

@@ -272,6 +272,15 @@ def test_pad_golden(name):
     assert torch.equal(h.grad.cpu(), g.gin["h"])
     unp = unpad_batch(g.inputs["padded_in"].to(DEV), g.inputs["prev"].to(DEV), num_nodes, origin, S)
     assert torch.equal(unp.cpu(), g.outs["2"])
+    # the reference's five return values (modules/utils.py:27-29): masks[i] == batch.eq(i), num_nodes[i] its count,
+    # S = min(max nodes, max_input_len); unpad_batch also takes the masks as a plain list of tensors
+    B = int(batch[-1]) + 1
+    assert len(origin) == B and len(num_nodes) == B
+    for i in (0, B - 1):
+        assert torch.equal(origin[i], batch.eq(i)) and int(num_nodes[i]) == int(batch.eq(i).sum())
+    assert S == min(int(max(num_nodes)), g.meta["max_input_len"])
+    unp2 = unpad_batch(g.inputs["padded_in"].to(DEV), g.inputs["prev"].to(DEV), num_nodes, [origin[i] for i in range(B)], S)
+    assert torch.equal(unp2.cpu(), g.outs["2"])
 
 
 @pytest.mark.parametrize("name", golden_names("G6_"))
