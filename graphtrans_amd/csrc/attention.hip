@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
-  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
+  const uint32_t thr16 = a.drop_thr << 16;
   TilePair<T, HD> stg;
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
@@ -255,20 +255,25 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     float mt = -INFINITY;
     bool full_tile = false;
     if constexpr (!DENSE) full_tile = k0 >= kv_off && k0 + TILE <= kv_end;  // block-uniform: every key valid
-    if (full_tile) {
+    // !DENSE: the running max is taken on the RAW scores (scale > 0) and the scale rides in the exponent's fma -- one multiply per score
+    // less; masked_fill instantiations keep the scaled domain (their fill value lives there)
+    if constexpr (!DENSE) {
+      if (!full_tile) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        s[i] *= a.scale_log2;
-        mt = fmaxf(mt, s[i]);
+        for (int i = 0; i < 8; ++i) {
+          const int kp = k0 + g * 8 + i;
+          s[i] = (kp >= kv_off && kp < kv_end) ? s[i] : -INFINITY;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mt = fmaxf(mt, s[i]);
+      mt *= a.scale_log2;
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int kp = k0 + g * 8 + i;
         s[i] = (kp >= kv_off && kp < kv_end) ? s[i] * a.scale_log2 : -INFINITY;
-        if constexpr (DENSE) {
-          if (qvalid && kp < npos && dense_masked(a, seq, qp, kp, npos)) s[i] = a.mask_fill2;
-        }
+        if (qvalid && kp < npos && dense_masked(a, seq, qp, kp, npos)) s[i] = a.mask_fill2;
         mt = fmaxf(mt, s[i]);
       }
     }
@@ -280,17 +285,18 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
     float p[8], psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      p[i] = fast_exp2(s[i] - m_new);
+      if constexpr (!DENSE) p[i] = fast_exp2(fmaf(s[i], a.scale_log2, -m_new));
+      else p[i] = fast_exp2(s[i] - m_new);
       psum += p[i];
     }
     lsum = lsum * alpha + psum;
-    if (a.drop_thr) {
+    if (a.drop_thr) {   // kept weights stay UNSCALED here: 1 / keep is folded into the final 1 / l (the P.V product is linear in it)
       const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {   // one hash decides a PAIR of adjacent keys (16 bits each)
         const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)i * RNG_CK);
-        p[i] = (h & 0xffffu) >= a.drop_thr ? p[i] * a.inv_keep : 0.f;
-        p[i + 1] = (h >> 16) >= a.drop_thr ? p[i + 1] * a.inv_keep : 0.f;
+        p[i] = (h << 16) >= thr16 ? p[i] : 0.f;      // == (h & 0xffff) >= thr
+        p[i + 1] = h >= thr16 ? p[i + 1] : 0.f;      // == (h >> 16) >= thr
       }
     }
     const Frag<T> bp = frag_from_f32<T>(p);
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
   if (!qvalid) return;
-  const float inv_l = 1.0f / lsum;
+  const float inv_l = (a.drop_thr ? a.inv_keep : 1.0f) / lsum;
   T* ctx = reinterpret_cast<T*>(a.out);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -368,8 +374,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   delta += __shfl_xor(delta, 32, 64);
   const float lse = qvalid ? a.lse[(int64_t)head * a.rows + qrow] : 0.f;
   const float logl = qvalid ? a.lse[((int64_t)a.nhead + head) * a.rows + qrow] : 0.f;
+  const float negl = -(lse + logl);
+  const uint32_t thr16 = a.drop_thr << 16;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
-  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   zero_pad_cols<T, HD>(sKb[0]);
   zero_pad_cols<T, HD>(sVb[0]);
   zero_pad_cols<T, HD>(sKb[1]);
@@ -398,6 +405,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
     const T* sV = sVb[cur];
     float ds[8];
     const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
+    bool full_tile = false;
+    if constexpr (!DENSE) full_tile = k0 >= kv_off && k0 + TILE <= kv_end;  // block-uniform: every key valid
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -411,15 +420,24 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int i = t * 4 + r;
         const int kp = k0 + g * 8 + i;
-        const bool kvalid = kp >= kv_off && kp < kv_end;
-        const bool filled = dense && qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
-        const float p = kvalid ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
-        float dpi = dp[r];
+        float dd;
         if (a.drop_thr) {   // the pair's hash (even key of the pair), this key's 16-bit half: the compiler shares it between r, r + 1
           const uint32_t h = rng_mix(hq, kpart0 + (uint32_t)(i & ~1) * RNG_CK);
-          dpi = ((i & 1) ? (h >> 16) : (h & 0xffffu)) >= a.drop_thr ? dpi * a.inv_keep : 0.f;
+          const uint32_t hs = (i & 1) ? h : h << 16;
+          dd = hs >= thr16 ? fmaf(dp[r], a.inv_keep, -delta) : -delta;
+        } else {
+          dd = dp[r] - delta;
         }
-        ds[i] = filled ? 0.f : p * (dpi - delta);  // masked_fill: no gradient through a filled score
+        if constexpr (!DENSE) {
+          float e = fmaf(c[r], a.scale_log2, negl);   // negl = -(max + log2 sum): one fma per score
+          if (!full_tile) e = (kp >= kv_off && kp < kv_end) ? e : -INFINITY;   // (block-uniform branch)
+          ds[i] = fast_exp2(e) * dd;
+        } else {
+          const bool kvalid = kp >= kv_off && kp < kv_end;
+          const bool filled = qvalid && kvalid && kp < npos && dense_masked(a, seq, qp, kp, npos);
+          const float p = kvalid ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - lse) - logl) : 0.f;
+          ds[i] = filled ? 0.f : p * dd;  // masked_fill: no gradient through a filled score
+        }
       }
     }
     const Frag<T> bds = frag_from_f32<T>(ds);
@@ -485,7 +503,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t kpart = rng_kpart(a.seed0, (uint32_t)(kp & ~1));   // dropout decisions come in pairs of adjacent keys
   const uint32_t hb = bh * RNG_CH + a.seed1;
-  constexpr bool dense = DENSE;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
+  const uint32_t thr16 = a.drop_thr << 16;
+  const uint32_t half_shift = (kp & 1) ? 0u : 16u;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
   TilePair<T, HD> stg;
@@ -498,7 +517,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   float aux_v = 0.f;
   auto load_aux = [&](int q0) {
     const int pos = q0 + aux_r;
-    aux_v = (threadIdx.x < 3 * TILE && pos < npos) ? aux_src[(int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride] : 0.f;
+    const int64_t o = (int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride;
+    aux_v = (threadIdx.x < 3 * TILE && pos < npos) ? aux_src[o] : 0.f;
+    if constexpr (!DENSE) {   // slot 0 carries -(max + log2 sum), the addend of the exponent's fma (slot 1 is not read)
+      if (aux_which == 0 && pos < npos) aux_v = -(aux_v + a.lse[(int64_t)a.nhead * a.rows + o]);
+    }
   };
   if (HD < 32) __syncthreads();
   if (any_valid) {
@@ -521,6 +544,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
     const float* sLogl = sAux[cur] + TILE;
     const float* sDelta = sAux[cur] + 2 * TILE;
     float pd[8], ds[8];
+    // (Sharing the pair's hash between lanes n and n ^ 1 -- each computes four of the eight and takes the rest by DPP -- was built
+    // and measured: 45 us against 43 us for this form on the Code2 batch; the kernel is not bound by its VALU instruction count.)
     const uint32_t qmul0 = (uint32_t)(q0 + g * 8) * RNG_CQ;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -537,18 +562,26 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         const int qi = g * 8 + i;  // query row inside the tile owned by this slot
         const int qpos = q0 + qi;
         const bool ok = kvalid && qpos < npos;
-        const bool filled = dense && ok && dense_masked(a, seq, qpos, kp, npos);
-        float p = ok ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - sLse[qi]) - sLogl[qi]) : 0.f;
-        float dpi = dp[r];
-        float pdrop = p;
+        const float a0 = sLse[qi], dlt = sDelta[qi];
+        float p;
+        bool filled = false;
+        if constexpr (!DENSE) {
+          p = ok ? fast_exp2(fmaf(c[r], a.scale_log2, a0)) : 0.f;   // slot 0 holds -(max + log2 sum) here
+        } else {
+          filled = ok && dense_masked(a, seq, qpos, kp, npos);
+          p = ok ? fast_exp2(((filled ? a.mask_fill2 : c[r] * a.scale_log2) - a0) - sLogl[qi]) : 0.f;
+        }
+        float dd, pdrop = p;   // kept weights stay unscaled in pd: 1 / keep is applied to dV once, at the end
         if (a.drop_thr) {
           const uint32_t h = rng_mix((qmul0 + (uint32_t)i * RNG_CQ) ^ hb, kpart);  // == rng_qpart(seed1, bh, qpos)
-          const bool keep = ((kp & 1) ? (h >> 16) : (h & 0xffffu)) >= a.drop_thr;
-          dpi = keep ? dpi * a.inv_keep : 0.f;
-          pdrop = keep ? p * a.inv_keep : 0.f;
+          const bool keep = (h << half_shift) >= thr16;   // this key's 16-bit half of its pair's hash
+          dd = keep ? fmaf(dp[r], a.inv_keep, -dlt) : -dlt;
+          pdrop = keep ? p : 0.f;
+        } else {
+          dd = dp[r] - dlt;
         }
         pd[i] = pdrop;
-        ds[i] = filled ? 0.f : p * (dpi - sDelta[qi]);
+        ds[i] = filled ? 0.f : p * dd;
       }
     }
     const Frag<T> bp = frag_from_f32<T>(pd);
@@ -570,9 +603,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt) {
     f32x4 o = dk[dt];
     o[0] *= a.scale; o[1] *= a.scale; o[2] *= a.scale; o[3] *= a.scale;
+    f32x4 ov = dv[dt];
+    if (a.drop_thr) { ov[0] *= a.inv_keep; ov[1] *= a.inv_keep; ov[2] *= a.inv_keep; ov[3] *= a.inv_keep; }
     if (dt * 16 + g * 4 < HD) {
       store4<T>(dqkv + krow * ld3 + a.d_model + head * HD + dt * 16 + g * 4, o);
-      store4<T>(dqkv + krow * ld3 + 2 * a.d_model + head * HD + dt * 16 + g * 4, dv[dt]);
+      store4<T>(dqkv + krow * ld3 + 2 * a.d_model + head * HD + dt * 16 + g * 4, ov);
     }
   }
 }
