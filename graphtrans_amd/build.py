@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
         if verbose and out:
             print(out.decode())
-    if rebuilt or not os.path.exists(LIB):
+    if rebuilt or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):   # (objects compiled by hand count)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
