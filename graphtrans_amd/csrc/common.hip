@@ -15,36 +15,6 @@ void gt_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- ticket pool of the "last block finishes" kernels (gt_common.h) ---------------------------------------------------------
-namespace {
-constexpr int GT_TICKETS = 4096, GT_TICKET_DEVS = 16;
-struct TicketPool {
-  unsigned* base[GT_TICKET_DEVS];
-  std::atomic<unsigned> next[GT_TICKET_DEVS];
-  std::mutex mu;
-};
-TicketPool g_tickets;
-}  // namespace
-unsigned* gt_ticket_next() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GT_TICKET_DEVS) return nullptr;
-  unsigned* b = g_tickets.base[dev];
-  if (!b) {
-    std::lock_guard<std::mutex> lk(g_tickets.mu);
-    b = g_tickets.base[dev];
-    if (!b) {
-      void* p = nullptr;
-      if (hipMalloc(&p, GT_TICKETS * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, GT_TICKETS * sizeof(unsigned)) != hipSuccess ||
-          hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      b = g_tickets.base[dev] = (unsigned*)p;
-    }
-  }
-  return b + g_tickets.next[dev].fetch_add(1u, std::memory_order_relaxed) % GT_TICKETS;
-}
-
 extern "C" int gt_version(void) { return 100; /* 0.1.0 */ }
 extern "C" const char* gt_last_error(void) { return g_err; }
 

@@ -51,29 +51,6 @@ struct GtProfScope {
 
 static inline int64_t gt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// ---- "the last block finishes": a partial -> finish pair of kernels as ONE launch --------------------------------------------
-// Every block writes its partial, then takes a ticket; the block that draws the last one sums the partials IN A FIXED ORDER (the
-// result does not depend on which block that is) and resets the ticket for the next launch.  Tickets come from a per-device
-// pool (common.hip), handed out round robin: a ticket is back at zero when its kernel ends, long before the pool wraps.
-unsigned* gt_ticket_next();   // device pointer; nullptr when the pool could not be allocated (callers fall back to two launches)
-#ifdef __HIPCC__
-__device__ __forceinline__ bool gt_ticket_last(unsigned* ticket, unsigned nblocks) {
-  __shared__ unsigned gt_ticket_flag__;
-  __threadfence();    // release: this thread's partial is visible device-wide (across the XCDs' L2s) ...
-  __syncthreads();    // ... for every thread of the block, before the block's ticket is drawn
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = t == nblocks - 1;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gt_ticket_flag__ = last ? 1u : 0u;
-  }
-  __syncthreads();
-  const bool last = gt_ticket_flag__ != 0u;
-  if (last) __threadfence();   // acquire: the other blocks' partials, not stale lines of this XCD's L2
-  return last;
-}
-#endif
-
 // ---- bf16 <-> f32 (storage type is a raw 16-bit pattern) -------------------------------------
 typedef uint16_t gt_bf16;
 
