@@ -210,3 +210,28 @@ def test_bf16_weight_gradient(M, N, K):
     assert rel(dw, dw64) < 2e-6 and rel(db, db64) < 2e-6      # exact bf16 products, fp32 accumulation
     _, dw2, db2 = bwd(x, W, dy, None, None, None, None, want_dw=True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("M,N,K,ldy,ldx", [(8197, 128, 128, 384, 256), (4096 + 77, 256, 128, 264, 136), (1024, 128, 256, 128, 512)], ids=lambda v: str(v))
+def test_bf16_weight_gradient_strided_operands(M, N, K, ldy, ldx):
+    """The LDS-DMA ring kernel (csrc/linear_dw16.h) on column slices of wider buffers (the q / k / v slices of qkv, one half of a
+    concatenation): pitches ldy > N and ldx > K, a ragged last stage, dW only / dW + db; against float64 of the same bf16 operands."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    torch.manual_seed(M + ldy)
+    xb = torch.randn(M, ldx, device=DEV).to(BF)
+    dyb = torch.randn(M, ldy, device=DEV).to(BF)
+    x, dy = xb[:, ldx - K:], dyb[:, ldy - N:]          # the LAST K / N columns: the base pointers are offset too (16-byte aligned)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(GT_BF16, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    dw64, db64 = dy.double().t() @ x.double(), dy.double().sum(0)
+    for want_db in (True, False):
+        dw = torch.zeros(N, K, device=DEV)
+        db = torch.zeros(N, device=DEV) if want_db else None
+        _lib.launch("gt_linear_bwd_ld2", GT_BF16, GT_BF16, GT_BF16, x.data_ptr(), _p(W), dy.data_ptr(), None, None, None, None, _p(dw), _p(db),
+                    M, N, K, ldx, ldy, 0.0, _p(ws), ws_bytes, _stream())
+        assert rel(dw, dw64) < 2e-6
+        assert float((dw.double() - dw64).abs().max()) < 1e-3 * float(dw64.abs().max())
+        if want_db:
+            assert rel(db, db64) < 2e-6
