@@ -48,6 +48,10 @@ def test_gemm_kernels_keep_their_register_budget():
     assert len(stat) >= 7
     for n, v in stat.items():
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
+    ring = {n: v for n, v in k.items() if re.search(r"6k_dw16E", n)}   # LDS-DMA ring dW (linear_dw16.h): two 64-KB blocks fit a CU beside
+    assert len(ring) == 1                                                 # each other; 64 accumulators + 16 db + fragments per lane
+    for n, v in ring.items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 256 and v["Occupancy"] >= 2, (n, v)
     for n, v in k.items():
         if re.search(r"12k_linear_(fwd|dx)I[ft][ft]tLi64E", n):   # the bf16-MFMA tiled kernels (encoder GEMMs), 64-row tiles
             assert v["Occupancy"] >= 3, (n, v)

@@ -29,6 +29,7 @@ ENTRY = {
     "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dx[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>",), r"k_linear_dx<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dw+reduce[bf16]": ((r"k_linear_dw<[^>]*" + BF16 + r">",), r"k_linear_dw<[^>]*" + BF16 + r">"),
+    "k_dw16+reduce[bf16]": ((r"k_dw16\(",), r"k_dw16\("),   # LDS-DMA ring dW of the encoder linears (its k_split_reduce: reported on its own)
     "k_split_reduce": ((r"k_split_reduce",), r"k_split_reduce"),
     "gt_aggregate_fwd": ((r"k_aggw?_fwd<",), r"k_aggw?_fwd<"),
     "gt_aggregate_bwd": ((r"k_aggw?_bwd<",), r"k_aggw?_bwd<"),   # (the gather kernel: its parameter-partials reduce, k_agg_reduce, runs on the overlap stream)
