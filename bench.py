@@ -15,11 +15,13 @@ Nothing is skipped or cached across steps (the per-batch graph structure is rebu
 reference's configured rates).  Inputs rotate over 4 seeded batches.
 
 Precision modes (`config.mode`):
-  mixed (default, the headline `value`): the reference's fp32 arithmetic (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32) for
-         message passing, the virtual-node MLPs, gnn2transformer and the prediction heads; bf16 token rows and bf16 MFMA
-         inside the encoder layers (attention / in- and out-projection / FFN) -- what BASELINE.json's north_star sanctions;
+  mixed (default, the headline `value`): fp32-accurate arithmetic for message passing, the virtual-node MLPs, gnn2transformer
+         and the prediction heads -- the big-M linears as six bf16 products per fp32 product on the bf16 matrix pipe (csrc/linear3x.h:
+         relative error to float64 like torch's fp32 GEMM; GT_F32_GEMM=exact selects v_mfma_f32_16x16x4_f32 everywhere), the short-M
+         ones on exact-fp32 MFMA; bf16 token rows and bf16 MFMA inside the encoder layers (attention / in- and out-projection / FFN)
+         -- what BASELINE.json's north_star sanctions;
   bf16:  bf16 MFMA for every GEMM (fp32 storage and master weights on the GNN side);
-  fp32:  exact fp32 everywhere.
+  fp32:  fp32-accurate GEMMs everywhere (fp32 token rows).
 Rank 0 prints ONE JSON line with the contract keys plus
   "roofline":     the dominant hand-written kernel (largest total HIP-event time inside the timed region): algorithmic
                   bytes|flops per launch (SURVEY.md 8d formulas) / average launch time; "traffic" = PMC bytes of the same
@@ -269,6 +271,11 @@ def pmc_traffic(workload, mode, per_gpu):
         pass
     return {}, ("not attached: profiles/%s was measured on another build (running build %s)" % (stale, bid)) if stale \
         else "no PMC profile for this workload / mode (running build %s)" % bid
+
+
+def _w3_enabled():
+    from graphtrans_amd import w3
+    return bool(w3.ENABLED)
 
 
 def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
@@ -631,7 +638,10 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                        "avg_nodes_per_batch": nodes, "avg_edges_per_batch": edges,
                        "parallelism": f"dp{world} (graph-sharded, RCCL grad all-reduce {sync.grad_bytes() >> 20} MiB)",
                        "step": ("collate+" if store is not None else "") + "zero_grad+graph_prep+fwd+loss+bwd+allreduce" + ("" if opt.no_optimizer else "+AdamW"),
-                       "gnn_dtype": "fp32 storage, %s MFMA GEMMs (message passing, VN MLP, gnn2transformer, heads)" % ("bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32"),
+                       "gnn_dtype": "fp32 storage, %s (message passing, VN MLP, gnn2transformer, heads)" % (
+                           "bf16 MFMA GEMMs" if matmul_dtype == torch.bfloat16 else
+                           ("fp32-accurate GEMMs: bf16x6 on the bf16 matrix pipe for the big-M linears (three-way bf16 split of both operands, six products, "
+                            "fp32 accumulation), exact-fp32 MFMA for the short-M ones" if _w3_enabled() else "exact-fp32 MFMA GEMMs")),
                        "transformer_dtype": "%s token rows, %s MFMA (encoder layers)" % (("bf16", "bf16") if dtype == torch.bfloat16 else ("fp32", "bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32")),
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout},
                        "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics"},
