@@ -227,17 +227,6 @@ def agg_bytes(meta, bwd):
     return E * 8 + (N + 1) * 8 + E * a + E * D * s + 2 * N * D * s + N * D * s
 
 
-def _unused_attn_flops(meta, bwd):
-    lay, d = meta["lay"], meta["d"]
-    desc = getattr(lay, "desc_cpu", None)
-    if desc is None:
-        return 0.0
-    n = desc[:, 3].astype(np.float64)   # valid keys per sequence (incl. CLS)
-    q = desc[:, 1].astype(np.float64)   # query positions computed
-    f = float((4.0 * q * n * d).sum())  # QK^T + PV over valid keys: 4*n^2*d per graph
-    return f * (2.5 if bwd else 1.0)
-
-
 def build_id():
     """sha256 over the sources that decide what runs on the GPU (kernels, C-ABI, the fused path): PMC traffic files carry
     the id of the build they were measured on, and are attached only to runs of the same build (no .git on the GPU box)."""

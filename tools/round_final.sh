@@ -1,6 +1,6 @@
 # full GPU suite, then the profile round (PMC passes, bench lines of all workloads, rocprofv3 kernel summaries)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-TAG=${1:-r03y}
+TAG=${1:-r04a}
 mkdir -p gpurun_out/$TAG
 python -m pytest tests -m gpu -x -q > gpurun_out/$TAG/pytest_gpu.txt 2>&1
 grep -E "passed|failed" gpurun_out/$TAG/pytest_gpu.txt | tail -3
