@@ -157,6 +157,15 @@ SIGNATURES = {
     "gt_repitch": (_i, [_p, _i64, _p, _i64, _i64, _i, _p]),
     "gt_rows_gather": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
     "gt_rows_scatter": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "gt_seq_layout_packed_host": (_i, [_p, _i64, _i64, _i, _p, _sz, _p]),
+    "gt_model_ctx_bytes": (_sz, []),
+    "gt_model_abi_sizes": (_i, [_p]),
+    "gt_model_grad_ranges": (_i, [_p, _p, _p]),
+    "gt_model_prepare": (_i, [_p, _p, _p, _p]),
+    "gt_model_forward": (_i, [_p, _p, _p, _p, _p]),
+    "gt_model_backward": (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    "gt_seq_gather_cls32": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p]),
+    "gt_colsum_f32": (_i, [_i, _p, _i64, _i64, _p, _p]),
     "gt_attn_fwd": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _f, _f, _f, _u64, _p]),
     "gt_attn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _f, _f, _f,
                          _u64, _p]),

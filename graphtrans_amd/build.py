@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libgraphtrans_hip.so")
-SOURCES = ["common.hip", "graph_prep.hip", "aggregate.hip", "segment.hip", "attention.hip", "norm.hip", "linear.hip", "layers.hip", "pna.hip", "embed.hip", "xent.hip", "optim.hip", "util.hip", "collate.hip"]
+SOURCES = ["common.hip", "graph_prep.hip", "aggregate.hip", "segment.hip", "attention.hip", "norm.hip", "linear.hip", "layers.hip", "model.hip", "pna.hip", "embed.hip", "xent.hip", "optim.hip", "util.hip", "collate.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

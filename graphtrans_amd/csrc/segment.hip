@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(SS_T) k_segsum_fixup(const T* __restrict__ add
 // tokens[row(b,p)] <- node row | cls | 0 ; grid (position tiles, B)
 template <typename T>
 __global__ void __launch_bounds__(SEG_THREADS) k_seq_gather(const T* __restrict__ h, const T* __restrict__ cls,
+                                                            const float* __restrict__ cls32,
                                                             const int32_t* __restrict__ gptr,
                                                             const int32_t* __restrict__ desc, int64_t row_stride,
                                                             int64_t max_npos, int with_cls, int64_t D,
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seq_gather(const T* __restrict_
     int j = p - kv_off;
     float4 v = gt_zero4();
     if (j >= 0 && j < kept) v = gt_load4<T>(h + (int64_t)(node0 + j) * D + c);
-    else if (with_cls && j == kept) v = gt_load4<T>(cls + c);
+    else if (with_cls && j == kept) v = cls32 ? gt_load4<float>(cls32 + c) : gt_load4<T>(cls + c);
     gt_store4<T>(tokens + ((int64_t)row0 + (int64_t)p * row_stride) * D + c, v);
   }
   if (pad_mask)
@@ -272,25 +273,74 @@ extern "C" int gt_segment_sum(int dtype, const void* x, const void* add, const i
   return GT_OK;
 }
 
-extern "C" int gt_seq_gather(int dtype, const void* h, const void* cls, const int32_t* graph_ptr,
-                             const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
-                             int with_cls, int64_t D, void* tokens, uint8_t* pad_mask, gt_stream_t stream_) {
-  int rc = check("gt_seq_gather", dtype, D);
+static int seq_gather_impl(const char* fn, int dtype, const void* h, const void* cls, const float* cls32, const int32_t* graph_ptr,
+                           const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                           int with_cls, int64_t D, void* tokens, uint8_t* pad_mask, gt_stream_t stream_) {
+  int rc = check(fn, dtype, D);
   if (rc) return rc;
-  GT_CHECK_ARG(h && graph_ptr && seq_desc && tokens, "null buffer");
-  GT_CHECK_ARG(!with_cls || cls, "with_cls needs the cls row");
+  if (!(h && graph_ptr && seq_desc && tokens)) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
+  if (with_cls && !cls && !cls32) { gt_set_error("%s: with_cls needs the cls row", fn); return GT_ERR_INVALID_ARG; }
   if (num_seqs == 0 || max_npos == 0) return GT_OK;
-  GT_CHECK_ARG(num_seqs <= 65535, "more than 65535 sequences");
+  if (num_seqs > 65535) { gt_set_error("%s: more than 65535 sequences", fn); return GT_ERR_INVALID_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
   int ppb = rows_per_block(D, dtype == GT_F32 ? 4 : 2);
   dim3 grid((unsigned)gt_cdiv(max_npos, ppb), (unsigned)num_seqs);
   if (dtype == GT_F32)
-    hipLaunchKernelGGL(k_seq_gather<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)h, (const float*)cls,
+    hipLaunchKernelGGL(k_seq_gather<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)h, (const float*)cls, cls32,
                        graph_ptr, seq_desc, row_stride, max_npos, with_cls, D, (float*)tokens, pad_mask, ppb);
   else
     hipLaunchKernelGGL(k_seq_gather<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)h,
-                       (const gt_bf16*)cls, graph_ptr, seq_desc, row_stride, max_npos, with_cls, D, (gt_bf16*)tokens,
+                       (const gt_bf16*)cls, cls32, graph_ptr, seq_desc, row_stride, max_npos, with_cls, D, (gt_bf16*)tokens,
                        pad_mask, ppb);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_seq_gather(int dtype, const void* h, const void* cls, const int32_t* graph_ptr,
+                             const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                             int with_cls, int64_t D, void* tokens, uint8_t* pad_mask, gt_stream_t stream_) {
+  return seq_gather_impl("gt_seq_gather", dtype, h, cls, nullptr, graph_ptr, seq_desc, num_seqs, row_stride, max_npos, with_cls, D,
+                         tokens, pad_mask, stream_);
+}
+
+extern "C" int gt_seq_gather_cls32(int dtype, const void* h, const float* cls32, const int32_t* graph_ptr,
+                                   const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                                   int with_cls, int64_t D, void* tokens, gt_stream_t stream_) {
+  return seq_gather_impl("gt_seq_gather_cls32", dtype, h, nullptr, cls32, graph_ptr, seq_desc, num_seqs, row_stride, max_npos,
+                         with_cls, D, tokens, nullptr, stream_);
+}
+
+// out[c] = sum over rows of x[r][c], fp32, fixed order: 4 row groups x (dim / 4) column chunks per block pass
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, int64_t rows, int64_t D, float* __restrict__ out) {
+  __shared__ float4 part[256];
+  const int64_t C = D / 4;
+  const int groups = 256 / 64;   // 64 column chunks per pass
+  const int g = threadIdx.x / 64, cl = threadIdx.x % 64;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < C; c0 += (int64_t)gridDim.x * 64) {
+    const int64_t c = c0 + cl;
+    float4 acc = gt_zero4();
+    if (c < C)
+      for (int64_t r = g; r < rows; r += groups) acc = gt_add4(acc, gt_load4<T>(x + r * D + c * 4));
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && c < C) {
+      float4 s = part[cl];
+      for (int k = 1; k < groups; ++k) s = gt_add4(s, part[k * 64 + cl]);
+      gt_store4<float>(out + c * 4, s);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int gt_colsum_f32(int dtype, const void* x, int64_t rows, int64_t D, float* out, gt_stream_t stream_) {
+  int rc = check("gt_colsum_f32", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(x && out, "null buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid((unsigned)gt_cdiv(D / 4, 64));
+  if (dtype == GT_F32) hipLaunchKernelGGL(k_colsum_f32<float>, grid, dim3(256), 0, stream, (const float*)x, rows, D, out);
+  else hipLaunchKernelGGL(k_colsum_f32<gt_bf16>, grid, dim3(256), 0, stream, (const gt_bf16*)x, rows, D, out);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -106,9 +106,7 @@ class GNNTransformer(BaseModel):
         enc = self.transformer_encoder
         max_len = int(enc.max_input_len)
         if engine.eligible(self, batched_data, perturb):  # whole model as one autograd node (engine.py)
-            gs = batch_structure(batched_data, engine.prep_for(batched_data.batch.device))   # gt_graph_prep beside the input embedding
-            lay = gs.layout("packed", max_len, enc.cls_embedding is not None)
-            out = engine.forward(self, batched_data, gs, lay)
+            out = engine.forward(self, batched_data)   # graph structure, token layout, forward: one C call (csrc/model.hip)
             if self.max_seq_len is None:
                 return out
             return StackedHeads(out.view(out.shape[0], self.max_seq_len, self.num_tasks))

@@ -9,9 +9,9 @@ from .conv import GCNConv, GINConv, edge_spec
 from .norm import BatchNorm1d, mlp_bn_relu
 
 
-def batch_structure(batched_data, prep=None):
-    """GraphStructure of a collated batch, built once and cached on the batch object.  prep: engine.Prep -- build on its side
-    stream (the caller's kernels wait for gs.ready_event before they read the structure)."""
+def batch_structure(batched_data):
+    """GraphStructure of a collated batch, built once and cached on the batch object (the fused model path builds its own inside
+    the driver's arena, csrc/model.hip, and reuses a cached one when it finds it)."""
     gs = getattr(batched_data, "_gt_structure", None)
     if gs is None:
         sizes = getattr(batched_data, "_sizes", None)
@@ -21,12 +21,7 @@ def batch_structure(batched_data, prep=None):
                 ng = batched_data.num_graphs
             except Exception:
                 ng = None
-        if prep is not None and sizes is not None:   # (without host-side sizes the token layout is built on the device from this structure)
-            prep.begin()
-            gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes, stream=prep.stream)
-            gs.ready_event = prep.graph_done()
-        else:
-            gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes)
+        gs = GraphStructure.build(batched_data.edge_index, batched_data.batch, num_graphs=ng, sizes=sizes)
         try:
             batched_data._gt_structure = gs
         except Exception:

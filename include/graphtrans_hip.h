@@ -735,6 +735,125 @@ int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, v
 int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, const void* d_x_add, void* d_x,
                      void* d_vn, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Whole-model driver: ONE C call per direction for the training step's forward and backward.
+ * Replaces the per-step Python sequencing of the composites above (the reference's step is
+ * `pred = model(batch); loss.backward()`, trainers/base_trainer.py:29-36, over models/gnn_transformer.py:90-128,
+ * modules/gnn_module.py:60-107 / :172-241, modules/transformer_encoder.py:42-61): graph structure, token layout, input
+ * embedding, L message-passing layers with the virtual-node chain on a second stream, gnn2transformer, token rows + CLS,
+ * norm_input, the encoder layers, the final norm, cls / last pooling and the (stacked) prediction heads; the backward in
+ * three stages (heads .. gnn2transformer | message passing | input encoder) so that a data-parallel caller can put each
+ * finished range of the flat gradient buffer on the wire between two calls.
+ *
+ * gt_model is filled ONCE per model (static pointers, sizes, gradient offsets, streams, events); gt_model_batch once per
+ * step (the collated batch); `ctx` (gt_model_ctx_bytes() of HOST memory, caller-owned, one per forward, kept until its
+ * backward) carries everything the backward needs.  All device memory is the caller's: gt_model_prepare (host only) says
+ * how many bytes of arena the forward and the backward need.
+ */
+#define GT_MODEL_MAX_LAYERS 16
+#define GT_MODEL_MAX_TABLES 16
+
+typedef struct gt_image_set {   /* images of a weight list (gt_w3_* or gt_w1_*): build jobs and bind table, HOST arrays */
+  int32_t n_jobs, n_bind;
+  const float* const* job_w;
+  const int64_t *job_N, *job_K;
+  const int* job_T;
+  void* const* job_img;
+  const float* const* bind_w;
+  const int64_t *bind_N, *bind_K;
+  const void* const* bind_f;
+  const void* const* bind_t;
+} gt_image_set;
+
+typedef struct gt_stage_ring {   /* pinned HOST staging slots for the token layout's H2D copy (one per device) */
+  void* base;                    /* slots x slot_bytes of pinned memory */
+  int64_t slot_bytes;
+  int32_t slots, next;
+  void* events[64];              /* gt_event per slot (recorded behind the copy that read the slot); slots <= 64 */
+} gt_stage_ring;
+
+typedef struct gt_model {
+  int32_t conv /* GT_CONV_GCN | GT_CONV_GIN */, L, n_enc, has_vn, jk_cat, residual;
+  int32_t embed_kind /* 0 one table per column of x (AtomEncoder), 1 nn.Linear, 2 ASTNodeEncoder (x[:,0], x[:,1], node_depth) */, n_tables, vn0_in_embed, embed_sorted;
+  int32_t with_cls, vn_defer_dw;
+  int64_t D, d, Nh, ldy, ne_K, max_input_len, dw_overlap_min_elems;
+  void* conv_layers;        /* gt_gcn_layer[L] | gt_gin_layer[L]: static fields filled by the caller */
+  gt_vn_update* vn;         /* [L-1] or NULL */
+  gt_encoder_layer* enc;    /* [n_enc] */
+  const float* tables[GT_MODEL_MAX_TABLES];
+  int64_t table_rows[GT_MODEL_MAX_TABLES], table_clamp[GT_MODEL_MAX_TABLES];
+  const float *vn_emb, *ne_w, *ne_b, *g2t_w, *g2t_b, *cls, *nin_w, *nin_b, *nout_w, *nout_b, *head_w, *head_b;
+  const int64_t* zero_i64;  /* one device int64 0 (index column of the virtual-node row in the embedding sum) */
+  float nin_eps, nout_eps;
+  /* offsets (floats) into the flat gradient buffer; -1 = absent */
+  int64_t off_tables[GT_MODEL_MAX_TABLES], off_ne_w, off_ne_b, off_vn_emb, off_conv[GT_MODEL_MAX_LAYERS],
+      off_vn[GT_MODEL_MAX_LAYERS], off_g2t_w, off_g2t_b, off_cls, off_nin_w, off_nin_b, off_enc[GT_MODEL_MAX_LAYERS],
+      off_nout_w, off_nout_b, off_head_w, off_head_b, grad_total;
+  /* streams (gt_stream_create; NULL = that overlap is off) and events (gt_event_create) */
+  void *st_vn, *st_dw, *st_prep;
+  void *ev_x[GT_MODEL_MAX_LAYERS], *ev_vn[GT_MODEL_MAX_LAYERS], *ev_dvn[GT_MODEL_MAX_LAYERS], *ev_extra[GT_MODEL_MAX_LAYERS],
+      *ev_pool[GT_MODEL_MAX_LAYERS];
+  void *ev_vnemb, *ev_sort[2], *ev_wt[2], *ev_prep_begin, *ev_graph, *ev_w1;
+  gt_image_set w3, w3_enc, w1;   /* bf16x3 images without / with the encoder weights, fragment-order encoder images */
+} gt_model;
+
+typedef struct gt_model_batch {
+  int64_t N, E, B;
+  /* the collated batch (PyG layout): edge_index [2][E] int64, batch [N] int64 sorted */
+  const int64_t *edge_index, *batch;
+  const int64_t* sizes_host;   /* HOST per-graph node counts or NULL (then the token layout is built on the device) */
+  /* optional, already built by the caller (gt_graph_prep outputs): graph_ptr != NULL skips the in-driver prep */
+  const int32_t *graph_ptr, *node_graph, *in_ptr, *in_src, *in_eid, *out_ptr, *out_dst, *out_eid;
+  const float *deg, *dis;
+  /* optional, already built token layout: seq_desc != NULL */
+  const int32_t* seq_desc;
+  const int64_t* last_rows;
+  const int32_t* work_items;
+  int64_t rows, max_npos, num_work;
+  int32_t lay_exact, pad0_;
+  /* inputs: tables: x [N][>= n_tables] int64 (element strides), ASTNodeEncoder: + node_depth; linear: x [N][ne_K] fp32 */
+  const void* x;
+  int64_t x_stride0, x_stride1;
+  const int64_t* node_depth;
+  int64_t depth_stride;
+  const void* edge_attr;
+  const int32_t *zeros_B, *ident_B, *ptr01;   /* [B] zeros, [B] 0..B-1, {0, B} (device, int32) */
+  int32_t training, compute /* GT_F32 | GT_BF16: the fp32-stored GEMMs */, tdt /* token rows */, will_bwd;
+  int32_t use_w3 /* 0 none, 1 gt_model.w3, 2 gt_model.w3_enc */, use_w1, sync_bn /* gt_bn_sync_set hook installed */, pad2_;
+  float gnn_p, enc_p;
+  uint64_t gnn_seed, enc_seed;
+  gt_stage_ring* ring;
+} gt_model_batch;
+
+typedef struct gt_model_sizes {
+  int64_t rows, max_npos, num_work, arena_bytes, barena_bytes;
+  int32_t exact /* 0: the arenas must be zero-filled by the caller */, pad_;
+} gt_model_sizes;
+
+size_t gt_model_ctx_bytes(void);
+int gt_model_prepare(const gt_model* model, const gt_model_batch* batch, void* ctx, gt_model_sizes* sizes);
+/* logits [B][ldy] fp32 */
+int gt_model_forward(const gt_model* model, void* ctx, void* arena, float* logits, gt_stream_t stream);
+/* dlogits [B][ldy] fp32 (pad columns zero); grads: the flat gradient buffer [grad_total] (overwritten);
+ * stages: bit 0 heads .. gnn2transformer, bit 1 message passing, bit 2 input encoder + final joins; in order, each once. */
+int gt_model_backward(const gt_model* model, void* ctx, const float* dlogits, float* grads, void* barena, int stages,
+                      gt_stream_t stream);
+/* first / one-past-last float of the gradient range each stage completes: {g2t..total, gnn_lo..g2t, 0..gnn_lo} */
+int gt_model_grad_ranges(const gt_model* model, int64_t* lo3, int64_t* hi3);
+/* out4 = sizeof {gt_model, gt_model_batch, gt_image_set, gt_stage_ring}: a binding checks its mirror of the layouts */
+int gt_model_abi_sizes(int64_t* out4);
+/* The host half of the packed token layout (what gt_model_prepare stages for its H2D copy) on its own: seq_desc [B][4] at offset 0,
+ * last_rows [B] int64 at meta6[3], the attention work list [num_work][2] at meta6[4]; meta6 = {rows, max_npos, num_work, offset of
+ * last_rows, offset of the work list, total bytes}.  out_host == NULL: sizes only.  Pure host code (no GPU needed). */
+int gt_seq_layout_packed_host(const int64_t* sizes_host, int64_t B, int64_t max_input_len, int with_cls, void* out_host,
+                              size_t out_bytes, int64_t* meta6);
+/* gt_seq_gather with the CLS row given in fp32 whatever the token dtype (converted while it is written) */
+int gt_seq_gather_cls32(int dtype, const void* h, const float* cls32, const int32_t* graph_ptr, const int32_t* seq_desc,
+                        int64_t num_seqs, int64_t row_stride, int64_t max_npos, int with_cls, int64_t dim,
+                        void* tokens, gt_stream_t stream);
+/* out[c] (fp32) = sum_r x[r][c] in a fixed order (the CLS embedding's gradient from its per-graph rows) */
+int gt_colsum_f32(int dtype, const void* x, int64_t rows, int64_t dim, float* out, gt_stream_t stream);
+
 /* Stand-alone dropout (F.dropout / nn.Dropout with no producing kernel to carry it: masked_transformer_encoder.py:54,75,
  * pna/pna_module.py:78): y[i] = keep(i, seed) ? x[i] / (1 - p) : 0 over n elements (n % 4 == 0; x == y allowed).  The same
  * call on the gradient is the backward (the mask is a function of (i, seed) only). */

@@ -7,7 +7,6 @@ import bench
 from graphtrans_amd import engine, ops as gt_ops
 from graphtrans_amd.dist import GradSync
 from graphtrans_amd.optim import FusedAdamW
-from graphtrans_amd.modules import gnn_module
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "molpcba"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -36,18 +35,34 @@ def wrap(obj, name, key):
         finally:
             T[key] = T.get(key, 0.0) + time.perf_counter() - t0
     setattr(obj, name, g)
-wrap(gnn_module, "batch_structure", "  fwd: batch_structure")
-from graphtrans_amd.models import gnn_transformer
-gnn_transformer.batch_structure = gnn_module.batch_structure
 wrap(engine, "forward", "  fwd: engine.forward")
 wrap(engine, "eligible", "  fwd: eligible")
-from graphtrans_amd import graph
-wrap(graph.GraphStructure, "layout", "  fwd: layout")
-wrap(engine._FusedModel, "_forward_body", "    engine: _forward_body")
-wrap(engine._FusedModel, "_backward_body", "    engine: _backward_body")
+L = engine._lib.lib()
+for fn in ("gt_model_prepare", "gt_model_forward", "gt_model_backward"):   # time inside the C driver (launches + event traffic)
+    f0 = getattr(L, fn)
+    def mk(f0=f0, fn=fn):
+        def g(*a):
+            t0 = time.perf_counter()
+            try:
+                return f0(*a)
+            finally:
+                T["      C: " + fn] = T.get("      C: " + fn, 0.0) + time.perf_counter() - t0
+        return g
+    setattr(L, fn, mk())
+prof = None
+import gc
+if os.environ.get('GT_GC') == 'off':
+    gc.disable()
+elif os.environ.get('GT_GC') == 'freeze':
+    gc.collect(); gc.freeze()
+elif os.environ.get('GT_GC') == 'debug':
+    gc.callbacks.append(lambda ph, info: T.__setitem__('gc gen%d' % info['generation'], T.get('gc gen%d' % info['generation'], 0.0) + (1e-6 if ph == 'start' else 0.0)))
 for i in range(20 + steps):
     if i == 20:
         torch.cuda.synchronize(); T.clear(); t_all = time.perf_counter()
+        if os.environ.get("GT_CPROFILE"):
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
     b = batches[i % 4]
     b.__dict__.pop("_gt_structure", None)
     t = time.perf_counter()
@@ -57,9 +72,17 @@ for i in range(20 + steps):
     loss.backward(); t = tick("backward", t)
     sync.finish(); t = tick("sync.finish", t)
     optim.step(); t = tick("optim.step", t)
+if prof is not None:
+    prof.disable()
 host = time.perf_counter() - t_all
 torch.cuda.synchronize()
 tot = time.perf_counter() - t_all
 print(f"{name}: host enqueue {host / steps * 1e3:.3f} ms/step, wall {tot / steps * 1e3:.3f} ms/step")
 for k, v in T.items():
     print(f"  {k:34s} {v / steps * 1e6:8.1f} us/step")
+if prof is not None:
+    import pstats, io
+    for key in ("tottime", "cumulative"):
+        b_ = io.StringIO()
+        pstats.Stats(prof, stream=b_).sort_stats(key).print_stats(28)
+        print(b_.getvalue()[:6000])

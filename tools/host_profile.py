@@ -12,3 +12,8 @@ for key in ("tottime", "cumulative"):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
     print(s.getvalue()[:9000])
+# who calls the slow built-ins (one hipGetDeviceCount costs ~1 ms of host time on these boxes)
+for pat in ("getDeviceCount", "is_available", "method 'to' of", "method 'contiguous'", "_lazy_init"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callers(pat)
+    print(s.getvalue()[:3000])
