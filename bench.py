@@ -579,6 +579,13 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     for i in range(opt.warmup):
         step(i)
     barrier()
+    # The interpreter's cyclic collector: a step allocates a few hundred tracked objects, so a full (generation-2) collection comes
+    # round every ~100 steps and walks the WHOLE heap -- ~1 M objects of torch / sympy module state, 50-80 ms a pass = 0.4 ms per
+    # step amortised on a 0.9 ms step (tools/host_phases.py with GT_GC=on|off|freeze: NCI1 1.28 / 0.91 / 0.88 ms).  gc.freeze() moves
+    # what exists after set-up into the permanent generation; collections still run, over the step's own objects only.
+    import gc
+    gc.collect()
+    gc.freeze()
     # HIP events around the aggregate / attention / linear launches of every 16th timed step (each event pair
     # costs ~3 us of stream time and the dW GEMMs stay on the main stream while bracketed, i.e. nothing overlaps them: a
     # sampled step is ~30 % slower; sampling keeps the timed region within ~2 % of a run with --no-kernel-timing)
@@ -633,7 +640,8 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                             "fp32 accumulation), exact-fp32 MFMA for the short-M ones" if _w3_enabled() else "exact-fp32 MFMA GEMMs")),
                        "transformer_dtype": "%s token rows, %s MFMA (encoder layers)" % (("bf16", "bf16") if dtype == torch.bfloat16 else ("fp32", "bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32")),
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout},
-                       "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics"},
+                       "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics",
+                       "interpreter": "gc.freeze() after warm-up (set-up heap out of the cyclic collector's full passes)"},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
         }
         if records:
@@ -659,6 +667,7 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                 res["roofline"] = r
                 res["kernels"] = rep
     del optim, sync
+    gc.unfreeze()
     return res, model, args, per_gpu
 
 
