@@ -158,6 +158,15 @@ SIGNATURES = {
     "gt_rows_gather": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
     "gt_rows_scatter": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),
     "gt_seq_layout_packed_host": (_i, [_p, _i64, _i64, _i, _p, _sz, _p]),
+    "gt_pna_layer_saved_bytes": (_sz, [_p]),
+    "gt_pna_layer_workspace_bytes": (_sz, [_p]),
+    "gt_pna_layer_grad_elems": (_i64, [_p]),
+    "gt_pna_layer_fwd": (_i, [_p, _p, _p, _p, _p, _sz, _p]),
+    "gt_pna_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_pna_scales": (_i, [_p, _i64, _i, _p, _f, _f, _p, _p]),
+    "gt_gather_f32": (_i, [_p, _p, _p, _i64, _p]),
+    "gt_pna_aggregate_fwd_uv": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gt_pna_aggregate_bwd_uv": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
     "gt_model_ctx_bytes": (_sz, []),
     "gt_model_abi_sizes": (_i, [_p]),
     "gt_model_grad_ranges": (_i, [_p, _p, _p]),

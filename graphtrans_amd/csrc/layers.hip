@@ -615,3 +615,128 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
   if (L->has_vn && d_vn) GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
   return GT_OK;
 }
+
+// =================================================================================================
+// PNA layer (modules/pna/pna_module.py:57-78; PNAConv math: modules/pna_layer.py:131-167)
+namespace {
+struct PnaSaved {
+  float *UV, *in5, *mean_v, *out, *z, *stats;
+  int32_t* arg;
+  size_t bytes;
+};
+PnaSaved pna_saved(const gt_pna_layer* L, void* p) {
+  Bump b(p);
+  PnaSaved s;
+  const size_t ND = (size_t)L->N * L->D;
+  s.UV = (float*)b.take(ND * 2 * 4);
+  s.in5 = (float*)b.take(ND * 5 * 4);
+  s.mean_v = (float*)b.take(ND * 4);
+  s.arg = (int32_t*)b.take(ND * 2 * 4);
+  s.out = (float*)b.take(ND * 4);
+  s.z = (float*)b.take(ND * 4);
+  s.stats = (float*)b.take((size_t)2 * L->D * 4);
+  s.bytes = b.off;
+  return s;
+}
+struct PnaWork {
+  float *Y, *g, *d_z, *d_out, *d_in5, *dUV, *dxpart;
+  void *bn_ws, *lin_ws, *post_ws, *pre_ws;   // one GEMM workspace each: a forked weight-gradient GEMM still uses its own while the next runs
+  size_t bn_ws_bytes, lin_ws_bytes, post_ws_bytes, pre_ws_bytes, bytes;
+};
+PnaWork pna_work(const gt_pna_layer* L, void* p) {
+  Bump b(p);
+  PnaWork w;
+  const size_t ND = (size_t)L->N * L->D;
+  const int64_t F = L->D / L->T;
+  w.Y = (float*)b.take(ND * L->S * 4);        // forward: the post-GEMM's S output blocks; backward: their gradient
+  w.g = (float*)b.take(ND * 4);
+  w.d_z = (float*)b.take(ND * 4);
+  w.d_out = (float*)b.take(ND * 4);
+  w.d_in5 = (float*)b.take(ND * 5 * 4);
+  w.dUV = (float*)b.take(ND * 2 * 4);
+  w.dxpart = (float*)b.take(ND * 4);
+  w.bn_ws_bytes = gt_batchnorm_workspace_bytes(L->N, L->D);
+  w.bn_ws = b.take(w.bn_ws_bytes);
+  w.lin_ws_bytes = gt_linear_bwd_workspace_bytes(L->compute, L->N, L->D, L->D);
+  w.lin_ws = b.take(w.lin_ws_bytes);
+  w.post_ws_bytes = gt_linear_bwd_grouped_workspace_bytes(L->compute, L->N, L->S * F, 5 * F, L->T);
+  w.post_ws = b.take(w.post_ws_bytes);
+  w.pre_ws_bytes = gt_linear_bwd_grouped_workspace_bytes(L->compute, L->N, 2 * F, F, L->T);
+  w.pre_ws = b.take(w.pre_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+int pna_layer_check(const char* fn, const gt_pna_layer* L) {
+  if (!L) { gt_set_error("%s: null descriptor", fn); return GT_ERR_INVALID_ARG; }
+  if (L->N < 0 || L->D <= 0 || L->T <= 0 || L->D % L->T || (L->D / L->T) % 4 || L->D > 1024 || L->S < 1 || L->S > 8) {
+    gt_set_error("%s: bad sizes (need D %% T == 0, (D / T) %% 4 == 0, D <= 1024, 1 <= S <= 8)", fn);
+    return GT_ERR_INVALID_ARG;
+  }
+  if (!(L->pre_w && L->pre_b && L->post_w && L->post_b && L->lin_w && L->lin_b && L->bn_w && L->bn_b && L->scales && L->in_ptr)) {
+    gt_set_error("%s: null parameter / structure pointer", fn);
+    return GT_ERR_INVALID_ARG;
+  }
+  return GT_OK;
+}
+}  // namespace
+
+extern "C" size_t gt_pna_layer_saved_bytes(const gt_pna_layer* L) { return L ? pna_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_pna_layer_workspace_bytes(const gt_pna_layer* L) { return L ? pna_work(L, nullptr).bytes : 0; }
+extern "C" int64_t gt_pna_layer_grad_elems(const gt_pna_layer* L) { return L ? L->D * L->D + 3 * L->D : 0; }
+
+extern "C" int gt_pna_layer_fwd(const gt_pna_layer* L, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
+                                gt_stream_t st) {
+  GT_TRY(pna_layer_check("gt_pna_layer_fwd", L));
+  GT_CHECK_ARG(x && y && saved && workspace, "null buffer");
+  const PnaWork w = pna_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_pna_layer_fwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const PnaSaved s = pna_saved(L, saved);
+  const int64_t N = L->N, D = L->D, F = D / L->T;
+  const int T = L->T, S = L->S;
+  // [U_t | V_t] = x_t [A_t ; B_t]^T + [b_t | 0]: the per-edge Linear(2F, F) split into its target-role and source-role halves
+  GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, L->pre_b, s.UV, N, 2 * F, F, D, 2 * D, T, F, 2 * F, 0, 0.f, 0, st));
+  GT_TRY(gt_pna_aggregate_fwd_uv(s.UV, (const float*)x, N, D, T, L->in_ptr, L->in_src, L->in_eid, s.in5, s.mean_v, s.arg, st));
+  // the post-Linear once on [x | agg]; its S per-scaler output blocks are combined with the degree scalers
+  GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, L->post_b, w.Y, N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0,
+                               0.f, 0, st));
+  GT_TRY(gt_scale_combine_fwd(w.Y, L->scales, N, T, S, (int)F, s.out, st));
+  GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.out, L->lin_w, L->lin_b, s.z, N, D, D, 0, 0.f, 0, st));
+  // h = relu(batch_norm(conv(x))); x = h + x; x = dropout(x)   (pna_module.py:73-78: the dropout follows the residual add)
+  GT_TRY(gt_batchnorm_fwd(GT_F32, s.z, L->bn_w, L->bn_b, L->bn_rm, L->bn_rv, L->training ? L->bn_nbt : nullptr, L->bn_momentum, L->bn_eps,
+                          L->training, 1, x, N, D, y, s.stats, s.stats + D, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
+  if (L->training && L->dropout_p > 0.f) GT_TRY(gt_dropout(GT_F32, y, y, N * D, L->dropout_p, L->seed, st));
+  return GT_OK;
+}
+
+extern "C" int gt_pna_layer_bwd(const gt_pna_layer* L, const void* x, const void* dy, const void* saved, void* dx, float* grads,
+                                void* workspace, size_t workspace_bytes, gt_stream_t st) {
+  GT_TRY(pna_layer_check("gt_pna_layer_bwd", L));
+  GT_CHECK_ARG(x && dy && saved && dx && grads && workspace, "null buffer");
+  GT_CHECK_ARG(L->d_pre_w && L->d_pre_b && L->d_post_w && L->d_post_b && L->out_ptr, "null image-gradient / structure pointer");
+  const PnaWork w = pna_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_pna_layer_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->N == 0) return GT_OK;
+  const PnaSaved s = pna_saved(L, const_cast<void*>(saved));
+  const int64_t N = L->N, D = L->D, F = D / L->T;
+  const int T = L->T, S = L->S;
+  float *g_lin_w = grads, *g_lin_b = grads + D * D, *g_bn_w = g_lin_b + D, *g_bn_b = g_bn_w + D;
+  const void* g = dy;
+  if (L->training && L->dropout_p > 0.f) {   // the mask is a function of (element, seed): the same call on the gradient
+    GT_TRY(gt_dropout(GT_F32, dy, w.g, N * D, L->dropout_p, L->seed, st));
+    g = w.g;
+  }
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z, g, L->bn_w, L->bn_b, s.stats, s.stats + D, L->training, 1, N, D, w.d_z, g_bn_w, g_bn_b, 0.f, 0, w.bn_ws,
+                          w.bn_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.out, L->lin_w, w.d_z, nullptr, nullptr, nullptr, w.d_out, g_lin_w, g_lin_b, N, D, D, 0.f,
+                       w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_scale_combine_bwd(w.d_out, L->scales, N, T, S, (int)F, w.Y, st));
+  GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, w.Y, nullptr, nullptr, nullptr, w.d_in5, L->d_post_w, L->d_post_b,
+                               N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0.f, w.post_ws, w.post_ws_bytes, st));
+  GT_TRY(gt_pna_aggregate_bwd_uv(s.UV, s.in5, s.mean_v, s.arg, w.d_in5, N, D, T, L->in_ptr, L->out_ptr, L->out_dst, L->out_eid, w.dUV,
+                                 w.dxpart, st));
+  // dx = dUV [A ; B] + (the x block of the post-Linear's operand) + (the residual branch)
+  GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, w.dUV, nullptr, w.dxpart, g, dx, L->d_pre_w, L->d_pre_b, N, 2 * F, F, D,
+                               2 * D, T, F, 2 * F, 0.f, w.pre_ws, w.pre_ws_bytes, st));
+  return GT_OK;
+}

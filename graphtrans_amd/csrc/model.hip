@@ -54,11 +54,13 @@ struct Ctx {
   // batch descriptors
   gt_gcn_layer gcn[MAXL];
   gt_gin_layer gin[MAXL];
+  gt_pna_layer pna[MAXL];
   gt_vn_update vn[MAXL];
   gt_encoder_layer enc[MAXL];
   // forward arena
   size_t o_h[MAXL + 1], o_x0, o_vn[MAXL], o_vn_saved[MAXL], o_conv_saved[MAXL], o_cat, o_hn, o_tok, o_xin, o_st0, o_xe[MAXL],
       o_enc_saved[MAXL], o_xo, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
+  size_t o_scales, q_dimg;
   size_t o_graph_ptr, o_node_graph, o_in_ptr, o_out_ptr, o_idx, o_dd, o_status, o_prep_ws, o_lay, o_lay_meta;
   size_t ws_bytes, ws2_bytes, eplan_bytes, esort_ws_bytes, prep_ws_bytes, arena_bytes;
   int cat2, want_wt, esort, late_wait;
@@ -86,6 +88,7 @@ constexpr uint32_t CTX_MAGIC = 0x67744d31u;
 
 inline gt_gcn_layer* gcn_static(const gt_model* m) { return (gt_gcn_layer*)m->conv_layers; }
 inline gt_gin_layer* gin_static(const gt_model* m) { return (gt_gin_layer*)m->conv_layers; }
+inline gt_pna_layer* pna_static(const gt_model* m) { return (gt_pna_layer*)m->conv_layers; }
 
 int model_check(const char* fn, const gt_model* m) {
   if (!m) { gt_set_error("%s: null model", fn); return GT_ERR_INVALID_ARG; }
@@ -95,7 +98,11 @@ int model_check(const char* fn, const gt_model* m) {
   }
   if (!m->conv_layers || (m->n_enc && !m->enc) || (m->has_vn && m->L > 1 && !m->vn)) { gt_set_error("%s: null descriptor array", fn); return GT_ERR_INVALID_ARG; }
   if (m->D <= 0 || m->D % 4 || m->d <= 0 || m->d % 8) { gt_set_error("%s: bad widths", fn); return GT_ERR_INVALID_ARG; }
-  if (m->conv != GT_CONV_GCN && m->conv != GT_CONV_GIN) { gt_set_error("%s: bad conv kind", fn); return GT_ERR_INVALID_ARG; }
+  if (m->conv != GT_CONV_GCN && m->conv != GT_CONV_GIN && m->conv != GT_CONV_PNA) { gt_set_error("%s: bad conv kind", fn); return GT_ERR_INVALID_ARG; }
+  if (m->conv == GT_CONV_PNA && (m->has_vn || m->jk_cat || !m->residual || !m->pna_src || !m->pna_img || !m->pna_map || !m->pna_inv)) {
+    gt_set_error("%s: the PNA stack runs without a virtual node, with JK = last, the residual connection and its weight images", fn);
+    return GT_ERR_INVALID_ARG;
+  }
   return GT_OK;
 }
 
@@ -182,9 +189,11 @@ struct BindGuard {   // the bind tables are per host thread: always undone on th
 };
 
 size_t conv_saved_bytes(const gt_model* m, const Ctx* c, int l) {
+  if (m->conv == GT_CONV_PNA) return gt_pna_layer_saved_bytes(&c->pna[l]);
   return m->conv == GT_CONV_GIN ? gt_gin_layer_saved_bytes(&c->gin[l]) : gt_gcn_layer_saved_bytes(&c->gcn[l]);
 }
 size_t conv_ws_bytes(const gt_model* m, const Ctx* c, int l) {
+  if (m->conv == GT_CONV_PNA) return gt_pna_layer_workspace_bytes(&c->pna[l]);
   return m->conv == GT_CONV_GIN ? gt_gin_layer_workspace_bytes(&c->gin[l]) : gt_gcn_layer_workspace_bytes(&c->gcn[l]);
 }
 
@@ -267,6 +276,13 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
       g.vn_next = nullptr; g.ev_vn_next = nullptr; g.lin_wt = nullptr;
       g.prev_saved = nullptr; g.prev_bn_w = g.prev_bn_b = nullptr; g.prev_bn_part = nullptr; g.bn_part_in = nullptr;
       g.prev_relu = 0; g.bn_nparts_in = 0; g.ev_graph_ready = nullptr;
+    } else if (m->conv == GT_CONV_PNA) {
+      gt_pna_layer& g = c->pna[l];
+      g = pna_static(m)[l];
+      g.N = N; g.E = E;
+      g.training = training; g.compute = c->compute;
+      g.dropout_p = training ? b->gnn_p : 0.f;
+      g.seed = b->gnn_seed + SEED_STEP * (uint64_t)(2 * l + 1);
     } else {
       gt_gin_layer& g = c->gin[l];
       g = gin_static(m)[l];
@@ -351,6 +367,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
     c->o_ne_w = a.take((size_t)D * Kp * 4);
   }
   c->o_hg = a.take((size_t)B * d * 4);
+  if (m->conv == GT_CONV_PNA) c->o_scales = a.take((size_t)N * c->pna[0].S * 4);
   size_t ws = 256, ws2 = 256;
   for (int l = 0; l < L; ++l) ws = std::max(ws, conv_ws_bytes(m, c, l));
   for (int l = 0; l < nvn; ++l) ws2 = std::max(ws2, gt_vn_update_workspace_bytes(&c->vn[l]));
@@ -359,7 +376,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   c->o_ws = a.take(ws);
   c->o_ws2 = a.take(ws2);
   const bool have_imgs = b->use_w3 != 0;
-  c->want_wt = (b->will_bwd && c->compute == GT_F32 && N >= 1024 && (!have_imgs || (!m->has_vn && m->conv == GT_CONV_GCN))) ? 1 : 0;
+  c->want_wt = (m->conv != GT_CONV_PNA && b->will_bwd && c->compute == GT_F32 && N >= 1024 && (!have_imgs || (!m->has_vn && m->conv == GT_CONV_GCN))) ? 1 : 0;
   if (c->want_wt) {
     for (int l = 0; l < L; ++l) c->o_wt[l] = a.take((size_t)(m->conv == GT_CONV_GIN ? 2 : 1) * 2 * D * D * 4);
     c->o_g2t_wt = a.take((size_t)d * Kc * 4);
@@ -426,6 +443,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   c->q_ws2 = q.take(c->ws2_bytes);
   c->seg_ws_bytes = m->has_vn ? gt_segment_sum_workspace_bytes(N, D) : 0;
   c->q_ws3 = q.take(c->seg_ws_bytes);
+  c->q_dimg = q.take(m->conv == GT_CONV_PNA ? (size_t)m->pna_n_img * 4 : 0);
   c->barena_bytes = std::max(q.off, (size_t)256);
 
   c->prepared = 1;
@@ -520,12 +538,18 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
       gt_gcn_layer& g = c->gcn[l];
       g.graph_ptr = graph_ptr; g.node_graph = node_graph; g.in_ptr = in_ptr; g.in_src = in_src; g.in_eid = in_eid;
       g.out_ptr = out_ptr; g.out_dst = out_dst; g.out_eid = out_eid; g.deg = deg; g.dis = dis;
+    } else if (m->conv == GT_CONV_PNA) {
+      gt_pna_layer& g = c->pna[l];
+      g.in_ptr = in_ptr; g.in_src = in_src; g.in_eid = in_eid; g.out_ptr = out_ptr; g.out_dst = out_dst; g.out_eid = out_eid;
+      g.scales = (const float*)P(c->o_scales);
     } else {
       gt_gin_layer& g = c->gin[l];
       g.graph_ptr = graph_ptr; g.node_graph = node_graph; g.in_ptr = in_ptr; g.in_src = in_src; g.in_eid = in_eid;
       g.out_ptr = out_ptr; g.out_dst = out_dst; g.out_eid = out_eid;
     }
   }
+  if (m->conv == GT_CONV_PNA)   // the towers' re-stacked weight images (the optimizer changed the weights: one launch for all layers)
+    GT_TRY(gt_gather_f32(m->pna_img, m->pna_src, m->pna_map, m->pna_n_img, st));
   for (int l = 0; l < nvn; ++l) { c->vn[l].graph_ptr = graph_ptr; c->vn[l].node_graph = node_graph; }
 
   gt_stream_t side = m->has_vn ? m->st_vn : nullptr;
@@ -610,7 +634,10 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
     if (!m->has_vn) return P(c->o_h[l]);
     return (l == 0 && !m->vn0_in_embed) ? P(c->o_x0) : P(c->o_h[l]);
   };
+  if (m->conv == GT_CONV_PNA)   // per-node degree scalers of this batch (in-degrees: the structure is ready on this stream here)
+    GT_TRY(gt_pna_scales(in_ptr, N, c->pna[0].S, m->pna_kinds, m->pna_avg_log, m->pna_avg_lin, (float*)P(c->o_scales), st));
   auto conv_fwd = [&](int l, const void* h_in, const void* vn, void* y) -> int {
+    if (m->conv == GT_CONV_PNA) return gt_pna_layer_fwd(&c->pna[l], h_in, y, P(c->o_conv_saved[l]), P(c->o_ws), c->ws_bytes, st);
     if (m->conv == GT_CONV_GIN)
       return gt_gin_layer_fwd(&c->gin[l], h_in, vn, nullptr, y, P(c->o_conv_saved[l]), P(c->o_ws), c->ws_bytes, st);
     return gt_gcn_layer_fwd(&c->gcn[l], h_in, vn, nullptr, y, P(c->o_conv_saved[l]), P(c->o_ws), c->ws_bytes, st);
@@ -811,7 +838,13 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       if (l == 0 && ov) gt_overlap_dw_urgent(1);   // layer 0's weight gradients are the last: nothing left to overlap them with
       const bool pool_on_side = m->has_vn && side;
       void* d_vn = (m->has_vn && !pool_on_side) ? Q(c->q_dvn[3]) : nullptr;
-      if (m->conv == GT_CONV_GIN)
+      if (m->conv == GT_CONV_PNA) {
+        gt_pna_layer& g = c->pna[l];
+        float* dimg = (float*)Q(c->q_dimg);
+        g.d_pre_w = dimg + m->pna_img_off[l][0]; g.d_pre_b = dimg + m->pna_img_off[l][1];
+        g.d_post_w = dimg + m->pna_img_off[l][2]; g.d_post_b = dimg + m->pna_img_off[l][3];
+        GT_TRY(gt_pna_layer_bwd(&g, c->xptr[l], dy, conv_saved(l), out, G + m->off_conv[l], W(), ws_bytes, st));
+      } else if (m->conv == GT_CONV_GIN)
         GT_TRY(gt_gin_layer_bwd(&c->gin[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
       else
         GT_TRY(gt_gcn_layer_bwd(&c->gcn[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
@@ -830,6 +863,10 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       dy = out;
     }
     c->d_h0 = dy;
+    if (m->conv == GT_CONV_PNA) {   // image gradients -> the tower parameters' gradients (every source element sits in the images at most once)
+      if (ov) gt_overlap_dw_sync();
+      GT_TRY(gt_gather_f32(G + m->off_pna_src, (const float*)Q(c->q_dimg), m->pna_inv, m->pna_n_src, st));
+    }
     if (m->has_vn) {
       gt_stream_t vst = side ? side : st;
       GT_TRY(gt_segment_sum(GT_F32, d_vn_next, nullptr, b.ptr01, B, 1, D, G + m->off_vn_emb, vst));

@@ -35,12 +35,22 @@ struct PnaArgs {
   float* dV;
   int64_t N, D;
   int T, F;
+  // layouts (elements): U / V / dU / dV element (n, t, f) at n * ldu + t * tsu + f; out / g aggregator block a of (n, t) at
+  // n * ldo + t * tso + ao + a * F.  The stand-alone entry points use ldu = D, tsu = F, ldo = 4 D, tso = 4 F, ao = 0.
+  int64_t ldu, ldo;
+  int tsu, tso, ao;
+  const float* xcopy;   // fwd, optional [N][D]: also written to out (n, t) columns [0, F) (the [x | agg] operand of the post-Linear)
+  float* dxpart;        // bwd, optional [N][D]: receives g (n, t) columns [0, F) (the gradient of that copy)
 };
 
 // column chunk c (4 floats at columns col..col+3) of aggregator `agg` lives at tower-major offset:
-__device__ __forceinline__ int64_t out_off(int64_t n, int col, int agg, int D, int F) {
-  const int t = col / F, f = col % F;
-  return n * 4 * (int64_t)D + (int64_t)t * 4 * F + agg * F + f;
+__device__ __forceinline__ int64_t out_off(const PnaArgs& a, int64_t n, int col, int agg) {
+  const int t = col / a.F, f = col % a.F;
+  return n * a.ldo + (int64_t)t * a.tso + a.ao + agg * a.F + f;
+}
+__device__ __forceinline__ int64_t uv_off(const PnaArgs& a, int64_t n, int col) {
+  const int t = col / a.F, f = col % a.F;
+  return n * a.ldu + (int64_t)t * a.tsu + f;
 }
 
 template <int LPN, int NCH>
@@ -66,7 +76,7 @@ __global__ void __launch_bounds__(PT) k_pna_fwd(PnaArgs a) {
     int4 amx = make_int4(-1, -1, -1, -1), amn = make_int4(-1, -1, -1, -1);
     for (int p = beg; p < end; ++p) {
       const int src = a.nbr[p], e = a.eid[p];
-      const float4 x = *reinterpret_cast<const float4*>(a.V + (int64_t)src * D + col);
+      const float4 x = *reinterpret_cast<const float4*>(a.V + uv_off(a, src, col));
       cnt += 1.f;
       const float ik = 1.0f / cnt;
       const float4 dl = make_float4(x.x - mv.x, x.y - mv.y, x.z - mv.z, x.w - mv.w);
@@ -85,7 +95,7 @@ __global__ void __launch_bounds__(PT) k_pna_fwd(PnaArgs a) {
     float4 mean = gt_zero4(), omax = gt_zero4(), omin = gt_zero4(), ostd;
     if (end > beg) {
       const float inv = 1.0f / deg;
-      const float4 u = *reinterpret_cast<const float4*>(a.U + v * D + col);
+      const float4 u = *reinterpret_cast<const float4*>(a.U + uv_off(a, v, col));
       mean = gt_add4(u, mv);
       omax = gt_add4(u, mx);
       omin = gt_add4(u, mn);
@@ -95,10 +105,11 @@ __global__ void __launch_bounds__(PT) k_pna_fwd(PnaArgs a) {
       const float e0 = sqrtf(1e-5f);
       ostd = make_float4(e0, e0, e0, e0);
     }
-    *reinterpret_cast<float4*>(a.out + out_off(v, col, 0, D, a.F)) = mean;
-    *reinterpret_cast<float4*>(a.out + out_off(v, col, 1, D, a.F)) = omax;
-    *reinterpret_cast<float4*>(a.out + out_off(v, col, 2, D, a.F)) = omin;
-    *reinterpret_cast<float4*>(a.out + out_off(v, col, 3, D, a.F)) = ostd;
+    *reinterpret_cast<float4*>(a.out + out_off(a, v, col, 0)) = mean;
+    *reinterpret_cast<float4*>(a.out + out_off(a, v, col, 1)) = omax;
+    *reinterpret_cast<float4*>(a.out + out_off(a, v, col, 2)) = omin;
+    *reinterpret_cast<float4*>(a.out + out_off(a, v, col, 3)) = ostd;
+    if (a.xcopy) *reinterpret_cast<float4*>(a.out + out_off(a, v, col, 0) - a.ao) = *reinterpret_cast<const float4*>(a.xcopy + v * D + col);
     *reinterpret_cast<float4*>(a.mean_v + v * D + col) = mv;
     *reinterpret_cast<int4*>(a.arg + (v * 2 + 0) * D + col) = amx;
     *reinterpret_cast<int4*>(a.arg + (v * 2 + 1) * D + col) = amn;
@@ -123,17 +134,17 @@ __global__ void __launch_bounds__(PT) k_pna_bwd(PnaArgs a) {
   for (int j = 0; j < NCH; ++j) {
     const int col = (sl + j * 64) * 4;
     if (col >= D) continue;
-    const float4 vu = *reinterpret_cast<const float4*>(a.V + u * D + col);
+    const float4 vu = *reinterpret_cast<const float4*>(a.V + uv_off(a, u, col));
     float4 acc = gt_zero4();
     for (int p = beg; p < end; ++p) {
       const int d = a.nbr[p], e = a.eid[p];
       const float degd = (float)(a.in_ptr[d + 1] - a.in_ptr[d]);
       const float inv = 1.0f / degd;
-      const float4 gm = *reinterpret_cast<const float4*>(a.g + out_off(d, col, 0, D, a.F));
-      const float4 gx = *reinterpret_cast<const float4*>(a.g + out_off(d, col, 1, D, a.F));
-      const float4 gn = *reinterpret_cast<const float4*>(a.g + out_off(d, col, 2, D, a.F));
-      const float4 gs = *reinterpret_cast<const float4*>(a.g + out_off(d, col, 3, D, a.F));
-      const float4 sd = *reinterpret_cast<const float4*>(a.out + out_off(d, col, 3, D, a.F));
+      const float4 gm = *reinterpret_cast<const float4*>(a.g + out_off(a, d, col, 0));
+      const float4 gx = *reinterpret_cast<const float4*>(a.g + out_off(a, d, col, 1));
+      const float4 gn = *reinterpret_cast<const float4*>(a.g + out_off(a, d, col, 2));
+      const float4 gs = *reinterpret_cast<const float4*>(a.g + out_off(a, d, col, 3));
+      const float4 sd = *reinterpret_cast<const float4*>(a.out + out_off(a, d, col, 3));
       const float4 mv = *reinterpret_cast<const float4*>(a.mean_v + (int64_t)d * D + col);
       const int4 ax = *reinterpret_cast<const int4*>(a.arg + ((int64_t)d * 2 + 0) * D + col);
       const int4 an = *reinterpret_cast<const int4*>(a.arg + ((int64_t)d * 2 + 1) * D + col);
@@ -150,14 +161,15 @@ __global__ void __launch_bounds__(PT) k_pna_bwd(PnaArgs a) {
       acc.z += term(gm.z, gx.z, gn.z, gs.z, sd.z, mv.z, ax.z, an.z, vu.z);
       acc.w += term(gm.w, gx.w, gn.w, gs.w, sd.w, mv.w, ax.w, an.w, vu.w);
     }
-    *reinterpret_cast<float4*>(a.dV + u * D + col) = acc;
+    *reinterpret_cast<float4*>(a.dV + uv_off(a, u, col)) = acc;
     float4 du = gt_zero4();
     if (has_in) {
-      du = gt_add4(gt_add4(*reinterpret_cast<const float4*>(a.g + out_off(u, col, 0, D, a.F)),
-                           *reinterpret_cast<const float4*>(a.g + out_off(u, col, 1, D, a.F))),
-                   *reinterpret_cast<const float4*>(a.g + out_off(u, col, 2, D, a.F)));
+      du = gt_add4(gt_add4(*reinterpret_cast<const float4*>(a.g + out_off(a, u, col, 0)),
+                           *reinterpret_cast<const float4*>(a.g + out_off(a, u, col, 1))),
+                   *reinterpret_cast<const float4*>(a.g + out_off(a, u, col, 2)));
     }
-    *reinterpret_cast<float4*>(a.dU + u * D + col) = du;
+    *reinterpret_cast<float4*>(a.dU + uv_off(a, u, col)) = du;
+    if (a.dxpart) *reinterpret_cast<float4*>(a.dxpart + u * D + col) = *reinterpret_cast<const float4*>(a.g + out_off(a, u, col, 0) - a.ao);
   }
 }
 
@@ -213,7 +225,44 @@ __global__ void __launch_bounds__(256) k_scale_combine_bwd(const float* __restri
   }
 }
 
+// per-node degree scalers (modules/pna/scalers.py:10-31): d = in-degree
+struct ScaleKinds { int k[8]; };
+__global__ void __launch_bounds__(256) k_pna_scales(const int32_t* __restrict__ in_ptr, int64_t N, int S, ScaleKinds kinds, float avg_log,
+                                                    float avg_lin, float* __restrict__ sc) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float d = (float)(in_ptr[n + 1] - in_ptr[n]);
+  const float lg = logf(d + 1.f);
+  for (int s = 0; s < S; ++s) {
+    float v = 1.f;
+    switch (kinds.k[s]) {
+      case 1: v = lg / avg_log; break;
+      case 2: v = d == 0.f ? 1.f : avg_log / lg; break;
+      case 3: v = d / avg_lin; break;
+      case 4: v = d == 0.f ? 1.f : avg_lin / d; break;
+      default: break;
+    }
+    sc[n * S + s] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int gt_pna_scales(const int32_t* in_ptr, int64_t N, int S, const int32_t* kinds_host, float avg_log, float avg_lin, float* scales,
+                             gt_stream_t stream_) {
+  GT_CHECK_ARG(N >= 0 && S >= 1 && S <= 8 && kinds_host, "bad arguments");
+  if (N == 0) return GT_OK;
+  GT_CHECK_ARG(in_ptr && scales, "null buffer");
+  ScaleKinds k{};
+  for (int s = 0; s < S; ++s) k.k[s] = kinds_host[s];
+  hipLaunchKernelGGL(k_pna_scales, dim3((unsigned)gt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream_, in_ptr, N, S, k, avg_log, avg_lin, scales);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+static void pna_classic(PnaArgs& a) {
+  a.ldu = a.D; a.tsu = a.F; a.ldo = 4 * a.D; a.tso = 4 * a.F; a.ao = 0;
+}
 
 extern "C" int gt_pna_aggregate_fwd(const float* U, const float* V, int64_t N, int64_t D, int towers, const int32_t* in_ptr,
                                     const int32_t* in_src, const int32_t* in_eid, float* out, float* mean_v, int32_t* arg,
@@ -225,6 +274,7 @@ extern "C" int gt_pna_aggregate_fwd(const float* U, const float* V, int64_t N, i
   PnaArgs a{};
   a.U = U; a.V = V; a.ptr = in_ptr; a.nbr = in_src; a.eid = in_eid; a.out = out; a.mean_v = mean_v; a.arg = arg;
   a.N = N; a.D = D; a.T = towers; a.F = (int)(D / towers);
+  pna_classic(a);
   GtProfScope prof__(GT_PROF_AGGREGATE, "gt_pna_aggregate_fwd", stream_, {N, in_ptr ? 0 : 0, D, 4, 0, 0});
   pna_launch<false>(a, (hipStream_t)stream_);
   GT_CHECK_LAUNCH();
@@ -243,6 +293,45 @@ extern "C" int gt_pna_aggregate_bwd(const float* V, const float* out, const floa
   a.V = V; a.out = const_cast<float*>(out); a.mean_v = const_cast<float*>(mean_v); a.arg = const_cast<int32_t*>(arg);
   a.g = grad_out; a.ptr = out_ptr; a.nbr = out_dst; a.eid = out_eid; a.in_ptr = in_ptr; a.dU = dU; a.dV = dV;
   a.N = N; a.D = D; a.T = towers; a.F = (int)(D / towers);
+  pna_classic(a);
+  GtProfScope prof__(GT_PROF_AGGREGATE, "gt_pna_aggregate_bwd", stream_, {N, 0, D, 4, 0, 0});
+  pna_launch<true>(a, (hipStream_t)stream_);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+// Layout of the fused PNA layer (gt_pna_layer_*, layers.hip): UV [N][T][2F] = [U_t | V_t] out of ONE grouped pre-GEMM, the
+// aggregates written straight into the post-Linear's operand in5 [N][T][5F] = [x_t | mean | max | min | std] (x copied on the way),
+// the backward reading its gradient from d_in5 [N][T][5F], writing dUV [N][T][2F] and the x block's gradient to dxpart [N][D].
+extern "C" int gt_pna_aggregate_fwd_uv(const float* UV, const float* x, int64_t N, int64_t D, int towers, const int32_t* in_ptr,
+                                       const int32_t* in_src, const int32_t* in_eid, float* in5, float* mean_v, int32_t* arg,
+                                       gt_stream_t stream_) {
+  int rc = pna_check("gt_pna_aggregate_fwd_uv", N, D, towers);
+  if (rc) return rc;
+  GT_CHECK_ARG(UV && x && in_ptr && in5 && mean_v && arg, "null buffer");
+  if (N == 0) return GT_OK;
+  PnaArgs a{};
+  a.N = N; a.D = D; a.T = towers; a.F = (int)(D / towers);
+  a.U = UV; a.V = UV + a.F; a.ptr = in_ptr; a.nbr = in_src; a.eid = in_eid; a.out = in5; a.mean_v = mean_v; a.arg = arg;
+  a.ldu = 2 * D; a.tsu = 2 * a.F; a.ldo = 5 * D; a.tso = 5 * a.F; a.ao = a.F; a.xcopy = x;
+  GtProfScope prof__(GT_PROF_AGGREGATE, "gt_pna_aggregate_fwd", stream_, {N, 0, D, 4, 0, 0});
+  pna_launch<false>(a, (hipStream_t)stream_);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_pna_aggregate_bwd_uv(const float* UV, const float* in5, const float* mean_v, const int32_t* arg, const float* d_in5,
+                                       int64_t N, int64_t D, int towers, const int32_t* in_ptr, const int32_t* out_ptr,
+                                       const int32_t* out_dst, const int32_t* out_eid, float* dUV, float* dxpart, gt_stream_t stream_) {
+  int rc = pna_check("gt_pna_aggregate_bwd_uv", N, D, towers);
+  if (rc) return rc;
+  GT_CHECK_ARG(UV && in5 && mean_v && arg && d_in5 && in_ptr && out_ptr && dUV && dxpart, "null buffer");
+  if (N == 0) return GT_OK;
+  PnaArgs a{};
+  a.N = N; a.D = D; a.T = towers; a.F = (int)(D / towers);
+  a.V = UV + a.F; a.out = const_cast<float*>(in5); a.mean_v = const_cast<float*>(mean_v); a.arg = const_cast<int32_t*>(arg);
+  a.g = d_in5; a.ptr = out_ptr; a.nbr = out_dst; a.eid = out_eid; a.in_ptr = in_ptr; a.dU = dUV; a.dV = dUV + a.F;
+  a.ldu = 2 * D; a.tsu = 2 * a.F; a.ldo = 5 * D; a.tso = 5 * a.F; a.ao = a.F; a.dxpart = dxpart;
   GtProfScope prof__(GT_PROF_AGGREGATE, "gt_pna_aggregate_bwd", stream_, {N, 0, D, 4, 0, 0});
   pna_launch<true>(a, (hipStream_t)stream_);
   GT_CHECK_LAUNCH();

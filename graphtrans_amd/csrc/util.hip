@@ -50,6 +50,15 @@ __global__ void __launch_bounds__(UT) k_add3(const float* __restrict__ a, const 
   }
 }
 
+// dst[i] = map[i] < 0 ? 0 : src[map[i]]: re-stacked weight images (and, through the inverse map, their gradients)
+__global__ void __launch_bounds__(UT) k_gather_f32(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ map,
+                                                   int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < n; i += (int64_t)gridDim.x * UT) {
+    const int32_t j = map[i];
+    dst[i] = j < 0 ? 0.f : src[j];
+  }
+}
+
 // dst[r][c] = c < src_cols ? src[r][c] : 0, contiguous rows of dst_cols / src_cols elements (any counts)
 template <typename U>
 __global__ void __launch_bounds__(UT) k_repitch(U* __restrict__ dst, int64_t dst_cols, const U* __restrict__ src,
@@ -77,6 +86,15 @@ extern "C" int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, in
                 (uintptr_t)width_bytes) % 16 == 0, "pointers, pitches and width must be multiples of 16 bytes");
   hipLaunchKernelGGL(k_copy2d, dim3(grid_for(rows * (width_bytes / 16))), dim3(UT), 0, (hipStream_t)stream_, (char*)dst,
                      dst_pitch_bytes, (const char*)src, src_pitch_bytes, width_bytes / 16, rows);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
+extern "C" int gt_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, gt_stream_t stream_) {
+  GT_CHECK_ARG(n >= 0, "bad size");
+  if (n == 0) return GT_OK;
+  GT_CHECK_ARG(dst && src && map, "null buffer");
+  hipLaunchKernelGGL(k_gather_f32, dim3(grid_for(n)), dim3(UT), 0, (hipStream_t)stream_, dst, src, map, n);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -71,7 +71,10 @@ class ModelDesc(C.Structure):   # gt_model
                 ("off_nout_b", _i64), ("off_head_w", _i64), ("off_head_b", _i64), ("grad_total", _i64),
                 ("st_vn", _vp), ("st_dw", _vp), ("st_prep", _vp), ("ev_x", _vp * MAXL), ("ev_vn", _vp * MAXL), ("ev_dvn", _vp * MAXL),
                 ("ev_extra", _vp * MAXL), ("ev_pool", _vp * MAXL), ("ev_vnemb", _vp), ("ev_sort", _vp * 2), ("ev_wt", _vp * 2),
-                ("ev_prep_begin", _vp), ("ev_graph", _vp), ("ev_w1", _vp), ("w3", ImageSet), ("w3_enc", ImageSet), ("w1", ImageSet)]
+                ("ev_prep_begin", _vp), ("ev_graph", _vp), ("ev_w1", _vp), ("w3", ImageSet), ("w3_enc", ImageSet), ("w1", ImageSet),
+                ("pna_src", _vp), ("pna_img", _vp), ("pna_map", _vp), ("pna_inv", _vp), ("pna_n_img", _i64), ("pna_n_src", _i64),
+                ("off_pna_src", _i64), ("pna_img_off", (_i64 * 4) * MAXL), ("pna_kinds", _i32 * 8), ("pna_avg_log", _f32),
+                ("pna_avg_lin", _f32)]
 
 
 class BatchDesc(C.Structure):   # gt_model_batch
@@ -176,9 +179,15 @@ class _Plan:
         lib = _lib.lib()
         gnn, enc = model.gnn_node, model.transformer_encoder
         self.L, self.has_vn = gnn.num_layer, isinstance(gnn, GNN_node_Virtualnode)
-        self.D = gnn.convs[0].emb_dim
+        if hasattr(gnn, "layers"):   # PNANodeEmbedding
+            self.kind = "pna"
+            self.D = gnn.layers[0].in_channels
+            self.jk_cat = False
+        else:
+            self.kind = "gin" if isinstance(gnn.convs[0], GINConv) else "gcn"
+            self.D = gnn.convs[0].emb_dim
+            self.jk_cat = gnn.JK == "cat"
         self.d = enc.d_model
-        self.jk_cat = gnn.JK == "cat"
         self.dev = next(model.parameters()).device
         self.total = 0
         self.params = []   # (param, offset)
@@ -216,76 +225,12 @@ class _Plan:
             cm.ne_K = self.ne_K
         self.vn_emb = gnn.virtualnode_embedding.weight if self.has_vn else None
         cm.off_vn_emb = seg(self.vn_emb) if self.has_vn else -1
-        # ---- conv layers.  Gradient block order of gt_gcn_layer_bwd: lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b;
-        # of gt_gin_layer_bwd: eps (20-float slot), edge tables | edge_w, edge_b, w1, b1, bn1_w, bn1_b, w2, b2, bn_w, bn_b
-        self.kind = "gin" if isinstance(gnn.convs[0], GINConv) else "gcn"
-        self.convs = list(zip(gnn.convs, gnn.batch_norms))
-        # BondEncoder-style tables: the aggregate kernels read ONE [rows][D] matrix per layer.  Instead of stacking a layer's tables
-        # by a torch.cat per step, the parameters' storage IS the stacked matrix -- each table's weight becomes a view of it (same
-        # Parameter objects, same state_dict keys; optim.FusedAdamW notices the move and rebuilds its tables)
-        self.etab_flat = None
-        tabs_all = [[t.weight for t in getattr(conv.edge_encoder, "bond_embedding_list", [])] for conv, _ in self.convs]
-        if any(tabs_all):
-            with torch.no_grad():
-                flat = torch.cat([t.detach() for tl in tabs_all for t in tl]).contiguous()
-                r0 = 0
-                for tl in tabs_all:
-                    for t in tl:
-                        n_ = int(t.shape[0])
-                        t.data = flat[r0:r0 + n_]
-                        r0 += n_
-            self.etab_flat = flat
-        self.conv_desc = ((layers.GinLayerDesc if self.kind == "gin" else layers.GcnLayerDesc) * L)()
         self.w3_weights = []
-        for l, (conv, bn) in enumerate(self.convs):
-            desc = self.conv_desc[l]
-            ee = conv.edge_encoder
-            tabs = tabs_all[l]
-            if tabs:
-                edge, mode = tabs, "tables"
-            elif isinstance(ee, torch.nn.Module):
-                edge, mode = [ee.weight, ee.bias], "linear"
-            else:
-                edge, mode = [], None
-            if self.kind == "gcn":
-                plist = [conv.linear.weight, conv.linear.bias, conv.root_emb.weight, *edge, bn.weight, bn.bias]
-                self.w3_weights.append(conv.linear.weight)
-            else:
-                m = list(conv.mlp)
-                plist = [conv.eps, *edge, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, bn.weight, bn.bias]
-                self.w3_weights += [m[0].weight, m[3].weight]
-            off = None
-            for p in plist:
-                o = seg(p)
-                off = o if off is None else off
-                if self.kind == "gin" and p is conv.eps:
-                    self.total = o + 20   # d_eps + the aggregate backward's scratch (GIN_EPS_SLOT in layers.hip)
-            cm.off_conv[l] = off
-            desc.D = D
-            if self.kind == "gcn":
-                desc.lin_w, desc.lin_b, desc.root = conv.linear.weight.data_ptr(), conv.linear.bias.data_ptr(), conv.root_emb.weight.data_ptr()
-            else:
-                desc.eps = conv.eps.data_ptr()
-                desc.w1, desc.b1, desc.bn1_w, desc.bn1_b = m[0].weight.data_ptr(), m[0].bias.data_ptr(), m[1].weight.data_ptr(), m[1].bias.data_ptr()
-                desc.w2, desc.b2 = m[3].weight.data_ptr(), m[3].bias.data_ptr()
-                desc.bn1_rm, desc.bn1_rv, desc.bn1_nbt = m[1].running_mean.data_ptr(), m[1].running_var.data_ptr(), m[1].num_batches_tracked.data_ptr()
-            if mode == "linear":
-                desc.edge_mode = GT_EDGE_LINEAR
-                desc.edge_cols = ee.weight.shape[1]
-                desc.edge_w, desc.edge_b = ee.weight.data_ptr(), ee.bias.data_ptr()
-            elif mode == "tables":
-                desc.edge_mode = GT_EDGE_TABLES
-                desc.edge_cols, desc.table_rows = len(tabs), sum(int(t.shape[0]) for t in tabs)
-                acc = 0
-                for i, t in enumerate(tabs):
-                    desc.tab_off[i] = acc
-                    acc += int(t.shape[0])
-                desc.edge_w = tabs[0].data_ptr()   # the layer's stacked [rows][D] block
-            else:
-                desc.edge_mode = GT_EDGE_NONE
-            desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
-            desc.bn_rm, desc.bn_rv, desc.bn_nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
-            desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+        self.etab_flat = None
+        if self.kind == "pna":
+            self._init_pna(gnn, seg)
+        else:
+            self._init_convs(gnn, seg)
         nvn = L - 1 if self.has_vn else 0
         self.vn_desc = (layers.VnUpdateDesc * max(nvn, 1))()
         if self.has_vn:
@@ -369,7 +314,7 @@ class _Plan:
         self.plist = [p for p, _ in self.params]
         self.param_ptrs = tuple(p.data_ptr() for p in self.plist)
         # ---- the rest of the static struct
-        cm.conv = 1 if self.kind == "gin" else 0
+        cm.conv = {"gcn": 0, "gin": 1, "pna": 2}[self.kind]
         cm.L, cm.n_enc, cm.has_vn, cm.jk_cat, cm.residual = L, len(self.enc_layers), int(self.has_vn), int(self.jk_cat), int(bool(gnn.residual))
         cm.D, cm.d, cm.Nh, cm.ldy = D, d, self.Nh, self.ldy
         cm.max_input_len = int(enc.max_input_len)
@@ -435,6 +380,197 @@ class _Plan:
         _lib.check(lib.gt_model_grad_ranges(C.byref(cm), lo, hi), "gt_model_grad_ranges")
         self.ranges = list(zip(lo, hi))
         self.cm_ref = C.byref(cm)
+
+    def _init_convs(self, gnn, seg):
+        from .modules.conv import GINConv
+        cm, L, D = self.cm, self.L, self.D
+        # ---- conv layers.  Gradient block order of gt_gcn_layer_bwd: lin_w, lin_b, root, edge_w, edge_b, bn_w, bn_b;
+        # of gt_gin_layer_bwd: eps (20-float slot), edge tables | edge_w, edge_b, w1, b1, bn1_w, bn1_b, w2, b2, bn_w, bn_b
+        self.convs = list(zip(gnn.convs, gnn.batch_norms))
+        # BondEncoder-style tables: the aggregate kernels read ONE [rows][D] matrix per layer.  Instead of stacking a layer's tables
+        # by a torch.cat per step, the parameters' storage IS the stacked matrix -- each table's weight becomes a view of it (same
+        # Parameter objects, same state_dict keys; optim.FusedAdamW notices the move and rebuilds its tables)
+        self.etab_flat = None
+        tabs_all = [[t.weight for t in getattr(conv.edge_encoder, "bond_embedding_list", [])] for conv, _ in self.convs]
+        if any(tabs_all):
+            with torch.no_grad():
+                flat = torch.cat([t.detach() for tl in tabs_all for t in tl]).contiguous()
+                r0 = 0
+                for tl in tabs_all:
+                    for t in tl:
+                        n_ = int(t.shape[0])
+                        t.data = flat[r0:r0 + n_]
+                        r0 += n_
+            self.etab_flat = flat
+        self.conv_desc = ((layers.GinLayerDesc if self.kind == "gin" else layers.GcnLayerDesc) * L)()
+        for l, (conv, bn) in enumerate(self.convs):
+            desc = self.conv_desc[l]
+            ee = conv.edge_encoder
+            tabs = tabs_all[l]
+            if tabs:
+                edge, mode = tabs, "tables"
+            elif isinstance(ee, torch.nn.Module):
+                edge, mode = [ee.weight, ee.bias], "linear"
+            else:
+                edge, mode = [], None
+            if self.kind == "gcn":
+                plist = [conv.linear.weight, conv.linear.bias, conv.root_emb.weight, *edge, bn.weight, bn.bias]
+                self.w3_weights.append(conv.linear.weight)
+            else:
+                m = list(conv.mlp)
+                plist = [conv.eps, *edge, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, bn.weight, bn.bias]
+                self.w3_weights += [m[0].weight, m[3].weight]
+            off = None
+            for p in plist:
+                o = seg(p)
+                off = o if off is None else off
+                if self.kind == "gin" and p is conv.eps:
+                    self.total = o + 20   # d_eps + the aggregate backward's scratch (GIN_EPS_SLOT in layers.hip)
+            cm.off_conv[l] = off
+            desc.D = D
+            if self.kind == "gcn":
+                desc.lin_w, desc.lin_b, desc.root = conv.linear.weight.data_ptr(), conv.linear.bias.data_ptr(), conv.root_emb.weight.data_ptr()
+            else:
+                desc.eps = conv.eps.data_ptr()
+                desc.w1, desc.b1, desc.bn1_w, desc.bn1_b = m[0].weight.data_ptr(), m[0].bias.data_ptr(), m[1].weight.data_ptr(), m[1].bias.data_ptr()
+                desc.w2, desc.b2 = m[3].weight.data_ptr(), m[3].bias.data_ptr()
+                desc.bn1_rm, desc.bn1_rv, desc.bn1_nbt = m[1].running_mean.data_ptr(), m[1].running_var.data_ptr(), m[1].num_batches_tracked.data_ptr()
+            if mode == "linear":
+                desc.edge_mode = GT_EDGE_LINEAR
+                desc.edge_cols = ee.weight.shape[1]
+                desc.edge_w, desc.edge_b = ee.weight.data_ptr(), ee.bias.data_ptr()
+            elif mode == "tables":
+                desc.edge_mode = GT_EDGE_TABLES
+                desc.edge_cols, desc.table_rows = len(tabs), sum(int(t.shape[0]) for t in tabs)
+                acc = 0
+                for i, t in enumerate(tabs):
+                    desc.tab_off[i] = acc
+                    acc += int(t.shape[0])
+                desc.edge_w = tabs[0].data_ptr()   # the layer's stacked [rows][D] block
+            else:
+                desc.edge_mode = GT_EDGE_NONE
+            desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
+            desc.bn_rm, desc.bn_rv, desc.bn_nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+            desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+
+    _SCALER_KIND = {None: 0, "identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
+
+    def _init_pna(self, gnn, seg):
+        """PNANodeEmbedding (modules/pna/pna_module.py:16-78): per layer lin / BatchNorm gradients in the layer block of the flat
+        buffer; the tower weights of ALL layers live in one flat storage (the parameters become views of it), from which the driver
+        rebuilds the re-stacked images [A ; B], [b | 0], the per-scaler post-Linear blocks and their bias with ONE gather per step."""
+        from .modules.pna.pna_module import _AGG_SLOT
+        cm, L, D = self.cm, self.L, self.D
+        convs = list(gnn.layers)
+        bns = [b.module for b in gnn.batch_norms]
+        self.convs = list(zip(convs, bns))
+        c0 = convs[0]
+        T, F = c0.towers, c0.F_in
+        A, S = len(c0.aggregators), len(c0._blocks)
+        first = S - len(c0.scalers)
+        cols = (A * len(c0.scalers) + 1) * F
+        self.conv_desc = (layers.PnaLayerDesc * L)()
+        # ---- flat tower storage: per layer [pre_w (T,F,2F) | pre_b (T,F) | post_w (T,F,cols) | post_b (T,F)]
+        per_layer = T * F * 2 * F + T * F + T * F * cols + T * F
+        n_src = L * per_layer
+        with torch.no_grad():
+            flat = torch.empty(n_src, dtype=torch.float32, device=self.dev)
+            off = 0
+            tower_params = []   # (param, offset inside the flat storage)
+            for conv in convs:
+                for group, shape in ((lambda m: m[0].weight, (F, 2 * F)), (lambda m: m[0].bias, (F,))):
+                    for t in range(T):
+                        p = group(conv.pre_nns[t])
+                        n_ = p.numel()
+                        flat[off:off + n_].copy_(p.detach().reshape(-1))
+                        p.data = flat[off:off + n_].view(shape)
+                        tower_params.append((p, off))
+                        off += n_
+                for group, shape in ((lambda m: m[0].weight, (F, cols)), (lambda m: m[0].bias, (F,))):
+                    for t in range(T):
+                        p = group(conv.post_nns[t])
+                        n_ = p.numel()
+                        flat[off:off + n_].copy_(p.detach().reshape(-1))
+                        p.data = flat[off:off + n_].view(shape)
+                        tower_params.append((p, off))
+                        off += n_
+            assert off == n_src
+        self.pna_flat = flat
+        # ---- image layout per layer: [pre_stack (T,2F,F) | pre_b2 (T,2F) | Wst (T,S*F,5F) | bst (T,S*F)] and the gather map
+        img_per_layer = T * 2 * F * F + T * 2 * F + T * S * F * 5 * F + T * S * F
+        n_img = L * img_per_layer
+        mp = np.full(n_img, -1, dtype=np.int64)
+        t_ = np.arange(T).reshape(T, 1, 1)
+        for l in range(L):
+            sb = l * per_layer                      # source bases of this layer
+            s_pre_w, s_pre_b = sb, sb + T * F * 2 * F
+            s_post_w, s_post_b = s_pre_b + T * F, s_pre_b + T * F + T * F * cols
+            ib = l * img_per_layer
+            i_pre_w, i_pre_b = ib, ib + T * 2 * F * F
+            i_post_w, i_post_b = i_pre_b + T * 2 * F, i_pre_b + T * 2 * F + T * S * F * 5 * F
+            r = np.arange(2 * F).reshape(1, 2 * F, 1)
+            k = np.arange(F).reshape(1, 1, F)
+            src = s_pre_w + t_ * (F * 2 * F) + np.where(r < F, r, r - F) * (2 * F) + np.where(r < F, 0, F) + k
+            mp[i_pre_w:i_pre_w + T * 2 * F * F] = src.reshape(-1)
+            rb = np.arange(2 * F).reshape(1, 2 * F)
+            srcb = np.where(rb < F, s_pre_b + np.arange(T).reshape(T, 1) * F + rb, -1)
+            mp[i_pre_b:i_pre_b + T * 2 * F] = srcb.reshape(-1)
+            # post: block s of tower t, output o, operand column c in [x | mean | max | min | std] (modules/pna/pna_module.py:_post_maps)
+            w = np.full((T, S * F, 5 * F), -1, dtype=np.int64)
+            o = np.arange(F).reshape(F, 1)
+            f = np.arange(F).reshape(1, F)
+            for t in range(T):
+                tb = s_post_w + t * F * cols
+                for s_ in range(S):
+                    rows = slice(s_ * F, (s_ + 1) * F)
+                    if s_ == 0:
+                        w[t, rows, 0:F] = tb + o * cols + f
+                    if s_ < first:
+                        continue
+                    for ai, a in enumerate(c0.aggregators):
+                        slot = _AGG_SLOT[a]
+                        w[t, rows, F + slot * F:F + (slot + 1) * F] = tb + o * cols + F + (s_ - first) * A * F + ai * F + f
+            mp[i_post_w:i_post_w + T * S * F * 5 * F] = w.reshape(-1)
+            bb = np.full((T, S * F), -1, dtype=np.int64)
+            bb[:, :F] = s_post_b + np.arange(T).reshape(T, 1) * F + np.arange(F).reshape(1, F)
+            mp[i_post_b:i_post_b + T * S * F] = bb.reshape(-1)
+            for j, v in enumerate((i_pre_w, i_pre_b, i_post_w, i_post_b)):
+                cm.pna_img_off[l][j] = v
+        inv = np.full(n_src, -1, dtype=np.int64)
+        used = mp >= 0
+        inv[mp[used]] = np.nonzero(used)[0]
+        assert (inv >= 0).all(), "every tower weight sits in the images exactly once"
+        self.pna_map = torch.from_numpy(mp.astype(np.int32)).to(self.dev)
+        self.pna_inv = torch.from_numpy(inv.astype(np.int32)).to(self.dev)
+        self.pna_img = torch.zeros(n_img, dtype=torch.float32, device=self.dev)
+        # ---- gradient layout: per layer [lin_w, lin_b, bn_w, bn_b] (gt_pna_layer_bwd's order), then the flat tower storage
+        for l, (conv, bn) in enumerate(self.convs):
+            off0 = None
+            for p in (conv.lin.weight, conv.lin.bias, bn.weight, bn.bias):
+                o_ = seg(p)
+                off0 = o_ if off0 is None else off0
+            cm.off_conv[l] = off0
+            self.w3_weights.append(conv.lin.weight)
+            desc = self.conv_desc[l]
+            desc.D, desc.T, desc.S = D, T, S
+            ib = l * img_per_layer
+            base = self.pna_img.data_ptr()
+            desc.pre_w, desc.pre_b = base + 4 * cm.pna_img_off[l][0], base + 4 * cm.pna_img_off[l][1]
+            desc.post_w, desc.post_b = base + 4 * cm.pna_img_off[l][2], base + 4 * cm.pna_img_off[l][3]
+            desc.lin_w, desc.lin_b = conv.lin.weight.data_ptr(), conv.lin.bias.data_ptr()
+            desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
+            desc.bn_rm, desc.bn_rv, desc.bn_nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+            desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+        cm.off_pna_src = self.total
+        for p, o_ in tower_params:
+            self.params.append((p, self.total + o_))
+        self.total += n_src
+        cm.pna_src, cm.pna_img = flat.data_ptr(), self.pna_img.data_ptr()
+        cm.pna_map, cm.pna_inv = self.pna_map.data_ptr(), self.pna_inv.data_ptr()
+        cm.pna_n_img, cm.pna_n_src = n_img, n_src
+        for i, blk in enumerate(c0._blocks):
+            cm.pna_kinds[i] = self._SCALER_KIND[blk]
+        cm.pna_avg_log, cm.pna_avg_lin = float(c0.avg_deg["log"]), float(c0.avg_deg["lin"])
 
     def _set_min_elems(self):
         self.min_elems = DW_OVERLAP_MIN_ELEMS
@@ -558,6 +694,8 @@ def eligible(model, batched_data, perturb):
             # e.g. the reference's `--feature simple` (dataset/mol.py:65-69) slices x to 2 columns: the fused kernels
             # index one column per table, so a different column count goes through the module path
             return False
+    if hasattr(gnn, "layers"):   # PNANodeEmbedding: no edge features on its path (modules/pna/pna_module.py:73)
+        return True
     # edge features: the aggregate kernels read `edge_cols` values per edge at that pitch
     ee = gnn.convs[0].edge_encoder
     ea = getattr(batched_data, "edge_attr", None)
@@ -603,6 +741,8 @@ def _eligible_static(model):
     from .modules.conv import GCNConv
     from .modules.norm import BatchNorm1d
     gnn, enc = model.gnn_node, model.transformer_encoder
+    if hasattr(gnn, "layers"):
+        return _eligible_static_pna(model)
     try:
         if not model._use_packed() or gnn.JK not in ("last", "cat"):
             return False
@@ -663,6 +803,59 @@ def _eligible_static(model):
         # (synchronised BatchNorm -- statistics over all data-parallel ranks -- runs on this path too: the library's BatchNorm calls
         # exchange their statistics through dist.BnSyncHook, installed around the pass; all of the model's BatchNorms or none)
         from .modules.norm import any_sync
+        bns = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
+        if any_sync(*bns) and not all(getattr(b, "sync", False) for b in bns):
+            return False
+        if any_sync(*bns) and len({id(getattr(b, "sync_group", None)) for b in bns}) != 1:
+            return False
+        for p in model.parameters():
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad):
+                return False
+    except Exception:
+        return False
+    return True
+
+
+def _eligible_static_pna(model):
+    """PNATransformer (models/pna_transformer.py:16-118) on the fused path: PNANodeEmbedding with the residual connection, towers
+    that divide the input, single-layer pre / post nets, packed token layout."""
+    from .modules.norm import BatchNorm1d, any_sync
+    from .modules.pna.pna_module import PNAConv, _AGG_SLOT
+    gnn, enc = model.gnn_node, model.transformer_encoder
+    try:
+        if not (model.pooling in ("cls", "last") and getattr(model, "layout", "auto") != "padded" and len(enc.transformer.layers) > 0):
+            return False
+        convs = list(gnn.layers)
+        if not convs or len(convs) > MAXL or len(enc.transformer.layers) > MAXL or not gnn.residual:
+            return False
+        c0 = convs[0]
+        for c in convs:
+            if not (isinstance(c, PNAConv) and c.divide_input and c.in_channels == c.out_channels == c0.in_channels and c.towers == c0.towers
+                    and c.F_in == c.F_out and c.aggregators == c0.aggregators and c.scalers == c0.scalers and c.avg_deg == c0.avg_deg):
+                return False
+        if len(c0._blocks) > 8 or any(a not in _AGG_SLOT for a in c0.aggregators) or c0.in_channels > 1024:
+            return False
+        if any(b not in _Plan._SCALER_KIND for b in c0._blocks):
+            return False
+        for bn in gnn.batch_norms:
+            m = getattr(bn, "module", None)
+            if not (isinstance(m, BatchNorm1d) and m.affine and m.track_running_stats and m.momentum is not None):
+                return False
+        ne = gnn.node_encoder
+        if type(ne) is torch.nn.Linear:
+            if ne.bias is None:
+                return False
+        elif not (hasattr(ne, "type_encoder") or hasattr(ne, "atom_embedding_list")):
+            return False
+        if hasattr(ne, "atom_embedding_list") and len(ne.atom_embedding_list) > 16:
+            return False
+        if model.gnn2transformer.in_features != c0.in_channels or c0.in_channels % 4:
+            return False
+        if enc.activation not in layers.ENC_ACT or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
+            return False
+        for mod in enc.transformer.layers:
+            if mod.linear1.weight.shape[0] % 8:
+                return False
         bns = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
         if any_sync(*bns) and not all(getattr(b, "sync", False) for b in bns):
             return False
@@ -755,7 +948,7 @@ class _FusedModel(torch.autograd.Function):
                 bt.node_depth, bt.depth_stride = depth.data_ptr(), (depth.stride(0) if N > 1 else 1)
                 keep.append(depth)
         ea = getattr(batched_data, "edge_attr", None)
-        mode0 = plan.conv_desc[0].edge_mode
+        mode0 = plan.conv_desc[0].edge_mode if plan.kind != "pna" else GT_EDGE_NONE
         if mode0 == GT_EDGE_LINEAR:
             ea = ea if (ea.dtype == torch.float32 and ea.is_contiguous()) else ea.float().contiguous()
         elif mode0 == GT_EDGE_TABLES:

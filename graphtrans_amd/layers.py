@@ -62,6 +62,16 @@ class VnUpdateDesc(C.Structure):
                [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad2_", C.c_int32), ("ev_dx_done", _fp)]
 
 
+class PnaLayerDesc(C.Structure):   # gt_pna_layer
+    _fields_ = [("N", C.c_int64), ("E", C.c_int64), ("D", C.c_int64),
+                ("T", C.c_int32), ("S", C.c_int32), ("training", C.c_int32), ("compute", C.c_int32),
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)] + \
+               [(n, _fp) for n in ("in_ptr", "in_src", "in_eid", "out_ptr", "out_dst", "out_eid", "scales", "pre_w", "pre_b", "post_w",
+                                   "post_b", "lin_w", "lin_b", "bn_w", "bn_b", "bn_rm", "bn_rv", "bn_nbt", "d_pre_w", "d_pre_b",
+                                   "d_post_w", "d_post_b")] + \
+               [("seed", C.c_uint64), ("dropout_p", C.c_float), ("pad_", C.c_int32)]
+
+
 def _any_sync(*bns):
     from .modules.norm import any_sync
     return any_sync(*bns)

@@ -66,6 +66,13 @@ class PNATransformer(BaseModel):
         self.layout = getattr(args, "token_layout", "auto")
 
     def forward(self, batched_data, perturb=None):
+        from .. import engine
+        if engine.eligible(self, batched_data, perturb):   # whole model as one autograd node, one C call per direction (engine.py)
+            out = engine.forward(self, batched_data)
+            if self.max_seq_len is None:
+                return out
+            from .base_model import StackedHeads
+            return StackedHeads(out.view(out.shape[0], self.max_seq_len, self.num_tasks))
         h_node = self.gnn_node(batched_data, perturb)
         h_node = ops.linear_module(self.gnn2transformer, h_node)
         gs = batch_structure(batched_data)
@@ -94,3 +101,5 @@ class PNATransformer(BaseModel):
         if self.freeze_gnn is not None and epoch >= self.freeze_gnn:
             for param in self.gnn_node.parameters():
                 param.requires_grad = False
+            from .. import engine
+            engine.invalidate(self)   # the fused path covers fully trainable models only

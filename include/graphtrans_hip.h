@@ -38,7 +38,7 @@ enum gt_status {
 };
 
 enum gt_dtype { GT_F32 = 0, GT_BF16 = 1 };
-enum gt_conv { GT_CONV_GCN = 0, GT_CONV_GIN = 1 };
+enum gt_conv { GT_CONV_GCN = 0, GT_CONV_GIN = 1, GT_CONV_PNA = 2 /* the whole-model driver's third layer kind (gt_pna_layer) */ };
 enum gt_edge_mode {
   GT_EDGE_NONE = 0,   /* edge embedding == 0          (dataset/tud.py:67-71)            */
   GT_EDGE_LINEAR = 1, /* nn.Linear(K, D) on f32 attrs (dataset/code.py:117), K <= 4     */
@@ -735,6 +735,56 @@ int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, v
 int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, const void* d_x_add, void* d_x,
                      void* d_vn, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
+/* PNA layer (modules/pna/pna_module.py:57-78 around PyG's PNAConv(towers = T, divide_input = True, no edge features); math stated
+ * in-tree by modules/pna_layer.py:131-167, modules/pna/aggregators.py:11-34, modules/pna/scalers.py:10-31):
+ *   x' = relu(BN(lin(post(cat[x, scaled aggregates of pre([x_i || x_j])])))) + x   [then F.dropout when dropout_p > 0]
+ * on re-stacked IMAGES of the tower weights (built by the caller with gt_gather_f32 once per step, all layers in one launch):
+ *   pre_w  [T][2F][F] = [A_t ; B_t] (pre_nns[t].weight [F][2F] = [A_t | B_t]: U = x_t A_t^T + b_t is the target-role term, V = x_t B_t^T the
+ *                       source-role term of the per-edge Linear), pre_b [T][2F] = [b_t | 0]
+ *   post_w [T][S Fo][5F]: block s = the columns of scaler s over the kernel's [x | mean | max | min | std] operand (x and the bias in
+ *                       block 0 only, zeros for unused aggregators), post_b [T][S Fo]; scales [N][S] = the per-node degree scalers.
+ * One grouped GEMM gives [U | V] for all towers, the aggregate kernel writes [x | mean | max | min | std] where the grouped post-GEMM
+ * reads it, its S output blocks are combined with the scalers, then lin + BatchNorm + ReLU + residual.  `grads` (gradient order):
+ * lin_w [D][D], lin_b [D], bn_w [D], bn_b [D]; the image gradients go to d_pre_w / d_pre_b / d_post_w / d_post_b (same shapes as the
+ * images; the caller maps them back onto the parameters with gt_gather_f32 through the inverse map). */
+typedef struct gt_pna_layer {
+  int64_t N, E, D;
+  int32_t T, S, training, compute;
+  float bn_momentum, bn_eps;
+  const int32_t *in_ptr, *in_src, *in_eid, *out_ptr, *out_dst, *out_eid;
+  const float* scales;
+  const float *pre_w, *pre_b, *post_w, *post_b;   /* images */
+  const float *lin_w, *lin_b, *bn_w, *bn_b;
+  float *bn_rm, *bn_rv;
+  int64_t* bn_nbt;
+  float *d_pre_w, *d_pre_b, *d_post_w, *d_post_b; /* image gradients (backward) */
+  uint64_t seed;
+  float dropout_p;
+  int32_t pad_;
+} gt_pna_layer;
+size_t gt_pna_layer_saved_bytes(const gt_pna_layer* layer);
+size_t gt_pna_layer_workspace_bytes(const gt_pna_layer* layer);
+int64_t gt_pna_layer_grad_elems(const gt_pna_layer* layer);
+int gt_pna_layer_fwd(const gt_pna_layer* layer, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
+                     gt_stream_t stream);
+int gt_pna_layer_bwd(const gt_pna_layer* layer, const void* x, const void* dy, const void* saved, void* dx, float* grads,
+                     void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* per-node degree scalers of PNAConv for one batch: scales[n][s], s over `kinds` (0 identity / none, 1 amplification
+ * log(d+1)/avg_log, 2 attenuation avg_log/log(d+1) (1 at d = 0), 3 linear d/avg_lin, 4 inverse_linear avg_lin/d (1 at d = 0)),
+ * d = in-degree from in_ptr (modules/pna/scalers.py:10-31). */
+int gt_pna_scales(const int32_t* in_ptr, int64_t num_nodes, int num_scalers, const int32_t* kinds_host, float avg_log, float avg_lin,
+                  float* scales, gt_stream_t stream);
+/* dst[i] = map[i] < 0 ? 0 : src[map[i]] (fp32): re-stacked weight images and, through the inverse map, their gradients */
+int gt_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, gt_stream_t stream);
+/* gt_pna_aggregate_* on the fused layer's layouts: UV [N][T][2F] = [U_t | V_t], in5 [N][T][5F] = [x_t | mean | max | min | std]
+ * (x copied on the way in), backward from d_in5 to dUV [N][T][2F] and the x block's gradient dxpart [N][D]. */
+int gt_pna_aggregate_fwd_uv(const float* UV, const float* x, int64_t num_nodes, int64_t dim, int towers, const int32_t* in_ptr,
+                            const int32_t* in_src, const int32_t* in_eid, float* in5, float* mean_v, int32_t* arg,
+                            gt_stream_t stream);
+int gt_pna_aggregate_bwd_uv(const float* UV, const float* in5, const float* mean_v, const int32_t* arg, const float* d_in5,
+                            int64_t num_nodes, int64_t dim, int towers, const int32_t* in_ptr, const int32_t* out_ptr,
+                            const int32_t* out_dst, const int32_t* out_eid, float* dUV, float* dxpart, gt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-model driver: ONE C call per direction for the training step's forward and backward.
  * Replaces the per-step Python sequencing of the composites above (the reference's step is
@@ -773,11 +823,11 @@ typedef struct gt_stage_ring {   /* pinned HOST staging slots for the token layo
 } gt_stage_ring;
 
 typedef struct gt_model {
-  int32_t conv /* GT_CONV_GCN | GT_CONV_GIN */, L, n_enc, has_vn, jk_cat, residual;
+  int32_t conv /* GT_CONV_GCN | GT_CONV_GIN | GT_CONV_PNA */, L, n_enc, has_vn, jk_cat, residual;
   int32_t embed_kind /* 0 one table per column of x (AtomEncoder), 1 nn.Linear, 2 ASTNodeEncoder (x[:,0], x[:,1], node_depth) */, n_tables, vn0_in_embed, embed_sorted;
   int32_t with_cls, vn_defer_dw;
   int64_t D, d, Nh, ldy, ne_K, max_input_len, dw_overlap_min_elems;
-  void* conv_layers;        /* gt_gcn_layer[L] | gt_gin_layer[L]: static fields filled by the caller */
+  void* conv_layers;        /* gt_gcn_layer[L] | gt_gin_layer[L] | gt_pna_layer[L]: static fields filled by the caller */
   gt_vn_update* vn;         /* [L-1] or NULL */
   gt_encoder_layer* enc;    /* [n_enc] */
   const float* tables[GT_MODEL_MAX_TABLES];
@@ -795,6 +845,17 @@ typedef struct gt_model {
       *ev_pool[GT_MODEL_MAX_LAYERS];
   void *ev_vnemb, *ev_sort[2], *ev_wt[2], *ev_prep_begin, *ev_graph, *ev_w1;
   gt_image_set w3, w3_enc, w1;   /* bf16x3 images without / with the encoder weights, fragment-order encoder images */
+  /* conv == GT_CONV_PNA (conv_layers = gt_pna_layer[L]; no virtual node, JK = last, residual): every tower weight of every layer
+   * lives in ONE flat fp32 buffer pna_src [pna_n_src]; the forward rebuilds the re-stacked images pna_img [pna_n_img] with one
+   * gt_gather_f32 through pna_map, the backward maps the image gradients back onto the flat gradient buffer at off_pna_src through
+   * pna_inv [pna_n_src].  pna_img_off[l] = offsets (floats) of layer l's {pre_w, pre_b, post_w, post_b} inside the image. */
+  const float* pna_src;
+  float* pna_img;
+  const int32_t *pna_map, *pna_inv;
+  int64_t pna_n_img, pna_n_src, off_pna_src;
+  int64_t pna_img_off[GT_MODEL_MAX_LAYERS][4];
+  int32_t pna_kinds[8];          /* degree scalers of the S output blocks (gt_pna_scales) */
+  float pna_avg_log, pna_avg_lin;
 } gt_model;
 
 typedef struct gt_model_batch {

@@ -224,3 +224,46 @@ def test_pna_transformer_c4_shape_vs_oracle():
     for k, p in model.named_parameters():
         if sd[k].grad is not None:
             assert_close(p.grad.cpu(), sd[k].grad, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("dropout,aggs,scalers", [(0.0, ["mean", "max", "min", "std"], ["identity", "amplification", "attenuation"]),
+                                                   (0.0, ["mean", "std"], ["amplification", "attenuation"]),
+                                                   (0.25, ["mean", "max", "min", "std"], ["identity", "amplification", "attenuation"])])
+def test_pna_fused_path_equals_module_path(dropout, aggs, scalers):
+    """PNATransformer on the fused path (engine.py -> gt_model_forward / gt_model_backward with gt_pna_layer_*) against the
+    module-by-module path: same parameters, same batch; outputs and every parameter gradient agree to GEMM-reordering noise.
+    With GNN dropout > 0 the two paths draw different masks, so only eligibility, finiteness and the eval-mode outputs are compared."""
+    import copy
+
+    from graphtrans_amd import engine, losses, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.pna_transformer import PNATransformer
+    from oracle import reference_math as rm
+
+    torch.manual_seed(11)
+    args = rm.default_args(gnn_virtual_node=False, gnn_num_layer=3, gnn_emb_dim=64, gnn_JK="last", gnn_residual=True,
+                           gnn_dropout=dropout, d_model=64, nhead=4, dim_feedforward=128, transformer_dropout=0.0,
+                           num_encoder_layers=2, transformer_norm_input=True, graph_pooling="cls", max_seq_len=3,
+                           aggregators=aggs, scalers=scalers, deg=torch.tensor([0, 40, 25, 9, 3]))
+    b = synth.code2_like(B=24, seed=2, mean_nodes=20.0, max_nodes=60).to(DEV)
+    model = PNATransformer(50, ASTNodeEncoder(64, 98, 10030, 20), None, args).to(DEV).train()
+    ref = copy.deepcopy(model)
+    ref.fused = False
+    assert engine.eligible(model, b, None) and not engine.eligible(ref, b, None)
+    model.eval(), ref.eval()   # (before any training step: the running statistics are still identical)
+    with torch.no_grad():
+        assert engine.eligible(model, b, None)
+        for o, r in zip(model(b), ref(b)):
+            assert_close(o.cpu(), r.cpu(), what="eval out")
+    model.train(), ref.train()
+    if dropout == 0.0:
+        for m in (model, ref):
+            loss = losses.code2_loss(m(b), b.y_arr)
+            loss.backward()
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert p.grad is not None and q.grad is not None, k
+            assert_close(p.grad.cpu(), q.grad.cpu(), what=f"grad {k}")
+    else:
+        loss = losses.code2_loss(model(b), b.y_arr)
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
