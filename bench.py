@@ -618,6 +618,18 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    # the host's own cost of a step: enqueue time measured from an IDLE device, one step at a time (in the timed loop above a
+    # GPU-bound step makes the host wait for queue space, so host_enqueue_ms_per_step there is bounded below by the device time)
+    idle = []
+    for i in range(min(12, max(opt.steps, 1))):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(opt.warmup + opt.steps + i)
+        idle.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    idle.sort()
+    host_idle_ms = 1e3 * idle[len(idle) // 2]
+    dp_stats = dict(sync.stats)
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps) if not sample(i))
     res = None
     if rank == 0:
@@ -643,7 +655,24 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                        "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics",
                        "interpreter": "gc.freeze() after warm-up (set-up heap out of the cyclic collector's full passes)"},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / opt.steps, 3),
+            "host_enqueue_ms_per_step_idle_device": round(host_idle_ms, 3),
         }
+        if world > 1:
+            import torch.distributed as dist
+            nsteps = opt.warmup + opt.steps + len(idle)
+            hook = None
+            try:
+                from graphtrans_amd import engine as _eng
+                hook = _eng.state(model).get("bn_hook")
+            except Exception:
+                pass
+            res["data_parallel"] = {
+                "backend": dist.get_backend(), "ranks": dist.get_world_size(), "rank0_device": str(device),
+                "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                "grad_allreduce_collectives_per_step": round(dp_stats["collectives"] / max(nsteps, 1), 2),
+                "grad_allreduce_mb_per_step": round(dp_stats["bytes"] / max(nsteps, 1) / 1e6, 2),
+                "syncbn_exchanges_per_step": round(hook.calls / max(nsteps, 1), 1) if hook is not None else 0,
+            }
         if records:
             d_model, max_len = args.d_model, int(args.max_input_len)
             fl = []
@@ -746,10 +775,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("GT_BENCH_BACKEND", "nccl")
+        # a rank that fails inside the second (other-scaling) measurement leaves its peers inside a collective: the group's timeout
+        # turns that hang into an exception on them, which the try/except around that measurement records next to the headline
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("GT_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     if opt.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {opt.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -771,7 +804,7 @@ def main():
         try:   # the second measurement must not take the headline line down with it (every rank takes the same branch)
             o, model, _, _ = measure(opt, opt.mode, other, world, rank, device, want_kernels=False)
             if rank == 0:
-                res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step")} | \
+                res[other + "_scaling"] = {k: o[k] for k in ("value", "ms_per_step", "scaling", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_idle_device", "data_parallel") if k in o} | \
                     {"graphs_per_gpu": o["config"]["graphs_per_gpu"], "global_batch": o["config"]["global_batch"],
                      "batchnorm": o["config"]["batchnorm"]}
             if other == "strong" and not opt.no_sync_bn:   # and what the synchronised statistics cost: the same split with per-rank statistics
@@ -785,13 +818,14 @@ def main():
             model = None
             if rank == 0:
                 res[other + "_scaling"] = {"error": repr(e)[:500]}
+            extra = False   # (the group may be broken: nothing collective after this)
     if extra and world == 1:
         others = [m for m in ("mixed", "bf16", "fp32") if m != opt.mode]
         res["modes"] = {}
         for m in others:
             del model
             o, model, _, _ = measure(opt, m, opt.scaling, world, rank, device)
-            res["modes"][m] = {k: o[k] for k in ("value", "ms_per_step", "ms_per_step_median_device", "dtype", "host_enqueue_ms_per_step", "final_loss") if k in o}
+            res["modes"][m] = {k: o[k] for k in ("value", "ms_per_step", "ms_per_step_median_device", "dtype", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_idle_device", "final_loss") if k in o}
             res["modes"][m]["config"] = {k: o["config"][k] for k in ("mode", "gnn_dtype", "transformer_dtype")}
             if "roofline" in o:
                 res["modes"][m]["roofline"] = o["roofline"]
@@ -822,8 +856,11 @@ def main():
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()   # rank 0 is still writing its report: leave the group together
-        dist.destroy_process_group()
+        try:
+            dist.barrier()   # rank 0 is still writing its report: leave the group together
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

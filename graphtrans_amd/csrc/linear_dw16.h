@@ -207,7 +207,10 @@ static inline bool dw16_ok(int x_dtype, int y_dtype, int compute, const void* x,
 }
 static inline int dw16_splits(int64_t M, int64_t N, int64_t K, int cap) {
   const int64_t tiles = (N / D16_T) * (K / D16_T);
-  int64_t s = dw16_blocks() / tiles;
+  // two blocks per CU (2 x 64 KB of LDS) once the contraction is long enough that the doubled partials stay small beside the operands:
+  // at M = 131 k (the Erdos-Renyi stress) 512 blocks run the N or K = 1024 shapes in 125-133 us against 174-185 us (tools/dw16_bench.py)
+  const int64_t target = (M >= 65536 && !getenv("GT_DW16_BLOCKS")) ? 2 * dw16_blocks() : dw16_blocks();
+  int64_t s = target / tiles;
   const int64_t maxs = gt_cdiv(M, 4 * D16_ROWS);   // at least four stages per split
   if (s > maxs) s = maxs;
   if (s > cap) s = cap;

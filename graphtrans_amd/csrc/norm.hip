@@ -781,25 +781,27 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd(LnArgs a) {
 // 16-byte load per operand -- four rows per wave and trip instead of two, half the trips and half the dependent shuffle steps of the
 // generic kernel (19 us for 40 MB at Code2's 32 k token rows: a chain of round trips, not bandwidth).  Same arithmetic, same dropout
 // hash, same partial layout ([block][2][D]) for k_ln_bwd_finish.
-template <int NTB>
+template <int NTB, int DD>
 __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [waves][2][128]
+  static_assert(DD == 128 || DD == 256, "8 columns per lane, 16 or 32 lanes per row");
+  constexpr int LPR = DD / 8, RPW = 64 / LPR;   // lanes per row, rows per wave and trip
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [waves][2][DD]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int sub = lane >> 4, sl = lane & 15, col = sl * 8;
+  const int sub = lane / LPR, sl = lane % LPR, col = sl * 8;
   const gt_bf16* dy = reinterpret_cast<const gt_bf16*>(a.dy);
   const gt_bf16* xin = reinterpret_cast<const gt_bf16*>(a.x);
   const gt_bf16* rin = reinterpret_cast<const gt_bf16*>(a.resid);
   float gw[8], aw[8], ab[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gw[e] = a.w[col + e]; aw[e] = 0.f; ab[e] = 0.f; }
-  const int64_t stride = (int64_t)gridDim.x * (NTB / 64) * 4;
-  int64_t row = ((int64_t)blockIdx.x * (NTB / 64) + wid) * 4 + sub;
+  const int64_t stride = (int64_t)gridDim.x * (NTB / 64) * RPW;
+  int64_t row = ((int64_t)blockIdx.x * (NTB / 64) + wid) * RPW + sub;
   // the next trip's operands are in flight while this trip is reduced
   uint4 cx, cr, cd, nx, nr, nd;
   float cmu, crs, nmu, nrs;
   auto clampr = [&](int64_t r) { return r < a.rows ? r : a.rows - 1; };
   {
-    const int64_t q = clampr(row) * 128 + col;
+    const int64_t q = clampr(row) * DD + col;
     cx = *reinterpret_cast<const uint4*>(xin + q);
     cr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
     cd = *reinterpret_cast<const uint4*>(dy + q);
@@ -808,7 +810,7 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
   }
   for (; row - sub < a.rows; row += stride) {   // (uniform per wave: its four rows start at row - sub)
     {
-      const int64_t rn = clampr(row + stride), q = rn * 128 + col;
+      const int64_t rn = clampr(row + stride), q = rn * DD + col;
       nx = *reinterpret_cast<const uint4*>(xin + q);
       nr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
       nd = *reinterpret_cast<const uint4*>(dy + q);
@@ -847,20 +849,20 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
     }
     s1 = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
     s2 = ((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) + ((g[4] * xh[4] + g[5] * xh[5]) + (g[6] * xh[6] + g[7] * xh[7]));
-    const float m1 = group_sum<16>(s1) * (1.0f / 128.0f), m2 = group_sum<16>(s2) * (1.0f / 128.0f);
+    const float m1 = group_sum<LPR>(s1) * (1.0f / (float)DD), m2 = group_sum<LPR>(s2) * (1.0f / (float)DD);
     float dz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) dz[e] = crs * (g[e] - m1 - xh[e] * m2);
     if (live) {
       if (a.dresid)
-        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dresid) + row * 128 + col) =
+        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dresid) + row * DD + col) =
             make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
       if (a.dx) {
         if (a.thr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dz[e] = keep[e] ? dz[e] * a.inv_keep : 0.f;
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dx) + row * 128 + col) =
+        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dx) + row * DD + col) =
             make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
       }
     }
@@ -869,23 +871,24 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
   // the four row groups of a wave -> the waves of the block -> one partial row per block
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    aw[e] += __shfl_xor(aw[e], 16, 64); aw[e] += __shfl_xor(aw[e], 32, 64);
-    ab[e] += __shfl_xor(ab[e], 16, 64); ab[e] += __shfl_xor(ab[e], 32, 64);
+    if (LPR == 16) { aw[e] += __shfl_xor(aw[e], 16, 64); ab[e] += __shfl_xor(ab[e], 16, 64); }
+    aw[e] += __shfl_xor(aw[e], 32, 64);
+    ab[e] += __shfl_xor(ab[e], 32, 64);
   }
   if (sub == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      lds[(wid * 2 + 0) * 128 + col + e] = aw[e];
-      lds[(wid * 2 + 1) * 128 + col + e] = ab[e];
+      lds[(wid * 2 + 0) * DD + col + e] = aw[e];
+      lds[(wid * 2 + 1) * DD + col + e] = ab[e];
     }
   }
   __syncthreads();
-  float* part = a.part + (int64_t)blockIdx.x * 256;
-  for (int i = threadIdx.x; i < 256; i += NTB) {
+  float* part = a.part + (int64_t)blockIdx.x * 2 * DD;
+  for (int i = threadIdx.x; i < 2 * DD; i += NTB) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NTB / 64; ++w) t += lds[w * 256 + i];
-    part[i] = t;   // [0][128] = dweight partial, [1][128] = dbias partial
+    for (int w = 0; w < NTB / 64; ++w) t += lds[w * 2 * DD + i];
+    part[i] = t;   // [0][DD] = dweight partial, [1][DD] = dbias partial
   }
 }
 __global__ void k_ln_bwd_finish(const float* __restrict__ part, int nblk, int64_t D, float* __restrict__ dweight,
@@ -907,7 +910,11 @@ void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
   if constexpr (BWD && sizeof(T) == 2) {
     static const bool d128 = [] { const char* e = getenv("GT_LN_BWD_D128"); return !e || atoi(e) != 0; }();   // (A/B knob)
     if (D == 128 && d128) {
-      hipLaunchKernelGGL((k_ln_bwd_d128<1024>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
+      hipLaunchKernelGGL((k_ln_bwd_d128<1024, 128>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
+      return;
+    }
+    if (D == 256 && d128) {   // the same scheme at 32 lanes per row (the Erdos-Renyi stress: d_model 256, 131 k token rows)
+      hipLaunchKernelGGL((k_ln_bwd_d128<1024, 256>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 256 * 4, stream, a);
       return;
     }
   }

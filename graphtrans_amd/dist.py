@@ -37,6 +37,7 @@ class GradSync:
         self.group = group
         self.always_reduce = always_reduce   # issue the collective even for one rank (tests)
         self._pending, self._flat_used = [], False
+        self.stats = dict(collectives=0, bytes=0)   # gradient collectives issued and bytes put on the wire by this rank (bench.py)
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []  # dict(flat, params, views)
@@ -80,6 +81,8 @@ class GradSync:
         if self.world > 1:
             seg.div_(self.world)
         self._pending.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.stats["collectives"] += 1
+        self.stats["bytes"] += seg.numel() * seg.element_size()
         self._flat_used = True
 
     def zero(self):
@@ -104,6 +107,8 @@ class GradSync:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
             b["flat"].div_(self.world)  # average (gloo has no AVG op; pre-scaling keeps fp32 range)
             handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.stats["collectives"] += 1
+            self.stats["bytes"] += b["flat"].numel() * b["flat"].element_size()
         for b, h in zip(self.buckets, handles):
             h.wait()
             for v, p in zip(b["views"], b["params"]):
