@@ -849,7 +849,7 @@ def _eligible_static_pna(model):
             return False
         if hasattr(ne, "atom_embedding_list") and len(ne.atom_embedding_list) > 16:
             return False
-        if model.gnn2transformer.in_features != c0.in_channels or c0.in_channels % 4:
+        if model.gnn2transformer.in_features != c0.in_channels or c0.in_channels % 4 or c0.F_in % 4:
             return False
         if enc.activation not in layers.ENC_ACT or enc.d_model % 8 or enc.compute_dtype not in (torch.float32, torch.bfloat16):
             return False

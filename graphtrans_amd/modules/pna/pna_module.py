@@ -55,9 +55,12 @@ class PNAConv(nn.Module):
         self.towers, self.divide_input = towers, divide_input
         self.F_in = in_channels // towers if divide_input else in_channels
         self.F_out = out_channels // towers
-        if self.F_in % 4 or self.F_out % 4:
-            raise ValueError("graphtrans_amd PNAConv: per-tower widths must be multiples of 4 (16-byte rows for the grouped "
-                             f"GEMM); got F_in = {self.F_in}, F_out = {self.F_out}")
+        # the kernels move 16-byte chunks of a tower's row: per-tower widths that are not multiples of 4 (the reference's default
+        # gnn_emb_dim 300 with 4 towers: F = 75, modules/pna/pna_module.py:43-51) run on zero-padded tower rows (forward())
+        self.F_pad = (self.F_in + 3) // 4 * 4
+        if self.F_in != self.F_out and (self.F_in % 4 or self.F_out % 4):
+            raise ValueError("graphtrans_amd PNAConv: unequal per-tower widths must be multiples of 4; got "
+                             f"F_in = {self.F_in}, F_out = {self.F_out}")
         # the post-Linear is evaluated per scaler block (see forward); the x_i columns and the bias are NOT scaled, so
         # they ride in a block of their own unless the first scaler is the identity
         self._blocks = list(self.scalers) if self.scalers and self.scalers[0] == "identity" else [None] + list(self.scalers)
@@ -136,6 +139,8 @@ class PNAConv(nn.Module):
             gs = GraphStructure.build(edge_index, torch.zeros(x.shape[0], dtype=torch.int64, device=x.device), num_graphs=1)
         N, T, Fi, Fo = x.shape[0], self.towers, self.F_in, self.F_out
         S = len(self._blocks)
+        if Fi % 4:
+            return self._forward_padded(x, gs)
         xt = (x.view(N, T, Fi) if self.divide_input else x.view(N, 1, Fi).expand(N, T, Fi)).contiguous()
         Wp = torch.stack([m[0].weight for m in self.pre_nns])  # (T, F, 2F): [A | B] on [x_i || x_j]
         bp = torch.stack([m[0].bias for m in self.pre_nns])    # (T, F)
@@ -164,6 +169,52 @@ class PNAConv(nn.Module):
                 pass
         out = ops.scale_combine(Y, cache[1])   # sum_s scale_s * Y[:, :, s]
         return ops.linear_module(self.lin, out.reshape(N, T * Fo))
+
+
+    def _forward_padded(self, x, gs):
+        """Per-tower width F not a multiple of 4 (F = 75 for the reference's default gnn_emb_dim 300 with 4 towers): every tower row is
+        zero-padded to Fp = ceil4(F) -- inputs, the pre-Linear's weight blocks and bias, the post-Linear's operand columns and
+        output rows.  Padded columns carry U = V = 0, so their aggregates are 0 / 0 / 0 / sqrt(1e-5) and meet zero weight columns in
+        the post-Linear; padded outputs are cut off before `lin`.  Same kernels as the aligned path on (N, T, Fp) operands; torch's
+        pad / slice ops and their autograd do the re-layout (this configuration is not on the fused path)."""
+        import torch.nn.functional as Fn
+        N, T, F = x.shape[0], self.towers, self.F_in
+        Fp, pad = self.F_pad, self.F_pad - self.F_in
+        A_, S_ = len(self.aggregators), len(self.scalers)
+        xt = x.view(N, T, F) if self.divide_input else x.view(N, 1, F).expand(N, T, F)
+        xt = Fn.pad(xt, (0, pad)).contiguous()                                       # (N, T, Fp)
+        Wp = torch.stack([m[0].weight for m in self.pre_nns])                          # (T, F, 2F)
+        bp = Fn.pad(torch.stack([m[0].bias for m in self.pre_nns]), (0, pad))          # (T, Fp)
+        Wa = Fn.pad(Wp[:, :, :F], (0, pad, 0, pad)).contiguous()                       # (T, Fp, Fp)
+        Wb = Fn.pad(Wp[:, :, F:], (0, pad, 0, pad)).contiguous()
+        U = ops.tower_linear(xt, Wa, bp).view(N, T * Fp)
+        V = ops.tower_linear(xt, Wb, None).view(N, T * Fp)
+        agg = ops.pna_aggregate(U, V, gs, T).view(N, T, 4, Fp)                         # kernel slots [mean | max | min | std]
+        sel = agg[:, :, [_AGG_SLOT[a] for a in self.aggregators], :]                   # (N, T, A, Fp) in the module's aggregator order
+        deg = (gs.in_ptr[1:] - gs.in_ptr[:-1]).to(torch.float32).view(-1, 1, 1, 1)
+        scs = []
+        for sname in self.scalers:
+            if sname == "identity":
+                scs.append(torch.ones_like(deg))
+            elif sname == "amplification":
+                scs.append(torch.log(deg + 1) / self.avg_deg["log"])
+            elif sname == "attenuation":
+                sc = self.avg_deg["log"] / torch.log(deg + 1)
+                scs.append(torch.where(deg == 0, torch.ones_like(sc), sc))
+            elif sname == "linear":
+                scs.append(deg / self.avg_deg["lin"])
+            elif sname == "inverse_linear":
+                sc = self.avg_deg["lin"] / deg
+                scs.append(torch.where(deg == 0, torch.ones_like(sc), sc))
+            else:
+                raise ValueError(sname)
+        scaled = torch.cat([sel * sc for sc in scs], dim=2)                            # (N, T, S*A, Fp): scaler-major like PyG's cat
+        inp = torch.cat([xt.unsqueeze(2), scaled], dim=2).reshape(N, T, (S_ * A_ + 1) * Fp).contiguous()
+        Wq = torch.stack([m[0].weight for m in self.post_nns]).view(T, self.F_out, S_ * A_ + 1, F)
+        Wq = Fn.pad(Wq, (0, pad, 0, 0, 0, pad)).reshape(T, Fp, (S_ * A_ + 1) * Fp).contiguous()   # output rows and operand blocks padded
+        bq = Fn.pad(torch.stack([m[0].bias for m in self.post_nns]), (0, pad))
+        out = ops.tower_linear(inp, Wq, bq)[:, :, :self.F_out].reshape(N, T * self.F_out)
+        return ops.linear_module(self.lin, out)
 
 
 class BatchNorm(nn.Module):

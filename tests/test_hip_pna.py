@@ -267,3 +267,40 @@ def test_pna_fused_path_equals_module_path(dropout, aggs, scalers):
         loss = losses.code2_loss(model(b), b.y_arr)
         loss.backward()
         assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_pna_transformer_unaligned_tower_width_vs_oracle():
+    """gnn_emb_dim 300 with 4 towers (the reference's default width, modules/pna/pna_module.py:43-51): F = 75 is not a multiple of 4;
+    the conv runs on zero-padded tower rows (module path) and must match the float64 oracle like the aligned widths do."""
+    from graphtrans_amd import engine
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.pna_transformer import PNATransformer
+    from oracle import reference_math as rm
+
+    torch.manual_seed(4)
+    args = rm.default_args(gnn_virtual_node=False, gnn_num_layer=2, gnn_emb_dim=300, gnn_JK="last", gnn_residual=True,
+                           gnn_dropout=0.0, d_model=32, nhead=2, dim_feedforward=48, transformer_dropout=0.0,
+                           num_encoder_layers=1, transformer_norm_input=True, graph_pooling="cls", max_seq_len=None,
+                           aggregators=["mean", "max", "min", "std"], scalers=["identity", "amplification", "attenuation"],
+                           deg=torch.tensor([0, 5, 9, 7, 3, 1, 0, 2]))
+    b = _graph(9, with_dupes=False)
+    model = PNATransformer(7, ASTNodeEncoder(300, 11, 13, 20), None, args)
+    _randomize(model, 5)
+    model.train()
+    sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = rm.pna_transformer(sd, args, b, None, True)
+        w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+        (ref * w).sum().backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    model = model.to(DEV)
+    bd = b.to(DEV)
+    assert not engine.eligible(model, bd, None)   # the fused layer wants 16-byte tower rows
+    out = model(bd)
+    (out * w.float().to(DEV)).sum().backward()
+    assert_close(out.detach().cpu(), ref.detach(), what="out")
+    for k, p in model.named_parameters():
+        if sd[k].grad is not None:
+            assert_close(p.grad.cpu(), sd[k].grad, what=f"grad {k}")
