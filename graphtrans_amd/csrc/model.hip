@@ -24,6 +24,7 @@ namespace {
 
 constexpr int MAXL = GT_MODEL_MAX_LAYERS;
 constexpr int MAXT = GT_MODEL_MAX_TABLES;
+constexpr int64_t PREP_MIN_EDGES = 400000;   // gt_graph_prep beside the first kernels only for batches this large (see gt_model_prepare)
 constexpr uint64_t SEED_STEP = 0x9E3779B97F4A7C15ULL;   // graphtrans_amd/modules/gnn_module.py:layer_seed / vn_seed
 
 struct Bump {
@@ -231,7 +232,10 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
 
   // ---- token layout
   c->build_graph = b->graph_ptr == nullptr;
-  c->use_prep = (m->st_prep && b->sizes_host && c->build_graph) ? 1 : 0;
+  // the prep stream pays for its stream switches and events (~0.4 ms of host time per step) only when the structure kernels are long:
+  // measured r4, Code2 / Molpcba / PNA (E <= 1e5): same step time with and without, host 0.15-0.4 ms cheaper without; the
+  // Erdos-Renyi stress (E = 1.05 M): 1 % faster with
+  c->use_prep = (m->st_prep && b->sizes_host && c->build_graph && E >= PREP_MIN_EDGES) ? 1 : 0;
   if (b->seq_desc) {
     c->rows = b->rows; c->max_npos = b->max_npos; c->num_work = b->num_work; c->exact = b->lay_exact;
   } else if (b->sizes_host) {
