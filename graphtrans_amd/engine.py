@@ -890,9 +890,8 @@ def _num_graphs(batched_data, sizes):
 
 class _FusedModel(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, trigger, model, batched_data):
-        from . import ops, w3
-        plan = _plan(model)
+    def forward(ctx, trigger, model, batched_data, plan):
+        from . import ops
         lib = _lib.lib()
         cm = plan.cm
         if plan.min_elems != DW_OVERLAP_MIN_ELEMS:
@@ -1017,7 +1016,7 @@ class _FusedModel(torch.autograd.Function):
             raise RuntimeError("graphtrans_amd fused model: backward through the graph a second time "
                                "(the saved activations are freed after the first backward)")
         if dlogits is None:
-            return None, None, None
+            return None, None, None, None
         plan, cbuf, arena, barena_bytes, exact, _keep, model_sync, hook, B = s
         from . import ops
         lib = _lib.lib()
@@ -1068,10 +1067,10 @@ class _FusedModel(torch.autograd.Function):
                 v = flat[o_:o_ + p.numel()].view(p.shape)
                 p.grad = v if p.grad is None else p.grad + v
         ctx.state = None
-        return None, None, None
+        return None, None, None, None
 
 
 def forward(model, batched_data):
     """logits (B, Nh) [row-padded storage] of the fused path; `model` must be `eligible`."""
     plan = _plan(model)
-    return _FusedModel.apply(plan.plist[0], model, batched_data)
+    return _FusedModel.apply(plan.plist[0], model, batched_data, plan)
