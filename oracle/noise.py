@@ -11,8 +11,12 @@ multiplied by (1 + 2^-9 u), u ~ U(-1, 1), and the relative L2 distance of each g
 gradient is the tensor's noise floor.  An ill-conditioned gradient (GINConv's `eps`, modules/conv.py:21,28 of the
 reference: one scalar = a sum of N x D products of both signs) shows up with a large floor because the ORACLE moves that
 much -- and a HIP gradient is then bounded by a small multiple of its own tensor's floor instead of a per-mode constant.
-Only weights are perturbed (activation rounding adds about as much again): the floor is a lower bound, the tests use
-factor 8.
+Round 4: activations too.  The reduced-precision modes also ROUND activations -- the encoder's token-row tensors are stored in
+bf16 (mixed, bf16) and every GEMM's row operand is rounded on the fly (bf16) -- and their gradients likewise.  reference_math
+carries identity taps at those points (`_tap(x, kind)`); `lowp_noise(..., activations=True)` installs a tap that multiplies the
+forward value AND the gradient flowing back through it by (1 + 2^-9 u), fresh u per tensor.  With both operand classes perturbed
+the floor is what the mode's arithmetic does to the oracle, and the bound on a HIP gradient is a small multiple of it without an
+absolute floor doing the work (12.8 x the weights-only floor on Code2 mixed).
 """
 import copy
 from types import SimpleNamespace
@@ -37,10 +41,26 @@ def gemm_weight_keys(sd, mode):
     return keys
 
 
-def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12), rel=BF16_EPS):
+class _RoundLike(torch.autograd.Function):
+    """x -> x (1 + rel u) forward, g -> g (1 + rel u') backward: a stored activation and its stored gradient, both rounded"""
+
+    @staticmethod
+    def forward(ctx, x, gen, rel):
+        ctx.gen, ctx.rel = gen, rel
+        return x * (1.0 + rel * (2.0 * torch.rand(x.shape, generator=gen, dtype=x.dtype) - 1.0))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * (1.0 + ctx.rel * (2.0 * torch.rand(g.shape, generator=ctx.gen, dtype=g.dtype) - 1.0)), None, None
+
+
+def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12), rel=BF16_EPS, activations=True):
     """-> {gradient key: max over seeds of ||g_perturbed - g64|| / ||g64||}.  sd64: float64 state dict (leaf tensors),
-    fwd: oracle.reference_math.gnn_transformer / pna_transformer, loss_of(outputs) -> scalar."""
+    fwd: oracle.reference_math.gnn_transformer / pna_transformer, loss_of(outputs) -> scalar.  activations: also perturb the
+    activations the mode rounds (and their gradients) through reference_math's storage taps."""
+    from . import reference_math as rm
     keys = gemm_weight_keys(sd64, mode)
+    kinds = ("enc",) if mode == "mixed" else ("enc", "gemm_in")
     noise = {k: 0.0 for k in ref_g64}
     b64 = copy.copy(batch)   # dense float inputs (TU / ER node features, Linear edge attributes) in the oracle's float64
     for name in ("x", "edge_attr"):
@@ -62,7 +82,12 @@ def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12), 
                     sd[k] = w.requires_grad_(True)
                 else:
                     sd[k] = v.clone() if torch.is_tensor(v) else copy.copy(v)
-            loss_of(fwd(sd, oargs, batch, None, True)).backward()
+            if activations:
+                rm._TAP = lambda x, kind, g_=g: _RoundLike.apply(x, g_, rel) if (kind in kinds and x.requires_grad) else x
+            try:
+                loss_of(fwd(sd, oargs, batch, None, True)).backward()
+            finally:
+                rm._TAP = None
             for k, r in ref_g64.items():
                 gk = sd[k].grad
                 if gk is None:

@@ -81,8 +81,18 @@ def layer_norm(x, sd, prefix, eps=1e-5):
     return (x - mean) / torch.sqrt(var + eps) * w + b
 
 
+# Storage taps (identity unless oracle/noise.py installs a function): the points where the HIP path ROUNDS an activation -- kind
+# "enc": a token-row tensor the encoder stores in bf16 (mixed / bf16 modes), kind "gemm_in": the row operand of a Linear (rounded
+# to bf16 on the fly in the bf16 mode).  oracle/noise.py perturbs there to measure the oracle's own sensitivity to that rounding.
+_TAP = None
+
+
+def _tap(x, kind):
+    return x if _TAP is None else _TAP(x, kind)
+
+
 def linear(x, sd, prefix):
-    return x @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
+    return _tap(x, "gemm_in") @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
 
 
 def dropout(x, p, training):
@@ -303,7 +313,7 @@ def mha_torch(x, key_padding_mask, sd, prefix, nhead, p, training):
     x: (S,B,d) seq-first; key_padding_mask: (B,S) True = ignore."""
     S, B, d = x.shape
     hd = d // nhead
-    qkv = x @ sd[prefix + ".in_proj_weight"].t() + sd[prefix + ".in_proj_bias"]
+    qkv = _tap(_tap(x, "gemm_in") @ sd[prefix + ".in_proj_weight"].t() + sd[prefix + ".in_proj_bias"], "enc")
     q, k, v = qkv.chunk(3, dim=-1)
     q = q * (float(hd) ** -0.5)
 
@@ -316,8 +326,8 @@ def mha_torch(x, key_padding_mask, sd, prefix, nhead, p, training):
     att = torch.softmax(att, dim=-1)
     att = dropout(att, p, training)
     y = att @ v  # (B,nhead,S,hd)
-    y = y.permute(2, 0, 1, 3).reshape(S, B, d)
-    return y @ sd[prefix + ".out_proj.weight"].t() + sd[prefix + ".out_proj.bias"]
+    y = _tap(y.permute(2, 0, 1, 3).reshape(S, B, d), "enc")
+    return _tap(_tap(y, "gemm_in") @ sd[prefix + ".out_proj.weight"].t() + sd[prefix + ".out_proj.bias"], "enc")
 
 
 def transformer_encoder_layer(x, mask, sd, prefix, args, training):
@@ -325,10 +335,10 @@ def transformer_encoder_layer(x, mask, sd, prefix, args, training):
     x = LN2(x + drop(W2 drop(act(W1 x))))."""
     p = args.transformer_dropout
     a = mha_torch(x, mask, sd, prefix + ".self_attn", args.nhead, p, training)
-    x = layer_norm(x + dropout(a, p, training), sd, prefix + ".norm1")
-    f = _act(args.transformer_activation)(linear(x, sd, prefix + ".linear1"))
-    f = linear(dropout(f, p, training), sd, prefix + ".linear2")
-    return layer_norm(x + dropout(f, p, training), sd, prefix + ".norm2")
+    x = _tap(layer_norm(x + dropout(a, p, training), sd, prefix + ".norm1"), "enc")
+    f = _tap(_act(args.transformer_activation)(linear(x, sd, prefix + ".linear1")), "enc")
+    f = _tap(linear(dropout(f, p, training), sd, prefix + ".linear2"), "enc")
+    return _tap(layer_norm(x + dropout(f, p, training), sd, prefix + ".norm2"), "enc")
 
 
 def transformer_node_encoder(sd, prefix, args, padded_h_node, src_padding_mask, training=True):
@@ -341,11 +351,12 @@ def transformer_node_encoder(sd, prefix, args, padded_h_node, src_padding_mask, 
         cls = s["cls_embedding"].expand(1, x.shape[1], -1)
         x = torch.cat([x, cls], dim=0)
         mask = torch.cat([mask, torch.zeros(mask.shape[0], 1, dtype=torch.bool)], dim=1)
+    x = _tap(x, "enc")
     if "norm_input.weight" in s:
-        x = layer_norm(x, s, "norm_input")
+        x = _tap(layer_norm(x, s, "norm_input"), "enc")
     for i in range(args.num_encoder_layers):
         x = transformer_encoder_layer(x, mask, s, f"transformer.layers.{i}", args, training)
-    x = layer_norm(x, s, "transformer.norm")
+    x = _tap(layer_norm(x, s, "transformer.norm"), "enc")
     return x, mask
 
 

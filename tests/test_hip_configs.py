@@ -342,14 +342,14 @@ def test_fused_precision_modes_vs_oracle(workload, graphs, mode):
         check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=f"{workload} {mode}")
 
 
-LOWP_FACTOR, LOWP_FLOOR = 10.0, 2.0 ** -8   # floor = one bf16 ulp: the token rows themselves are stored in bf16 (activation rounding is not in the weight-only noise model)
+LOWP_FACTOR, LOWP_FLOOR = 4.0, 2.5e-4   # floor: only a guard against a vanishing noise estimate (r4: the noise model rounds activations and their gradients too)
 
 
 def check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=""):
     """Reduced-precision modes, tensor by tensor: the relative L2 error of every parameter gradient against the float64
     oracle is bounded by LOWP_FACTOR x the ORACLE's own response of that tensor to bf16-sized perturbations of the GEMM
-    weights the mode rounds (oracle/noise.py: 2^-9 relative, weights only -- activation rounding adds about as much
-    again, hence the factor), never less than LOWP_FLOOR (2^-8: the storage rounding of the bf16 token rows, which the weight-only noise model leaves out).  An ill-conditioned gradient (GINConv.eps: one scalar summed
+    weights AND of the activations / activation gradients the mode rounds (oracle/noise.py: 2^-9 relative, through reference_math's
+    storage taps), never less than LOWP_FLOOR (a guard against a vanishing estimate).  An ill-conditioned gradient (GINConv.eps: one scalar summed
     from N x D products of both signs, modules/conv.py:21,28) gets a wide bound because the oracle itself moves that
     much, every well-conditioned tensor a tight one -- instead of one blanket bound per mode."""
     from conftest import rel_l2
