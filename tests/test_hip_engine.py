@@ -471,3 +471,65 @@ def test_gradient_accumulation_at_benchmark_size_with_the_overlap_stream(workloa
             scale = max(1e-6, float(ref.abs().max()))
             err = float((p.grad - ref).abs().max()) / scale
             assert err < 1e-5, (rep, n, err)
+
+
+def _small_model(big=False, **kw):
+    from graphtrans_amd import synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    torch.manual_seed(0)
+    model = GNNTransformer(50, ASTNodeEncoder(64, 98, 300, 20), lambda d: torch.nn.Linear(2, d), _args(**kw)).to(DEV).train()
+    # big: >= 1024 nodes, so that the big-M GEMMs run on the bound weight images (the cache ADVICE r3 was about)
+    b = synth.code2_like(B=48 if big else 12, seed=5, num_nodeattributes=300, mean_nodes=40.0 if big else 30.0).to(DEV)
+    return model, b
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weights_changed_through_data_are_seen_by_the_next_forward(dtype):
+    """writes through `p.data` (EMA swaps, clamp_, raw-pointer optimizers) bump no version counter; the weight images
+    (bf16x3 for the message-passing GEMMs, fragment-order bf16 for the encoder) are rebuilt by the driver at EVERY forward, so the
+    fused path must follow such a write exactly like the module path."""
+    from graphtrans_amd import engine
+    model, b = _small_model(big=True, transformer_dropout=0.0, compute_dtype=dtype)
+    assert b.batch.numel() >= 1024 and engine.eligible(model, b, None)
+    ref = copy.deepcopy(model)
+    ref.fused = False
+    with torch.no_grad():
+        out0 = torch.stack(list(model(b)))
+        for m in (model, ref):
+            m.gnn_node.convs[1].linear.weight.data.mul_(1.7)                      # an image-backed big-M GEMM weight
+            m.transformer_encoder.transformer.layers[0].linear1.weight.data.add_(0.05)   # an encoder weight
+            m.gnn2transformer.weight.data.clamp_(-0.05, 0.05)
+        out1, outr = torch.stack(list(model(b))), torch.stack(list(ref(b)))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    assert (out1 - out0).abs().max() > 1e-3, "the write must change the output"
+    assert torch.allclose(out1.float(), outr.float(), **tol), (out1.float() - outr.float()).abs().max()
+
+
+def test_hooks_registered_after_the_first_fused_forward_are_honoured():
+    """eligibility looks at the parameters' hooks on EVERY call; a hook added after a warm-up forward sends the model
+    through the module path (where autograd fires it) instead of being skipped silently."""
+    from graphtrans_amd import engine, losses
+    model, b = _small_model()
+    y = torch.randint(0, 50, (12, 5), device=DEV)
+    assert engine.eligible(model, b, None)
+    losses.code2_loss(model(b), y).backward()
+    fired = []
+    h = model.gnn2transformer.weight.register_hook(lambda g: fired.append(1))
+    assert not engine.eligible(model, b, None)
+    for p in model.parameters():
+        p.grad = None
+    losses.code2_loss(model(b), y).backward()
+    assert fired, "the hook must have run (module path)"
+    h.remove()
+    assert engine.eligible(model, b, None)
+
+
+def test_second_backward_through_the_fused_node_raises():
+    from graphtrans_amd import losses
+    model, b = _small_model()
+    y = torch.randint(0, 50, (12, 5), device=DEV)
+    loss = losses.code2_loss(model(b), y)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
