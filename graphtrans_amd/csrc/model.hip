@@ -60,7 +60,7 @@ struct Ctx {
   gt_encoder_layer enc[MAXL];
   // forward arena
   size_t o_h[MAXL + 1], o_x0, o_vn[MAXL], o_vn_saved[MAXL], o_conv_saved[MAXL], o_cat, o_hn, o_tok, o_xin, o_st0, o_xe[MAXL],
-      o_enc_saved[MAXL], o_xo, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
+      o_enc_saved[MAXL], o_hgin, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
   size_t o_scales, q_dimg;
   size_t o_graph_ptr, o_node_graph, o_in_ptr, o_out_ptr, o_idx, o_dd, o_status, o_prep_ws, o_lay, o_lay_meta;
   size_t ws_bytes, ws2_bytes, eplan_bytes, esort_ws_bytes, prep_ws_bytes, arena_bytes;
@@ -76,6 +76,7 @@ struct Ctx {
   const int64_t* e_idx[MAXT + 1];
   int64_t e_str[MAXT + 1], e_clamp[MAXT + 1], e_rows[MAXT + 1];
   // backward arena
+  size_t q_d_hgin;
   size_t q_d_hg, q_dtok[2], q_d_hn, q_d_cls, q_d_rep, q_dA, q_dB, q_dC, q_dJ, q_dvn[4], q_ne_dw, q_bnpart[MAXL], q_heads_ws,
       q_ws[2], q_ws2, q_ws3;
   size_t bws_bytes, heads_ws_bytes, seg_ws_bytes, barena_bytes;
@@ -352,9 +353,9 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   }
   for (int i = 0; i < nenc; ++i) c->o_xe[i] = a.take((size_t)rows * d * tsz);
   for (int i = 0; i < nenc; ++i) c->o_enc_saved[i] = a.take(gt_encoder_layer_saved_bytes(&c->enc[i]));
-  if (m->nout_w) {
-    c->o_xo = a.take((size_t)rows * d * tsz);
-    c->o_sto = a.take((size_t)2 * rows * 4);
+  if (m->nout_w) {   // the final norm runs on the POOLED rows only (cls / last pooling reads nothing else of it: gnn_transformer.py:113-114)
+    c->o_hgin = a.take((size_t)B * d * 4);
+    c->o_sto = a.take((size_t)2 * B * 4);
   }
   c->T = m->embed_kind != 1 ? m->n_tables : 0;
   for (int t = 0; t < c->T; ++t) c->e_rows[t] = m->table_rows[t];
@@ -410,6 +411,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   // ---- backward arena
   Bump q;
   c->q_d_hg = q.take((size_t)B * d * 4);
+  c->q_d_hgin = q.take(m->nout_w ? (size_t)B * d * 4 : 0);
   c->q_dtok[0] = q.take((size_t)rows * d * tsz);
   c->q_dtok[1] = q.take((size_t)rows * d * tsz);
   c->q_d_hn = q.take((size_t)N * d * tsz);
@@ -420,7 +422,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   for (int i = 0; i < 4; ++i) c->q_dvn[i] = q.take((size_t)B * D * 4);
   size_t enc_ws = 256;
   for (int i = 0; i < nenc; ++i) enc_ws = std::max(enc_ws, gt_encoder_layer_workspace_bytes(&c->enc[i]));
-  const size_t ln_ws = gt_layernorm_bwd_workspace_bytes(rows, d);
+  const size_t ln_ws = std::max(gt_layernorm_bwd_workspace_bytes(rows, d), gt_layernorm_bwd_workspace_bytes(B, d));
   const size_t lin_ws = std::max(gt_linear_bwd_workspace_bytes(c->compute, B, m->Nh, d), gt_linear_bwd_workspace_bytes(c->compute, N, d, Kc));
   size_t emb_ws;
   if (m->embed_kind == 1) {
@@ -703,11 +705,14 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   }
   c->pre_out = cur;
   if (m->nout_w) {
-    GT_TRY(gt_layernorm_fwd(tdt, cur, nullptr, m->nout_w, m->nout_b, m->nout_eps, 0.f, 0, rows, d, P(c->o_xo), (float*)P(c->o_sto),
-                            (float*)P(c->o_sto) + rows, st));
-    cur = P(c->o_xo);
+    // transformer.norm (transformer_encoder.py:28-32) is row-wise and only the pooled row of every graph is read afterwards: the
+    // rows are gathered first (fp32) and normalised there -- B rows instead of every token row, forward and backward
+    GT_TRY(gt_rows_gather(tdt, cur, c->last_rows, B, d, (float*)P(c->o_hgin), st));
+    GT_TRY(gt_layernorm_fwd(GT_F32, P(c->o_hgin), nullptr, m->nout_w, m->nout_b, m->nout_eps, 0.f, 0, B, d, P(c->o_hg), (float*)P(c->o_sto),
+                            (float*)P(c->o_sto) + B, st));
+  } else {
+    GT_TRY(gt_rows_gather(tdt, cur, c->last_rows, B, d, (float*)P(c->o_hg), st));
   }
-  GT_TRY(gt_rows_gather(tdt, cur, c->last_rows, B, d, (float*)P(c->o_hg), st));
   // ---- prediction heads as one GEMM over the stacked weights   (gnn_transformer.py:120-126)
   GT_TRY(gt_linear_fwd_ld(GT_F32, GT_F32, compute, P(c->o_hg), m->head_w, m->head_b, logits, B, m->Nh, d, m->ldy, 0, 0.f, 0, st));
   // the side streams wrote into this arena: join them before anything can hand it back to the allocator
@@ -770,12 +775,13 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
                             B, m->Nh, d, m->ldy, 0.f, W(), ws_bytes, st));
     // ---- pooled rows -> token rows
     void *dcur = Q(c->q_dtok[0]), *dnext = Q(c->q_dtok[1]);
-    GT_TRY(gt_rows_scatter(tdt, (const float*)Q(c->q_d_hg), c->last_rows, B, rows, d, dcur, st));
-    if (m->nout_w) {
-      GT_TRY(gt_layernorm_bwd(tdt, c->pre_out, nullptr, dcur, m->nout_w, (float*)P(c->o_sto), (float*)P(c->o_sto) + rows, 0.f, 0, rows, d,
-                              dnext, nullptr, G + m->off_nout_w, G + m->off_nout_b, W(), ws_bytes, st));
-      std::swap(dcur, dnext);
+    const float* d_pool = (const float*)Q(c->q_d_hg);
+    if (m->nout_w) {   // the final norm on the pooled rows
+      GT_TRY(gt_layernorm_bwd(GT_F32, P(c->o_hgin), nullptr, Q(c->q_d_hg), m->nout_w, (float*)P(c->o_sto), (float*)P(c->o_sto) + B, 0.f, 0, B, d,
+                              Q(c->q_d_hgin), nullptr, G + m->off_nout_w, G + m->off_nout_b, W(), ws_bytes, st));
+      d_pool = (const float*)Q(c->q_d_hgin);
     }
+    GT_TRY(gt_rows_scatter(tdt, d_pool, c->last_rows, B, rows, d, dcur, st));
     for (int i = nenc - 1; i >= 0; --i) {
       GT_TRY(gt_encoder_layer_bwd(&c->enc[i], c->enc_in[i], dcur, P(c->o_enc_saved[i]), dnext, G + m->off_enc[i], W(), ws_bytes, st));
       std::swap(dcur, dnext);
