@@ -167,6 +167,15 @@ SIGNATURES = {
     "gt_gather_f32": (_i, [_p, _p, _p, _i64, _p]),
     "gt_pna_aggregate_fwd_uv": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
     "gt_pna_aggregate_bwd_uv": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gt_rows_take": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
+    "gt_rows_put": (_i, [_i, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "gt_rows_add": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
+    "gt_attn_fwd_last": (_i, [_i, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _f, _f, _u64, _p]),
+    "gt_attn_bwd_last": (_i, [_i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _i64, _p, _i64, _f, _f, _u64, _p]),
+    "gt_encoder_layer_pooled_saved_bytes": (_sz, [_p]),
+    "gt_encoder_layer_pooled_workspace_bytes": (_sz, [_p]),
+    "gt_encoder_layer_pooled_fwd": (_i, [_p, _p, _p, _p, _p, _p]),
+    "gt_encoder_layer_pooled_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_model_ctx_bytes": (_sz, []),
     "gt_model_abi_sizes": (_i, [_p]),
     "gt_model_grad_ranges": (_i, [_p, _p, _p]),

@@ -76,6 +76,10 @@ struct AttnArgs {
   float inv_keep;     // 1/(1-p)
   uint32_t drop_thr;  // keep iff the key's 16-bit half of its pair's hash >= thr ; 0 -> no dropout
   uint32_t seed0, seed1;
+  // pooled mode (cls / last pooling reads ONE row per sequence after the last encoder layer, models/gnn_transformer.py:113-114):
+  //   last_only   fwd / dQ: a block per (sequence, head) computes the 64-query tile that holds the sequence's LAST position only
+  //   q_last_only dK / dV: every key tile, but the query loop starts at the 32-query step that holds the last position
+  int last_only, q_last_only;
 };
 
 // head dims 8 / 16 are zero-padded to one 32-deep MFMA step (HDP); LDS rows are HDP wide + 16 B pad
@@ -90,7 +94,7 @@ __device__ __forceinline__ bool dense_masked(const AttnArgs& a, int seq, int qpo
 // and walks it head-fastest, so every tile and head of a sequence -- which all read that sequence's K
 // and V rows -- hit the same L2 (PMC before: 95 MB fetched per forward launch for 24.5 MB of qkv).
 __device__ __forceinline__ bool block_item(const AttnArgs& a, int& seq, int& tile, int& head) {
-  if (a.work) {
+  if (a.work && !a.last_only) {
     const int b = blockIdx.x;
     const int slot = b / 8;
     const int w = (b % 8) * a.work_per_xcd + slot / a.nhead;
@@ -198,6 +202,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
+  if (a.last_only) tile_ = npos > 0 ? (npos - 1) / BLOCK_N : 0;
   const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -340,6 +345,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
+  if (a.last_only) tile_ = npos > 0 ? (npos - 1) / BLOCK_N : 0;
   const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -523,16 +529,17 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
       if (aux_which == 0 && pos < npos) aux_v = -(aux_v + a.lse[(int64_t)a.nhead * a.rows + o]);
     }
   };
+  const int q_begin = (a.q_last_only && npos > 0) ? ((npos - 1) / TILE) * TILE : 0;   // pooled mode: only the last position's gradient is non-zero
   if (HD < 32) __syncthreads();
   if (any_valid) {
-    stg.load(0, 0, npos);
-    load_aux(0);
+    stg.load(q_begin, 0, npos);
+    load_aux(q_begin);
     stg.store(sQb[0], sDOb[0]);
     if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
   }
   __syncthreads();
   int cur = 0;
-  for (int q0 = 0; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
+  for (int q0 = q_begin; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
     const bool more = q0 + TILE < npos;
     if (more) {
       stg.load(q0 + TILE, 0, npos);
@@ -642,7 +649,7 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
 
 }  // namespace
 
-extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
+static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
                            int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
                            int64_t max_npos, const int32_t* work_items, int64_t num_work, const float* dense_mask,
                            const float* key_valid, float mask_value, float scale, float dropout_p, uint64_t seed,
@@ -658,8 +665,9 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
                          row_stride, scale, dropout_p, seed, dense_mask, key_valid, mask_value);
   a.num_work = (int)num_work;
   a.work_per_xcd = (int)gt_cdiv(num_work, 8);
-  dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
-                         : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+  a.last_only = pooled;
+  dim3 grid = (work_items && !pooled) ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
+                                      : dim3(pooled ? 1u : (unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
   const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
 #define GT_LAUNCH(T, HD)                                                                                     \
@@ -679,7 +687,23 @@ extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, in
   return GT_OK;
 }
 
-extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
+extern "C" int gt_attn_fwd(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
+                           int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
+                           int64_t max_npos, const int32_t* work_items, int64_t num_work, const float* dense_mask,
+                           const float* key_valid, float mask_value, float scale, float dropout_p, uint64_t seed,
+                           gt_stream_t stream_) {
+  return attn_fwd_impl(0, dtype, qkv, ctx, lse, total_rows, d_model, nhead, seq_desc, num_seqs, row_stride, max_npos, work_items, num_work,
+                       dense_mask, key_valid, mask_value, scale, dropout_p, seed, stream_);
+}
+// the 64-row tile that holds the LAST position of every sequence only (ctx / lse rows outside those tiles are not written)
+extern "C" int gt_attn_fwd_last(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
+                                int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                                float scale, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  return attn_fwd_impl(1, dtype, qkv, ctx, lse, total_rows, d_model, nhead, seq_desc, num_seqs, row_stride, max_npos, nullptr, 0,
+                       nullptr, nullptr, 0.f, scale, dropout_p, seed, stream_);
+}
+
+static int attn_bwd_impl(int pooled, int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
                            float* delta, void* d_qkv, int64_t total_rows, int64_t d_model, int nhead,
                            const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
                            const int32_t* work_items, int64_t num_work, const float* dense_mask,
@@ -698,15 +722,24 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   a.work_per_xcd = (int)gt_cdiv(num_work, 8);
   dim3 grid = work_items ? dim3((unsigned)(8 * a.work_per_xcd * nhead), 1, 1)
                          : dim3((unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
+  // pooled: dQ for the last tile of every sequence (a block per sequence and head), dK / dV for every key tile with the query loop cut
+  // to the last step; the dQ rows outside the last tiles are zero (the caller zero-fills d_qkv)
+  AttnArgs aq = a;
+  dim3 grid_q = grid;
+  if (pooled) {
+    aq.last_only = 1;
+    grid_q = dim3(1u, (unsigned)nhead, (unsigned)num_seqs);
+    a.q_last_only = 1;
+  }
   const int hd = (int)(d_model / nhead);
   const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
 #define GT_LAUNCH(T, HD)                                                                        \
   do {                                                                                          \
     if (dense_launch) {                                                                         \
-      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a);  \
+      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, true>), grid_q, dim3(ATT_THREADS), 0, stream, aq);  \
       hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a); \
     } else {                                                                                    \
-      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a); \
+      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, false>), grid_q, dim3(ATT_THREADS), 0, stream, aq); \
       hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);\
     }                                                                                           \
   } while (0)
@@ -720,4 +753,23 @@ extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
 #undef GT_LAUNCH
   GT_CHECK_LAUNCH();
   return GT_OK;
+}
+
+extern "C" int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse,
+                           float* delta, void* d_qkv, int64_t total_rows, int64_t d_model, int nhead,
+                           const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos,
+                           const int32_t* work_items, int64_t num_work, const float* dense_mask,
+                           const float* key_valid, float mask_value, float scale, float dropout_p, uint64_t seed,
+                           gt_stream_t stream_) {
+  return attn_bwd_impl(0, dtype, qkv, ctx, d_ctx, lse, delta, d_qkv, total_rows, d_model, nhead, seq_desc, num_seqs, row_stride, max_npos,
+                       work_items, num_work, dense_mask, key_valid, mask_value, scale, dropout_p, seed, stream_);
+}
+// backward of gt_attn_fwd_last: d_ctx is non-zero only in the last position of every sequence; d_qkv must be ZERO-FILLED by the caller
+// (dQ is written for the last 64-row tiles only); work_items: the full attention work list (key tiles)
+extern "C" int gt_attn_bwd_last(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse, float* delta,
+                                void* d_qkv, int64_t total_rows, int64_t d_model, int nhead, const int32_t* seq_desc, int64_t num_seqs,
+                                int64_t row_stride, int64_t max_npos, const int32_t* work_items, int64_t num_work, float scale,
+                                float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  return attn_bwd_impl(1, dtype, qkv, ctx, d_ctx, lse, delta, d_qkv, total_rows, d_model, nhead, seq_desc, num_seqs, row_stride, max_npos,
+                       work_items, num_work, nullptr, nullptr, 0.f, scale, dropout_p, seed, stream_);
 }

@@ -617,6 +617,165 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
 }
 
 // =================================================================================================
+// The LAST encoder layer under cls / last pooling: only one row per sequence is read afterwards (transformer_out[-1],
+// models/gnn_transformer.py:113-114; the reference computes every row and drops the rest).  Keys and values are needed for every row,
+// everything behind the attention only for the pooled row: in_proj on all rows, attention for the tile of the pooled row, then
+// out_proj / norm1 / FFN / norm2 on B rows.  The skipped rows influence neither the output nor any gradient.
+namespace {
+struct EncPoolSaved {
+  void *qkv, *ctx, *xp, *ctxp, *a, *x1, *f1, *f2, *g1;
+  float *lse, *st1, *st2;
+  size_t bytes;
+};
+EncPoolSaved encp_saved(const gt_encoder_layer* L, void* p) {
+  Bump b(p);
+  const size_t e = elt(L->dtype);
+  const size_t R = (size_t)L->rows, B = (size_t)L->num_seqs, d = (size_t)L->d_model, F = (size_t)L->ffn;
+  EncPoolSaved s;
+  s.qkv = b.take(R * 3 * d * e);
+  s.ctx = b.take(R * d * e);
+  s.lse = (float*)b.take((size_t)2 * L->nhead * R * 4);
+  s.xp = b.take(B * d * e);
+  s.ctxp = b.take(B * d * e);
+  s.a = b.take(B * d * e);
+  s.x1 = b.take(B * d * e);
+  s.f1 = b.take(B * F * e);
+  s.f2 = b.take(B * d * e);
+  s.g1 = b.take(L->act == 1 ? B * F * e : 0);
+  s.st1 = (float*)b.take(2 * B * 4);
+  s.st2 = (float*)b.take(2 * B * 4);
+  s.bytes = b.off;
+  return s;
+}
+struct EncPoolWork {
+  void *d_f2, *d_x1, *d_f1, *d_a, *d_ctxp, *d_xp, *d_ctx, *d_qkv, *lin_ws, *lin_ws_in, *ln_ws, *ln_ws1;
+  float* delta;
+  size_t lin_ws_bytes, lin_ws_in_bytes, ln_ws_bytes, bytes;
+};
+EncPoolWork encp_work(const gt_encoder_layer* L, void* p) {
+  Bump b(p);
+  const size_t e = elt(L->dtype);
+  const int64_t R = L->rows, B = L->num_seqs, d = L->d_model, F = L->ffn;
+  const int c = L->dtype == GT_BF16 ? GT_BF16 : L->compute;
+  EncPoolWork w;
+  w.d_f2 = b.take((size_t)B * d * e);
+  w.d_x1 = b.take((size_t)B * d * e);
+  w.d_f1 = b.take((size_t)B * F * e);
+  w.d_a = b.take((size_t)B * d * e);
+  w.d_ctxp = b.take((size_t)B * d * e);
+  w.d_xp = b.take((size_t)B * d * e);
+  w.d_ctx = b.take((size_t)R * d * e);
+  w.d_qkv = b.take((size_t)R * 3 * d * e);
+  w.delta = (float*)b.take((size_t)L->nhead * R * 4);
+  size_t m = 0, q;
+  q = gt_linear_bwd_workspace_bytes(c, B, d, d); m = q > m ? q : m;
+  q = gt_linear_bwd_workspace_bytes(c, B, F, d); m = q > m ? q : m;
+  q = gt_linear_bwd_workspace_bytes(c, B, d, F); m = q > m ? q : m;
+  w.lin_ws_bytes = m;
+  w.lin_ws = b.take(m);
+  w.lin_ws_in_bytes = gt_linear_bwd_workspace_bytes(c, R, 3 * d, d);
+  w.lin_ws_in = b.take(w.lin_ws_in_bytes);
+  w.ln_ws_bytes = gt_layernorm_bwd_workspace_bytes(B, d);
+  w.ln_ws = b.take(w.ln_ws_bytes);
+  w.ln_ws1 = b.take(w.ln_ws_bytes);
+  w.bytes = b.off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t gt_encoder_layer_pooled_saved_bytes(const gt_encoder_layer* L) { return L ? encp_saved(L, nullptr).bytes : 0; }
+extern "C" size_t gt_encoder_layer_pooled_workspace_bytes(const gt_encoder_layer* L) { return L ? encp_work(L, nullptr).bytes : 0; }
+
+extern "C" int gt_encoder_layer_pooled_fwd(const gt_encoder_layer* L, const void* x, const int64_t* pool_rows, void* y_pool, void* saved,
+                                           gt_stream_t st) {
+  GT_TRY(enc_check("gt_encoder_layer_pooled_fwd", L));
+  GT_CHECK_ARG(x && pool_rows && y_pool && saved, "null buffer");
+  if (L->rows == 0 || L->num_seqs == 0) return GT_OK;
+  const EncPoolSaved s = encp_saved(L, saved);
+  const int t = L->dtype, c = t == GT_BF16 ? GT_BF16 : L->compute;
+  const int64_t R = L->rows, B = L->num_seqs, d = L->d_model, F = L->ffn;
+  const float p = L->training ? L->dropout_p : 0.f;
+  const float scale = 1.0f / sqrtf((float)(d / L->nhead));
+  GT_TRY(gt_linear_fwd(t, t, c, x, L->in_w, L->in_b, s.qkv, R, 3 * d, d, 0, 0.f, 0, st));
+  GT_TRY(gt_attn_fwd_last(t, s.qkv, s.ctx, s.lse, R, d, L->nhead, L->seq_desc, L->num_seqs, L->row_stride, L->max_npos, scale, p, L->seed, st));
+  GT_TRY(gt_rows_take(t, x, pool_rows, B, d, s.xp, st));
+  GT_TRY(gt_rows_take(t, s.ctx, pool_rows, B, d, s.ctxp, st));
+  // from here on: the same launches as gt_encoder_layer_fwd on B rows
+  if (gt_linear_layernorm_fwd_ok(t, c, L->out_w, B, d, d)) {
+    GT_TRY(gt_linear_layernorm_fwd(t, c, s.ctxp, L->out_w, L->out_b, s.a, B, d, d, s.xp, L->n1_w, L->n1_b, L->ln_eps, p,
+                                   L->seed ^ 0x5851F42D4C957F2DULL, s.x1, s.st1, s.st1 + B, st));
+  } else {
+    GT_TRY(gt_linear_fwd(t, t, c, s.ctxp, L->out_w, L->out_b, s.a, B, d, d, 0, 0.f, 0, st));
+    GT_TRY(gt_layernorm_fwd(t, s.a, s.xp, L->n1_w, L->n1_b, L->ln_eps, p, L->seed ^ 0x5851F42D4C957F2DULL, B, d, s.x1, s.st1, s.st1 + B, st));
+  }
+  if (L->act == 1)
+    GT_TRY(gt_linear_fwd_gelu(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, s.g1, B, F, d, d, F, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
+  else
+    GT_TRY(gt_linear_fwd(t, t, c, s.x1, L->l1_w, L->l1_b, s.f1, B, F, d, 1, p, L->seed ^ 0x2545F4914F6CDD1DULL, st));
+  if (gt_linear_layernorm_fwd_ok(t, c, L->l2_w, B, d, F)) {
+    GT_TRY(gt_linear_layernorm_fwd(t, c, s.f1, L->l2_w, L->l2_b, s.f2, B, d, F, s.x1, L->n2_w, L->n2_b, L->ln_eps, p,
+                                   L->seed ^ 0x14057B7EF767814FULL, y_pool, s.st2, s.st2 + B, st));
+  } else {
+    GT_TRY(gt_linear_fwd(t, t, c, s.f1, L->l2_w, L->l2_b, s.f2, B, d, F, 0, 0.f, 0, st));
+    GT_TRY(gt_layernorm_fwd(t, s.f2, s.x1, L->n2_w, L->n2_b, L->ln_eps, p, L->seed ^ 0x14057B7EF767814FULL, B, d, y_pool, s.st2, s.st2 + B, st));
+  }
+  return GT_OK;
+}
+
+extern "C" int gt_encoder_layer_pooled_bwd(const gt_encoder_layer* L, const void* x, const int64_t* pool_rows, const void* dy_pool,
+                                           const void* saved, void* dx, float* grads, void* workspace, size_t workspace_bytes,
+                                           gt_stream_t st) {
+  GT_TRY(enc_check("gt_encoder_layer_pooled_bwd", L));
+  GT_CHECK_ARG(x && pool_rows && dy_pool && saved && dx && grads && workspace, "null buffer");
+  const EncPoolWork w = encp_work(L, workspace);
+  if (workspace_bytes < w.bytes) { gt_set_error("gt_encoder_layer_pooled_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
+  if (L->rows == 0 || L->num_seqs == 0) return GT_OK;
+  const EncPoolSaved s = encp_saved(L, const_cast<void*>(saved));
+  const EncGrads g = enc_grads(L, grads);
+  const int t = L->dtype, c = t == GT_BF16 ? GT_BF16 : L->compute;
+  const int64_t R = L->rows, B = L->num_seqs, d = L->d_model, F = L->ffn;
+  const float p = L->training ? L->dropout_p : 0.f;
+  const float scale = 1.0f / sqrtf((float)(d / L->nhead));
+  // ---- the row-wise half on the B pooled rows (gt_encoder_layer_bwd's launches)
+  GT_TRY(gt_layernorm_bwd(t, s.f2, s.x1, dy_pool, L->n2_w, s.st2, s.st2 + B, p, L->seed ^ 0x14057B7EF767814FULL, B, d, w.d_f2, w.d_x1, g.n2_w,
+                          g.n2_b, w.ln_ws, w.ln_ws_bytes, st));
+  if (gt_linear_bwd_gate_out_ok(t, t, c, L->l2_w, B, d, F)) {
+    GT_TRY(gt_linear_bwd_gate_out(t, t, c, s.f1, L->l2_w, w.d_f2, L->act == 1 ? s.g1 : s.f1, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, B, d, F,
+                                  F, d, L->act == 1 ? -1.f : p, w.lin_ws, w.lin_ws_bytes, st));
+    GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, B, F, d, 0.f, w.lin_ws,
+                         w.lin_ws_bytes, st));
+  } else {
+    GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, B, d, F, 0.f, w.lin_ws,
+                         w.lin_ws_bytes, st));
+    if (L->act == 1)
+      GT_TRY(gt_linear_bwd_mul(t, t, c, s.x1, L->l1_w, w.d_f1, s.g1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, B, F, d, d, F, w.lin_ws,
+                               w.lin_ws_bytes, st));
+    else
+      GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, s.f1, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, B, F, d, p, w.lin_ws,
+                           w.lin_ws_bytes, st));
+  }
+  GT_TRY(gt_layernorm_bwd(t, s.a, s.xp, w.d_x1, L->n1_w, s.st1, s.st1 + B, p, L->seed ^ 0x5851F42D4C957F2DULL, B, d, w.d_a, w.d_xp, g.n1_w,
+                          g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
+  GT_TRY(gt_linear_bwd(t, t, c, s.ctxp, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctxp, g.out_w, g.out_b, B, d, d, 0.f, w.lin_ws,
+                       w.lin_ws_bytes, st));
+  // ---- attention: d_ctx is zero outside the pooled rows; dQ exists for the last tiles only, dK / dV for every row
+  GT_TRY(gt_rows_put(t, w.d_ctxp, pool_rows, B, R, d, w.d_ctx, st));
+  if (hipMemsetAsync(w.d_qkv, 0, (size_t)R * 3 * d * elt(t), (hipStream_t)st) != hipSuccess) {
+    gt_set_error("gt_encoder_layer_pooled_bwd: memset failed");
+    return GT_ERR_LAUNCH;
+  }
+  GT_TRY(gt_attn_bwd_last(t, s.qkv, s.ctx, w.d_ctx, s.lse, w.delta, w.d_qkv, R, d, L->nhead, L->seq_desc, L->num_seqs, L->row_stride,
+                          L->max_npos, L->work_items, L->num_work, scale, p, L->seed, st));
+  // ---- in_proj on every row; the residual branch's gradient exists in the pooled rows only
+  GT_TRY(gt_linear_bwd_dw_forked(t, t, c, x, L->in_w, w.d_qkv, nullptr, g.in_w, g.in_b, R, 3 * d, d, d, 3 * d, 0.f, w.lin_ws_in,
+                                 w.lin_ws_in_bytes, st));
+  GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, nullptr, nullptr, dx, nullptr, nullptr, R, 3 * d, d, 0.f, w.lin_ws_in,
+                       w.lin_ws_in_bytes, st));
+  GT_TRY(gt_rows_add(t, w.d_xp, pool_rows, B, d, dx, st));
+  return GT_OK;
+}
+
+// =================================================================================================
 // PNA layer (modules/pna/pna_module.py:57-78; PNAConv math: modules/pna_layer.py:131-167)
 namespace {
 struct PnaSaved {

@@ -76,7 +76,7 @@ struct Ctx {
   const int64_t* e_idx[MAXT + 1];
   int64_t e_str[MAXT + 1], e_clamp[MAXT + 1], e_rows[MAXT + 1];
   // backward arena
-  size_t q_d_hgin;
+  size_t q_d_hgin, q_dyp;
   size_t q_d_hg, q_dtok[2], q_d_hn, q_d_cls, q_d_rep, q_dA, q_dB, q_dC, q_dJ, q_dvn[4], q_ne_dw, q_bnpart[MAXL], q_heads_ws,
       q_ws[2], q_ws2, q_ws3;
   size_t bws_bytes, heads_ws_bytes, seg_ws_bytes, barena_bytes;
@@ -351,8 +351,10 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
     c->o_xin = a.take((size_t)rows * d * tsz);
     c->o_st0 = a.take((size_t)2 * rows * 4);
   }
-  for (int i = 0; i < nenc; ++i) c->o_xe[i] = a.take((size_t)rows * d * tsz);
-  for (int i = 0; i < nenc; ++i) c->o_enc_saved[i] = a.take(gt_encoder_layer_saved_bytes(&c->enc[i]));
+  // the LAST encoder layer is the pooled variant (gt_encoder_layer_pooled_*): cls / last pooling reads one row per sequence of it
+  for (int i = 0; i < nenc; ++i) c->o_xe[i] = a.take((size_t)(i == nenc - 1 ? B : rows) * d * tsz);
+  for (int i = 0; i < nenc; ++i)
+    c->o_enc_saved[i] = a.take(i == nenc - 1 ? gt_encoder_layer_pooled_saved_bytes(&c->enc[i]) : gt_encoder_layer_saved_bytes(&c->enc[i]));
   if (m->nout_w) {   // the final norm runs on the POOLED rows only (cls / last pooling reads nothing else of it: gnn_transformer.py:113-114)
     c->o_hgin = a.take((size_t)B * d * 4);
     c->o_sto = a.take((size_t)2 * B * 4);
@@ -412,6 +414,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   Bump q;
   c->q_d_hg = q.take((size_t)B * d * 4);
   c->q_d_hgin = q.take(m->nout_w ? (size_t)B * d * 4 : 0);
+  c->q_dyp = q.take((size_t)B * d * tsz);
   c->q_dtok[0] = q.take((size_t)rows * d * tsz);
   c->q_dtok[1] = q.take((size_t)rows * d * tsz);
   c->q_d_hn = q.take((size_t)N * d * tsz);
@@ -421,7 +424,8 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   c->q_dJ = q.take(m->jk_cat ? ND4 : 0);
   for (int i = 0; i < 4; ++i) c->q_dvn[i] = q.take((size_t)B * D * 4);
   size_t enc_ws = 256;
-  for (int i = 0; i < nenc; ++i) enc_ws = std::max(enc_ws, gt_encoder_layer_workspace_bytes(&c->enc[i]));
+  for (int i = 0; i < nenc; ++i)
+    enc_ws = std::max(enc_ws, i == nenc - 1 ? gt_encoder_layer_pooled_workspace_bytes(&c->enc[i]) : gt_encoder_layer_workspace_bytes(&c->enc[i]));
   const size_t ln_ws = std::max(gt_layernorm_bwd_workspace_bytes(rows, d), gt_layernorm_bwd_workspace_bytes(B, d));
   const size_t lin_ws = std::max(gt_linear_bwd_workspace_bytes(c->compute, B, m->Nh, d), gt_linear_bwd_workspace_bytes(c->compute, N, d, Kc));
   size_t emb_ws;
@@ -700,18 +704,21 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   }
   for (int i = 0; i < nenc; ++i) {
     c->enc_in[i] = cur;
-    GT_TRY(gt_encoder_layer_fwd(&c->enc[i], cur, P(c->o_xe[i]), P(c->o_enc_saved[i]), st));
+    if (i == nenc - 1) {   // only the pooled row of every sequence is read behind the last layer: y = [B][d]
+      GT_TRY(gt_encoder_layer_pooled_fwd(&c->enc[i], cur, c->last_rows, P(c->o_xe[i]), P(c->o_enc_saved[i]), st));
+    } else {
+      GT_TRY(gt_encoder_layer_fwd(&c->enc[i], cur, P(c->o_xe[i]), P(c->o_enc_saved[i]), st));
+    }
     cur = P(c->o_xe[i]);
   }
-  c->pre_out = cur;
+  c->pre_out = cur;   // [B][d]: the pooled rows
   if (m->nout_w) {
-    // transformer.norm (transformer_encoder.py:28-32) is row-wise and only the pooled row of every graph is read afterwards: the
-    // rows are gathered first (fp32) and normalised there -- B rows instead of every token row, forward and backward
-    GT_TRY(gt_rows_gather(tdt, cur, c->last_rows, B, d, (float*)P(c->o_hgin), st));
+    // transformer.norm (transformer_encoder.py:28-32) is row-wise: on the pooled rows (fp32 copies), forward and backward
+    GT_TRY(gt_rows_gather(tdt, cur, nullptr, B, d, (float*)P(c->o_hgin), st));
     GT_TRY(gt_layernorm_fwd(GT_F32, P(c->o_hgin), nullptr, m->nout_w, m->nout_b, m->nout_eps, 0.f, 0, B, d, P(c->o_hg), (float*)P(c->o_sto),
                             (float*)P(c->o_sto) + B, st));
   } else {
-    GT_TRY(gt_rows_gather(tdt, cur, c->last_rows, B, d, (float*)P(c->o_hg), st));
+    GT_TRY(gt_rows_gather(tdt, cur, nullptr, B, d, (float*)P(c->o_hg), st));
   }
   // ---- prediction heads as one GEMM over the stacked weights   (gnn_transformer.py:120-126)
   GT_TRY(gt_linear_fwd_ld(GT_F32, GT_F32, compute, P(c->o_hg), m->head_w, m->head_b, logits, B, m->Nh, d, m->ldy, 0, 0.f, 0, st));
@@ -781,9 +788,13 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
                               Q(c->q_d_hgin), nullptr, G + m->off_nout_w, G + m->off_nout_b, W(), ws_bytes, st));
       d_pool = (const float*)Q(c->q_d_hgin);
     }
-    GT_TRY(gt_rows_scatter(tdt, d_pool, c->last_rows, B, rows, d, dcur, st));
+    GT_TRY(gt_rows_scatter(tdt, d_pool, nullptr, B, B, d, Q(c->q_dyp), st));   // the pooled rows' gradient in the token dtype
     for (int i = nenc - 1; i >= 0; --i) {
-      GT_TRY(gt_encoder_layer_bwd(&c->enc[i], c->enc_in[i], dcur, P(c->o_enc_saved[i]), dnext, G + m->off_enc[i], W(), ws_bytes, st));
+      if (i == nenc - 1)
+        GT_TRY(gt_encoder_layer_pooled_bwd(&c->enc[i], c->enc_in[i], c->last_rows, Q(c->q_dyp), P(c->o_enc_saved[i]), dnext, G + m->off_enc[i],
+                                           W(), ws_bytes, st));
+      else
+        GT_TRY(gt_encoder_layer_bwd(&c->enc[i], c->enc_in[i], dcur, P(c->o_enc_saved[i]), dnext, G + m->off_enc[i], W(), ws_bytes, st));
       std::swap(dcur, dnext);
     }
     if (m->nin_w) {

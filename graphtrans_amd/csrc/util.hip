@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(UT) k_rows_gather(const T* __restrict__ x, con
   const int64_t C = dim / 4, total = n * C;
   for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
     const int64_t r = i / C, c = (i % C) * 4;
-    *reinterpret_cast<float4*>(out + r * dim + c) = gt_load4<T>(x + idx[r] * dim + c);
+    *reinterpret_cast<float4*>(out + r * dim + c) = gt_load4<T>(x + (idx ? idx[r] : r) * dim + c);
   }
 }
 
@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(UT) k_rows_scatter(const float* __restrict__ g
   const int64_t C = dim / 4, total = n * C;
   for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
     const int64_t r = i / C, c = (i % C) * 4;
-    gt_store4<T>(out + idx[r] * dim + c, *reinterpret_cast<const float4*>(g + r * dim + c));
+    gt_store4<T>(out + (idx ? idx[r] : r) * dim + c, *reinterpret_cast<const float4*>(g + r * dim + c));
   }
 }
 
@@ -47,6 +47,25 @@ __global__ void __launch_bounds__(UT) k_add3(const float* __restrict__ a, const 
     float4 v = gt_add4(*reinterpret_cast<const float4*>(a + i * 4), *reinterpret_cast<const float4*>(b + i * 4));
     if (c) v = gt_add4(v, *reinterpret_cast<const float4*>(c + i * 4));
     *reinterpret_cast<float4*>(out + i * 4) = v;
+  }
+}
+
+// rows moved in their storage type (the pooled rows of the last encoder layer): mode 0 out[i] = x[idx[i]] (gather), 1 out[idx[i]] = x[i]
+// (scatter into a zero-filled matrix), 2 out[idx[i]] += x[i] (fp32 add, idx must not repeat)
+template <typename T>
+__global__ void __launch_bounds__(UT) k_rows_move(const T* __restrict__ x, const int64_t* __restrict__ idx, int64_t n, int64_t dim,
+                                                  T* __restrict__ out, int mode) {
+  const int64_t C = dim / 4, total = n * C;
+  for (int64_t i = (int64_t)blockIdx.x * UT + threadIdx.x; i < total; i += (int64_t)gridDim.x * UT) {
+    const int64_t r = i / C, c = (i % C) * 4;
+    if (mode == 0) {
+      gt_store4<T>(out + r * dim + c, gt_load4<T>(x + idx[r] * dim + c));
+    } else {
+      T* o = out + idx[r] * dim + c;
+      float4 v = gt_load4<T>(x + r * dim + c);
+      if (mode == 2) v = gt_add4(v, gt_load4<T>(o));
+      gt_store4<T>(o, v);
+    }
   }
 }
 
@@ -90,6 +109,37 @@ extern "C" int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, in
   return GT_OK;
 }
 
+static int rows_move(const char* fn, int mode, int dtype, const void* x, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim,
+                     void* out, gt_stream_t stream_) {
+  if (dtype != GT_F32 && dtype != GT_BF16) { gt_set_error("%s: bad dtype", fn); return GT_ERR_INVALID_ARG; }
+  if (n < 0 || dim <= 0 || dim % 4) { gt_set_error("%s: dim must be a positive multiple of 4", fn); return GT_ERR_INVALID_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  if (mode == 1) {
+    if (total_rows == 0) return GT_OK;
+    if (!out) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
+    (void)hipMemsetAsync(out, 0, (size_t)total_rows * dim * (dtype == GT_F32 ? 4 : 2), stream);
+  }
+  if (n == 0) return GT_OK;
+  if (!(x && idx && out)) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_rows_move<float>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, stream, (const float*)x, idx, n, dim, (float*)out, mode);
+  else
+    hipLaunchKernelGGL(k_rows_move<gt_bf16>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, stream, (const gt_bf16*)x, idx, n, dim, (gt_bf16*)out,
+                       mode);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+extern "C" int gt_rows_take(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, void* out, gt_stream_t stream) {
+  return rows_move("gt_rows_take", 0, dtype, x, idx, n, 0, dim, out, stream);
+}
+extern "C" int gt_rows_put(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim, void* out,
+                           gt_stream_t stream) {
+  return rows_move("gt_rows_put", 1, dtype, x, idx, n, total_rows, dim, out, stream);
+}
+extern "C" int gt_rows_add(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, void* out, gt_stream_t stream) {
+  return rows_move("gt_rows_add", 2, dtype, x, idx, n, 0, dim, out, stream);
+}
+
 extern "C" int gt_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, gt_stream_t stream_) {
   GT_CHECK_ARG(n >= 0, "bad size");
   if (n == 0) return GT_OK;
@@ -120,7 +170,7 @@ extern "C" int gt_rows_gather(int dtype, const void* x, const int64_t* idx, int6
   GT_CHECK_ARG(dtype == GT_F32 || dtype == GT_BF16, "bad dtype");
   GT_CHECK_ARG(n >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
   if (n == 0) return GT_OK;
-  GT_CHECK_ARG(x && idx && out, "null buffer");
+  GT_CHECK_ARG(x && out, "null buffer");   // idx == NULL: rows 0 .. n-1 (a storage-type -> fp32 conversion of n rows)
   if (dtype == GT_F32)
     hipLaunchKernelGGL(k_rows_gather<float>, dim3(grid_for(n * dim / 4)), dim3(UT), 0, (hipStream_t)stream_, (const float*)x, idx,
                        n, dim, out);
@@ -136,7 +186,7 @@ extern "C" int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx,
   GT_CHECK_ARG(dtype == GT_F32 || dtype == GT_BF16, "bad dtype");
   GT_CHECK_ARG(n >= 0 && total_rows >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
   if (total_rows == 0) return GT_OK;
-  GT_CHECK_ARG(out && (n == 0 || (grad && idx)), "null buffer");
+  GT_CHECK_ARG(out && (n == 0 || grad), "null buffer");   // idx == NULL: rows 0 .. n-1
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipMemsetAsync(out, 0, (size_t)total_rows * dim * (dtype == GT_F32 ? 4 : 2), stream);
   if (n == 0) return GT_OK;

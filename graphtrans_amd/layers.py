@@ -168,6 +168,64 @@ class _EncoderLayer(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None, *_split(grads, params))
 
 
+class _EncoderLayerPooled(torch.autograd.Function):
+    """The LAST encoder layer under cls / last pooling (gt_encoder_layer_pooled_*): x (rows, d) -> y (B, d), the layer's output in the
+    pooled row of every sequence only (what transformer_out[-1] reads, models/gnn_transformer.py:113-114)."""
+
+    @staticmethod
+    def forward(ctx, x, lay, nhead, dropout_p, seed, training, ln_eps, act, *params):
+        L = _bind()
+        x = x.contiguous()
+        rows, d = x.shape
+        desc = EncoderLayerDesc()
+        desc.rows, desc.d_model, desc.ffn = rows, d, params[4].shape[0]
+        desc.nhead = nhead
+        desc.dtype = GT_BF16 if x.dtype == torch.bfloat16 else GT_F32
+        desc.compute = _compute_code()
+        desc.training = 1 if training else 0
+        desc.seq_desc = _ptr(lay.desc)
+        desc.num_seqs, desc.row_stride, desc.max_npos = lay.B, lay.row_stride, lay.max_npos
+        desc.work_items, desc.num_work = _ptr(getattr(lay, "work", None)), getattr(lay, "num_work", 0)
+        desc.dropout_p, desc.ln_eps, desc.seed = float(dropout_p), float(ln_eps), int(seed)
+        desc.act = ENC_ACT[act]
+        for name, p in zip(("in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w",
+                            "n2_b"), params):
+            setattr(desc, name, _ptr(_f32c(p)))
+        zero = not getattr(lay, "exact", True)
+        saved = _bytes(L.gt_encoder_layer_pooled_saved_bytes(C.byref(desc)), x.device)
+        if zero:
+            saved.zero_()
+        y = torch.empty((lay.B, d), dtype=x.dtype, device=x.device)
+        _lib.check(L.gt_encoder_layer_pooled_fwd(C.byref(desc), _ptr(x), _ptr(lay.last_rows), _ptr(y), _ptr(saved), _stream()),
+                   "gt_encoder_layer_pooled_fwd")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.desc, ctx.lay = desc, lay
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _bind()
+        x, saved = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        desc = ctx.desc
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        grads = torch.empty(L.gt_encoder_layer_grad_elems(C.byref(desc)), dtype=torch.float32, device=x.device)
+        ws_bytes = L.gt_encoder_layer_pooled_workspace_bytes(C.byref(desc))
+        ws = _bytes(ws_bytes, x.device)
+        if not getattr(ctx.lay, "exact", True):
+            ws.zero_()
+        _lib.check(L.gt_encoder_layer_pooled_bwd(C.byref(desc), _ptr(x), _ptr(ctx.lay.last_rows), _ptr(dy), _ptr(saved), _ptr(dx), _ptr(grads),
+                                                 _ptr(ws), ws_bytes, _stream()), "gt_encoder_layer_pooled_bwd")
+        return (dx, None, None, None, None, None, None, None, *_split(grads, params))
+
+
+def encoder_layer_pooled(x, mod, lay, nhead, dropout_p, seed, training, activation="relu"):
+    return _EncoderLayerPooled.apply(x, lay, nhead, dropout_p, seed, training, mod.norm1.eps, activation, *encoder_layer_params(mod))
+
+
 ENC_ACT = {"relu": 0, "gelu": 1}   # gt_encoder_layer.act
 
 

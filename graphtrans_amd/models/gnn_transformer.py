@@ -118,8 +118,7 @@ class GNNTransformer(BaseModel):
             with_cls = enc.cls_embedding is not None
             lay = gs.layout("packed", max_len, with_cls)
             tokens, _ = ops.seq_gather(h_node, enc.cls_embedding if with_cls else None, gs, lay)
-            out = enc.forward_tokens(tokens, lay)
-            h_graph = out.index_select(0, lay.last_rows).float()  # out[-1] of every sequence
+            h_graph = enc.forward_tokens(tokens, lay, pooled=True).float()  # out[-1] of every sequence (the only rows read)
         else:
             padded_h_node, src_padding_mask, num_nodes, mask, max_num_nodes = pad_batch(
                 h_node, batched_data.batch, max_len, get_mask=True, graph=gs)

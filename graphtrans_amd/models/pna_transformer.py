@@ -82,7 +82,7 @@ class PNATransformer(BaseModel):
             with_cls = enc.cls_embedding is not None
             lay = gs.layout("packed", max_len, with_cls)
             tokens, _ = ops.seq_gather(h_node, enc.cls_embedding if with_cls else None, gs, lay)
-            h_graph = enc.forward_tokens(tokens, lay).index_select(0, lay.last_rows).float()
+            h_graph = enc.forward_tokens(tokens, lay, pooled=True).float()
         else:
             padded_h_node, src_padding_mask = pad_batch(h_node, batched_data.batch, max_len, graph=gs)
             transformer_out, mask = enc(padded_h_node, src_padding_mask)

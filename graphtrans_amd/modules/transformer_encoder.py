@@ -86,14 +86,30 @@ class TransformerNodeEncoder(nn.Module):
         f = ops.linear(f, mod.linear2.weight, mod.linear2.bias)
         return self._ln(f, mod.norm2, resid=x, seed=seed ^ 0x14057B7EF767814F)
 
-    def forward_tokens(self, tokens, lay):
-        """tokens (lay.rows, d) already containing the CLS rows -> (lay.rows, d)."""
+    def forward_tokens(self, tokens, lay, pooled=False):
+        """tokens (lay.rows, d) already containing the CLS rows -> (lay.rows, d).
+        pooled=True (cls / last pooling: only transformer_out[-1] of every sequence is read, models/gnn_transformer.py:113-114) ->
+        (lay.B, d), the output in the LAST position of every sequence: the last layer then computes keys and values for every row
+        but attention, out_proj, the FFN and both norms for the pooled rows only (layers.encoder_layer_pooled), and the final norm
+        runs on those B rows.  Same values as the full computation followed by the row selection (at dropout 0)."""
         x = tokens.to(self.compute_dtype)
         if self.norm_input is not None:
             x = self._ln(x, self.norm_input)
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if (self.training and self.dropout_p > 0) else 0
+        nl = len(self.transformer.layers)
+        done = False
         for i, mod in enumerate(self.transformer.layers):
-            x = self._layer(x, mod, lay, (seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF)
+            s_i = (seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF
+            if pooled and i == nl - 1 and layers.encoder_layer_eligible(mod, x, self.activation) and lay.kind == "packed":
+                p = self.dropout_p if self.training else 0.0
+                x = layers.encoder_layer_pooled(x, mod, lay, self.nhead, p, s_i, self.training, self.activation)
+                done = True
+            else:
+                x = self._layer(x, mod, lay, s_i)
+        if pooled and not done:
+            x = x.index_select(0, lay.last_rows)
+        if pooled:
+            x = x.float()   # the final norm on fp32 copies of the pooled rows (what the fused path does)
         if self.transformer.norm is not None:
             x = self._ln(x, self.transformer.norm)
         return x

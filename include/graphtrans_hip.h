@@ -318,6 +318,17 @@ int gt_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* d_ctx, 
                 int64_t num_seqs, int64_t row_stride, int64_t max_npos, const int32_t* work_items, int64_t num_work,
                 const float* dense_mask, const float* key_valid, float mask_value, float scale, float dropout_p,
                 uint64_t seed, gt_stream_t stream);
+/* Pooled mode: after the LAST encoder layer only one row per sequence is read (cls / last pooling, models/gnn_transformer.py:113-114):
+ * gt_attn_fwd_last computes the 64-row tile that holds the LAST position of every sequence only (ctx / lse rows outside those tiles
+ * are not written); gt_attn_bwd_last is its backward for a d_ctx that is non-zero in those last positions only: dQ for the last
+ * tiles, dK / dV for every row; d_qkv must be ZERO-FILLED by the caller; work_items = the full work list (key tiles). */
+int gt_attn_fwd_last(int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model, int nhead,
+                     const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int64_t max_npos, float scale, float dropout_p,
+                     uint64_t seed, gt_stream_t stream);
+int gt_attn_bwd_last(int dtype, const void* qkv, const void* ctx, const void* d_ctx, const float* lse, float* delta, void* d_qkv,
+                     int64_t total_rows, int64_t d_model, int nhead, const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride,
+                     int64_t max_npos, const int32_t* work_items, int64_t num_work, float scale, float dropout_p, uint64_t seed,
+                     gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d over the rows of an [rows][dim] matrix (channels = columns), optional fused ReLU.
@@ -627,6 +638,17 @@ int64_t gt_encoder_layer_grad_elems(const gt_encoder_layer* layer);
 int gt_encoder_layer_fwd(const gt_encoder_layer* layer, const void* x, void* y, void* saved, gt_stream_t stream);
 int gt_encoder_layer_bwd(const gt_encoder_layer* layer, const void* x, const void* dy, const void* saved, void* dx,
                          float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* The LAST encoder layer when only one row per sequence is read afterwards (cls / last pooling: transformer_out[-1],
+ * models/gnn_transformer.py:113-114 -- the reference computes every row and drops the rest): in_proj for every row (keys and values),
+ * attention for the tile of the pooled row, out_proj / norm1 / FFN / norm2 on the POOLED rows only.  pool_rows [num_seqs] = token row
+ * of the last position of every sequence; y_pool / dy_pool [num_seqs][d_model] in the token dtype.  Same parameters, same gradients:
+ * the skipped rows influence neither the output nor any gradient.  (The row-wise dropouts are drawn per pooled-row index.) */
+size_t gt_encoder_layer_pooled_saved_bytes(const gt_encoder_layer* layer);
+size_t gt_encoder_layer_pooled_workspace_bytes(const gt_encoder_layer* layer);
+int gt_encoder_layer_pooled_fwd(const gt_encoder_layer* layer, const void* x, const int64_t* pool_rows, void* y_pool, void* saved,
+                                gt_stream_t stream);
+int gt_encoder_layer_pooled_bwd(const gt_encoder_layer* layer, const void* x, const int64_t* pool_rows, const void* dy_pool,
+                                const void* saved, void* dx, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 
 typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [relu] [+ x]; fp32 rows */
   int64_t N, E, B, D;
@@ -938,6 +960,11 @@ int gt_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_p
               int64_t rows, gt_stream_t stream);
 int gt_add3(const float* a, const float* b, const float* c /* or NULL */, int64_t n, float* out, gt_stream_t stream);
 int gt_rows_gather(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, float* out, gt_stream_t stream);
+/* rows moved in their storage type (the pooled rows of the last encoder layer): take out[i] = x[idx[i]]; put out[idx[i]] = x[i] into
+ * a zero-filled [total_rows][dim] matrix; add out[idx[i]] += x[i] (idx must not repeat) */
+int gt_rows_take(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, void* out, gt_stream_t stream);
+int gt_rows_put(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim, void* out, gt_stream_t stream);
+int gt_rows_add(int dtype, const void* x, const int64_t* idx, int64_t n, int64_t dim, void* out, gt_stream_t stream);
 int gt_rows_scatter(int dtype, const float* grad, const int64_t* idx, int64_t n, int64_t total_rows, int64_t dim,
                     void* out, gt_stream_t stream);
 
