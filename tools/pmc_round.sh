@@ -9,8 +9,9 @@ tag=${1:-r02a}
 shift || true
 modes=${@:-mixed bf16}
 mkdir -p gpurun_out/$tag
-for w in code2 molpcba; do
+for w in code2 molpcba er; do
   for m in $modes; do
+    [ $w = er ] && [ $m != mixed ] && continue   # the stress workload: the headline mode only
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_${w}_${m}_$c
       timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_${w}_${m}_$c -o res -- python bench.py --workload $w --mode $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_${w}_${m}_$c.log 2>&1 || true

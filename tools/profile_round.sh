@@ -1,4 +1,5 @@
 # usage (GPU box): bash tools/profile_round.sh <round tag>   -- PMC passes first (bench.py attaches their build-stamped JSON),
+# (rocpd_summary divides by 52 steps: 10 warm-up + 30 timed + the 12 single steps of the idle-device host measurement)
 # then the bench lines of all workloads and the rocprofv3 kernel summaries; everything lands in gpurun_out/<tag>/
 set -e
 TAG=${1:-r02a}
@@ -16,11 +17,12 @@ python bench.py --workload code2-pna --no-extra > gpurun_out/$TAG/bench_code2pna
 python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 > gpurun_out/$TAG/bench_code2_mixed_clean.json 2>/dev/null
 python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --mode bf16 > gpurun_out/$TAG/bench_code2_bf16_clean.json 2>/dev/null
 for m in mixed bf16; do
-  for w in code2 molpcba; do
+  for w in code2 molpcba er code2-pna nci1; do
+    [ $w != code2 ] && [ $w != molpcba ] && [ $m != mixed ] && continue
     rm -rf /tmp/prof_${w}_$m
     rocprofv3 --kernel-trace --stats -d /tmp/prof_${w}_$m -o res -- python bench.py --workload $w --mode $m --steps 30 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$TAG/prof_${w}_$m.log 2>&1 || true
     db=$(find /tmp/prof_${w}_$m -name "*.db" | head -1)
-    python tools/rocpd_summary.py $db 40 gpurun_out/$TAG/${TAG}_${w}_b256_${m} >> gpurun_out/$TAG/prof_${w}_$m.log 2>&1 || true
+    python tools/rocpd_summary.py $db 52 gpurun_out/$TAG/${TAG}_${w}_b256_${m} >> gpurun_out/$TAG/prof_${w}_$m.log 2>&1 || true
   done
 done
 ls gpurun_out/$TAG
