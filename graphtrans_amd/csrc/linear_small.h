@@ -70,8 +70,11 @@ __global__ void __launch_bounds__(256) k_small_fwd(SmallArgs a) {
   const int wq = threadIdx.x >> 6;
   const int64_t wave = KS == 1 ? (int64_t)blockIdx.x * 4 + wq : (int64_t)blockIdx.x;
   const int64_t ntp = (a.N + 31) / 32;
-  const int64_t mt = wave / ntp, np = wave % ntp;
-  const bool live = mt * 16 < a.M;
+  // KS == 1 (wide outputs: the prediction heads, 256 x 25 010 x 128): the row tiles of one column pair are NEIGHBOURS -- the four
+  // waves of a block read the same 32 weight rows (L1 hits) instead of re-reading them from L2 once per row tile
+  const int64_t mtp = (a.M + 15) / 16;
+  const int64_t mt = KS == 1 ? wave % mtp : wave / ntp, np = KS == 1 ? wave / mtp : wave % ntp;
+  const bool live = mt * 16 < a.M && np < ntp;
   if (KS == 1 && !live) return;
   const int64_t mrow = live ? mt * 16 : 0;
   const int64_t m = mrow + n < a.M ? mrow + n : a.M - 1;          // clamped rows are computed and never stored
