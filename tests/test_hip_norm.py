@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("rows,D", [(257, 300), (5000, 600), (4, 16), (32407, 300), (300, 2048), (1024, 600), (1025, 36), (2, 4)])
+@pytest.mark.parametrize("rows,D", [(257, 300), (5000, 600), (4, 16), (32407, 300), (300, 2048), (1024, 600), (1025, 36), (2, 4),
+                                     (3000, 300), (8192, 300), (8193, 300), (6611, 600)])   # 1025 .. 8192 rows: the one-launch kernels (k_bn_mid_*)
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_batchnorm_matches_torch(rows, D, relu, training):
@@ -117,7 +118,7 @@ def test_layernorm_dropout_replay():
 
 
 @pytest.mark.parametrize("relu", [False, True])
-@pytest.mark.parametrize("rows,D", [(1000, 300), (257, 64)])
+@pytest.mark.parametrize("rows,D", [(1000, 300), (257, 64), (5000, 300), (2000, 64)])
 def test_batchnorm_fused_dropout(rows, D, relu):
     """F.dropout behind the layer BatchNorm (gnn_module.py:88-90,209-212) fused into gt_batchnorm_*: the
     kept set is replayed by the backward; values are bn(x)[relu] / (1 - p) or 0."""
@@ -159,3 +160,66 @@ def test_batchnorm_fused_dropout(rows, D, relu):
     ye = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm, rv, None, 0.1, 1e-5, False, relu, dropout_p=p, seed=1)
     ye0 = ops.batch_norm(x.detach(), w.detach(), b.detach(), rm, rv, None, 0.1, 1e-5, False, relu)
     assert torch.equal(ye, ye0)
+
+
+@pytest.mark.parametrize("rows,D,B", [(1500, 300, 40), (6611, 600, 256), (8192, 128, 7)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
+    """gt_batchnorm_fwd_bcast at 1025 .. 8192 rows (one launch, rows in registers): relu + dropout + residual + the next layer's
+    virtual-node rows (gnn_module.py:199,204-212) against float64 torch with the kernel's own dropout mask, and the backward
+    of the same call."""
+    import ctypes as C
+    from graphtrans_amd import _lib
+    torch.manual_seed(11)
+    p, seed, eps, mom = 0.25, 99, 1e-5, 0.1
+    x = (torch.randn(rows, D) * 1.5 + torch.linspace(-20, 20, D)).to(DEV)
+    w = (torch.rand(D) + 0.5).to(DEV)
+    b = (torch.randn(D) * 0.2).to(DEV)
+    resid = torch.randn(rows, D, device=DEV)
+    vn = torch.randn(B, D, device=DEV)
+    idx = torch.sort(torch.randint(0, B, (rows,), dtype=torch.int32)).values.to(DEV)
+    rm, rv = torch.zeros(D, device=DEV), torch.ones(D, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    wsb = _lib.lib().gt_batchnorm_workspace_bytes(rows, D)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm), ptr(rv), ptr(nbt), mom, eps, 1, int(relu), ptr(resid),
+                ptr(vn), ptr(idx), None, rows, D, ptr(y), ptr(mean), ptr(rstd), p, seed, ptr(ws), wsb, st)
+    # the same call without dropout / addends gives the mask
+    y0 = torch.empty_like(x)
+    _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm.clone()), ptr(rv.clone()), None, mom, eps, 1, int(relu), None,
+                None, None, None, rows, D, ptr(y0), ptr(mean.clone()), ptr(rstd.clone()), 0.0, 0, ptr(ws), wsb, st)
+    add = resid + vn[idx.long()]
+    kept = ((y - add).abs() > 1e-12) & (y0 != 0)
+    xd = x.double().cpu()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    yr = (xd - mu) / torch.sqrt(var + eps) * w.double().cpu() + b.double().cpu()
+    if relu:   # the kernel's own gate (an output within fp32 rounding of 0 is a coin flip)
+        yr = yr * (y0 > 0).double().cpu()
+    yr = yr * kept.double().cpu() / (1 - p) + add.double().cpu()
+    live = y0 != 0
+    rate = 1.0 - (kept & live).sum().item() / live.sum().item()
+    assert abs(rate - p) < 0.02, rate
+    assert_close(y.cpu().double(), yr, atol=1e-4, rtol=1e-4, what="y")
+    assert_close(mean.cpu().double(), mu, atol=1e-4, rtol=1e-5, what="mean")
+    assert_close(rm.cpu().double(), mom * mu, atol=1e-4, rtol=1e-5, what="running_mean")
+    assert_close(rv.cpu().double(), (1 - mom) + mom * xd.var(0, unbiased=True), atol=1e-4, rtol=1e-4, what="running_var")
+    assert int(nbt) == 1
+    # backward of the same call
+    g = torch.randn(rows, D, device=DEV)
+    dx, dw, db = torch.empty_like(x), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    _lib.launch("gt_batchnorm_bwd", 0, ptr(x), ptr(g), ptr(w), ptr(b), ptr(mean), ptr(rstd), 1, int(relu), rows, D, ptr(dx), ptr(dw), ptr(db),
+                p, seed, ptr(ws), wsb, st)
+    xr = xd.clone().requires_grad_(True)
+    wr, br = w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    m2, v2 = xr.mean(0), xr.var(0, unbiased=False)
+    z = (xr - m2) / torch.sqrt(v2 + eps) * wr + br
+    if relu:
+        z = z * (y0 > 0).double().cpu()
+    (z * kept.double().cpu() / (1 - p) * g.double().cpu()).sum().backward()
+    assert_close(dx.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4, what="dx")
+    assert_close(dw.cpu().double(), wr.grad, atol=1e-4, rtol=1e-4, what="dw")
+    assert_close(db.cpu().double(), br.grad, atol=1e-4, rtol=1e-4, what="db")
