@@ -477,7 +477,9 @@ __device__ __forceinline__ int mid_quad(int nq) {   // block -> column quad (con
   return (((int)blockIdx.x >> 3) < per && q < nq) ? q : -1;
 }
 
-template <int RPT>
+// (every load is unconditional on a clamped row: a load under `if (r < N)` costs an exec-mask branch and an s_waitcnt per pair of
+// rows -- the round trips then run one after the other instead of together)
+template <int RPT, bool ADD>
 __global__ void __launch_bounds__(MID_NT) k_bn_mid_fwd(
     const float* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
     const float* __restrict__ b, const float* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
@@ -489,12 +491,18 @@ __global__ void __launch_bounds__(MID_NT) k_bn_mid_fwd(
   const int64_t c = (int64_t)q * 4;
   if (q == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
   float4 v[RPT];
+  int bi[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT, rc = r < N ? r : N - 1;
+    v[i] = *reinterpret_cast<const float4*>(x + rc * D + c);
+    if constexpr (ADD) bi[i] = (bcast ? bidx : reinterpret_cast<const int32_t*>(x))[rc];   // (no branch around a load: see above)
+  }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    v[i] = r < N ? *reinterpret_cast<const float4*>(x + r * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s = gt_add4(s, v[i]);
+    const float live = (int64_t)threadIdx.x + (int64_t)i * MID_NT < N ? 1.f : 0.f;
+    s.x = fmaf(v[i].x, live, s.x); s.y = fmaf(v[i].y, live, s.y); s.z = fmaf(v[i].z, live, s.z); s.w = fmaf(v[i].w, live, s.w);
   }
   const float inv_n = 1.0f / (float)N;
   float4 mu = mid_block_sum(s, sm);
@@ -502,11 +510,10 @@ __global__ void __launch_bounds__(MID_NT) k_bn_mid_fwd(
   s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    if (r < N) {
-      const float4 dlt = make_float4(v[i].x - mu.x, v[i].y - mu.y, v[i].z - mu.z, v[i].w - mu.w);
-      s.x = fmaf(dlt.x, dlt.x, s.x); s.y = fmaf(dlt.y, dlt.y, s.y); s.z = fmaf(dlt.z, dlt.z, s.z); s.w = fmaf(dlt.w, dlt.w, s.w);
-    }
+    const float live = (int64_t)threadIdx.x + (int64_t)i * MID_NT < N ? 1.f : 0.f;
+    const float4 dlt = make_float4(v[i].x - mu.x, v[i].y - mu.y, v[i].z - mu.z, v[i].w - mu.w);
+    s.x = fmaf(dlt.x * live, dlt.x, s.x); s.y = fmaf(dlt.y * live, dlt.y, s.y);
+    s.z = fmaf(dlt.z * live, dlt.z, s.z); s.w = fmaf(dlt.w * live, dlt.w, s.w);
   }
   float4 var = mid_block_sum(s, sm);
   var = make_float4(var.x * inv_n, var.y * inv_n, var.z * inv_n, var.w * inv_n);
@@ -525,17 +532,31 @@ __global__ void __launch_bounds__(MID_NT) k_bn_mid_fwd(
     }
   }
   const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+  // four rows at a time: their addend loads (residual rows, the virtual-node rows) are in flight together
 #pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    if (r < N) {
+  for (int i0 = 0; i0 < RPT; i0 += 4) {
+    float4 ra[4], rb[4];
+    if constexpr (ADD) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = (int64_t)threadIdx.x + (int64_t)(i0 + u) * MID_NT, rc = r < N ? r : N - 1;
+        ra[u] = *reinterpret_cast<const float4*>((resid ? resid : x) + rc * D + c);
+        rb[u] = *reinterpret_cast<const float4*>(bcast ? bcast + (int64_t)bi[i0 + u] * D + c : x + rc * D + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
       float4 o = make_float4((v[i].x - mu.x) * rs.x * ww.x + bb.x, (v[i].y - mu.y) * rs.y * ww.y + bb.y,
                              (v[i].z - mu.z) * rs.z * ww.z + bb.z, (v[i].w - mu.w) * rs.w * ww.w + bb.w);
       if (relu) o = gt_relu4(o);
       if (drop.thr) o = bn_drop4(o, drop, (uint32_t)r, (uint32_t)c);
-      if (resid) o = gt_add4(o, *reinterpret_cast<const float4*>(resid + r * D + c));
-      if (bcast) o = gt_add4(o, *reinterpret_cast<const float4*>(bcast + (int64_t)bidx[r] * D + c));
-      *reinterpret_cast<float4*>(y + r * D + c) = o;
+      if constexpr (ADD) {
+        if (resid) o = gt_add4(o, ra[u]);
+        if (bcast) o = gt_add4(o, rb[u]);
+      }
+      if (r < N) *reinterpret_cast<float4*>(y + r * D + c) = o;
     }
   }
 }
@@ -550,30 +571,26 @@ __global__ void __launch_bounds__(MID_NT) k_bn_mid_bwd(
   const int q = mid_quad((int)(D / 4));
   if (q < 0) return;
   const int64_t c = (int64_t)q * 4;
+  float4 g[RPT], xh[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT, rc = r < N ? r : N - 1;
+    g[i] = *reinterpret_cast<const float4*>(dy + rc * D + c);
+    xh[i] = *reinterpret_cast<const float4*>(x + rc * D + c);
+  }
   const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
   const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-  float4 g[RPT], xh[RPT];
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    xh[i] = g[i];
-    if (r < N) {
-      g[i] = *reinterpret_cast<const float4*>(dy + r * D + c);
-      xh[i] = *reinterpret_cast<const float4*>(x + r * D + c);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    if (r < N) {
-      xh[i] = make_float4((xh[i].x - mu.x) * rs.x, (xh[i].y - mu.y) * rs.y, (xh[i].z - mu.z) * rs.z, (xh[i].w - mu.w) * rs.w);
-      if (drop.thr) g[i] = bn_drop4(g[i], drop, (uint32_t)r, (uint32_t)c);
-      if (relu)   // the gate of k_bn_bwd_partial / _apply: 1[(x - mean) * rstd * w + b > 0]
-        g[i] = make_float4(xh[i].x * ww.x + bb.x > 0.f ? g[i].x : 0.f, xh[i].y * ww.y + bb.y > 0.f ? g[i].y : 0.f,
-                           xh[i].z * ww.z + bb.z > 0.f ? g[i].z : 0.f, xh[i].w * ww.w + bb.w > 0.f ? g[i].w : 0.f);
-    }
+    const float live = r < N ? 1.f : 0.f;
+    xh[i] = make_float4((xh[i].x - mu.x) * rs.x, (xh[i].y - mu.y) * rs.y, (xh[i].z - mu.z) * rs.z, (xh[i].w - mu.w) * rs.w);
+    g[i] = make_float4(g[i].x * live, g[i].y * live, g[i].z * live, g[i].w * live);
+    if (drop.thr) g[i] = bn_drop4(g[i], drop, (uint32_t)r, (uint32_t)c);
+    if (relu)   // the gate of k_bn_bwd_partial / _apply: 1[(x - mean) * rstd * w + b > 0]
+      g[i] = make_float4(xh[i].x * ww.x + bb.x > 0.f ? g[i].x : 0.f, xh[i].y * ww.y + bb.y > 0.f ? g[i].y : 0.f,
+                         xh[i].z * ww.z + bb.z > 0.f ? g[i].z : 0.f, xh[i].w * ww.w + bb.w > 0.f ? g[i].w : 0.f);
     s0 = gt_add4(s0, g[i]);
     s1.x = fmaf(g[i].x, xh[i].x, s1.x); s1.y = fmaf(g[i].y, xh[i].y, s1.y);
     s1.z = fmaf(g[i].z, xh[i].z, s1.z); s1.w = fmaf(g[i].w, xh[i].w, s1.w);
@@ -587,14 +604,12 @@ __global__ void __launch_bounds__(MID_NT) k_bn_mid_bwd(
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    if (r < N) {
-      float4 o;
-      o.x = ww.x * rs.x * (g[i].x - db.x * inv_n - xh[i].x * dw.x * inv_n);
-      o.y = ww.y * rs.y * (g[i].y - db.y * inv_n - xh[i].y * dw.y * inv_n);
-      o.z = ww.z * rs.z * (g[i].z - db.z * inv_n - xh[i].z * dw.z * inv_n);
-      o.w = ww.w * rs.w * (g[i].w - db.w * inv_n - xh[i].w * dw.w * inv_n);
-      *reinterpret_cast<float4*>(dx + r * D + c) = o;
-    }
+    float4 o;
+    o.x = ww.x * rs.x * (g[i].x - db.x * inv_n - xh[i].x * dw.x * inv_n);
+    o.y = ww.y * rs.y * (g[i].y - db.y * inv_n - xh[i].y * dw.y * inv_n);
+    o.z = ww.z * rs.z * (g[i].z - db.z * inv_n - xh[i].z * dw.z * inv_n);
+    o.w = ww.w * rs.w * (g[i].w - db.w * inv_n - xh[i].w * dw.w * inv_n);
+    if (r < N) *reinterpret_cast<float4*>(dx + r * D + c) = o;
   }
 }
 static inline bool bn_mid_ok(int dtype, int64_t rows, int64_t dim) {
@@ -1177,14 +1192,16 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
         rc = gt_stream_wait_event(stream_, ev_bcast_ready);
         if (rc) return rc;
       }
-#define GT_BN_MID_FWD(RPT_)                                                                                                        \
-  hipLaunchKernelGGL(k_bn_mid_fwd<RPT_>, dim3(bn_mid_grid(dim)), dim3(MID_NT), 0, stream, (const float*)x, rows, dim, eps, momentum, \
+#define GT_BN_MID_FWD2(RPT_, ADD_)                                                                                                       \
+  hipLaunchKernelGGL((k_bn_mid_fwd<RPT_, ADD_>), dim3(bn_mid_grid(dim)), dim3(MID_NT), 0, stream, (const float*)x, rows, dim, eps, momentum, \
                      weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean, running_var,               \
                      num_batches_tracked, (float*)y, (const float*)bcast, bcast_index)
+#define GT_BN_MID_FWD(RPT_) do { if (resid || bcast) GT_BN_MID_FWD2(RPT_, true); else GT_BN_MID_FWD2(RPT_, false); } while (0)
       if (rows <= 4 * MID_NT) GT_BN_MID_FWD(4);
       else if (rows <= 8 * MID_NT) GT_BN_MID_FWD(8);
       else GT_BN_MID_FWD(16);
 #undef GT_BN_MID_FWD
+#undef GT_BN_MID_FWD2
       GT_CHECK_LAUNCH();
       return GT_OK;
     }

@@ -162,6 +162,21 @@ def test_batchnorm_fused_dropout(rows, D, relu):
     assert torch.equal(ye, ye0)
 
 
+def _bn_keep_mask(rows, D, p, seed):
+    """the kept set of the BatchNorm dropout (csrc/norm.hip: bn_hash of (seed, row, column) >= p * 2^32), restated with int64 tensors"""
+    M = 0xFFFFFFFF
+    r = torch.arange(rows, dtype=torch.int64).reshape(-1, 1)
+    c = torch.arange(D, dtype=torch.int64).reshape(1, -1)
+    s0, s1 = seed & M, (seed >> 32) & M
+    x = (((r * 0x9E3779B1) & M) + s0 & M) ^ (((c * 0x85EBCA77) & M) + s1 & M)
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M
+    x = x ^ (x >> 15); x = (x * 0x846ca68b) & M
+    x = x ^ (x >> 16)
+    thr = min(max(int(p * 4294967296.0), 1), 4294967295)
+    return x >= thr
+
+
+
 @pytest.mark.parametrize("rows,D,B", [(1500, 300, 40), (6611, 600, 256), (8192, 128, 7)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
@@ -193,15 +208,16 @@ def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
     _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm.clone()), ptr(rv.clone()), None, mom, eps, 1, int(relu), None,
                 None, None, None, rows, D, ptr(y0), ptr(mean.clone()), ptr(rstd.clone()), 0.0, 0, ptr(ws), wsb, st)
     add = resid + vn[idx.long()]
-    kept = ((y - add).abs() > 1e-12) & (y0 != 0)
+    kept = _bn_keep_mask(rows, D, p, seed).to(DEV)
+    clear = y0.abs() > 1e-3   # (a kept value that small may vanish in the sum with the addends)
+    assert torch.equal(((y - add) != 0)[clear], kept[clear])
     xd = x.double().cpu()
     mu, var = xd.mean(0), xd.var(0, unbiased=False)
     yr = (xd - mu) / torch.sqrt(var + eps) * w.double().cpu() + b.double().cpu()
     if relu:   # the kernel's own gate (an output within fp32 rounding of 0 is a coin flip)
         yr = yr * (y0 > 0).double().cpu()
     yr = yr * kept.double().cpu() / (1 - p) + add.double().cpu()
-    live = y0 != 0
-    rate = 1.0 - (kept & live).sum().item() / live.sum().item()
+    rate = 1.0 - kept.double().mean().item()
     assert abs(rate - p) < 0.02, rate
     assert_close(y.cpu().double(), yr, atol=1e-4, rtol=1e-4, what="y")
     assert_close(mean.cpu().double(), mu, atol=1e-4, rtol=1e-5, what="mean")
