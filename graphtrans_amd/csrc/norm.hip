@@ -446,178 +446,6 @@ __global__ void __launch_bounds__(SM_COLS * SM_LANES) k_bn_small_bwd(
   }
 }
 
-// ---- a few thousand rows (Molpcba's 6.6 k node rows x 300 / 600 columns, Code2 at 32 graphs per rank, PNA b128): ONE launch per
-// direction instead of three.  The three-kernel scheme above is a chain of three dependent launches of 6-11 us each on 8-16 MB --
-// launch-to-launch latency, not bandwidth (profiles/r04m_molpcba_*: 10 BatchNorms x (21 + 30) us of a 2.6 ms step).  Here a
-// 512-thread block owns FOUR columns (one 16-byte chunk per row) x ALL rows, every thread keeps its <= RPT rows IN REGISTERS:
-// the statistics are an exact two-pass (mean, then centred squares) over registers, the apply pass writes from registers -- the
-// input is read once.  Column quads are dealt to the XCDs in contiguous ranges (block b -> XCD b & 7): the 8 quads of a 128-byte
-// line are fetched into ONE L2, not eight.  Fixed-order block reduction: bitwise reproducible.
-constexpr int MID_ROWS = 8192;
-constexpr int MID_NT = 512;   // 8 waves: 256 registers per thread hold 16 rows of x and dy
-
-// sum of a float4 over the block, result in every thread (fixed order: lanes by xor-shuffle, then the 16 waves in order)
-__device__ __forceinline__ float4 mid_block_sum(float4 v, float4* sm) {
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) {
-    v.x += __shfl_xor(v.x, sh, 64); v.y += __shfl_xor(v.y, sh, 64);
-    v.z += __shfl_xor(v.z, sh, 64); v.w += __shfl_xor(v.w, sh, 64);
-  }
-  __syncthreads();   // (the previous use of sm is over)
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float4 t = sm[0];
-#pragma unroll
-  for (int w = 1; w < MID_NT / 64; ++w) { const float4 u = sm[w]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-  return t;
-}
-__device__ __forceinline__ int mid_quad(int nq) {   // block -> column quad (contiguous ranges per XCD), -1: no work
-  const int per = (nq + 7) / 8;
-  const int q = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  return (((int)blockIdx.x >> 3) < per && q < nq) ? q : -1;
-}
-
-// (every load is unconditional on a clamped row: a load under `if (r < N)` costs an exec-mask branch and an s_waitcnt per pair of
-// rows -- the round trips then run one after the other instead of together)
-template <int RPT, bool ADD>
-__global__ void __launch_bounds__(MID_NT) k_bn_mid_fwd(
-    const float* __restrict__ x, int64_t N, int64_t D, float eps, float momentum, const float* __restrict__ w,
-    const float* __restrict__ b, const float* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
-    float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ num_batches_tracked, float* __restrict__ y, const float* __restrict__ bcast, const int32_t* __restrict__ bidx) {
-  __shared__ float4 sm[MID_NT / 64];
-  const int q = mid_quad((int)(D / 4));
-  if (q < 0) return;
-  const int64_t c = (int64_t)q * 4;
-  if (q == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-  float4 v[RPT];
-  int bi[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT, rc = r < N ? r : N - 1;
-    v[i] = *reinterpret_cast<const float4*>(x + rc * D + c);
-    if constexpr (ADD) bi[i] = (bcast ? bidx : reinterpret_cast<const int32_t*>(x))[rc];   // (no branch around a load: see above)
-  }
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const float live = (int64_t)threadIdx.x + (int64_t)i * MID_NT < N ? 1.f : 0.f;
-    s.x = fmaf(v[i].x, live, s.x); s.y = fmaf(v[i].y, live, s.y); s.z = fmaf(v[i].z, live, s.z); s.w = fmaf(v[i].w, live, s.w);
-  }
-  const float inv_n = 1.0f / (float)N;
-  float4 mu = mid_block_sum(s, sm);
-  mu = make_float4(mu.x * inv_n, mu.y * inv_n, mu.z * inv_n, mu.w * inv_n);
-  s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const float live = (int64_t)threadIdx.x + (int64_t)i * MID_NT < N ? 1.f : 0.f;
-    const float4 dlt = make_float4(v[i].x - mu.x, v[i].y - mu.y, v[i].z - mu.z, v[i].w - mu.w);
-    s.x = fmaf(dlt.x * live, dlt.x, s.x); s.y = fmaf(dlt.y * live, dlt.y, s.y);
-    s.z = fmaf(dlt.z * live, dlt.z, s.z); s.w = fmaf(dlt.w * live, dlt.w, s.w);
-  }
-  float4 var = mid_block_sum(s, sm);
-  var = make_float4(var.x * inv_n, var.y * inv_n, var.z * inv_n, var.w * inv_n);
-  const float4 rs = make_float4(1.0f / sqrtf(var.x + eps), 1.0f / sqrtf(var.y + eps), 1.0f / sqrtf(var.z + eps), 1.0f / sqrtf(var.w + eps));
-  if (threadIdx.x == 0) {
-    *reinterpret_cast<float4*>(mean + c) = mu;
-    *reinterpret_cast<float4*>(rstd + c) = rs;
-    if (running_mean) {
-      const float ub = N > 1 ? (float)N / (float)(N - 1) : 1.f;
-      const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, v4[4] = {var.x, var.y, var.z, var.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        running_mean[c + e] = (1.f - momentum) * running_mean[c + e] + momentum * m4[e];
-        running_var[c + e] = (1.f - momentum) * running_var[c + e] + momentum * v4[e] * ub;
-      }
-    }
-  }
-  const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-  // four rows at a time: their addend loads (residual rows, the virtual-node rows) are in flight together
-#pragma unroll
-  for (int i0 = 0; i0 < RPT; i0 += 4) {
-    float4 ra[4], rb[4];
-    if constexpr (ADD) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t r = (int64_t)threadIdx.x + (int64_t)(i0 + u) * MID_NT, rc = r < N ? r : N - 1;
-        ra[u] = *reinterpret_cast<const float4*>((resid ? resid : x) + rc * D + c);
-        rb[u] = *reinterpret_cast<const float4*>(bcast ? bcast + (int64_t)bi[i0 + u] * D + c : x + rc * D + c);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u;
-      const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-      float4 o = make_float4((v[i].x - mu.x) * rs.x * ww.x + bb.x, (v[i].y - mu.y) * rs.y * ww.y + bb.y,
-                             (v[i].z - mu.z) * rs.z * ww.z + bb.z, (v[i].w - mu.w) * rs.w * ww.w + bb.w);
-      if (relu) o = gt_relu4(o);
-      if (drop.thr) o = bn_drop4(o, drop, (uint32_t)r, (uint32_t)c);
-      if constexpr (ADD) {
-        if (resid) o = gt_add4(o, ra[u]);
-        if (bcast) o = gt_add4(o, rb[u]);
-      }
-      if (r < N) *reinterpret_cast<float4*>(y + r * D + c) = o;
-    }
-  }
-}
-
-// backward: dy' = gate(drop(dy)), sums over registers, dx from registers (x and dy read once)
-template <int RPT>
-__global__ void __launch_bounds__(MID_NT) k_bn_mid_bwd(
-    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ w, const float* __restrict__ b, int relu, int training, BnDrop drop, int64_t N, int64_t D,
-    float* __restrict__ dbias, float* __restrict__ dweight, float* __restrict__ dx) {
-  __shared__ float4 sm[MID_NT / 64];
-  const int q = mid_quad((int)(D / 4));
-  if (q < 0) return;
-  const int64_t c = (int64_t)q * 4;
-  float4 g[RPT], xh[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT, rc = r < N ? r : N - 1;
-    g[i] = *reinterpret_cast<const float4*>(dy + rc * D + c);
-    xh[i] = *reinterpret_cast<const float4*>(x + rc * D + c);
-  }
-  const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
-  const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    const float live = r < N ? 1.f : 0.f;
-    xh[i] = make_float4((xh[i].x - mu.x) * rs.x, (xh[i].y - mu.y) * rs.y, (xh[i].z - mu.z) * rs.z, (xh[i].w - mu.w) * rs.w);
-    g[i] = make_float4(g[i].x * live, g[i].y * live, g[i].z * live, g[i].w * live);
-    if (drop.thr) g[i] = bn_drop4(g[i], drop, (uint32_t)r, (uint32_t)c);
-    if (relu)   // the gate of k_bn_bwd_partial / _apply: 1[(x - mean) * rstd * w + b > 0]
-      g[i] = make_float4(xh[i].x * ww.x + bb.x > 0.f ? g[i].x : 0.f, xh[i].y * ww.y + bb.y > 0.f ? g[i].y : 0.f,
-                         xh[i].z * ww.z + bb.z > 0.f ? g[i].z : 0.f, xh[i].w * ww.w + bb.w > 0.f ? g[i].w : 0.f);
-    s0 = gt_add4(s0, g[i]);
-    s1.x = fmaf(g[i].x, xh[i].x, s1.x); s1.y = fmaf(g[i].y, xh[i].y, s1.y);
-    s1.z = fmaf(g[i].z, xh[i].z, s1.z); s1.w = fmaf(g[i].w, xh[i].w, s1.w);
-  }
-  const float4 db = mid_block_sum(s0, sm), dw = mid_block_sum(s1, sm);
-  if (threadIdx.x == 0) {
-    *reinterpret_cast<float4*>(dbias + c) = db;
-    *reinterpret_cast<float4*>(dweight + c) = dw;
-  }
-  const float inv_n = training ? 1.0f / (float)N : 0.f;
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int64_t r = (int64_t)threadIdx.x + (int64_t)i * MID_NT;
-    float4 o;
-    o.x = ww.x * rs.x * (g[i].x - db.x * inv_n - xh[i].x * dw.x * inv_n);
-    o.y = ww.y * rs.y * (g[i].y - db.y * inv_n - xh[i].y * dw.y * inv_n);
-    o.z = ww.z * rs.z * (g[i].z - db.z * inv_n - xh[i].z * dw.z * inv_n);
-    o.w = ww.w * rs.w * (g[i].w - db.w * inv_n - xh[i].w * dw.w * inv_n);
-    if (r < N) *reinterpret_cast<float4*>(dx + r * D + c) = o;
-  }
-}
-static inline bool bn_mid_ok(int dtype, int64_t rows, int64_t dim) {
-  static const int64_t lim = [] { const char* e = getenv("GT_BN_MID_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)MID_ROWS; }();   // (A/B knob; 0 = off)
-  return dtype == GT_F32 && rows > SMALL_ROWS && rows <= lim && rows <= MID_ROWS && dim % 4 == 0;
-}
-static inline unsigned bn_mid_grid(int64_t dim) { return (unsigned)(8 * ((dim / 4 + 7) / 8)); }
-
 // ---- synchronised statistics across data-parallel ranks (modules/gnn_module.py:204,164,167 normalise over the
 // single-device batch, which graph sharding splits).  The collective belongs to the caller (torch.distributed / RCCL): while a hook
 // is set for the calling HOST THREAD every training-mode BatchNorm of this library -- also the ones inside the composite layer
@@ -1187,24 +1015,6 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
       GT_CHECK_LAUNCH();
       return GT_OK;
     }
-    if (!sync && bn_mid_ok(dtype, rows, dim)) {
-      if (bcast && ev_bcast_ready) {
-        rc = gt_stream_wait_event(stream_, ev_bcast_ready);
-        if (rc) return rc;
-      }
-#define GT_BN_MID_FWD2(RPT_, ADD_)                                                                                                       \
-  hipLaunchKernelGGL((k_bn_mid_fwd<RPT_, ADD_>), dim3(bn_mid_grid(dim)), dim3(MID_NT), 0, stream, (const float*)x, rows, dim, eps, momentum, \
-                     weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, running_mean, running_var,               \
-                     num_batches_tracked, (float*)y, (const float*)bcast, bcast_index)
-#define GT_BN_MID_FWD(RPT_) do { if (resid || bcast) GT_BN_MID_FWD2(RPT_, true); else GT_BN_MID_FWD2(RPT_, false); } while (0)
-      if (rows <= 4 * MID_NT) GT_BN_MID_FWD(4);
-      else if (rows <= 8 * MID_NT) GT_BN_MID_FWD(8);
-      else GT_BN_MID_FWD(16);
-#undef GT_BN_MID_FWD
-#undef GT_BN_MID_FWD2
-      GT_CHECK_LAUNCH();
-      return GT_OK;
-    }
     const int nb = part_blocks(rows);
     if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
       gt_set_error("gt_batchnorm_fwd: workspace too small");
@@ -1320,17 +1130,6 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
       hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const gt_bf16*)x,
                          (const gt_bf16*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias,
                          dweight, (gt_bf16*)dx);
-    GT_CHECK_LAUNCH();
-    return GT_OK;
-  }
-  if (bn_mid_ok(dtype, rows, dim)) {
-#define GT_BN_MID_BWD(RPT_)                                                                                                       \
-  hipLaunchKernelGGL(k_bn_mid_bwd<RPT_>, dim3(bn_mid_grid(dim)), dim3(MID_NT), 0, stream, (const float*)x, (const float*)dy,     \
-                     save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias, dweight, (float*)dx)
-    if (rows <= 4 * MID_NT) GT_BN_MID_BWD(4);
-    else if (rows <= 8 * MID_NT) GT_BN_MID_BWD(8);
-    else GT_BN_MID_BWD(16);
-#undef GT_BN_MID_BWD
     GT_CHECK_LAUNCH();
     return GT_OK;
   }

@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("rows,D", [(257, 300), (5000, 600), (4, 16), (32407, 300), (300, 2048), (1024, 600), (1025, 36), (2, 4),
-                                     (3000, 300), (8192, 300), (8193, 300), (6611, 600)])   # 1025 .. 8192 rows: the one-launch kernels (k_bn_mid_*)
+                                     (3000, 300), (8192, 300), (8193, 300), (6611, 600)])   # a few thousand rows: Molpcba, Code2 at 32 graphs per rank
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_batchnorm_matches_torch(rows, D, relu, training):
@@ -180,7 +180,7 @@ def _bn_keep_mask(rows, D, p, seed):
 @pytest.mark.parametrize("rows,D,B", [(1500, 300, 40), (6611, 600, 256), (8192, 128, 7)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
-    """gt_batchnorm_fwd_bcast at 1025 .. 8192 rows (one launch, rows in registers): relu + dropout + residual + the next layer's
+    """gt_batchnorm_fwd_bcast at a few thousand rows (Molpcba, Code2 at 32 graphs per rank): relu + dropout + residual + the next layer's
     virtual-node rows (gnn_module.py:199,204-212) against float64 torch with the kernel's own dropout mask, and the backward
     of the same call."""
     import ctypes as C
