@@ -205,6 +205,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 #include "linear3x.h"
 #include "linear1.h"
 #include "linear_small.h"
+#include "linear_heads.h"
 #include "linear_dw16.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -889,6 +890,16 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
   a.a = x; a.w = weight; a.bias = bias; a.out = y; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.act = act; a.gout = gout;
   fill_drop(a, dropout_p, seed);
   a.g_x = x_group_stride; a.g_y = y_group_stride; a.g_w = N * K; a.g_b = N;
+  if (heads_shape_ok(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) && act == 0 && !a.thr && !gout) {   // the prediction heads (linear_heads.h)
+    HeadsArgs h{};
+    h.x = (const float*)x; h.w = weight; h.bias = bias; h.out = (float*)y; h.M = M; h.N = N; h.ldx = ldx; h.ldy = ldy;
+    {
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_heads_fwd", stream, {M, N, K, x_dtype, y_dtype, compute});
+      heads_launch_fwd(compute, stream, h);
+    }
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   if (small_eligible(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) || small_wide_ok(x_dtype, y_dtype, M, K, ldx, ldy, groups)) {
     SmallArgs sa{};
     sa.x = (const float*)x; sa.w = weight; sa.bias = bias; sa.out = (float*)y; sa.M = M; sa.N = N; sa.K = K; sa.ldx = ldx; sa.ldy = ldy;
@@ -955,7 +966,8 @@ extern "C" size_t gt_linear_bwd_workspace_bytes(int compute, int64_t M, int64_t 
   }
   const size_t dw = (size_t)dw_splits(M, N, K, compute) * (size_t)(N * K + N) * sizeof(float);
   const int dxs = dx_splits(M, N, K, pick_bm(M));
-  const size_t dx = dxs > 1 ? (size_t)dxs * M * K * sizeof(float) : 0;
+  size_t dx = dxs > 1 ? (size_t)dxs * M * K * sizeof(float) : 0;
+  if (heads_shape_ok(GT_F32, GT_F32, M, N, K, 4, 4, 1) && heads_dx_workspace_bytes(M, N) > dx) dx = heads_dx_workspace_bytes(M, N);
   return (dw > dx ? dw : dx) + 256;  // the dx partials are consumed before dw reuses the space
 }
 
@@ -1256,6 +1268,14 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (dx && !dx_done) { gt_set_error("gt_linear_bwd_gate_out: not covered (ask gt_linear_bwd_gate_out_ok)"); return GT_ERR_UNSUPPORTED; }
     a.ymask = nullptr;   // the gate belongs to the dX output, not to dY: the weight gradient below reads dY as it is
     y_for_mask = nullptr;
+  }
+  if (dx && !dx_done && !y_for_mask && heads_shape_ok(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) && workspace &&
+      workspace_bytes >= heads_dx_workspace_bytes(M, N)) {   // the prediction heads: the contraction is their 25 010 columns (linear_heads.h)
+    HeadsArgs h{};
+    h.w = weight; h.dy = (const float*)dy; h.M = M; h.N = N; h.ldx = ldx; h.ldy = ldy;
+    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_heads_dx+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+    heads_launch_dx(compute, stream, h, workspace, (float*)dx, (const float*)dx_add1, (const float*)dx_add2);
+    dx_done = true;
   }
   if (dx && !dx_done) {
     const int bm = pick_bm(M);

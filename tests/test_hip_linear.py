@@ -127,7 +127,7 @@ def test_linear_fused_dropout():
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 25010, 128), (64, 5002, 128), (33, 10, 8), (300, 2050, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 25010, 128), (64, 5002, 128), (33, 10, 8), (300, 2050, 64), (300, 4102, 128), (17, 4097, 128), (513, 8200, 128)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16c_fp32s"])
 def test_linear_padded_rows_and_split_dx(M, N, K, mode):
     """gt_linear_*_ld: an N that is not a multiple of 4 lands in row-padded storage (the 5 x 5002-way
