@@ -1,6 +1,31 @@
 // gt_common.h — shared helpers for the gfx950 kernels (device code + C-ABI plumbing).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifdef GT_DEBUG_SKIP   // tools/skip_probe_build.sh: a what-if build, every launch behind GT_SKIP (never the shipped library)
+#include <cstdlib>
+#include <cstring>
+static inline bool gt_dbg_skip(const char* kernel) {
+  static const char* e = getenv("GT_SKIP");
+  if (!e || !*e) return false;
+  const char* p = e;
+  while (*p) {
+    const char* q = strchr(p, ',');
+    const size_t n = q ? (size_t)(q - p) : strlen(p);
+    char buf[128];
+    if (n > 0 && n < sizeof(buf)) {
+      memcpy(buf, p, n);
+      buf[n] = 0;
+      if (strstr(kernel, buf)) return true;
+    }
+    if (!q) break;
+    p = q + 1;
+  }
+  return false;
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(k, g, b, l, s, ...) \
+  do { if (!gt_dbg_skip(#k)) hipLaunchKernelGGLInternal((k), (g), (b), (l), (s), __VA_ARGS__); } while (0)
+#endif
 #include <stdint.h>
 #include <stdio.h>
 
