@@ -72,9 +72,6 @@ SIGNATURES = {
     "gt_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_layernorm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_linear_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _u64, _p]),
-    "gt_layernorm_bwd_finish": (_i, [_p, _i64, _i64, _p, _p, _p]),
-    "gt_linear_bwd_dx_layernorm_bwd_ok": (_i, [_i, _i, _p, _i64, _i64, _i64]),
-    "gt_linear_bwd_dx_layernorm_bwd": (_i, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _f, _u64, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_linear_fwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_adamw_chunk_elems": (_i, []),

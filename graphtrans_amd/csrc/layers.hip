@@ -293,7 +293,6 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   const int64_t R = L->rows, d = L->d_model, F = L->ffn;
   const float p = L->training ? L->dropout_p : 0.f;
   const float scale = 1.0f / sqrtf((float)(d / L->nhead));
-  bool ln1_done = false;
   // x2 = LN2(x1 + drop(f2))
   GT_TRY(gt_layernorm_bwd(t, s.f2, s.x1, dy, L->n2_w, s.st2, s.st2 + R, p, L->seed ^ 0x14057B7EF767814FULL, R, d, w.d_f2,
                           w.d_x1, g.n2_w, g.n2_b, w.ln_ws, w.ln_ws_bytes, st));
@@ -303,17 +302,8 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
     // tensor both GEMMs of linear1's backward read (the tiled kernels gate d_f1 while they stage it, twice)
     GT_TRY(gt_linear_bwd_gate_out(t, t, c, s.f1, L->l2_w, w.d_f2, L->act == 1 ? s.g1 : s.f1, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F,
                                   F, d, L->act == 1 ? -1.f : p, w.lin_ws, w.lin_ws_bytes, st));
-    if (gt_linear_bwd_dx_layernorm_bwd_ok(t, c, L->l1_w, R, F, d)) {
-      // linear1's dX GEMM runs norm1's backward in its epilogue (the gradient reaching x1 = its result + LayerNorm 2's residual
-      // branch stays in registers): writes d_a and the residual part of dx directly -- no d_x1 round trip, no LayerNorm launch
-      GT_TRY(gt_linear_bwd_dw_forked(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, g.l1_w, g.l1_b, R, F, d, d, F, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-      GT_TRY(gt_linear_bwd_dx_layernorm_bwd(w.d_f1, L->l1_w, R, F, d, w.d_x1, nullptr, s.a, x, L->n1_w, s.st1, s.st1 + R, p,
-                                            L->seed ^ 0x5851F42D4C957F2DULL, w.d_a, dx, g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
-      ln1_done = true;
-    } else {
-      GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, 0.f, w.lin_ws,
-                           w.lin_ws_bytes, st));
-    }
+    GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, 0.f, w.lin_ws,
+                         w.lin_ws_bytes, st));
   } else {
     GT_TRY(gt_linear_bwd(t, t, c, s.f1, L->l2_w, w.d_f2, nullptr, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F, 0.f,
                          w.lin_ws, w.lin_ws_bytes, st));
@@ -325,9 +315,8 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
                            w.lin_ws_bytes, st));
   }
   // x1 = LN1(x + drop(a))
-  if (!ln1_done)
-    GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
-                            g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
+  GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
+                          g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
   // a = ctx Wo^T + bo
   GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));

@@ -1498,46 +1498,6 @@ extern "C" int gt_w1_unbind(void) {
   g_w1.n = 0;
   return GT_OK;
 }
-// dX of y = x W^T (W [N][K], bf16 rows, bound weight image) FOLLOWED BY the backward of the LayerNorm whose output x is
-// (x = LN(ln_resid + dropout(ln_x)) * ln_w + ln_b, d_model = K = 128): the gradient reaching x, dX + dx_add1 + dx_add2, never leaves
-// the GEMM's epilogue (linear1.h, LNB) -- it writes what gt_layernorm_bwd writes: d_sub = dropout'(dz) (gradient of ln_x), d_resid = dz,
-// d_ln_w / d_ln_b through the same partial rows + column finish.  One launch + the finish instead of GEMM, LayerNorm backward, finish;
-// the [M][K] gradient is neither stored nor re-read.  Ask gt_linear_bwd_dx_layernorm_bwd_ok first.
-extern "C" int gt_linear_bwd_dx_layernorm_bwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
-  static const bool on = [] { const char* e = getenv("GT_LNB_FUSE"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return (on && dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && K == 128 && N % 128 == 0 && N >= 128 && N <= 512 &&
-          w1_lookup(weight, N, K, true) && w1_pick_ntw(K, N) == 2) ? 1 : 0;
-}
-extern "C" int gt_linear_bwd_dx_layernorm_bwd(const void* dy, const float* weight, int64_t M, int64_t N, int64_t K, const void* dx_add1,
-                                              const void* dx_add2, const void* ln_x, const void* ln_resid, const float* ln_w,
-                                              const float* ln_mean, const float* ln_rstd, float dropout_p, uint64_t seed, void* d_sub,
-                                              void* d_resid, float* d_ln_w, float* d_ln_b, void* workspace, size_t workspace_bytes,
-                                              gt_stream_t stream_) {
-  GT_CHECK_ARG(dy && weight && ln_x && ln_w && ln_mean && ln_rstd && (d_sub || d_resid) && d_ln_w && d_ln_b && workspace, "null buffer");
-  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
-  GT_CHECK_ARG(gt_linear_bwd_dx_layernorm_bwd_ok(GT_BF16, GT_BF16, weight, M, N, K), "shape not covered (ask gt_linear_bwd_dx_layernorm_bwd_ok)");
-  GT_CHECK_ARG(workspace_bytes >= gt_layernorm_bwd_workspace_bytes(M, K), "workspace too small (gt_layernorm_bwd_workspace_bytes)");
-  hipStream_t stream = (hipStream_t)stream_;
-  L1Args l{};
-  l.a = (const gt_bf16*)dy; l.img = (const unsigned char*)w1_lookup(weight, N, K, true);
-  l.add1 = (const gt_bf16*)dx_add1; l.add2 = (const gt_bf16*)dx_add2;
-  l.M = M; l.lda = N; l.ldo = K; l.N = (int)K; l.K = (int)N;
-  l.lb_x = (const gt_bf16*)ln_x; l.lb_resid = (const gt_bf16*)ln_resid; l.lb_w = ln_w; l.lb_mean = ln_mean; l.lb_rstd = ln_rstd;
-  l.lb_dx = (gt_bf16*)d_sub; l.lb_dresid = (gt_bf16*)d_resid; l.lb_part = (float*)workspace;
-  l.lb_inv_keep = 1.0f / (1.0f - dropout_p);
-  {
-    const double thr = (double)dropout_p * 4294967296.0;
-    l.lb_thr = dropout_p > 0.f ? (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : (thr < 1.0 ? 1.0 : thr)) : 0u;
-  }
-  l.lb_s0 = (uint32_t)seed; l.lb_s1 = (uint32_t)(seed >> 32);
-  {
-    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[dx+ln_bwd]", stream, {M, N, K, GT_BF16, GT_BF16, GT_BF16});
-    if (!w1_launch(stream, l)) { gt_set_error("gt_linear_bwd_dx_layernorm_bwd: launch set-up failed"); return GT_ERR_LAUNCH; }
-  }
-  GT_CHECK_LAUNCH();
-  return gt_layernorm_bwd_finish((const float*)workspace, (int64_t)8 * l.ncb * l.sgroups, K, d_ln_w, d_ln_b, stream_);
-}
-
 // gt_linear_bwd_ld2 whose gate (`y_or_mul` [M][ldx]: the forward output of the layer BELOW when dropout_p >= 0 -- dZ = dX * 1[y > 0]
 // / (1 - p) -- or, with dropout_p < 0, a saved multiplier) applies to the dX OUTPUT of this call; dY is used as it is (also by the
 // weight gradient).  Only on the weight-stationary path: ask gt_linear_bwd_gate_out_ok first.

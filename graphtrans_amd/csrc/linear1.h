@@ -77,19 +77,6 @@ struct L1Args {
   float* ln_rstd;
   float ln_eps, ln_inv_keep;
   uint32_t ln_thr, ln_s0, ln_s1;
-  // LNB instantiations (dX form, one column block = the whole row): the GEMM result + addends is the gradient d reaching a LayerNorm
-  // OUTPUT y = LN(lb_resid + dropout(lb_x)) * lb_w + b; the epilogue runs that LayerNorm's backward on the row it holds:
-  //   lb_dresid = dz, lb_dx = dropout'(dz), part[block][0][N] += sum d * xhat, part[block][1][N] += sum d   (gt_layernorm_bwd's outputs)
-  const gt_bf16* lb_x;        // [M][ldo] the saved sub-layer output
-  const gt_bf16* lb_resid;    // [M][ldo] or null
-  const float* lb_w;          // [N]
-  const float* lb_mean;       // [M]
-  const float* lb_rstd;
-  gt_bf16* lb_dx;             // [M][ldo] or null
-  gt_bf16* lb_dresid;         // [M][ldo] or null
-  float* lb_part;             // [grid][2][N]
-  float lb_inv_keep;
-  uint32_t lb_thr, lb_s0, lb_s1;
   int ncb;                    // column blocks of 64 * NTW columns
   int sgroups;                // row-tile groups in flight: grid = 8 * ncb * sgroups
   int row_tiles;              // ceil(M / 64)
@@ -113,7 +100,7 @@ __device__ __forceinline__ void w1_merge(float& mean, float& m2, float mean_b, f
 }
 
 // KS = K / 32 k-steps (K % 128 == 0), NTW = n-tiles per wave (column block = 4 * NTW * 16 columns)
-template <int KS, int NTW, bool LN = false, bool LNB = false>
+template <int KS, int NTW, bool LN = false>
 __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   constexpr int KCH = KS / 4;                 // 128-deep chunks per row tile
   constexpr int PLD = w1_patch_ld<NTW>();
@@ -141,26 +128,7 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   const int first_tile = sg * 8 + xcd;
   const int my_tiles = first_tile < a.row_tiles ? (a.row_tiles - first_tile + tile_stride - 1) / tile_stride : 0;
   const int nchunks = my_tiles * KCH;
-  if (nchunks == 0) {
-    if constexpr (LNB) {   // the column finish sums every block's partial row
-      for (int i = tid; i < 2 * NTW * 64; i += W1_THREADS) a.lb_part[(int64_t)blockIdx.x * 2 * NTW * 64 + i] = 0.f;
-    }
-    return;
-  }
-  // LNB: this lane's 8 columns of the epilogue are the same for every row tile: their LayerNorm weights and column sums live in registers
-  constexpr int LB_CPR = NTW * 2, LB_NQ = LNB ? (16 * LB_CPR) / 64 : 1;
-  float lb_gw[LB_NQ][8], lb_aw[LB_NQ][8], lb_ab[LB_NQ][8];
-  if constexpr (LNB) {
-    static_assert((16 * LB_CPR) % 64 == 0, "LNB epilogue: whole waves of chunks");
-#pragma unroll
-    for (int q = 0; q < LB_NQ; ++q)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        lb_gw[q][e] = a.lb_w[col0 + ((lane + q * 64) % LB_CPR) * 8 + e];
-        lb_aw[q][e] = 0.f;
-        lb_ab[q][e] = 0.f;
-      }
-  }
+  if (nchunks == 0) return;
 
   // staging: thread -> 2 x 16 bytes of a chunk: p = tid + q * 512 -> row p / 16, 16-byte column p % 16 (a wave reads 4 whole rows).
   // (plain values, no lambdas writing captured registers: those end up in scratch)
@@ -321,129 +289,6 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
             }
           }
         }
-      } else if constexpr (LNB) {
-        // ---- LayerNorm-backward epilogue: phase A per wave (d = bf16(acc + addends); xhat from the saved sub-layer output; the wave's
-        // sum d w and sum d w xhat over its NTW x 16 columns of every row -> LDS), block barrier, phase B (row sums over the 4 column
-        // waves, dz, the two stores).  Same arithmetic as k_ln_bwd_d128 on the same (bf16-rounded) d.
-        constexpr int CPR = LB_CPR, NQ = LB_NQ;
-        float gk[2][NQ][8], xk[2][NQ][8], rsk[2][NQ];
-        uint32_t kept[2][NQ];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            *reinterpret_cast<float4*>(patch + n * PLD + j * 16 + g * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int ch = lane + q * 64;
-            const int r = ch / CPR, c8 = (ch % CPR) * 8;
-            int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
-            const float live = m < a.M ? 1.f : 0.f;
-            if (m >= a.M) m = a.M - 1;   // (tail rows compute on a valid row, count for nothing and store nothing)
-            const int col = col0 + c8;
-            const int64_t o = m * a.ldo + col;
-            float v[8];
-            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(patch + r * PLD + c8);
-            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(patch + r * PLD + c8 + 4);
-            const uint4 ux = *reinterpret_cast<const uint4*>(a.lb_x + o);
-            const uint4 ur = a.lb_resid ? *reinterpret_cast<const uint4*>(a.lb_resid + o) : make_uint4(0, 0, 0, 0);
-            const float mu = a.lb_mean[m], rs = a.lb_rstd[m];
-            if (a.add1) {
-              const uint4 ad = *reinterpret_cast<const uint4*>(a.add1 + o);
-              const uint32_t u[4] = {ad.x, ad.y, ad.z, ad.w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] += __uint_as_float(u[e] << 16);
-                v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
-              }
-            }
-            if (a.add2) {
-              const uint4 ad = *reinterpret_cast<const uint4*>(a.add2 + o);
-              const uint32_t u[4] = {ad.x, ad.y, ad.z, ad.w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] += __uint_as_float(u[e] << 16);
-                v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
-              }
-            }
-            {   // d as the stand-alone pair stores and re-reads it: bf16
-              const uint32_t pk[4] = {gt_pack_bf16(v[0], v[1]), gt_pack_bf16(v[2], v[3]), gt_pack_bf16(v[4], v[5]), gt_pack_bf16(v[6], v[7])};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] = __uint_as_float(pk[e] << 16);
-                v[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
-              }
-            }
-            const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wr[4] = {ur.x, ur.y, ur.z, ur.w};
-            uint32_t km = 0xffu;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
-              const float rv = (e & 1) ? __uint_as_float(wr[e >> 1] & 0xffff0000u) : __uint_as_float(wr[e >> 1] << 16);
-              if (a.lb_thr) {
-                const bool keep = lin_hash(a.lb_s0, a.lb_s1, (uint32_t)m, (uint32_t)(col + e)) >= a.lb_thr;
-                xv = keep ? xv * a.lb_inv_keep : 0.f;
-                if (!keep) km &= ~(1u << e);
-              }
-              const float z = a.lb_resid ? xv + rv : xv;
-              const float xh = (z - mu) * rs;
-              const float gg = v[e] * lb_gw[q][e];
-              lb_ab[q][e] = fmaf(v[e], live, lb_ab[q][e]);
-              lb_aw[q][e] = fmaf(v[e] * live, xh, lb_aw[q][e]);
-              gk[i][q][e] = gg;
-              xk[i][q][e] = xh;
-            }
-            s1 = ((gk[i][q][0] + gk[i][q][1]) + (gk[i][q][2] + gk[i][q][3])) + ((gk[i][q][4] + gk[i][q][5]) + (gk[i][q][6] + gk[i][q][7]));
-            s2 = ((gk[i][q][0] * xk[i][q][0] + gk[i][q][1] * xk[i][q][1]) + (gk[i][q][2] * xk[i][q][2] + gk[i][q][3] * xk[i][q][3])) +
-                 ((gk[i][q][4] * xk[i][q][4] + gk[i][q][5] * xk[i][q][5]) + (gk[i][q][6] * xk[i][q][6] + gk[i][q][7] * xk[i][q][7]));
-#pragma unroll
-            for (int sh = 1; sh < CPR; sh <<= 1) {   // the CPR adjacent lanes of a row
-              s1 += __shfl_xor(s1, sh, 64);
-              s2 += __shfl_xor(s2, sh, 64);
-            }
-            if ((ch % CPR) == 0) rowstat[(wm * 32 + i * 16 + r) * 4 + wn] = make_float2(s1, s2);
-            kept[i][q] = km;
-            rsk[i][q] = rs;
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int ch = lane + q * 64;
-            const int r = ch / CPR, c8 = (ch % CPR) * 8;
-            const int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
-            const float2* rsp = rowstat + (wm * 32 + i * 16 + r) * 4;
-            const float2 p0 = rsp[0], p1 = rsp[1], p2 = rsp[2], p3 = rsp[3];
-            const float m1 = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / (float)(NTW * 64));
-            const float m2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / (float)(NTW * 64));
-            if (m < a.M) {
-              const int64_t o = m * a.ldo + col0 + c8;
-              float dz[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) dz[e] = rsk[i][q] * (gk[i][q][e] - m1 - xk[i][q][e] * m2);
-              if (a.lb_dresid)
-                *reinterpret_cast<uint4*>(a.lb_dresid + o) =
-                    make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
-              if (a.lb_dx) {
-                if (a.lb_thr) {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) dz[e] = (kept[i][q] >> e) & 1u ? dz[e] * a.lb_inv_keep : 0.f;
-                }
-                *reinterpret_cast<uint4*>(a.lb_dx + o) =
-                    make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
-              }
-            }
-          }
-        }
       } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -520,34 +365,6 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
     }
   }
 #undef W1_CHUNK_PTR
-  if constexpr (LNB) {
-    // column sums: the 16 lanes that share a column chunk -> the two row halves of the block -> part[block][2][N]   (fixed order)
-    constexpr int CPR = LB_CPR, NQ = LB_NQ, NW = NTW * 16, N = NTW * 64;
-    float* red = reinterpret_cast<float*>(smem1);   // [wm][wn][2][NQ... columns of the wave]  (the stages are idle: the loop ended on a barrier)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int sh = CPR; sh < 64; sh <<= 1) {
-          lb_aw[q][e] += __shfl_xor(lb_aw[q][e], sh, 64);
-          lb_ab[q][e] += __shfl_xor(lb_ab[q][e], sh, 64);
-        }
-      }
-    static_assert(NQ == 1, "LNB: one 8-column chunk per lane");
-    if (lane < CPR) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[((wm * 4 + wn) * 2 + 0) * NW + lane * 8 + e] = lb_aw[0][e];
-        red[((wm * 4 + wn) * 2 + 1) * NW + lane * 8 + e] = lb_ab[0][e];
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * N; i += W1_THREADS) {
-      const int k = i / N, c = i % N, w4 = c / NW, cc = c % NW;
-      a.lb_part[(int64_t)blockIdx.x * 2 * N + i] = red[((0 * 4 + w4) * 2 + k) * NW + cc] + red[((1 * 4 + w4) * 2 + k) * NW + cc];
-    }
-  }
 }
 
 // ---- shapes ---------------------------------------------------------------------------------------------------------
@@ -566,7 +383,7 @@ static inline int w1_pick_ntw(int64_t R, int64_t C) {
   return 0;
 }
 
-template <int KS, int NTW, bool LN = false, bool LNB = false>
+template <int KS, int NTW, bool LN = false>
 static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a) {
   static std::mutex mu;
   static bool set[64] = {};
@@ -576,11 +393,11 @@ static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a)
   if (dev >= 0 && dev < 64) {
     std::lock_guard<std::mutex> lk(mu);
     if (!set[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW, LN, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
       set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((k_lin1<KS, NTW, LN, LNB>), grid, dim3(W1_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((k_lin1<KS, NTW, LN>), grid, dim3(W1_THREADS), lds, stream, a);
   return true;
 }
 
@@ -606,13 +423,6 @@ static inline bool w1_launch(hipStream_t stream, L1Args& a) {
 #define GT_W1_LN_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_, true>(grid, stream, a)
     GT_W1_LN_CASE(4, 2); GT_W1_LN_CASE(8, 2); GT_W1_LN_CASE(16, 2); GT_W1_LN_CASE(8, 4);
 #undef GT_W1_LN_CASE
-    return false;
-  }
-  if (a.lb_part) {   // LayerNorm-backward epilogue: the row must lie in ONE column block of two n-tiles per wave
-    if (a.ncb != 1 || ntw != 2) return false;
-#define GT_W1_LNB_CASE(KS_) if (ks == KS_) return w1_launch_one<KS_, 2, false, true>(grid, stream, a)
-    GT_W1_LNB_CASE(4); GT_W1_LNB_CASE(8); GT_W1_LNB_CASE(12); GT_W1_LNB_CASE(16);
-#undef GT_W1_LNB_CASE
     return false;
   }
 #define GT_W1_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_>(grid, stream, a)

@@ -1254,16 +1254,6 @@ extern "C" int gt_layernorm_fwd(int dtype, const void* x, const void* resid, con
   return GT_OK;
 }
 
-// the column finish of gt_layernorm_bwd on its own: dweight[c] = sum_p part[p][0][c], dbias[c] = sum_p part[p][1][c] in partial order --
-// for producers that run the row-wise part of the backward elsewhere (the dX GEMM epilogue of gt_linear_bwd_dx_layernorm_bwd)
-extern "C" int gt_layernorm_bwd_finish(const float* part, int64_t nparts, int64_t dim, float* dweight, float* dbias, gt_stream_t stream_) {
-  GT_CHECK_ARG(part && dweight && dbias && nparts >= 1 && nparts <= 0x7fffffff && dim > 0, "bad arguments");
-  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, (hipStream_t)stream_, part, (int)nparts,
-                     dim, dweight, dbias);
-  GT_CHECK_LAUNCH();
-  return GT_OK;
-}
-
 extern "C" size_t gt_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
   (void)rows;
   return (size_t)LN_BWD_BLOCKS * 2 * dim * sizeof(float) + 256;

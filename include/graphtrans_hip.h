@@ -403,9 +403,6 @@ int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy
                      const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed, int64_t rows,
                      int64_t dim, void* dx, void* dresid, float* dweight, float* dbias, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
-/* The column finish of gt_layernorm_bwd on its own (dweight[c] = sum_p part[p][0][c], dbias[c] = sum_p part[p][1][c], partial order):
- * for producers that run the row-wise part of the backward elsewhere (gt_linear_bwd_dx_layernorm_bwd). */
-int gt_layernorm_bwd_finish(const float* part, int64_t nparts, int64_t dim, float* dweight, float* dbias, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nn.Linear on the matrix cores with fused bias / ReLU / dropout, forward and backward.
@@ -545,17 +542,6 @@ int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, const void* x,
                            const void* y_or_mul, const void* dx_add1, const void* dx_add2, void* dx, float* dweight, float* dbias,
                            int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, float dropout_p, void* workspace,
                            size_t workspace_bytes, gt_stream_t stream);
-/* dX of y = x W^T (bf16 rows, bound weight image, K = d_model = 128) followed by the backward of the LayerNorm whose OUTPUT x is
- * (modules/transformer_encoder.py:28-32, post-norm layers: x = LN(ln_resid + dropout(ln_x)) * ln_w + ln_b): the gradient
- * dX + dx_add1 + dx_add2 stays in the GEMM's epilogue, which writes gt_layernorm_bwd's outputs (d_sub = gradient of ln_x with its
- * dropout, d_resid = gradient of ln_resid, d_ln_w / d_ln_b).  workspace >= gt_layernorm_bwd_workspace_bytes(M, K).
- * gt_linear_bwd_dx_layernorm_bwd_ok says whether (weight, M, N, K) is covered; the weight gradient is a separate gt_linear_bwd call. */
-int gt_linear_bwd_dx_layernorm_bwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K);
-int gt_linear_bwd_dx_layernorm_bwd(const void* dy, const float* weight, int64_t M, int64_t N, int64_t K, const void* dx_add1,
-                                   const void* dx_add2, const void* ln_x, const void* ln_resid, const float* ln_w,
-                                   const float* ln_mean, const float* ln_rstd, float dropout_p, uint64_t seed, void* d_sub,
-                                   void* d_resid, float* d_ln_w, float* d_ln_b, void* workspace, size_t workspace_bytes,
-                                   gt_stream_t stream);
 /* dW / db only; inside an overlap section it still runs on the overlap stream (ordered behind what `stream` holds so far):
  * a caller can start a GEMM's weight gradient ahead of its dX GEMM. */
 int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

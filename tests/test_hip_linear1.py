@@ -235,51 +235,3 @@ def test_bf16_weight_gradient_strided_operands(M, N, K, ldy, ldx):
         assert float((dw.double() - dw64).abs().max()) < 1e-3 * float(dw64.abs().max())
         if want_db:
             assert rel(db, db64) < 2e-6
-
-
-@pytest.mark.parametrize("M,N,K", [(31598, 512, 128), (31598, 384, 128), (2000, 256, 128), (700, 128, 128), (63, 512, 128)])
-@pytest.mark.parametrize("p", [0.0, 0.3])
-@pytest.mark.parametrize("with_resid,two_adds", [(True, False), (True, True), (False, False)])
-def test_dx_gemm_with_layernorm_backward_epilogue_equals_the_two_kernels(M, N, K, p, with_resid, two_adds):
-    """gt_linear_bwd_dx_layernorm_bwd (linear1.h, LNB: linear1's / in_proj's dX GEMM runs the backward of the LayerNorm whose output
-    it differentiates, modules/transformer_encoder.py:28-32 post-norm layers) against gt_linear_bwd_ld2 + gt_layernorm_bwd on the same
-    operands: the row-wise outputs bit for bit (same bf16-rounded gradient, same reduction tree), the column sums to fp32 order."""
-    from graphtrans_amd import _lib
-    from graphtrans_amd.graph import _stream
-    from graphtrans_amd.w3 import W1Images
-    lib = _lib.lib()
-    torch.manual_seed(M + N)
-    W = (torch.randn(N, K, device=DEV) / K ** 0.5)
-    dy = torch.randn(M, N, device=DEV).to(BF)
-    add1 = torch.randn(M, K, device=DEV).to(BF)
-    add2 = torch.randn(M, K, device=DEV).to(BF) if two_adds else None
-    sub = torch.randn(M, K, device=DEV).to(BF)            # the saved sub-layer output
-    resid = torch.randn(M, K, device=DEV).to(BF) if with_resid else None
-    lw = (torch.rand(K, device=DEV) + 0.5)
-    lb = torch.randn(K, device=DEV) * 0.1
-    seed = 0x1234567 + M
-    # the LayerNorm forward gives the saved statistics
-    y = torch.empty(M, K, dtype=BF, device=DEV)
-    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    _lib.launch("gt_layernorm_fwd", GT_BF16, _p(sub), _p(resid), _p(lw), _p(lb), 1e-5, p, seed, M, K, _p(y), _p(mean), _p(rstd), _stream())
-    imgs = W1Images([W])
-    wsb = lib.gt_layernorm_bwd_workspace_bytes(M, K)
-    with imgs.bound():
-        assert lib.gt_linear_bwd_dx_layernorm_bwd_ok(GT_BF16, GT_BF16, _p(W), M, N, K) == 1
-        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-        d_sub, d_res = torch.empty(M, K, dtype=BF, device=DEV), torch.empty(M, K, dtype=BF, device=DEV)
-        dlw, dlb = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
-        _lib.launch("gt_linear_bwd_dx_layernorm_bwd", _p(dy), _p(W), M, N, K, _p(add1), _p(add2), _p(sub), _p(resid), _p(lw), _p(mean), _p(rstd),
-                    p, seed, _p(d_sub), _p(d_res), _p(dlw), _p(dlb), _p(ws), wsb, _stream())
-    # the two kernels
-    g = bwd(None, W, dy, None, add1, add2, imgs)
-    ws2 = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-    r_sub, r_res = torch.empty(M, K, dtype=BF, device=DEV), torch.empty(M, K, dtype=BF, device=DEV)
-    rlw, rlb = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
-    _lib.launch("gt_layernorm_bwd", GT_BF16, _p(sub), _p(resid), _p(g), _p(lw), _p(mean), _p(rstd), p, seed, M, K, _p(r_sub), _p(r_res), _p(rlw), _p(rlb),
-                _p(ws2), wsb, _stream())
-    assert torch.equal(d_res, r_res), rel(d_res.float(), r_res.float())
-    assert torch.equal(d_sub, r_sub), rel(d_sub.float(), r_sub.float())
-    assert rel(dlw, rlw) < 2e-5 and rel(dlb, rlb) < 2e-5, (rel(dlw, rlw), rel(dlb, rlb))
-    if p > 0:
-        assert abs(float((d_sub == 0).float().mean()) - p) < 0.02
