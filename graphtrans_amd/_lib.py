@@ -72,6 +72,10 @@ SIGNATURES = {
     "gt_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_layernorm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_linear_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _u64, _p]),
+    "gt_colsum_rows_f32": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
+    "gt_seq_token_rows": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
+    "gt_linear_rows_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
+    "gt_linear_set_rows": (_i, [_p]),
     "gt_linear_fwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_adamw_chunk_elems": (_i, []),

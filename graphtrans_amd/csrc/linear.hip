@@ -850,6 +850,18 @@ struct Cat2Scope {
   ~Cat2Scope() { g_cat2 = Cat2Req{}; }
 };
 
+// A row map for ONE call (gt_linear_set_rows; per host thread, consumed by the next gt_linear_fwd* / gt_linear_bwd* call whatever its
+// outcome): forward stores output row m at row rows[m] of y, backward reads row m of dY from row rows[m] of dy; -1 = no such row
+// (nothing stored / zeros read).  Honoured by the bf16x6 path only: gt_linear_rows_ok.
+thread_local const int32_t* g_rows = nullptr;
+struct RowsTake {   // takes the request out of the thread state on entry: it can never leak into a later call
+  const int32_t* rows;
+  RowsTake() : rows(g_rows) { g_rows = nullptr; }
+};
+static inline bool rows_eligible(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
+  return w32_eligible(compute, x_dtype, M, 1) && (y_dtype == GT_F32 || N % 8 == 0) && w3_lookup(weight, N, K, false) && w3_lookup(weight, N, K, true);
+}
+
 extern "C" int gt_linear_fwd_grouped(int x_dtype, int y_dtype, int compute, const void* x, const float* weight,
                                      const float* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
                                      int groups, int64_t x_group_stride, int64_t y_group_stride, int act, float dropout_p,
@@ -871,6 +883,9 @@ extern "C" int gt_linear_fwd_gelu(int x_dtype, int y_dtype, int compute, const v
 static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* bias, void* y,
                            void* gout, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups, int64_t x_group_stride,
                            int64_t y_group_stride, int act, float dropout_p, uint64_t seed, gt_stream_t stream_) {
+  const RowsTake rows__;
+  GT_CHECK_ARG(!rows__.rows || (groups == 1 && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)),
+               "gt_linear_set_rows: this GEMM does not take a row map (ask gt_linear_rows_ok)");
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
                                (N * K) % 4 == 0),
@@ -921,6 +936,10 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     if (g_cat2.x2) {
       if (!w.w3 || x_dtype != GT_F32) { gt_set_error("gt_linear_fwd_cat2: needs a bound weight image and fp32 rows"); return GT_ERR_UNSUPPORTED; }
       w.a2 = g_cat2.x2; w.a_split = g_cat2.split; w.lda2 = g_cat2.ld2;
+    }
+    if (rows__.rows) {
+      if (!w.w3) { gt_set_error("gt_linear_set_rows: needs a bound weight image"); return GT_ERR_UNSUPPORTED; }
+      w.out_rows = rows__.rows;
     }
     {
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
@@ -1094,6 +1113,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
   BwdOptScope opt_scope__;   // the per-call options live for exactly this call
+  const RowsTake rows__;
+  GT_CHECK_ARG(!rows__.rows || (groups == 1 && !y_for_mask && !g_opt.bns.part && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)),
+               "gt_linear_set_rows: this GEMM does not take a row map (ask gt_linear_rows_ok)");
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
                                (N * K) % 4 == 0),
@@ -1188,6 +1210,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.bn_relu = q.relu; w.bn_part = q.part;
       }
       w.w3 = w3t;
+      if (rows__.rows) {
+        if (!w3t) { gt_set_error("gt_linear_set_rows: needs the bound image of W^T"); return GT_ERR_UNSUPPORTED; }
+        w.a_rows = rows__.rows;
+      }
       if (g_cat2.dx2) {
         if (!w3t || dx_add1 || dx_add2) { gt_set_error("gt_linear_bwd_cat2: needs a bound weight image and no addends"); return GT_ERR_UNSUPPORTED; }
         w.out2 = g_cat2.dx2; w.out_split = g_cat2.split; w.ldo2 = g_cat2.ld2;
@@ -1209,6 +1235,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       if (g_cat2.x2) { d.x2 = g_cat2.x2; d.x_split = g_cat2.split; d.ldx2 = g_cat2.ld2; }
       // weights with bound images run the bf16x6 dW kernel too (160 x 160 output tiles, split over M; linear3x.h)
       const bool split3 = x_dtype == GT_F32 && w3_lookup(weight, N, K, false) != nullptr && (y_dtype == GT_F32 || N % 8 == 0);
+      if (rows__.rows && !split3) { gt_set_error("gt_linear_set_rows: needs the bound weight image"); return GT_ERR_UNSUPPORTED; }
+      d.dy_rows = rows__.rows;
       if (split3) {
         const int nkb3 = (int)gt_cdiv(K, W3D_T), nnb3 = (int)gt_cdiv(N, W3D_T);
         int s3 = w3_dw_splits(M, nkb3 * nnb3);
@@ -1383,6 +1411,16 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
 extern "C" int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, int64_t K1, int64_t K2) {
   return (w32_eligible(compute, GT_F32, M, 1) && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0 && w3_lookup(weight, N, K1 + K2, false) &&
           w3_lookup(weight, N, K1 + K2, true)) ? 1 : 0;
+}
+// ---- a row map on the output (forward) / on dY (backward): gnn2transformer writing and reading the Transformer's token rows in place
+// (models/gnn_transformer.py:92-96, modules/utils.py:5-29: no pad / unpad pass over the node rows) -----------------------------------
+extern "C" int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
+  static const bool on = [] { const char* e = getenv("GT_LINEAR_ROWS"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return (on && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)) ? 1 : 0;
+}
+extern "C" int gt_linear_set_rows(const int32_t* rows) {
+  g_rows = rows;
+  return GT_OK;
 }
 // Y[M][N] = [X1 | X2] W^T + b with X1 [M][K1] (pitch ldx1), X2 [M][K2] (pitch ldx2), W [N][K1 + K2]; fp32 rows, y_dtype fp32 / bf16
 extern "C" int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2,

@@ -47,6 +47,10 @@ struct L32Args {
   int64_t a_split, lda2;
   void* out2;          // output columns [out_split, Nout) go to this matrix (pitch ldo2); null = none (then no addends)
   int64_t out_split, ldo2;
+  // k_lin3 only -- a ROW MAP between the GEMM's rows (graph nodes) and the rows of a token matrix (gnn2transformer writing / reading
+  // the Transformer's token rows in place, models/gnn_transformer.py:92-96): int32 [M], -1 = the node has no token row (truncated)
+  const int32_t* out_rows;   // forward: output row m is stored at row out_rows[m] of `out` (skipped when < 0)
+  const int32_t* a_rows;     // dX form: row m of the row operand is row a_rows[m] of `a` (zeros when < 0)
 };
 
 // 16-byte chunk of TA -> up to 8 floats
@@ -348,6 +352,7 @@ struct L32DwArgs {
   int64_t m_per_split;
   const void* x2;      // columns [x_split, K) of X come from this matrix (pitch ldx2); null = none
   int64_t x_split, ldx2;
+  const int32_t* dy_rows;   // k_lin3_dw only: row m of dY is row dy_rows[m] of `dy` (zeros when < 0); see L32Args
 };
 
 template <typename TY, typename TX, int NT, bool MASK>

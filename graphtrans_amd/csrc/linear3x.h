@@ -131,11 +131,19 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
   const TA* a_src[AR];
   const TA* a2_src[AR];   // second row operand (virtual concatenation), columns [a_split, Kc)
   const TA* m_src[AR];
+  bool a_none[AR];
   const bool cat2 = a.a2 != nullptr;
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const int64_t a_row = m0 + ar + 64 * r < a.M ? m0 + ar + 64 * r : a.M - 1;
-    a_src[r] = A + a_row * a.lda;
+    int64_t src_row = a_row;
+    a_none[r] = false;
+    if (a.a_rows) {   // the row operand's rows through the row map: a node without a token row contributes zeros
+      const int32_t t = a.a_rows[a_row];
+      a_none[r] = t < 0;
+      src_row = t < 0 ? 0 : t;
+    }
+    a_src[r] = A + src_row * a.lda;
     a2_src[r] = cat2 ? reinterpret_cast<const TA*>(a.a2) + a_row * a.lda2 - a.a_split : nullptr;
     m_src[r] = has_mask ? Am + a_row * a.lda : nullptr;
   }
@@ -182,15 +190,15 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
       const int row = ar + 64 * r;
       unsigned char* dst = sA + row * 64 + ((q ^ ((row >> 1) & 3)) << 4);
       if constexpr (NPA == 1) {
-        *reinterpret_cast<uint4*>(dst) = R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r];
+        *reinterpret_cast<uint4*>(dst) = (R.z0 || a_none[r]) ? make_uint4(0, 0, 0, 0) : R.v0[r];
       } else {
         float f[8];
         if constexpr (sizeof(TA) == 4) {
-          const uint4 u0 = R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r], u1 = R.z1 ? make_uint4(0, 0, 0, 0) : R.v1[r];
+          const uint4 u0 = (R.z0 || a_none[r]) ? make_uint4(0, 0, 0, 0) : R.v0[r], u1 = (R.z1 || a_none[r]) ? make_uint4(0, 0, 0, 0) : R.v1[r];
           f[0] = __uint_as_float(u0.x); f[1] = __uint_as_float(u0.y); f[2] = __uint_as_float(u0.z); f[3] = __uint_as_float(u0.w);
           f[4] = __uint_as_float(u1.x); f[5] = __uint_as_float(u1.y); f[6] = __uint_as_float(u1.z); f[7] = __uint_as_float(u1.w);
         } else {
-          chunk_to_f32<TA>(R.z0 ? make_uint4(0, 0, 0, 0) : R.v0[r], f);
+          chunk_to_f32<TA>((R.z0 || a_none[r]) ? make_uint4(0, 0, 0, 0) : R.v0[r], f);
         }
         if constexpr (MASK) {
           if (has_mask) {
@@ -366,7 +374,10 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
       if (ok[t] && (!(W3_ABL & 8) || v[t].x == 12345.678f)) {
         const int64_t col = ncol0 + c4;
         if (a.out2 && col >= a.out_split) gt_store4<TO>(reinterpret_cast<TO*>(a.out2) + (mrow0 + r) * a.ldo2 + col - a.out_split, v[t]);
-        else gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + col, v[t]);
+        else if (a.out_rows) {   // the output row through the row map (a token row), nothing for a node without one
+          const int32_t orow = a.out_rows[mrow0 + r];
+          if (orow >= 0) gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (int64_t)orow * a.ldo + col, v[t]);
+        } else gt_store4<TO>(reinterpret_cast<TO*>(a.out) + (mrow0 + r) * a.ldo + col, v[t]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -450,7 +461,7 @@ constexpr int W3D_T = 160, W3D_LD = W3D_T + 8, W3D_PLANE = 32 * W3D_LD;   // bf1
 template <typename TS>
 __device__ __forceinline__ void w3d_load_chunks(const TS* src, int64_t ld, int64_t row0, int64_t rows_end, int64_t col0, int64_t cols_end,
                                                 uint4* v, const TS* msrc, uint4* vm, const TS* src2 = nullptr, int64_t split = 0,
-                                                int64_t ld2 = 0) {
+                                                int64_t ld2 = 0, const int32_t* rows = nullptr, uint32_t* none = nullptr) {
   // a [32][160] tile as 16-byte chunks, chunk c = tid + 256 i: row c / CH, column chunk c % CH; out-of-range chunks are clamped to a
   // valid address (branch-free loads) and zeroed at store time
   constexpr int E = 16 / sizeof(TS), CH = W3D_T / E, NIT = (32 * CH + 255) / 256;
@@ -461,6 +472,12 @@ __device__ __forceinline__ void w3d_load_chunks(const TS* src, int64_t ld, int64
     int64_t row = row0 + r, col = col0 + cc;
     row = row < rows_end ? row : rows_end - 1;
     col = col < cols_end ? col : 0;
+    if (rows && r < 32) {   // rows through a row map (L32DwArgs::dy_rows): chunks of rows without a source are zeroed at store time
+      const int32_t t = rows[row];
+      if (t < 0) *none |= 1u << i;
+      else *none &= ~(1u << i);
+      row = t < 0 ? 0 : t;
+    }
     if (r < 32) {
       if (src2 && col >= split) v[i] = *reinterpret_cast<const uint4*>(src2 + row * ld2 + (col - split));   // columns [split, ..) of a virtual concatenation
       else v[i] = *reinterpret_cast<const uint4*>(src + row * ld + col);
@@ -471,14 +488,14 @@ __device__ __forceinline__ void w3d_load_chunks(const TS* src, int64_t ld, int64
 
 template <typename TS, bool MASK>
 __device__ __forceinline__ void w3d_store_chunks(gt_bf16* planes, int64_t row0, int64_t rows_end, int64_t col0, int64_t cols_end,
-                                                 const uint4* v, const uint4* vm, bool has_mask, float inv_keep) {
+                                                 const uint4* v, const uint4* vm, bool has_mask, float inv_keep, uint32_t none = 0) {
   constexpr int E = 16 / sizeof(TS), CH = W3D_T / E, NIT = (32 * CH + 255) / 256;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int c = threadIdx.x + i * 256;
     const int r = c / CH, cc = (c % CH) * E;
     if (r >= 32) continue;
-    const bool ok = row0 + r < rows_end && col0 + cc < cols_end;
+    const bool ok = row0 + r < rows_end && col0 + cc < cols_end && !((none >> i) & 1u);
     float f[E];
     chunk_to_f32<TS>(ok ? v[i] : make_uint4(0, 0, 0, 0), f);
     if constexpr (MASK) {
@@ -542,17 +559,18 @@ __global__ void __launch_bounds__(256, 1) k_lin3_dw(L32DwArgs a) {
   float dbacc = 0.f;   // kb == 0, tid < 160: column n0 + tid
 
   uint4 vz[ZIT], vmk[MASK ? ZIT : 1], vx[XIT];
+  uint32_t znone = 0;   // dy_rows: chunks of vz whose row has no source
   if (mb < me) {
-    w3d_load_chunks<TY>(dY, a.ldy, mb, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk);
+    w3d_load_chunks<TY>(dY, a.ldy, mb, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk, nullptr, 0, 0, a.dy_rows, &znone);
     w3d_load_chunks<TX>(X, a.ldx, mb, me, k0, a.K, vx, nullptr, nullptr, reinterpret_cast<const TX*>(a.x2), a.x_split, a.ldx2);
   }
   for (int64_t m0 = mb; m0 < me; m0 += 32) {
     __syncthreads();   // every wave is done with the previous stage's planes
-    w3d_store_chunks<TY, MASK>(sZ, m0, me, n0, a.N, vz, vmk, has_mask, a.inv_keep);
+    w3d_store_chunks<TY, MASK>(sZ, m0, me, n0, a.N, vz, vmk, has_mask, a.inv_keep, znone);
     w3d_store_chunks<TX, false>(sX, m0, me, k0, a.K, vx, nullptr, false, 1.f);
     __syncthreads();
     if (m0 + 32 < me) {
-      w3d_load_chunks<TY>(dY, a.ldy, m0 + 32, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk);
+      w3d_load_chunks<TY>(dY, a.ldy, m0 + 32, me, n0, a.N, vz, has_mask ? Ym : nullptr, vmk, nullptr, 0, 0, a.dy_rows, &znone);
       w3d_load_chunks<TX>(X, a.ldx, m0 + 32, me, k0, a.K, vx, nullptr, nullptr, reinterpret_cast<const TX*>(a.x2), a.x_split, a.ldx2);
     }
     if (kb == 0 && tid < W3D_T) {   // db: the three planes of a value add back to the value exactly

@@ -59,6 +59,8 @@ struct Ctx {
   gt_vn_update vn[MAXL];
   gt_encoder_layer enc[MAXL];
   // forward arena
+  size_t o_rowmap;   // int32 [N]: the token row of every node (gt_seq_token_rows), when gnn2transformer writes the token rows itself
+  int fuse_rows;
   size_t o_h[MAXL + 1], o_x0, o_vn[MAXL], o_vn_saved[MAXL], o_conv_saved[MAXL], o_cat, o_hn, o_tok, o_xin, o_st0, o_xe[MAXL],
       o_enc_saved[MAXL], o_hgin, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
   size_t o_scales, q_dimg;
@@ -346,6 +348,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   }
   c->o_cat = a.take((m->jk_cat && !c->cat2) ? (size_t)N * Kc * 4 : 0);
   c->o_hn = a.take((size_t)N * d * tsz);
+  c->o_rowmap = a.take((size_t)N * 4);
   c->o_tok = a.take((size_t)rows * d * tsz);
   if (m->nin_w) {
     c->o_xin = a.take((size_t)rows * d * tsz);
@@ -682,9 +685,18 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   c->h_last = P(c->o_h[L]);
   if (ev_w1) GT_TRY(gt_stream_wait_event(st, ev_w1));   // the encoder's weight images were built on the prep stream
   // ---- gnn2transformer + token rows + encoder   (models/gnn_transformer.py:92-114)
+  // the GEMM's epilogue writes the token rows itself (row map; CLS rows by the map's kernel) when the layout is the packed one built
+  // here and the bf16x6 kernel runs it: no pad pass over the node rows (modules/utils.py:5-29), no [N][d] intermediate
+  c->fuse_rows = (!b.seq_desc && gt_linear_rows_ok(compute, GT_F32, tdt, m->g2t_w, N, d, c->Kc)) ? 1 : 0;
+  void* g2t_out = P(c->o_hn);
+  if (c->fuse_rows) {
+    GT_TRY(gt_seq_token_rows(tdt, m->cls, graph_ptr, node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, P(c->o_tok), (int32_t*)P(c->o_rowmap), st));
+    GT_TRY(gt_linear_set_rows((const int32_t*)P(c->o_rowmap)));
+    g2t_out = P(c->o_tok);
+  }
   if (c->cat2) {
     c->node_rep = nullptr;
-    GT_TRY(gt_linear_fwd_cat2(tdt, compute, c->first, D, D, c->h_last, D, D, m->g2t_w, m->g2t_b, P(c->o_hn), N, d, d, st));
+    GT_TRY(gt_linear_fwd_cat2(tdt, compute, c->first, D, D, c->h_last, D, D, m->g2t_w, m->g2t_b, g2t_out, N, d, d, st));
   } else {
     if (m->jk_cat) {   // torch.cat([h_list[0], h_list[-1]], 1)   (gnn_module.py:104-105)
       GT_TRY(gt_copy2d(P(c->o_cat), c->Kc * 4, c->first, D * 4, D * 4, N, st));
@@ -693,9 +705,10 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
     } else {
       c->node_rep = c->h_last;
     }
-    GT_TRY(gt_linear_fwd(GT_F32, tdt, compute, c->node_rep, m->g2t_w, m->g2t_b, P(c->o_hn), N, d, c->Kc, 0, 0.f, 0, st));
+    GT_TRY(gt_linear_fwd(GT_F32, tdt, compute, c->node_rep, m->g2t_w, m->g2t_b, g2t_out, N, d, c->Kc, 0, 0.f, 0, st));
   }
-  GT_TRY(gt_seq_gather_cls32(tdt, P(c->o_hn), m->cls, graph_ptr, c->seq_desc, B, 1, c->max_npos, m->with_cls ? 1 : 0, d, P(c->o_tok), st));
+  if (!c->fuse_rows)
+    GT_TRY(gt_seq_gather_cls32(tdt, P(c->o_hn), m->cls, graph_ptr, c->seq_desc, B, 1, c->max_npos, m->with_cls ? 1 : 0, d, P(c->o_tok), st));
   const void* cur = P(c->o_tok);
   if (m->nin_w) {
     GT_TRY(gt_layernorm_fwd(tdt, cur, nullptr, m->nin_w, m->nin_b, m->nin_eps, 0.f, 0, rows, d, P(c->o_xin), (float*)P(c->o_st0),
@@ -803,16 +816,23 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       std::swap(dcur, dnext);
     }
     // ---- token rows -> node rows (+ the CLS gradient)
-    GT_TRY(gt_seq_scatter(tdt, dcur, nullptr, c->graph_ptr, c->node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, Q(c->q_d_hn),
-                          m->cls ? Q(c->q_d_cls) : nullptr, st));
-    if (m->cls) GT_TRY(gt_colsum_f32(tdt, Q(c->q_d_cls), B, d, G + m->off_cls, st));
+    const void* d_hn = Q(c->q_d_hn);
+    if (c->fuse_rows) {   // the GEMMs read the token-row gradient through the row map; the cls gradient = column sums of the CLS rows
+      if (m->cls) GT_TRY(gt_colsum_rows_f32(tdt, dcur, c->last_rows, B, d, G + m->off_cls, st));
+      GT_TRY(gt_linear_set_rows((const int32_t*)P(c->o_rowmap)));
+      d_hn = dcur;
+    } else {
+      GT_TRY(gt_seq_scatter(tdt, dcur, nullptr, c->graph_ptr, c->node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, Q(c->q_d_hn),
+                            m->cls ? Q(c->q_d_cls) : nullptr, st));
+      if (m->cls) GT_TRY(gt_colsum_f32(tdt, Q(c->q_d_cls), B, d, G + m->off_cls, st));
+    }
     if (c->g2t_wt && m->st_dw) GT_TRY(gt_stream_wait_event(st, m->ev_wt[1]));   // W^T was written on the overlap stream beside the forward
     if (c->cat2) {   // d h_list[0] -> dJ, d h_list[-1] -> dA straight from the GEMM
-      GT_TRY(gt_linear_bwd_cat2(tdt, compute, c->first, D, D, c->h_last, D, D, m->g2t_w, Q(c->q_d_hn), Q(c->q_dJ), D, Q(c->q_dA), D,
+      GT_TRY(gt_linear_bwd_cat2(tdt, compute, c->first, D, D, c->h_last, D, D, m->g2t_w, d_hn, Q(c->q_dJ), D, Q(c->q_dA), D,
                                 G + m->off_g2t_w, G + m->off_g2t_b, N, d, d, W(), ws_bytes, st));
       c->dy = Q(c->q_dA);
     } else {
-      GT_TRY(gt_linear_bwd_wt(GT_F32, tdt, compute, c->node_rep, m->g2t_w, c->g2t_wt, Q(c->q_d_hn), nullptr, nullptr, nullptr, Q(c->q_d_rep),
+      GT_TRY(gt_linear_bwd_wt(GT_F32, tdt, compute, c->node_rep, m->g2t_w, c->g2t_wt, d_hn, nullptr, nullptr, nullptr, Q(c->q_d_rep),
                               G + m->off_g2t_w, G + m->off_g2t_b, N, d, Kc, 0.f, W(), ws_bytes, st));
       if (m->jk_cat) c->dy = nullptr;   // split below (stage 2 prologue)
       else c->dy = Q(c->q_d_rep);

@@ -312,7 +312,8 @@ extern "C" int gt_seq_gather_cls32(int dtype, const void* h, const float* cls32,
 
 // out[c] = sum over rows of x[r][c], fp32, fixed order: 4 row groups x (dim / 4) column chunks per block pass
 template <typename T>
-__global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, int64_t rows, int64_t D, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, const int64_t* __restrict__ row_idx, int64_t rows, int64_t D,
+                                                    float* __restrict__ out) {
   __shared__ float4 part[256];
   const int64_t C = D / 4;
   const int groups = 256 / 64;   // 64 column chunks per pass
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, int
     const int64_t c = c0 + cl;
     float4 acc = gt_zero4();
     if (c < C)
-      for (int64_t r = g; r < rows; r += groups) acc = gt_add4(acc, gt_load4<T>(x + r * D + c * 4));
+      for (int64_t r = g; r < rows; r += groups) acc = gt_add4(acc, gt_load4<T>(x + (row_idx ? row_idx[r] : r) * D + c * 4));
     part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c < C) {
@@ -333,14 +334,67 @@ __global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, int
   }
 }
 
-extern "C" int gt_colsum_f32(int dtype, const void* x, int64_t rows, int64_t D, float* out, gt_stream_t stream_) {
-  int rc = check("gt_colsum_f32", dtype, D);
+static int colsum_impl(const char* fn, int dtype, const void* x, const int64_t* row_idx, int64_t rows, int64_t D, float* out, gt_stream_t stream_) {
+  int rc = check(fn, dtype, D);
   if (rc) return rc;
-  GT_CHECK_ARG(x && out, "null buffer");
+  if (!(x && out)) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid((unsigned)gt_cdiv(D / 4, 64));
-  if (dtype == GT_F32) hipLaunchKernelGGL(k_colsum_f32<float>, grid, dim3(256), 0, stream, (const float*)x, rows, D, out);
-  else hipLaunchKernelGGL(k_colsum_f32<gt_bf16>, grid, dim3(256), 0, stream, (const gt_bf16*)x, rows, D, out);
+  if (dtype == GT_F32) hipLaunchKernelGGL(k_colsum_f32<float>, grid, dim3(256), 0, stream, (const float*)x, row_idx, rows, D, out);
+  else hipLaunchKernelGGL(k_colsum_f32<gt_bf16>, grid, dim3(256), 0, stream, (const gt_bf16*)x, row_idx, rows, D, out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+extern "C" int gt_colsum_f32(int dtype, const void* x, int64_t rows, int64_t D, float* out, gt_stream_t stream_) {
+  return colsum_impl("gt_colsum_f32", dtype, x, nullptr, rows, D, out, stream_);
+}
+// ... over the rows row_idx[0 .. rows) of x (the CLS rows of the token matrix: the gradient of the cls embedding without a gather)
+extern "C" int gt_colsum_rows_f32(int dtype, const void* x, const int64_t* row_idx, int64_t rows, int64_t D, float* out, gt_stream_t stream_) {
+  GT_CHECK_ARG(row_idx, "null row index");
+  return colsum_impl("gt_colsum_rows_f32", dtype, x, row_idx, rows, D, out, stream_);
+}
+
+// The token row of every node (the row map of gt_linear_set_rows) + the CLS rows of the token matrix, for layouts WITHOUT pad rows
+// (the packed layout: kv_off = 0, npos = kv_len): rows[r] = row0(b) + (kv_off + r - first kept node of b) * row_stride, -1 for the
+// leading nodes a truncated graph drops (modules/utils.py:17-21 keeps the LAST max_num_nodes); tokens[cls row of b] = cls32.
+template <typename T>
+__global__ void __launch_bounds__(SEG_THREADS) k_seq_token_rows(const float* __restrict__ cls32, const int32_t* __restrict__ gptr,
+                                                                const int32_t* __restrict__ node_graph, const int32_t* __restrict__ desc,
+                                                                int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D,
+                                                                T* __restrict__ tokens, int32_t* __restrict__ rows) {
+  const int64_t C = D / 4;
+  const int64_t t0 = (int64_t)blockIdx.x * SEG_THREADS + threadIdx.x, step = (int64_t)gridDim.x * SEG_THREADS;
+  for (int64_t r = t0; r < N; r += step) {
+    const int b = node_graph[r];
+    const int4 d = *reinterpret_cast<const int4*>(desc + b * 4);   // {row0, npos, kv_off, kv_len}
+    const int node0 = gptr[b + 1] - (d.w - with_cls);
+    rows[r] = r >= node0 ? (int32_t)(d.x + (int64_t)(d.z + (int)r - node0) * row_stride) : -1;
+  }
+  if (with_cls) {
+    for (int64_t i = t0; i < num_seqs * C; i += step) {
+      const int64_t b = i / C, c = (i % C) * 4;
+      const int4 d = *reinterpret_cast<const int4*>(desc + b * 4);
+      gt_store4<T>(tokens + ((int64_t)d.x + (int64_t)(d.z + d.w - 1) * row_stride) * D + c, gt_load4<float>(cls32 + c));
+    }
+  }
+}
+extern "C" int gt_seq_token_rows(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* seq_desc,
+                                 int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D, void* tokens, int32_t* rows,
+                                 gt_stream_t stream_) {
+  int rc = check("gt_seq_token_rows", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(graph_ptr && node_graph && seq_desc && tokens && rows, "null buffer");
+  GT_CHECK_ARG(!with_cls || cls32, "with_cls needs the cls row");
+  if (num_seqs == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t items = N > num_seqs * (D / 4) ? N : num_seqs * (D / 4);
+  dim3 grid((unsigned)(gt_cdiv(items, SEG_THREADS) < 1024 ? gt_cdiv(items, SEG_THREADS) : 1024));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_seq_token_rows<float>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
+                       with_cls, N, D, (float*)tokens, rows);
+  else
+    hipLaunchKernelGGL(k_seq_token_rows<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
+                       with_cls, N, D, (gt_bf16*)tokens, rows);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

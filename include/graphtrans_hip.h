@@ -496,6 +496,13 @@ int gt_transpose(const float* in /* [N][K] */, float* out /* [K][N] */, int64_t 
  * models/gnn_transformer.py:92): the GEMM reads its row operand from two matrices side by side and its backward writes the two
  * gradients where their consumers read them.  Only on weights whose images are bound (ask gt_linear_cat2_ok first). */
 int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, int64_t K1, int64_t K2);
+/* A row map for the NEXT gt_linear_fwd* / gt_linear_bwd* call of this host thread (consumed by that call whatever its outcome):
+ * forward stores output row m at row rows[m] of y, backward reads row m of dY from row rows[m] of dy; rows[m] = -1: no such row
+ * (nothing stored / zeros read).  int32 [M] on the device.  This is gnn2transformer writing / reading the Transformer's token rows in
+ * place (models/gnn_transformer.py:92-96; modules/utils.py:5-29 pad_batch / unpad_batch without their pass over the node rows):
+ * rows = gt_seq_token_rows.  Only the fp32-accurate big-M path with bound weight images takes it: ask gt_linear_rows_ok. */
+int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K);
+int gt_linear_set_rows(const int32_t* rows);
 int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
                        const float* weight, const float* bias, void* y, int64_t M, int64_t N, int64_t ldy, gt_stream_t stream);
 int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
@@ -936,6 +943,15 @@ int gt_seq_gather_cls32(int dtype, const void* h, const float* cls32, const int3
                         void* tokens, gt_stream_t stream);
 /* out[c] (fp32) = sum_r x[r][c] in a fixed order (the CLS embedding's gradient from its per-graph rows) */
 int gt_colsum_f32(int dtype, const void* x, int64_t rows, int64_t dim, float* out, gt_stream_t stream);
+/* ... over the rows row_idx[0 .. rows) of x only (the CLS rows of the token matrix) */
+int gt_colsum_rows_f32(int dtype, const void* x, const int64_t* row_idx, int64_t rows, int64_t D, float* out, gt_stream_t stream);
+/* The token row of every node -- the row map of gt_linear_set_rows -- and the CLS rows of the token matrix, for token layouts WITHOUT
+ * pad rows (the packed layout of gt_seq_layout_packed: kv_off = 0, npos = kv_len): rows[r] (int32 [N]) = the row gt_seq_gather would
+ * copy node r to, -1 for the leading nodes a truncated graph drops (modules/utils.py:17-21 keeps the last max_num_nodes);
+ * tokens[cls row of sequence b] = cls32 (fp32 [D]).  With gt_linear_set_rows this replaces gt_seq_gather / gt_seq_scatter. */
+int gt_seq_token_rows(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* seq_desc,
+                      int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D, void* tokens, int32_t* rows,
+                      gt_stream_t stream);
 
 /* Stand-alone dropout (F.dropout / nn.Dropout with no producing kernel to carry it: masked_transformer_encoder.py:54,75,
  * pna/pna_module.py:78): y[i] = keep(i, seed) ? x[i] / (1 - p) : 0 over n elements (n % 4 == 0; x == y allowed).  The same

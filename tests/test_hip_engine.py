@@ -533,3 +533,38 @@ def test_second_backward_through_the_fused_node_raises():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
+
+
+ROWS_CASES = [dict(max_input_len=60), dict(), dict(gnn_JK="last", max_input_len=100), dict(graph_pooling="last", transformer_norm_input=False, max_input_len=80),
+              dict(compute_dtype=torch.bfloat16, max_input_len=60)]
+
+
+@pytest.mark.parametrize("kw", ROWS_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in ROWS_CASES])
+def test_gnn2transformer_writes_the_token_rows_itself(kw):
+    """At GEMM sizes the bf16x6 kernel takes (>= 1024 node rows, d_model 128) the fused path lets gnn2transformer's epilogue store the
+    token rows through a row map and its backward read the token-row gradient through it (gt_seq_token_rows + gt_linear_set_rows; no
+    pad_batch / unpad_batch pass, modules/utils.py:5-29) -- against the module path, which pads and unpads with gt_seq_gather /
+    gt_seq_scatter; graphs longer than max_input_len keep their LAST nodes, the dropped ones get zero gradient from this branch."""
+    from graphtrans_amd import engine, ops, synth
+    from graphtrans_amd.encoders import ASTNodeEncoder
+    from graphtrans_amd.models.gnn_transformer import GNNTransformer
+    args = _args(gnn_emb_dim=128, d_model=128, dim_feedforward=256, transformer_dropout=0.0, **kw)
+    bf16 = args.compute_dtype == torch.bfloat16
+    ops.set_matmul_dtype(torch.bfloat16 if bf16 else torch.float32)
+    try:
+        torch.manual_seed(0)
+        model = GNNTransformer(50, ASTNodeEncoder(128, 98, 300, 20), lambda d: torch.nn.Linear(2, d), args).to(DEV).train()
+        b = synth.code2_like(B=24, seed=21, num_nodeattributes=300).to(DEV)
+        assert b.x.shape[0] >= 1024
+        y = torch.randint(0, 50, (24, 3), device=DEV)
+        assert engine.eligible(model, b, None)
+        ref = copy.deepcopy(model)
+        l0, g0, _ = _run(ref, b, y, False, 5)
+        l1, g1, _ = _run(model, b, y, True, 5)
+        tol = 3e-2 if bf16 else 1e-4
+        assert torch.allclose(l0, l1, rtol=tol, atol=tol * 1e-2), (l0, l1)
+        for n in g0:
+            scale = max(1.0, float(g0[n].abs().max()))
+            assert torch.allclose(g0[n] / scale, g1[n] / scale, rtol=tol, atol=tol * 1e-2 + 1e-6), n
+    finally:
+        ops.set_matmul_dtype(torch.float32)
