@@ -74,6 +74,11 @@ SIGNATURES = {
     "gt_linear_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_colsum_rows_f32": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
     "gt_seq_token_rows": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
+    "gt_defer_begin": (_i, [_p, _sz]),
+    "gt_defer_take": (_p, [_sz]),
+    "gt_defer_push": (_i, [_p, _i, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gt_defer_flush": (_i, [_p]),
+    "gt_defer_end": (_i, []),
     "gt_linear_rows_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_set_rows": (_i, [_p]),
     "gt_linear_fwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),

@@ -712,6 +712,71 @@ void dw_forked(const void* workspace, size_t bytes) {
   (void)hipEventRecord(e.ev, g_dw.side);
 }
 
+// ---- deferred partial-sum reduces ----------------------------------------------------------------------------------------------
+// Every weight-gradient GEMM ends in a fixed-order sum over its M-split partials (k_split_reduce), every LayerNorm backward in a column
+// finish over its block partials: ~30 launches of 5-15 us per step that produce PARAMETER gradients only -- nothing before the
+// optimizer / the gradient all-reduce reads them.  Inside a section (gt_defer_begin: the whole-model backward, csrc/model.hip) the
+// producers put their partials into the section's arena (gt_defer_take) and queue the sum (gt_defer_push); gt_defer_flush runs all
+// queued sums as ONE launch (k_defer_reduce: job list in the kernel arguments, same summation order as k_split_reduce -> same bits).
+// The arena is never reused inside a section, so a flush may run on any stream that is ordered behind the producers.
+struct DeferJob {
+  const float *part, *part2;   // part[s * stride + i], s < nparts
+  float *out, *out2;
+  int64_t len, len2, stride, stride2;
+  int32_t nparts, block0;
+};
+constexpr int DEFER_MAX_JOBS = 48;   // 48 x 72 bytes of kernel arguments
+struct DeferJobs {
+  DeferJob j[DEFER_MAX_JOBS];
+  int n;
+};
+struct DeferState {
+  bool active = false;
+  char* arena = nullptr;
+  size_t cap = 0, used = 0;
+  DeferJobs jobs{};
+  int blocks = 0;
+};
+thread_local DeferState g_defer;
+
+__global__ void __launch_bounds__(256) k_defer_reduce(DeferJobs J) {
+  int ji = 0;
+  for (int i = 1; i < J.n; ++i)
+    if ((int)blockIdx.x >= J.j[i].block0) ji = i;
+  const DeferJob& q = J.j[ji];
+  const int nb = (ji + 1 < J.n ? J.j[ji + 1].block0 : (int)gridDim.x) - q.block0;
+  for (int64_t i0 = (int64_t)((int)blockIdx.x - q.block0) * 256 + threadIdx.x; i0 < q.len + q.len2; i0 += (int64_t)nb * 256) {
+    const bool second = i0 >= q.len;
+    const float* p = second ? q.part2 : q.part;
+    const int64_t st = second ? q.stride2 : q.stride, i = second ? i0 - q.len : i0;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= q.nparts; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(s + u) * st + i];
+    }
+    for (; s < q.nparts; ++s) acc[0] += p[(int64_t)s * st + i];
+    (second ? q.out2 : q.out)[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+}
+
+// the end of a weight-gradient GEMM: queue the sum over its partials (they live in the section's arena) or run it now
+void dw_reduce(hipStream_t stream, bool deferred, const float* part, int splits, int64_t len, float* out, const float* part2, int64_t len2,
+               float* out2) {
+  if (deferred) {
+    (void)gt_defer_push(part, splits, len, len, out, part2, len2, len2, out2);
+    return;
+  }
+  const int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+  hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, part, splits, len, out, part2, len2, out2, (int64_t)0);
+}
+// its partial buffer: the open section's arena when it has room, else the caller's workspace
+float* dw_part(float* ws_part, int splits, int64_t N, int64_t K, bool* deferred) {
+  void* p = gt_defer_take((size_t)splits * (size_t)(N * K + N) * sizeof(float));
+  *deferred = p != nullptr;
+  return p ? (float*)p : ws_part;
+}
+
 int pick_bm(int64_t M) {
   (void)M;
   return 64;   // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs
@@ -1242,7 +1307,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         int s3 = w3_dw_splits(M, nkb3 * nnb3);
         const int cap = w32_dw_splits(M, nkb, nnb, false);   // the workspace is sized for this many partial copies
         if (s3 > cap) s3 = cap;
-        d.part = part; d.dbpart = dbias ? part + (size_t)s3 * N * K : nullptr;
+        bool deferred;
+        float* part3 = dw_part(part, s3, N, K, &deferred);
+        d.part = part3; d.dbpart = dbias ? part3 + (size_t)s3 * N * K : nullptr;
         d.splits = s3; d.nkb = nkb3; d.nnb = nnb3;
         d.m_per_split = gt_cdiv(gt_cdiv(M, s3), 32) * 32;
         dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3));
@@ -1250,16 +1317,15 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
           GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
           if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
           else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
-          const int64_t len = N * K, len2 = dbias ? N : 0;
-          int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-          hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, s3, len, dweight,
-                             (const float*)d.dbpart, len2, dbias, (int64_t)0);
+          dw_reduce(stream, deferred, part3, s3, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
         }
         if (forked) dw_forked(workspace, workspace_bytes);
         GT_CHECK_LAUNCH();
         return GT_OK;
       }
-      d.part = part; d.dbpart = dbias ? part + (size_t)splits * N * K : nullptr;
+      bool deferred;
+      float* part2w = dw_part(part, splits, N, K, &deferred);
+      d.part = part2w; d.dbpart = dbias ? part2w + (size_t)splits * N * K : nullptr;
       d.splits = splits; d.nkb = nkb; d.nnb = nnb;
       d.m_per_split = gt_cdiv(gt_cdiv(M, splits), 16) * 16;
       dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * nkb * nnb));
@@ -1267,10 +1333,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin32_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
         if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
         else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
-        const int64_t len = N * K, len2 = dbias ? N : 0;
-        int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-        hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)part, splits, len, dweight,
-                           (const float*)d.dbpart, len2, dbias, (int64_t)0);
+        dw_reduce(stream, deferred, part2w, splits, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
       }
       if (forked) dw_forked(workspace, workspace_bytes);
     }
@@ -1367,17 +1430,15 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       d.dy = (const gt_bf16*)dy; d.x = (const gt_bf16*)x; d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx;
       d.splits = dw16_splits(M, N, K, splits);
       d.m_per_split = gt_cdiv(gt_cdiv(M, d.splits), D16_ROWS) * D16_ROWS;
-      d.part = reinterpret_cast<float*>(workspace);
+      bool deferred;
+      d.part = dw_part(reinterpret_cast<float*>(workspace), d.splits, N, K, &deferred);
       d.dbpart = dbias ? d.part + (size_t)d.splits * N * K : nullptr;
       d.ntx = (int)(N / D16_T);
       d.ntiles = d.ntx * (int)(K / D16_T);
       {
         GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_dw16+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
         hipLaunchKernelGGL(k_dw16, dim3((unsigned)(gt_cdiv(d.splits, 8) * 8 * d.ntiles)), dim3(256), 0, stream, d);
-        const int64_t len = N * K, len2 = dbias ? N : 0;
-        int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-        hipLaunchKernelGGL(k_split_reduce, dim3(rg, 1), dim3(256), 0, stream, (const float*)d.part, d.splits, len, dweight,
-                           (const float*)d.dbpart, len2, dbias, (int64_t)0);
+        dw_reduce(stream, deferred, d.part, d.splits, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
       }
       if (forked) dw_forked(workspace, workspace_bytes);
       GT_CHECK_LAUNCH();
@@ -1593,6 +1654,50 @@ extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, co
 }
 
 // ---- overlap section -------------------------------------------------------------------------------
+extern "C" int gt_defer_begin(void* arena, size_t bytes) {
+  static const bool on = [] { const char* e = getenv("GT_DEFER_REDUCE"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  g_defer.active = on && arena && bytes > 0;
+  g_defer.arena = (char*)arena;
+  g_defer.cap = bytes;
+  g_defer.used = 0;
+  g_defer.jobs.n = 0;
+  g_defer.blocks = 0;
+  return GT_OK;
+}
+extern "C" void* gt_defer_take(size_t bytes) {
+  if (!g_defer.active || g_defer.jobs.n >= DEFER_MAX_JOBS) return nullptr;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (g_defer.used + need > g_defer.cap) return nullptr;
+  void* p = g_defer.arena + g_defer.used;
+  g_defer.used += need;
+  return p;
+}
+extern "C" int gt_defer_push(const float* part, int nparts, int64_t len, int64_t stride, float* out, const float* part2, int64_t len2,
+                             int64_t stride2, float* out2) {
+  GT_CHECK_ARG(g_defer.active && g_defer.jobs.n < DEFER_MAX_JOBS, "no open section / job list full (a gt_defer_take came first?)");
+  GT_CHECK_ARG(part && out && nparts >= 1 && len > 0 && (len2 == 0 || (part2 && out2)), "bad job");
+  DeferJob& q = g_defer.jobs.j[g_defer.jobs.n++];
+  q.part = part; q.part2 = len2 ? part2 : nullptr; q.out = out; q.out2 = len2 ? out2 : nullptr;
+  q.len = len; q.len2 = len2; q.stride = stride; q.stride2 = stride2; q.nparts = nparts;
+  q.block0 = g_defer.blocks;
+  const int64_t nb = gt_cdiv(len + len2, 256);
+  g_defer.blocks += (int)(nb < 512 ? nb : 512);
+  return GT_OK;
+}
+extern "C" int gt_defer_flush(gt_stream_t stream_) {
+  if (!g_defer.active || g_defer.jobs.n == 0) return GT_OK;
+  hipLaunchKernelGGL(k_defer_reduce, dim3((unsigned)g_defer.blocks), dim3(256), 0, (hipStream_t)stream_, g_defer.jobs);
+  g_defer.jobs.n = 0;
+  g_defer.blocks = 0;
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+extern "C" int gt_defer_end(void) {
+  GT_CHECK_ARG(!g_defer.active || g_defer.jobs.n == 0, "queued sums were never flushed");
+  g_defer.active = false;
+  return GT_OK;
+}
+
 extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
   GT_CHECK_ARG(side_ && main_ != side_, "need a distinct side stream");
   if (!g_dw.ev_fork) {

@@ -79,6 +79,7 @@ struct Ctx {
   int64_t e_str[MAXT + 1], e_clamp[MAXT + 1], e_rows[MAXT + 1];
   // backward arena
   size_t q_d_hgin, q_dyp;
+  size_t q_defer, defer_bytes;   // the arena of the backward's deferred partial-sum reduces (gt_defer_begin)
   size_t q_d_hg, q_dtok[2], q_d_hn, q_d_cls, q_d_rep, q_dA, q_dB, q_dC, q_dJ, q_dvn[4], q_ne_dw, q_bnpart[MAXL], q_heads_ws,
       q_ws[2], q_ws2, q_ws3;
   size_t bws_bytes, heads_ws_bytes, seg_ws_bytes, barena_bytes;
@@ -457,6 +458,19 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   c->seg_ws_bytes = m->has_vn ? gt_segment_sum_workspace_bytes(N, D) : 0;
   c->q_ws3 = q.take(c->seg_ws_bytes);
   c->q_dimg = q.take(m->conv == GT_CONV_PNA ? (size_t)m->pna_n_img * 4 : 0);
+  {   // room for every weight-gradient GEMM's partials and every LayerNorm's block partials of one backward (an upper bound: a producer
+      // that finds the arena full reduces on the spot)
+    size_t need = lin_ws + emb_ws + (size_t)(2 * nenc + 2) * ln_ws;
+    for (int l = 0; l < L; ++l) need += (m->conv == GT_CONV_GIN ? 2 : 1) * (m->conv == GT_CONV_PNA ? 0 : conv_ws_bytes(m, c, l));
+    for (int i = 0; i < nenc; ++i) {
+      const gt_encoder_layer& e = c->enc[i];
+      const int ec = e.dtype == GT_BF16 ? GT_BF16 : e.compute;
+      need += gt_linear_bwd_workspace_bytes(ec, e.rows, 3 * e.d_model, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.d_model) +
+              gt_linear_bwd_workspace_bytes(ec, e.rows, e.ffn, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.ffn);
+    }
+    c->defer_bytes = need + 64 * 256;
+    c->q_defer = q.take(c->defer_bytes);
+  }
   c->barena_bytes = std::max(q.off, (size_t)256);
 
   c->prepared = 1;
@@ -774,6 +788,15 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     if (!c->stages_done) GT_TRY(gt_overlap_dw_begin(st, m->st_dw));
     guard.dw = (stages & 4) != 0;   // the section stays open between the stage calls of one backward (same host thread)
   }
+  // the sums over weight-gradient / LayerNorm partials of a stage: queued by their producers, ONE launch at the end of the stage
+  // (section open across the stage calls like the overlap section; the arena is not reused inside one backward)
+  if (!c->stages_done) GT_TRY(gt_defer_begin(Q(c->q_defer), c->defer_bytes));
+  auto flush = [&]() -> int {
+    gt_stream_t fs = ov ? gt_overlap_dw_fork(st, 0) : st;   // behind everything queued on the main stream, on the overlap stream
+    GT_TRY(gt_defer_flush(fs));
+    if (fs != st) gt_overlap_dw_booked(Q(c->q_defer), c->defer_bytes);
+    return GT_OK;
+  };
   // (an error return in a middle stage leaves the section open on this thread: the next gt_overlap_dw_begin resets it)
 
   // the next stage's workspace: the two slots alternate, so the weight-gradient GEMMs a stage forks onto the third stream (their
@@ -837,6 +860,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       if (m->jk_cat) c->dy = nullptr;   // split below (stage 2 prologue)
       else c->dy = Q(c->q_d_rep);
     }
+    GT_TRY(flush());
     c->stages_done |= 1;
   }
 
@@ -913,6 +937,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       GT_TRY(gt_segment_sum(GT_F32, d_vn_next, nullptr, b.ptr01, B, 1, D, G + m->off_vn_emb, vst));
       if (side) GT_TRY(gt_event_record(m->ev_vnemb, side));
     }
+    GT_TRY(flush());
     c->stages_done |= 2;
   }
 
@@ -924,6 +949,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       float* dw = Kp == K ? G + m->off_ne_w : (float*)Q(c->q_ne_dw);
       GT_TRY(gt_linear_bwd(GT_F32, GT_F32, compute, c->ne_x, c->ne_w, d_h0, nullptr, nullptr, nullptr, nullptr, dw, G + m->off_ne_b, N, D, Kp,
                            0.f, W(), ws_bytes, st));
+      if (Kp != K) GT_TRY(flush());   // the re-pitch below reads the summed gradient
       if (ov) gt_overlap_dw_sync();
       if (Kp != K) GT_TRY(gt_repitch(G + m->off_ne_w, K, dw, Kp, D, 4, st));
     } else {
@@ -936,6 +962,8 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     }
     // the virtual-node chain's tail (d vn_0 reduced on the second stream) joins here; the overlap section closes in the guard
     if (m->has_vn && side) GT_TRY(gt_stream_wait_event(st, m->ev_vnemb));
+    GT_TRY(flush());
+    GT_TRY(gt_defer_end());
     c->stages_done |= 4;
   }
   return GT_OK;

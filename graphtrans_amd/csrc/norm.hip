@@ -1282,8 +1282,16 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   const int bwd_waves = dim <= 256 ? 16 : NT / 64;   // waves per block of the launch below
   int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), bwd_waves);
   const int grid = (int)(want < LN_BWD_BLOCKS ? want : LN_BWD_BLOCKS);
+  // inside a deferred-reduce section (gt_defer_begin: the whole-model backward) the block partials go to the section's arena and their
+  // column sums join the section's one reduce launch: no 5-us finish kernel between two GEMMs of the caller's stream
+  void* dpart = gt_defer_take((size_t)grid * 2 * dim * sizeof(float));
+  if (dpart) a.part = (float*)dpart;
   if (dtype == GT_F32) ln_launch<float, true>(a, grid, stream);
   else ln_launch<gt_bf16, true>(a, grid, stream);
+  if (dpart) {
+    GT_CHECK_LAUNCH();
+    return gt_defer_push(a.part, grid, dim, 2 * dim, dweight, a.part + dim, dim, 2 * dim, dbias);
+  }
   // d gamma / d beta are parameter gradients, nothing on the critical path reads them -- but their 5-us column finish stays on the
   // caller's stream: forking it onto the overlap stream costs the caller's queue an event record now and a wait when the workspace is
   // handed on, two queue packets for one, and measured 0.5 % slower end to end on Code2 (GT_LN_FINISH_FORK=1: the forked form)

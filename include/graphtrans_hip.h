@@ -557,6 +557,19 @@ int gt_linear_bwd_dw_forked(int x_dtype, int y_dtype, int compute, const void* x
 int gt_linear_bwd_mul_dw_forked(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
                                 const void* gmul, float* dweight, float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx,
                                 int64_t ldy, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* Deferred partial-sum reduces.  Every weight-gradient GEMM ends in a fixed-order sum over its M-split partials, every LayerNorm
+ * backward in a column finish over its block partials: launches that only produce PARAMETER gradients.  Between gt_defer_begin(arena)
+ * and gt_defer_end (per host thread; the whole-model backward opens one) gt_linear_bwd* / gt_layernorm_bwd put their partials into the
+ * arena and queue the sum instead of launching it; gt_defer_flush(stream) runs everything queued as ONE launch on `stream` (the
+ * caller orders it behind the producers, e.g. through gt_overlap_dw_fork).  Same summation order -> the same bits.  Without a
+ * section, or when the arena / the job list is full, every call reduces on the spot as before.  (take / push are what the
+ * library's own producers call; listed for completeness.) */
+int gt_defer_begin(void* arena, size_t bytes);
+void* gt_defer_take(size_t bytes);
+int gt_defer_push(const float* part, int nparts, int64_t len, int64_t stride, float* out, const float* part2, int64_t len2,
+                  int64_t stride2, float* out2);
+int gt_defer_flush(gt_stream_t stream);
+int gt_defer_end(void);
 int gt_overlap_dw_sync(void);
 int gt_overlap_dw_release(const void* workspace, size_t bytes);
 /* the weight-gradient GEMMs forked from now on are the last work of the backward (the optimizer waits for them): they get the

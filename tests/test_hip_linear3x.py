@@ -259,3 +259,89 @@ def test_virtual_concatenation_equals_the_copied_one():
         dxr, dwr, dbr = bwd_all(cat, W, dy, None, imgs)
         assert torch.equal(torch.cat([dx1, dx2], 1), dxr)
         assert torch.equal(dw, dwr) and torch.equal(db, dbr)
+
+
+@pytest.mark.parametrize("tok_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("max_len,with_cls", [(1000, 1), (50, 1), (50, 0), (7, 1)])
+def test_row_map_equals_pad_and_unpad_passes(tok_dtype, max_len, with_cls):
+    """gt_linear_set_rows (gnn2transformer storing the token rows / reading the token-row gradient through gt_seq_token_rows' map,
+    models/gnn_transformer.py:92-96) against the same GEMM calls with gt_seq_gather_cls32 behind the forward and gt_seq_scatter in
+    front of the backward (modules/utils.py:5-29): bit for bit, truncated graphs (their leading nodes have no token row) included."""
+    import numpy as np
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W3Images
+    lib = _lib.lib()
+    rng = np.random.default_rng(max_len)
+    B, K, N = 40, 256, 128
+    sizes = rng.integers(1, 120, B)
+    sizes[3] = 1
+    Nn = int(sizes.sum())
+    assert Nn >= 1024
+    gptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    kept = np.minimum(sizes, min(int(sizes.max()), max_len))
+    kv = kept + with_cls
+    tok_ptr = np.concatenate([[0], np.cumsum(kv)])
+    desc = np.zeros((B, 4), np.int32)
+    desc[:, 0], desc[:, 1], desc[:, 3] = tok_ptr[:-1], kv, kv
+    rows = int(tok_ptr[-1])
+    last = torch.tensor(tok_ptr[1:] - 1, dtype=torch.int64, device=DEV)
+    d_gptr, d_desc = torch.tensor(gptr, device=DEV), torch.tensor(desc, device=DEV)
+    d_ng = torch.tensor(np.repeat(np.arange(B, dtype=np.int32), sizes), device=DEV)
+    torch.manual_seed(1)
+    x = torch.randn(Nn, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    bias = torch.randn(N, device=DEV)
+    cls = torch.randn(N, device=DEV)
+    tcode = GT_BF16 if tok_dtype == torch.bfloat16 else GT_F32
+    imgs = W3Images([W])
+    imgs.build()
+    st = _stream()
+    with imgs.bound():
+        assert lib.gt_linear_rows_ok(GT_F32, GT_F32, tcode, _p(W), Nn, N, K) == 1
+        # forward
+        hn = torch.empty(Nn, N, dtype=tok_dtype, device=DEV)
+        _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(hn), Nn, N, K, K, N, 0, 0.0, 0, st)
+        tok_ref = torch.full((rows, N), 7.0, dtype=tok_dtype, device=DEV)
+        _lib.launch("gt_seq_gather_cls32", tcode, _p(hn), _p(cls), _p(d_gptr), _p(d_desc), B, 1, int(kv.max()), with_cls, N, _p(tok_ref), st)
+        tok = torch.full((rows, N), 7.0, dtype=tok_dtype, device=DEV)
+        rmap = torch.empty(Nn, dtype=torch.int32, device=DEV)
+        _lib.launch("gt_seq_token_rows", tcode, _p(cls) if with_cls else None, _p(d_gptr), _p(d_ng), _p(d_desc), B, 1, with_cls, Nn, N, _p(tok), _p(rmap), st)
+        _lib.launch("gt_linear_set_rows", _p(rmap))
+        _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(tok), Nn, N, K, K, N, 0, 0.0, 0, st)
+        assert torch.equal(tok, tok_ref)
+        want = np.full(Nn, -1, np.int64)
+        for b in range(B):
+            n0 = gptr[b + 1] - kept[b]
+            want[n0:gptr[b + 1]] = tok_ptr[b] + np.arange(kept[b])
+        assert np.array_equal(rmap.cpu().numpy().astype(np.int64), want)
+        # backward
+        dtok = torch.randn(rows, N, device=DEV).to(tok_dtype)
+        wsb = lib.gt_linear_bwd_workspace_bytes(GT_F32, Nn, N, K)
+        res = []
+        for mapped in (False, True):
+            ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+            dx, dw, db = torch.empty(Nn, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+            if mapped:
+                _lib.launch("gt_linear_set_rows", _p(rmap))
+                dy = dtok
+            else:
+                dy = torch.empty(Nn, N, dtype=tok_dtype, device=DEV)
+                _lib.launch("gt_seq_scatter", tcode, _p(dtok), None, _p(d_gptr), _p(d_ng), _p(d_desc), B, 1, with_cls, Nn, N, _p(dy), None, st)
+            _lib.launch("gt_linear_bwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(dy), None, None, None, _p(dx), _p(dw), _p(db), Nn, N, K, K, N, 0.0,
+                        _p(ws), wsb, st)
+            torch.cuda.synchronize()
+            res.append((dx, dw, db))
+        for a, b_, what in zip(res[0], res[1], ("dx", "dw", "db")):
+            assert torch.equal(a, b_), (what, rel(b_, a))
+        dropped = torch.tensor(want < 0, device=DEV)
+        assert float(res[1][0][dropped].abs().max()) == 0.0 if bool(dropped.any()) else True
+        if with_cls:   # the cls gradient: column sums of the CLS rows
+            got = torch.empty(N, device=DEV)
+            _lib.launch("gt_colsum_rows_f32", tcode, _p(dtok), _p(last), B, N, _p(got), st)
+            assert rel(got, dtok[last].double().sum(0).float()) < 1e-5
+    # a GEMM that does not take a row map refuses it, and the request does not leak into the next call
+    _lib.launch("gt_linear_set_rows", _p(rmap))
+    with pytest.raises(RuntimeError):
+        _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(tok), Nn, N, K, K, N, 0, 0.0, 0, st)   # no bound image
+    _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(hn), Nn, N, K, K, N, 0, 0.0, 0, st)
