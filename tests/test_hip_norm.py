@@ -205,8 +205,9 @@ def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
                 ptr(vn), ptr(idx), None, rows, D, ptr(y), ptr(mean), ptr(rstd), p, seed, ptr(ws), wsb, st)
     # the same call without dropout / addends gives the mask
     y0 = torch.empty_like(x)
-    _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm.clone()), ptr(rv.clone()), None, mom, eps, 1, int(relu), None,
-                None, None, None, rows, D, ptr(y0), ptr(mean.clone()), ptr(rstd.clone()), 0.0, 0, ptr(ws), wsb, st)
+    rm2, rv2, mean2, rstd2 = rm.clone(), rv.clone(), torch.empty_like(mean), torch.empty_like(rstd)   # (named: temporaries would share one block)
+    _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm2), ptr(rv2), None, mom, eps, 1, int(relu), None,
+                None, None, None, rows, D, ptr(y0), ptr(mean2), ptr(rstd2), 0.0, 0, ptr(ws), wsb, st)
     add = resid + vn[idx.long()]
     kept = _bn_keep_mask(rows, D, p, seed).to(DEV)
     clear = y0.abs() > 1e-3   # (a kept value that small may vanish in the sum with the addends)
