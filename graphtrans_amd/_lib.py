@@ -79,7 +79,6 @@ SIGNATURES = {
     "gt_defer_push": (_i, [_p, _i, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gt_defer_flush": (_i, [_p]),
     "gt_defer_end": (_i, []),
-    "gt_linear_w3_bound": (_i, [_p, _i64, _i64]),
     "gt_linear_rows_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_set_rows": (_i, [_p]),
     "gt_linear_fwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),

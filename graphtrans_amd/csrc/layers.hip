@@ -843,10 +843,6 @@ extern "C" size_t gt_pna_layer_saved_bytes(const gt_pna_layer* L) { return L ? p
 extern "C" size_t gt_pna_layer_workspace_bytes(const gt_pna_layer* L) { return L ? pna_work(L, nullptr).bytes : 0; }
 extern "C" int64_t gt_pna_layer_grad_elems(const gt_pna_layer* L) { return L ? L->D * L->D + 3 * L->D : 0; }
 
-static bool pna_tower3_on() {
-  static const bool on = [] { const char* e = getenv("GT_PNA_TOWER3"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
 extern "C" int gt_pna_layer_fwd(const gt_pna_layer* L, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
                                 gt_stream_t st) {
   GT_TRY(pna_layer_check("gt_pna_layer_fwd", L));
@@ -858,26 +854,11 @@ extern "C" int gt_pna_layer_fwd(const gt_pna_layer* L, const void* x, void* y, v
   const int64_t N = L->N, D = L->D, F = D / L->T;
   const int T = L->T, S = L->S;
   // [U_t | V_t] = x_t [A_t ; B_t]^T + [b_t | 0]: the per-edge Linear(2F, F) split into its target-role and source-role halves
-  // (towers whose weight images are bound -- the fused model path binds them -- run the bf16x6 kernel one tower per launch: the grouped
-  // launch only exists on the tiled round-1 kernels, 2-3 x slower on these 16 k x {68..340} x {136, 204} GEMMs)
-  const bool tower3 = pna_tower3_on() && L->N >= 1024 && gt_linear_w3_bound(L->pre_w, 2 * F, F) && gt_linear_w3_bound(L->post_w, S * F, 5 * F);
-  if (tower3) {
-    for (int t = 0; t < T; ++t)
-      GT_TRY(gt_linear_fwd_ld2(GT_F32, GT_F32, L->compute, (const float*)x + t * F, L->pre_w + (int64_t)t * 2 * F * F, L->pre_b + t * 2 * F,
-                               (float*)s.UV + t * 2 * F, N, 2 * F, F, D, 2 * D, 0, 0.f, 0, st));
-  } else {
-    GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, L->pre_b, s.UV, N, 2 * F, F, D, 2 * D, T, F, 2 * F, 0, 0.f, 0, st));
-  }
+  GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, L->pre_b, s.UV, N, 2 * F, F, D, 2 * D, T, F, 2 * F, 0, 0.f, 0, st));
   GT_TRY(gt_pna_aggregate_fwd_uv(s.UV, (const float*)x, N, D, T, L->in_ptr, L->in_src, L->in_eid, s.in5, s.mean_v, s.arg, st));
   // the post-Linear once on [x | agg]; its S per-scaler output blocks are combined with the degree scalers
-  if (tower3) {
-    for (int t = 0; t < T; ++t)
-      GT_TRY(gt_linear_fwd_ld2(GT_F32, GT_F32, L->compute, (const float*)s.in5 + t * 5 * F, L->post_w + (int64_t)t * S * F * 5 * F,
-                               L->post_b + t * S * F, (float*)w.Y + t * S * F, N, S * F, 5 * F, 5 * D, S * D, 0, 0.f, 0, st));
-  } else {
-    GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, L->post_b, w.Y, N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0,
-                                 0.f, 0, st));
-  }
+  GT_TRY(gt_linear_fwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, L->post_b, w.Y, N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0,
+                               0.f, 0, st));
   GT_TRY(gt_scale_combine_fwd(w.Y, L->scales, N, T, S, (int)F, s.out, st));
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.out, L->lin_w, L->lin_b, s.z, N, D, D, 0, 0.f, 0, st));
   // h = relu(batch_norm(conv(x))); x = h + x; x = dropout(x)   (pna_module.py:73-78: the dropout follows the residual add)
@@ -909,29 +890,12 @@ extern "C" int gt_pna_layer_bwd(const gt_pna_layer* L, const void* x, const void
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.out, L->lin_w, w.d_z, nullptr, nullptr, nullptr, w.d_out, g_lin_w, g_lin_b, N, D, D, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));
   GT_TRY(gt_scale_combine_bwd(w.d_out, L->scales, N, T, S, (int)F, w.Y, st));
-  const bool tower3 = pna_tower3_on() && L->N >= 1024 && gt_linear_w3_bound(L->pre_w, 2 * F, F) && gt_linear_w3_bound(L->post_w, S * F, 5 * F);
-  if (tower3) {
-    for (int t = 0; t < T; ++t)
-      GT_TRY(gt_linear_bwd_ld2(GT_F32, GT_F32, L->compute, (const float*)s.in5 + t * 5 * F, L->post_w + (int64_t)t * S * F * 5 * F,
-                               (const float*)w.Y + t * S * F, nullptr, nullptr, nullptr, (float*)w.d_in5 + t * 5 * F,
-                               L->d_post_w + (int64_t)t * S * F * 5 * F, L->d_post_b + t * S * F, N, S * F, 5 * F, 5 * D, S * D, 0.f, w.post_ws,
-                               w.post_ws_bytes, st));
-  } else {
-    GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, w.Y, nullptr, nullptr, nullptr, w.d_in5, L->d_post_w, L->d_post_b,
-                                 N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0.f, w.post_ws, w.post_ws_bytes, st));
-  }
+  GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, s.in5, L->post_w, w.Y, nullptr, nullptr, nullptr, w.d_in5, L->d_post_w, L->d_post_b,
+                               N, S * F, 5 * F, 5 * D, S * D, T, 5 * F, S * F, 0.f, w.post_ws, w.post_ws_bytes, st));
   GT_TRY(gt_pna_aggregate_bwd_uv(s.UV, s.in5, s.mean_v, s.arg, w.d_in5, N, D, T, L->in_ptr, L->out_ptr, L->out_dst, L->out_eid, w.dUV,
                                  w.dxpart, st));
   // dx = dUV [A ; B] + (the x block of the post-Linear's operand) + (the residual branch)
-  if (tower3) {
-    for (int t = 0; t < T; ++t)
-      GT_TRY(gt_linear_bwd_ld2(GT_F32, GT_F32, L->compute, (const float*)x + t * F, L->pre_w + (int64_t)t * 2 * F * F, (const float*)w.dUV + t * 2 * F,
-                               nullptr, (const float*)w.dxpart + t * F, (const float*)g + t * F, (float*)dx + t * F,
-                               L->d_pre_w + (int64_t)t * 2 * F * F, L->d_pre_b + t * 2 * F, N, 2 * F, F, D, 2 * D, 0.f, w.pre_ws, w.pre_ws_bytes,
-                               st));
-  } else {
-    GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, w.dUV, nullptr, w.dxpart, g, dx, L->d_pre_w, L->d_pre_b, N, 2 * F, F, D,
-                                 2 * D, T, F, 2 * F, 0.f, w.pre_ws, w.pre_ws_bytes, st));
-  }
+  GT_TRY(gt_linear_bwd_grouped(GT_F32, GT_F32, L->compute, x, L->pre_w, w.dUV, nullptr, w.dxpart, g, dx, L->d_pre_w, L->d_pre_b, N, 2 * F, F, D,
+                               2 * D, T, F, 2 * F, 0.f, w.pre_ws, w.pre_ws_bytes, st));
   return GT_OK;
 }

@@ -1475,10 +1475,6 @@ extern "C" int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, in
 }
 // ---- a row map on the output (forward) / on dY (backward): gnn2transformer writing and reading the Transformer's token rows in place
 // (models/gnn_transformer.py:92-96, modules/utils.py:5-29: no pad / unpad pass over the node rows) -----------------------------------
-// 1 when both bf16x3 images (forward and dX form) of this weight are bound on the calling thread: its big-M fp32 GEMMs run k_lin3
-extern "C" int gt_linear_w3_bound(const float* weight, int64_t N, int64_t K) {
-  return (w3_lookup(weight, N, K, false) && w3_lookup(weight, N, K, true)) ? 1 : 0;
-}
 extern "C" int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
   static const bool on = [] { const char* e = getenv("GT_LINEAR_ROWS"); return !e || atoi(e) != 0; }();   // (A/B knob)
   return (on && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)) ? 1 : 0;

@@ -551,13 +551,6 @@ class _Plan:
                 off0 = o_ if off0 is None else off0
             cm.off_conv[l] = off0
             self.w3_weights.append(conv.lin.weight)
-            # the re-stacked tower weights are GEMM weights too: with their bf16x3 images bound, gt_pna_layer_* runs every tower on the
-            # bf16x6 kernel (one launch per tower) instead of the grouped tiled kernel
-            for t in range(T):
-                o_pre = cm.pna_img_off[l][0] + t * 2 * F * F
-                o_post = cm.pna_img_off[l][2] + t * S * F * 5 * F
-                self.w3_weights.append(self.pna_img[o_pre:o_pre + 2 * F * F].view(2 * F, F))
-                self.w3_weights.append(self.pna_img[o_post:o_post + S * F * 5 * F].view(S * F, 5 * F))
             desc = self.conv_desc[l]
             desc.D, desc.T, desc.S = D, T, S
             ib = l * img_per_layer

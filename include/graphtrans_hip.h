@@ -501,8 +501,6 @@ int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, in
  * (nothing stored / zeros read).  int32 [M] on the device.  This is gnn2transformer writing / reading the Transformer's token rows in
  * place (models/gnn_transformer.py:92-96; modules/utils.py:5-29 pad_batch / unpad_batch without their pass over the node rows):
  * rows = gt_seq_token_rows.  Only the fp32-accurate big-M path with bound weight images takes it: ask gt_linear_rows_ok. */
-/* 1 when both bf16x3 images (forward and dX form) of `weight` [N][K] are bound on the calling thread (gt_w3_bind) */
-int gt_linear_w3_bound(const float* weight, int64_t N, int64_t K);
 int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K);
 int gt_linear_set_rows(const int32_t* rows);
 int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
