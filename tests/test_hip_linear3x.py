@@ -345,3 +345,72 @@ def test_row_map_equals_pad_and_unpad_passes(tok_dtype, max_len, with_cls):
     with pytest.raises(RuntimeError):
         _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(tok), Nn, N, K, K, N, 0, 0.0, 0, st)   # no bound image
     _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(hn), Nn, N, K, K, N, 0, 0.0, 0, st)
+
+
+def test_deferred_partial_sums_equal_the_immediate_reduces():
+    """gt_defer_begin / _flush (csrc/linear.hip): weight-gradient GEMMs and a LayerNorm backward inside a section queue their partial
+    sums into ONE launch; dW / db / d gamma / d beta equal the immediate reduces bit for bit (dW: same summation order; the LayerNorm's
+    column sums: k_split_reduce's order instead of the finish kernel's -> fp32 order), a full arena falls back to reducing on the
+    spot, and an open section without a flush is reported."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W3Images
+    lib = _lib.lib()
+    st = _stream()
+    torch.manual_seed(5)
+    M, N, K = 9000, 300, 300
+    x = torch.randn(M, K, device=DEV)
+    dy = torch.randn(M, N, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    imgs = W3Images([W])
+    imgs.build()
+    wsb = lib.gt_linear_bwd_workspace_bytes(GT_F32, M, N, K)
+
+    def dw_call(bound):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dw, db = torch.full((N, K), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+        call = lambda: _lib.launch("gt_linear_bwd_ld2", GT_F32, GT_F32, GT_F32, _p(x), _p(W), _p(dy), None, None, None, None, _p(dw), _p(db), M, N, K, K, N,
+                                   0.0, _p(ws), wsb, st)
+        if bound:
+            with imgs.bound():
+                call()
+        else:
+            call()
+        return dw, db, ws
+
+    # LayerNorm backward operands
+    R, D = 5000, 128
+    lx, lg = torch.randn(R, D, device=DEV).bfloat16(), torch.randn(R, D, device=DEV).bfloat16()
+    lw = torch.rand(D, device=DEV) + 0.5
+    mean, rstd = lx.float().mean(1), 1.0 / (lx.float().var(1, unbiased=False) + 1e-5).sqrt()
+    lnb = lib.gt_layernorm_bwd_workspace_bytes(R, D)
+
+    def ln_call():
+        ws = torch.empty(lnb, dtype=torch.uint8, device=DEV)
+        dx = torch.empty(R, D, dtype=torch.bfloat16, device=DEV)
+        gw, gb = torch.full((D,), 7.0, device=DEV), torch.full((D,), 7.0, device=DEV)
+        _lib.launch("gt_layernorm_bwd", GT_BF16, _p(lx), None, _p(lg), _p(lw), _p(mean), _p(rstd), 0.0, 0, R, D, _p(dx), None, _p(gw), _p(gb), _p(ws), lnb, st)
+        return dx, gw, gb, ws
+
+    ref = [dw_call(True), dw_call(False), ln_call()]
+    arena = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    _lib.launch("gt_defer_begin", _p(arena), arena.numel())
+    got = [dw_call(True), dw_call(False), ln_call()]
+    torch.cuda.synchronize()
+    assert float(got[0][0][0, 0]) == 7.0 and float(got[2][1][0]) == 7.0    # nothing summed yet
+    with pytest.raises(RuntimeError):
+        _lib.launch("gt_defer_end")                                         # queued sums were never flushed
+    _lib.launch("gt_defer_flush", st)
+    _lib.launch("gt_defer_end")
+    torch.cuda.synchronize()
+    for r, g in zip(ref[:2], got[:2]):
+        assert torch.equal(r[0], g[0]) and torch.equal(r[1], g[1])
+    assert torch.equal(ref[2][0], got[2][0])
+    assert rel(got[2][1], ref[2][1]) < 1e-5 and rel(got[2][2], ref[2][2]) < 1e-5
+    # an arena too small for the partials: the producer reduces on the spot
+    small = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    _lib.launch("gt_defer_begin", _p(small), small.numel())
+    dw, db, _ = dw_call(True)
+    _lib.launch("gt_defer_flush", st)
+    _lib.launch("gt_defer_end")
+    assert torch.equal(dw, ref[0][0]) and torch.equal(db, ref[0][1])
