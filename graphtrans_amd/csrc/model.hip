@@ -445,7 +445,11 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   // BatchNorm-backward statistics summed in the dX epilogue of the layer above (GCN, exact-fp32 GEMMs, no GNN dropout, no virtual node)
   c->fuse_bn = 0;
   c->bn_rows = 0;
-  if (!b->sync_bn && !m->has_vn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f && gt_linear_bwd_bnstats_ok(c->compute, GT_F32, GT_F32, N)) {
+  static const bool fuse_bn_on = [] { const char* e = getenv("GT_FUSE_BN"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  // (not beyond 64 k rows: the statistics ride in the EXACT-fp32 dX kernel -- at the Erdos-Renyi stress' 131 k x 256 x 256 that GEMM is
+  // 219 us against 116 us for the bf16x6 kernel + a 50-us partial pass: 17.6 k -> 17.9 k graphs/s without)
+  if (fuse_bn_on && N <= 65536 && !b->sync_bn && !m->has_vn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f &&
+      gt_linear_bwd_bnstats_ok(c->compute, GT_F32, GT_F32, N)) {
     c->fuse_bn = 1;
     c->bn_rows = (int)gt_linear_bwd_bnstats_rows(N);
   }
