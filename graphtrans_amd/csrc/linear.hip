@@ -923,6 +923,9 @@ struct RowsTake {   // takes the request out of the thread state on entry: it ca
   const int32_t* rows;
   RowsTake() : rows(g_rows) { g_rows = nullptr; }
 };
+struct RowsClear {   // for entry points that can fail in front of the call that takes the request
+  ~RowsClear() { g_rows = nullptr; }
+};
 static inline bool rows_eligible(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
   return w32_eligible(compute, x_dtype, M, 1) && (y_dtype == GT_F32 || N % 8 == 0) && w3_lookup(weight, N, K, false) && w3_lookup(weight, N, K, true);
 }
@@ -1487,6 +1490,7 @@ extern "C" int gt_linear_set_rows(const int32_t* rows) {
 extern "C" int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2,
                                   int64_t ldx2, const float* weight, const float* bias, void* y, int64_t M, int64_t N, int64_t ldy,
                                   gt_stream_t stream_) {
+  RowsClear rows_clear__;
   GT_CHECK_ARG(x1 && x2 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0 && ldx2 >= K2 && ldx2 % 4 == 0, "bad second operand");
   Cat2Scope scope__;
   g_cat2.x2 = x2; g_cat2.split = K1; g_cat2.ld2 = ldx2;
@@ -1497,6 +1501,7 @@ extern "C" int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int6
                                   int64_t ldx2, const float* weight, const void* dy, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2,
                                   float* dweight, float* dbias, int64_t M, int64_t N, int64_t ldy, void* workspace,
                                   size_t workspace_bytes, gt_stream_t stream_) {
+  RowsClear rows_clear__;
   GT_CHECK_ARG(x1 && x2 && dx1 && dx2 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0, "bad operands");
   GT_CHECK_ARG(ldx1 == lddx1 && ldx2 == lddx2, "dX pitches must equal the X pitches");   // (one pitch per matrix in the kernel arguments)
   Cat2Scope scope__;

@@ -186,10 +186,12 @@ int bind_images(const gt_model* m, const Ctx* c) {
 }
 struct BindGuard {   // the bind tables are per host thread: always undone on the way out
   bool dw = false;
+  bool defer_abort = false;   // an error return must not leave the deferred-reduce section open on this thread (its arena dies with the step)
   ~BindGuard() {
     gt_w3_unbind();
     gt_w1_unbind();
     if (dw) gt_overlap_dw_end();
+    if (defer_abort) (void)gt_defer_begin(nullptr, 0);
   }
 };
 
@@ -795,6 +797,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
   // the sums over weight-gradient / LayerNorm partials of a stage: queued by their producers, ONE launch at the end of the stage
   // (section open across the stage calls like the overlap section; the arena is not reused inside one backward)
   if (!c->stages_done) GT_TRY(gt_defer_begin(Q(c->q_defer), c->defer_bytes));
+  guard.defer_abort = true;   // cleared on the successful way out
   auto flush = [&]() -> int {
     gt_stream_t fs = ov ? gt_overlap_dw_fork(st, 0) : st;   // behind everything queued on the main stream, on the overlap stream
     GT_TRY(gt_defer_flush(fs));
@@ -970,6 +973,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     GT_TRY(gt_defer_end());
     c->stages_done |= 4;
   }
+  guard.defer_abort = false;   // (between the stage calls of one backward the section stays open, like the overlap section)
   return GT_OK;
 }
 
