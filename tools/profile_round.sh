@@ -16,6 +16,13 @@ python bench.py --workload er --steps 20 --warmup 5 --no-extra --mode bf16 --no-
 python bench.py --workload code2-pna --no-extra > gpurun_out/$TAG/bench_code2pna.json 2> gpurun_out/$TAG/bench_code2pna.err
 python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 > gpurun_out/$TAG/bench_code2_mixed_clean.json 2>/dev/null
 python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --mode bf16 > gpurun_out/$TAG/bench_code2_bf16_clean.json 2>/dev/null
+# the per-rank shape of the global batch of 256 split over 8 GPUs (strong scaling), on one GPU
+python bench.py --batch 32 --no-cpu-baseline --no-extra > gpurun_out/$TAG/bench_code2_b32.json 2> gpurun_out/$TAG/bench_code2_b32.err
+# clean lines (no kernel brackets, no CPU baseline) of the other workloads
+for w in molpcba nci1 code2-pna er; do
+  S=100; [ $w = er ] && S=20
+  python bench.py --workload $w --steps $S --warmup 10 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$TAG/bench_${w}_clean.json 2>/dev/null
+done
 for m in mixed bf16; do
   for w in code2 molpcba er code2-pna nci1; do
     [ $w != code2 ] && [ $w != molpcba ] && [ $m != mixed ] && continue
