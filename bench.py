@@ -587,12 +587,12 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     import gc
     gc.collect()
     gc.freeze()
-    # HIP events around the aggregate / attention / linear launches of every 16th timed step (each event pair
+    # HIP events around the aggregate / attention / linear launches of every 24th timed step (each event pair
     # costs ~3 us of stream time and the dW GEMMs stay on the main stream while bracketed, i.e. nothing overlaps them: a
     # sampled step is ~30 % slower; sampling keeps the timed region within ~2 % of a run with --no-kernel-timing)
     timing = want_kernels and not opt.no_kernel_timing
     off = 8 if opt.steps > 8 else opt.steps // 2   # short runs still get one sampled step
-    sample = (lambda i: i % 16 == off) if timing else (lambda i: False)
+    sample = (lambda i: i % 24 == off) if timing else (lambda i: False)
     L = _lib.lib()
     if timing:
         _lib.profile_enable(PROF_MASK)

@@ -5,5 +5,5 @@ import sys, json, re
 d = json.loads(sys.stdin.read())
 print('ms_per_step', d['ms_per_step'])
 for k, v in sorted(d['kernels'].items()):
-    if re.search(r'$P', k): print('  %-46s %8.2f us x %5.1f/step' % (k, v['avg_us'], v['calls'] / 3.0))
+    if re.search(r'$P', k): print('  %-46s %8.2f us x %5.1f/step' % (k, v['avg_us'], v['calls'] / 2.0))
 "
