@@ -304,121 +304,6 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
   }
 }
 
-// ---- the column finish INSIDE the apply pass (fp32, local statistics): two launches per direction instead of three.  Block =
-// 32 columns x a row range (grid: column slabs x row ranges): every block first sums ITS 32 columns of the partial rows -- the
-// finish kernel's work for one slab, repeated by the slab's row-range blocks in the same order, so they all hold the same bits --
-// then applies to its rows, 8 rows x 128 bytes per wave instruction (whole lines).  The blocks of row range 0 write what the finish
-// kernel wrote (saved statistics, running statistics / the parameter gradients).
-constexpr int FIN2_ROWS = 32;   // row lanes of a block (x 8 column chunks of 16 bytes = 256 threads)
-__device__ __forceinline__ void fin2_sums(const float* __restrict__ part, int nblk, int64_t D, int64_t c0, float* sm, float* s_a, float* s_b) {
-  // thread -> (column cl of the slab, partial lane p of 8); totals of both partial arrays for the slab's 32 columns -> s_a / s_b
-  const int cl = threadIdx.x % FIN_COLS;
-  const bool act = c0 + cl < D;
-  const float t1 = finish_sum<8>(part, nblk, 2 * D, c0 + cl, act, sm);
-  const float t2 = finish_sum<8>(part, nblk, 2 * D, D + c0 + cl, act, sm);
-  if (threadIdx.x < FIN_COLS) { s_a[cl] = act ? t1 : 0.f; s_b[cl] = act ? t2 : 0.f; }
-  __syncthreads();
-}
-__global__ void __launch_bounds__(256) k_bn_apply_fin(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t N, int64_t D,
-                                                      float eps, float momentum, const float* __restrict__ w, const float* __restrict__ b,
-                                                      const float* __restrict__ resid, int relu, BnDrop drop, float* __restrict__ mean,
-                                                      float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                      float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
-                                                      float* __restrict__ y, const float* __restrict__ bcast, const int32_t* __restrict__ bidx) {
-  __shared__ float sm[8 * FIN_COLS];
-  __shared__ __attribute__((aligned(16))) float s_a[FIN_COLS];
-  __shared__ __attribute__((aligned(16))) float s_b[FIN_COLS];
-  const int64_t c0 = (int64_t)blockIdx.x * FIN_COLS;
-  fin2_sums(part, nblk, D, c0, sm, s_a, s_b);
-  if (threadIdx.x < FIN_COLS) {   // sums -> (mean, rstd) of column c0 + threadIdx.x, as k_bn_stats_finish
-    const int64_t c = c0 + threadIdx.x;
-    if (c < D) {
-      const float piv = x[c], inv_n = 1.0f / (float)N;
-      const float m1 = s_a[threadIdx.x] * inv_n;
-      float var = s_b[threadIdx.x] * inv_n - m1 * m1;
-      var = var < 0.f ? 0.f : var;
-      const float mu = piv + m1, rs = 1.0f / sqrtf(var + eps);
-      s_a[threadIdx.x] = mu;
-      s_b[threadIdx.x] = rs;
-      if (blockIdx.y == 0) {
-        mean[c] = mu;
-        rstd[c] = rs;
-        if (running_mean) {
-          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-          const float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-        }
-        if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-      }
-    }
-  }
-  __syncthreads();
-  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int64_t c = c0 + cq * 4;
-  if (c >= D) return;
-  const float4 mu = *reinterpret_cast<const float4*>(s_a + cq * 4), rs = *reinterpret_cast<const float4*>(s_b + cq * 4);
-  const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-  const int64_t rows_per = (N + gridDim.y - 1) / gridDim.y;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
-  for (int64_t r = r0 + rl; r < r1; r += FIN2_ROWS) {
-    float4 v = *reinterpret_cast<const float4*>(x + r * D + c);
-    v = make_float4((v.x - mu.x) * rs.x * ww.x + bb.x, (v.y - mu.y) * rs.y * ww.y + bb.y, (v.z - mu.z) * rs.z * ww.z + bb.z,
-                    (v.w - mu.w) * rs.w * ww.w + bb.w);
-    if (relu) v = gt_relu4(v);
-    if (drop.thr) v = bn_drop4(v, drop, (uint32_t)r, (uint32_t)c);
-    if (resid) v = gt_add4(v, *reinterpret_cast<const float4*>(resid + r * D + c));
-    if (bcast) v = gt_add4(v, *reinterpret_cast<const float4*>(bcast + (int64_t)bidx[r] * D + c));
-    *reinterpret_cast<float4*>(y + r * D + c) = v;
-  }
-}
-__global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ part,
-                                                          int nblk, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ w, const float* __restrict__ b, int relu, float inv_n,
-                                                          BnDrop drop, int64_t N, int64_t D, float* __restrict__ dbias,
-                                                          float* __restrict__ dweight, float* __restrict__ dx) {
-  __shared__ float sm[8 * FIN_COLS];
-  __shared__ __attribute__((aligned(16))) float s_a[FIN_COLS];
-  __shared__ __attribute__((aligned(16))) float s_b[FIN_COLS];
-  const int64_t c0 = (int64_t)blockIdx.x * FIN_COLS;
-  fin2_sums(part, nblk, D, c0, sm, s_a, s_b);
-  if (blockIdx.y == 0 && threadIdx.x < FIN_COLS && c0 + threadIdx.x < D) {
-    dbias[c0 + threadIdx.x] = s_a[threadIdx.x];
-    dweight[c0 + threadIdx.x] = s_b[threadIdx.x];
-  }
-  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int64_t c = c0 + cq * 4;
-  if (c >= D) return;
-  const float4 db = *reinterpret_cast<const float4*>(s_a + cq * 4), dw = *reinterpret_cast<const float4*>(s_b + cq * 4);
-  const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
-  const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-  const int64_t rows_per = (N + gridDim.y - 1) / gridDim.y;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
-  for (int64_t r = r0 + rl; r < r1; r += FIN2_ROWS) {
-    float4 g = *reinterpret_cast<const float4*>(dy + r * D + c);
-    const float4 v = *reinterpret_cast<const float4*>(x + r * D + c);
-    if (drop.thr) g = bn_drop4(g, drop, (uint32_t)r, (uint32_t)c);
-    if (relu) g = bn_gate(g, v, mu, rs, ww, bb);
-    float4 o;
-    o.x = ww.x * rs.x * (g.x - db.x * inv_n - (v.x - mu.x) * rs.x * dw.x * inv_n);
-    o.y = ww.y * rs.y * (g.y - db.y * inv_n - (v.y - mu.y) * rs.y * dw.y * inv_n);
-    o.z = ww.z * rs.z * (g.z - db.z * inv_n - (v.z - mu.z) * rs.z * dw.z * inv_n);
-    o.w = ww.w * rs.w * (g.w - db.w * inv_n - (v.w - mu.w) * rs.w * dw.w * inv_n);
-    *reinterpret_cast<float4*>(dx + r * D + c) = o;
-  }
-}
-static inline bool bn_fin2_on() {
-  static const bool on = [] { const char* e = getenv("GT_BN_FIN2"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
-static inline dim3 bn_fin2_grid(int64_t rows, int64_t dim) {
-  const int64_t slabs = gt_cdiv(dim, FIN_COLS);
-  int64_t rr = gt_cdiv(1024, slabs);
-  const int64_t cap = gt_cdiv(rows, 2 * FIN2_ROWS);   // at least two trips of rows per block
-  if (rr > cap) rr = cap;
-  if (rr < 1) rr = 1;
-  return dim3((unsigned)slabs, (unsigned)rr);
-}
-
 // ---- few rows (the virtual-node MLP normalises B = 256 graph rows, modules/gnn_module.py:161-170): ONE launch
 // per direction instead of three.  A block owns 32 columns x all rows (8 row lanes); statistics and apply in
 // the same kernel, the second sweep over the <= 1024 x 32 slab comes from L1 / L2.
@@ -1142,18 +1027,6 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
     float* rv_l = sync ? nullptr : running_var;
     int64_t* nbt_l = sync ? nullptr : num_batches_tracked;
     if (rows > 0) {
-      if (dtype == GT_F32 && !sync && bn_fin2_on()) {   // statistics partials, then the apply pass finishes its own columns: two launches
-        hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
-        if (bcast && ev_bcast_ready) {
-          rc = gt_stream_wait_event(stream_, ev_bcast_ready);
-          if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_bn_apply_fin, bn_fin2_grid(rows, dim), dim3(256), 0, stream, (const float*)x, (const float*)part, nb, rows, dim, eps,
-                           momentum, weight, bias, (const float*)resid, relu, drop, save_mean, save_rstd, rm_l, rv_l, nbt_l, (float*)y,
-                           (const float*)bcast, bcast_index);
-        GT_CHECK_LAUNCH();
-        return GT_OK;
-      }
       if (dtype == GT_F32) {
         hipLaunchKernelGGL(k_bn_stats_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, rows, dim, part);
         hipLaunchKernelGGL(k_bn_stats_finish<float>, dim3(cgrid), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)x, part, nb, rows,
@@ -1257,15 +1130,6 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
       hipLaunchKernelGGL(k_bn_small_bwd<gt_bf16>, dim3((unsigned)gt_cdiv(dim, SM_COLS)), dim3(SM_COLS * SM_LANES), 0, stream, (const gt_bf16*)x,
                          (const gt_bf16*)dy, save_mean, save_rstd, weight, bias, relu, training, drop, rows, dim, dbias,
                          dweight, (gt_bf16*)dx);
-    GT_CHECK_LAUNCH();
-    return GT_OK;
-  }
-  if (dtype == GT_F32 && bn_fin2_on()) {
-    hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
-                       weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
-    hipLaunchKernelGGL(k_bn_bwd_apply_fin, bn_fin2_grid(rows, dim), dim3(256), 0, stream, (const float*)x, (const float*)dy, (const float*)part, nb,
-                       save_mean, save_rstd, weight, bias, relu, training ? 1.0f / (float)rows : 0.f, drop, rows, dim, dbias, dweight,
-                       (float*)dx);
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
