@@ -91,9 +91,6 @@ template <int NTW>
 constexpr int w1_patch_ld() { return NTW * 16 + 4; }
 template <int NTW>
 constexpr size_t w1_lds_bytes() { return 2 * W1_STAGE + 8 * 16 * w1_patch_ld<NTW>() * sizeof(float) + 64 * 4 * 2 * sizeof(float); }
-// + the accumulator exchange of the K-split form: 8 waves x 2 m-tiles x NTW n-tiles x 64 lanes x 16 bytes
-template <int NTW>
-constexpr size_t w1_xchg_bytes() { return (size_t)8 * 2 * NTW * 64 * 16; }
 
 // Chan's merge of two (mean, M2) partials over EQUAL counts n each
 __device__ __forceinline__ void w1_merge(float& mean, float& m2, float mean_b, float m2_b, float n) {
@@ -103,17 +100,11 @@ __device__ __forceinline__ void w1_merge(float& mean, float& m2, float mean_b, f
 }
 
 // KS = K / 32 k-steps (K % 128 == 0), NTW = n-tiles per wave (column block = 4 * NTW * 16 columns)
-// KSPLIT (K = 768 / 1024, the d_model 256 / ffn 1024 encoder of the Erdos-Renyi stress): the two row halves of a block become two
-// halves of K -- wave (kq = wid >> 2, wn) holds the weight fragments of k-steps {2 kq, 2 kq + 1} of every 128-deep chunk (KS / 2
-// fragments per n-tile: 128 VGPRs at K = 1024, NTW = 2) and multiplies ALL 64 rows of the tile with them; at the end of a tile the
-// halves swap the two m-tiles they do not own through LDS and each runs the usual epilogue on its 32 rows.
-template <int KS, int NTW, bool LN = false, bool KSPLIT = false>
+template <int KS, int NTW, bool LN = false>
 __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   constexpr int KCH = KS / 4;                 // 128-deep chunks per row tile
   constexpr int PLD = w1_patch_ld<NTW>();
-  constexpr int KSW = KSPLIT ? KS / 2 : KS;   // resident k-steps per wave
-  static_assert(KS % 4 == 0 && NTW * KSW * 4 <= 128, "weight fragments must fit 128 VGPRs");
-  static_assert(!(KSPLIT && LN), "the K-split form has no LayerNorm epilogue");
+  static_assert(KS % 4 == 0 && NTW * KS * 4 <= 128, "weight fragments must fit 128 VGPRs");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, g = lane >> 4, wm = wid >> 2, wn = wid & 3;
@@ -124,16 +115,13 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   const int col0 = (cb * 4 + wn) * NTW * 16;   // first output column of this wave
 
   // ---- the wave's weight fragments: NTW x KS coalesced 1-KB loads, resident from here on
-  Frag<gt_bf16> wf[NTW][KSW];
+  Frag<gt_bf16> wf[NTW][KS];
   {
     const uint4* wi = reinterpret_cast<const uint4*>(a.img) + (int64_t)(col0 / 16) * KS * 64 + lane;
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int s = 0; s < KSW; ++s) {
-        const int ks = KSPLIT ? (s >> 1) * 4 + wm * 2 + (s & 1) : s;   // K-split: k-steps {2 kq, 2 kq + 1} of chunk s / 2
-        wf[j][s].v = wi[(j * KS + ks) * 64];
-      }
+      for (int s = 0; s < KS; ++s) wf[j][s].v = wi[(j * KS + s) * 64];
   }
   // my row tiles: (sg + it * sgroups) * 8 + xcd
   const int tile_stride = a.sgroups * 8;
@@ -155,13 +143,6 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 acck[KSPLIT ? 4 : 1][NTW];   // K-split: this wave's K half of all four m-tiles
-  if constexpr (KSPLIT) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acck[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 
   ra0 = *W1_CHUNK_PTR(0, sr0);
   ra1 = *W1_CHUNK_PTR(0, sr1);
@@ -189,47 +170,6 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
       ra1 = *W1_CHUNK_PTR(c2, sr1);
     }
     const unsigned char* st = smem1 + cur * W1_STAGE;
-    if constexpr (KSPLIT) {
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl) {
-        const int s4 = wm * 2 + sl;
-        Frag<gt_bf16> fx[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = i * 16 + n;
-          fx[i].v = *reinterpret_cast<const uint4*>(st + r * 256 + (((s4 * 4 + g) ^ (r & 15)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acck[i][j] = mma(wf[j][kc * 2 + sl], fx[i], acck[i][j]);
-      }
-      if (kc == KCH - 1) {
-        // the halves meet: each wave hands over the two m-tiles of the OTHER half's rows and adds what it is handed
-        float4* xch = reinterpret_cast<float4*>(smem1 + w1_lds_bytes<NTW>());
-        const int other = (wm ^ 1) * 4 + wn;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            const f32x4 v = acck[(wm ^ 1) * 2 + i][j];
-            xch[((other * 2 + i) * NTW + j) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            const float4 t = xch[((wid * 2 + i) * NTW + j) * 64 + lane];
-            const f32x4 own = acck[wm * 2 + i][j];
-            acc[i][j] = f32x4{own[0] + t.x, own[1] + t.y, own[2] + t.z, own[3] + t.w};
-          }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) acck[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    } else {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       Frag<gt_bf16> fx[2];
@@ -242,7 +182,6 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i][j] = mma(wf[j][kc * 4 + s4], fx[i], acc[i][j]);
-    }
     }
     if (kc == KCH - 1) {
       // ---- epilogue of this row tile: per wave, 2 m-tiles x (NTW x 16) columns through the wave's patch
@@ -431,15 +370,10 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
 // ---- shapes ---------------------------------------------------------------------------------------------------------
 // n-tiles per wave for an (output columns R, contraction C) GEMM, 0 = not covered (the tiled kernels take it)
 static inline int w1_pick_ntw(int64_t R, int64_t C) {
-  if (R <= 0 || C <= 0 || R % 64 || C % 128 || C > 1024) return 0;
-  if (C > 512) {   // the K-split form (K = 768 / 1024): column blocks of 128, two n-tiles per wave
-    static const bool ksplit = [] { const char* e = getenv("GT_W1_KSPLIT"); return !e || atoi(e) != 0; }();   // (A/B knob)
-    return (ksplit && (C == 768 || C == 1024) && R % 128 == 0) ? 2 : 0;
-  }
+  if (R <= 0 || C <= 0 || R % 64 || C % 128 || C > 512) return 0;
   const int ks = (int)(C / 32), q = (int)(R / 64);   // q = n-tiles per wave if ONE column block covered R
   static const int cand[6][5] = {{4, 6, 4, 2, 0}, {8, 4, 2, 0, 0}, {12, 2, 0, 0, 0}, {16, 2, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
-  // (K = 768 / 1024 with ONE n-tile per wave -- the ER shapes 256 x 1024, 256 x 768 -- measured slower than the tiled kernels; r4: the
-  // K-split form above)
+  // (K = 768 / 1024 with ONE n-tile per wave -- the ER shapes 256 x 1024, 256 x 768 -- measured slower than the tiled kernels: not covered)
   // (NTW = 8 for 512 columns x K = 128 measured no faster than two column blocks of NTW = 4 and needs all 256 registers)
   static const int max_ntw = [] { const char* e = getenv("GT_W1_MAX_NTW"); return e ? atoi(e) : 8; }();   // (A/B knob)
   for (int i = 0; i < 6; ++i)
@@ -449,21 +383,21 @@ static inline int w1_pick_ntw(int64_t R, int64_t C) {
   return 0;
 }
 
-template <int KS, int NTW, bool LN = false, bool KSPLIT = false>
+template <int KS, int NTW, bool LN = false>
 static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a) {
   static std::mutex mu;
   static bool set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  constexpr size_t lds = w1_lds_bytes<NTW>() + (KSPLIT ? w1_xchg_bytes<NTW>() : 0);
+  constexpr size_t lds = w1_lds_bytes<NTW>();
   if (dev >= 0 && dev < 64) {
     std::lock_guard<std::mutex> lk(mu);
     if (!set[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW, LN, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lin1<KS, NTW, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
       set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((k_lin1<KS, NTW, LN, KSPLIT>), grid, dim3(W1_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((k_lin1<KS, NTW, LN>), grid, dim3(W1_THREADS), lds, stream, a);
   return true;
 }
 
@@ -489,12 +423,6 @@ static inline bool w1_launch(hipStream_t stream, L1Args& a) {
 #define GT_W1_LN_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_, true>(grid, stream, a)
     GT_W1_LN_CASE(4, 2); GT_W1_LN_CASE(8, 2); GT_W1_LN_CASE(16, 2); GT_W1_LN_CASE(8, 4);
 #undef GT_W1_LN_CASE
-    return false;
-  }
-  if (ks > 16) {   // K = 768 / 1024: the K-split form
-    if (ntw != 2) return false;
-    if (ks == 24) return w1_launch_one<24, 2, false, true>(grid, stream, a);
-    if (ks == 32) return w1_launch_one<32, 2, false, true>(grid, stream, a);
     return false;
   }
 #define GT_W1_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_>(grid, stream, a)

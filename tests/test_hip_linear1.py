@@ -60,7 +60,6 @@ def bwd(x, W, dy, ymask, add1, add2, bound, p=0.0, gate_out=False, want_dw=False
 SHAPES = [(31598, 384, 128), (31598, 128, 128), (31598, 512, 128), (31598, 128, 512),   # Code2 / Molpcba / PNA encoder
           (1153, 256, 128), (1153, 128, 256),                                         # NCI1 ffn 256
           (20011, 256, 256), (20011, 512, 256), (20011, 256, 512),   # d_model 256
-          (20011, 256, 1024), (20011, 1024, 256), (20011, 768, 256), (131, 256, 768),   # ... with ffn 1024 (the K-split form: K = 768 / 1024 in either direction)
           (63, 384, 128), (64, 128, 512), (1, 512, 128), (4099, 128, 128)]
 
 
