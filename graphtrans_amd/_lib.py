@@ -73,6 +73,7 @@ SIGNATURES = {
     "gt_layernorm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gt_linear_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_colsum_rows_f32": (_i, [_i, _p, _p, _i64, _i64, _p, _p]),
+    "gt_seq_token_rows_layernorm": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p, _p, _f, _p, _p, _p, _p]),
     "gt_seq_token_rows": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
     "gt_defer_begin": (_i, [_p, _sz]),
     "gt_defer_take": (_p, [_sz]),
@@ -81,6 +82,8 @@ SIGNATURES = {
     "gt_defer_end": (_i, []),
     "gt_linear_rows_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_set_rows": (_i, [_p]),
+    "gt_linear_rows_layernorm_ok": (_i, [_i64]),
+    "gt_linear_set_rows_layernorm": (_i, [_p, _p, _p, _f, _p, _p, _p]),
     "gt_linear_fwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_ld": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_adamw_chunk_elems": (_i, []),

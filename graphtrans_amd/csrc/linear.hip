@@ -777,9 +777,12 @@ float* dw_part(float* ws_part, int splits, int64_t N, int64_t K, bool* deferred)
   return p ? (float*)p : ws_part;
 }
 
-int pick_bm(int64_t M) {
-  (void)M;
-  return 64;   // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs
+int pick_bm(int64_t M, int64_t K = 0, bool fwd = false) {
+  // 128-row tiles (half the blocks) measured 0.3-0.7 % slower end to end even for the 256-row GEMMs -- except the forward of a long
+  // contraction over very many rows (the Erdos-Renyi stress' linear2, 131 k x 256 x 1024: every 64-row block re-stages the fp32
+  // master weight, 2 GB of L2 reads for 335 MB of operands): 180 -> 144 us with 128 rows; its dX form gets slower (236 us)
+  if (fwd && M >= 65536 && K >= 768) return 128;
+  return 64;
 }
 
 
@@ -919,12 +922,20 @@ struct Cat2Scope {
 // outcome): forward stores output row m at row rows[m] of y, backward reads row m of dY from row rows[m] of dy; -1 = no such row
 // (nothing stored / zeros read).  Honoured by the bf16x6 path only: gt_linear_rows_ok.
 thread_local const int32_t* g_rows = nullptr;
+struct RowsLn {   // + a LayerNorm of the stored output row in the forward's epilogue (gt_linear_set_rows_layernorm)
+  const float *w = nullptr, *b = nullptr;
+  void* out = nullptr;
+  float *mean = nullptr, *rstd = nullptr;
+  float eps = 0.f;
+};
+thread_local RowsLn g_rows_ln;
 struct RowsTake {   // takes the request out of the thread state on entry: it can never leak into a later call
   const int32_t* rows;
-  RowsTake() : rows(g_rows) { g_rows = nullptr; }
+  RowsLn ln;
+  RowsTake() : rows(g_rows), ln(g_rows_ln) { g_rows = nullptr; g_rows_ln = RowsLn{}; }
 };
 struct RowsClear {   // for entry points that can fail in front of the call that takes the request
-  ~RowsClear() { g_rows = nullptr; }
+  ~RowsClear() { g_rows = nullptr; g_rows_ln = RowsLn{}; }
 };
 static inline bool rows_eligible(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
   return w32_eligible(compute, x_dtype, M, 1) && (y_dtype == GT_F32 || N % 8 == 0) && w3_lookup(weight, N, K, false) && w3_lookup(weight, N, K, true);
@@ -1008,6 +1019,11 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     if (rows__.rows) {
       if (!w.w3) { gt_set_error("gt_linear_set_rows: needs a bound weight image"); return GT_ERR_UNSUPPORTED; }
       w.out_rows = rows__.rows;
+      if (rows__.ln.out) {
+        if (w3_pick_nt(N) * 16 != N || act != 0 || a.thr || ldy != N) { gt_set_error("gt_linear_set_rows_layernorm: the row must fill one column block (ask gt_linear_rows_layernorm_ok)"); return GT_ERR_UNSUPPORTED; }
+        w.ln_w = rows__.ln.w; w.ln_b = rows__.ln.b; w.ln_out = rows__.ln.out; w.ln_mean = rows__.ln.mean; w.ln_rstd = rows__.ln.rstd;
+        w.ln_eps = rows__.ln.eps;
+      }
     }
     {
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
@@ -1032,7 +1048,7 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
       if (ok) { GT_CHECK_LAUNCH(); return GT_OK; }
     }
   }
-  const int bm = pick_bm(M);
+  const int bm = pick_bm(M, K, true);
   a.ntiles = (int)gt_cdiv(N, BN);
   dim3 grid((unsigned)(gt_cdiv(gt_cdiv(M, bm), 8) * 8 * a.ntiles), (unsigned)groups);
   const int t0 = x_dtype, t1 = y_dtype;
@@ -1182,7 +1198,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      size_t workspace_bytes, gt_stream_t stream_) {
   BwdOptScope opt_scope__;   // the per-call options live for exactly this call
   const RowsTake rows__;
-  GT_CHECK_ARG(!rows__.rows || (groups == 1 && !y_for_mask && !g_opt.bns.part && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)),
+  GT_CHECK_ARG(!rows__.rows || (groups == 1 && !y_for_mask && !g_opt.bns.part && !rows__.ln.out && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)),
                "gt_linear_set_rows: this GEMM does not take a row map (ask gt_linear_rows_ok)");
   GT_CHECK_ARG(groups >= 1 && groups <= 65535, "1..65535 groups");
   GT_CHECK_ARG(groups == 1 || (x_group_stride % (x_dtype == GT_BF16 ? 8 : 4) == 0 && y_group_stride % (y_dtype == GT_BF16 ? 8 : 4) == 0 &&
@@ -1484,6 +1500,16 @@ extern "C" int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const fl
 }
 extern "C" int gt_linear_set_rows(const int32_t* rows) {
   g_rows = rows;
+  return GT_OK;
+}
+// ... and LayerNorm(ln_w, ln_b, eps) of every stored row in the same epilogue (forward only): ln_out (storage type and pitch of y) gets
+// the normalised row, ln_mean / ln_rstd its statistics, all at the row the output goes to.  N must fill one column block of the kernel.
+extern "C" int gt_linear_rows_layernorm_ok(int64_t N) { return (N > 0 && N % 16 == 0 && (int64_t)w3_pick_nt(N) * 16 == N) ? 1 : 0; }
+extern "C" int gt_linear_set_rows_layernorm(const int32_t* rows, const float* ln_w, const float* ln_b, float eps, void* ln_out,
+                                            float* ln_mean, float* ln_rstd) {
+  GT_CHECK_ARG(rows && ln_w && ln_b && ln_out && ln_mean && ln_rstd, "null buffer");
+  g_rows = rows;
+  g_rows_ln.w = ln_w; g_rows_ln.b = ln_b; g_rows_ln.out = ln_out; g_rows_ln.mean = ln_mean; g_rows_ln.rstd = ln_rstd; g_rows_ln.eps = eps;
   return GT_OK;
 }
 // Y[M][N] = [X1 | X2] W^T + b with X1 [M][K1] (pitch ldx1), X2 [M][K2] (pitch ldx2), W [N][K1 + K2]; fp32 rows, y_dtype fp32 / bf16

@@ -51,6 +51,13 @@ struct L32Args {
   // the Transformer's token rows in place, models/gnn_transformer.py:92-96): int32 [M], -1 = the node has no token row (truncated)
   const int32_t* out_rows;   // forward: output row m is stored at row out_rows[m] of `out` (skipped when < 0)
   const int32_t* a_rows;     // dX form: row m of the row operand is row a_rows[m] of `a` (zeros when < 0)
+  // k_lin3 forward only, one column block = the whole row (Nout = NT x 16): LayerNorm of the stored (TO-rounded) output row in the
+  // same epilogue (transformer_encoder.py:53-57 norm_input behind gnn2transformer): ln_out[row] = LN(out[row]) * ln_w + ln_b,
+  // ln_mean / ln_rstd[row] = its statistics; rows are the OUTPUT rows (through out_rows when set)
+  const float *ln_w, *ln_b;
+  void* ln_out;              // [.][ldo], TO
+  float *ln_mean, *ln_rstd;
+  float ln_eps;
 };
 
 // 16-byte chunk of TA -> up to 8 floats

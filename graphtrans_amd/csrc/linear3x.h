@@ -367,6 +367,56 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
         v[t] = gt_add4(gt_add4(v[t], e1[t]), e2[t]);
       }
     }
+    if (a.ln_out) {
+      // ---- LayerNorm of the row in the same epilogue (Nout = NT x 16: the block holds whole rows, half in each column wave):
+      // two-pass statistics like k_ln_fwd on the STORED values (TO rounding first), the halves meet through LDS.  Every lane's HT
+      // chunks belong to HT different rows (r = lane / 16 + 4 t at CPR = 16); the 16 lanes of a row are neighbours.
+      static_assert(HT * 4 == CPR, "chunks per patch row");
+      float2* stat = reinterpret_cast<float2*>(sB + NT * 16) + i * 64;   // [wm][wn][16 rows] x {sum | centred squares}, one slot per m-tile
+      float mu[HT], rs[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        if constexpr (sizeof(TO) == 2) {   // the LayerNorm sees what is stored
+          const uint32_t p0 = gt_pack_bf16(v[t].x, v[t].y), p1 = gt_pack_bf16(v[t].z, v[t].w);
+          v[t] = make_float4(__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u));
+        }
+        float s = ok[t] ? (v[t].x + v[t].y) + (v[t].z + v[t].w) : 0.f;
+#pragma unroll
+        for (int sh = 1; sh < CPR; sh <<= 1) s += __shfl_xor(s, sh, 64);
+        const int r = (lane + t * 64) / CPR;
+        if ((lane & (CPR - 1)) == 0) stat[(wm * 2 + wn) * 16 + r].x = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const int r = (lane + t * 64) / CPR;
+        mu[t] = (stat[(wm * 2 + 0) * 16 + r].x + stat[(wm * 2 + 1) * 16 + r].x) * (1.0f / (float)(NT * 16));
+        const float dx = v[t].x - mu[t], dy = v[t].y - mu[t], dz = v[t].z - mu[t], dw = v[t].w - mu[t];
+        float q = ok[t] ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f;
+#pragma unroll
+        for (int sh = 1; sh < CPR; sh <<= 1) q += __shfl_xor(q, sh, 64);
+        if ((lane & (CPR - 1)) == 0) stat[(wm * 2 + wn) * 16 + r].y = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const int c = lane + t * 64;
+        const int r = c / CPR, c4 = (c % CPR) * 4;
+        rs[t] = 1.0f / sqrtf((stat[(wm * 2 + 0) * 16 + r].y + stat[(wm * 2 + 1) * 16 + r].y) * (1.0f / (float)(NT * 16)) + a.ln_eps);
+        if (!ok[t]) continue;
+        const int64_t col = ncol0 + c4;
+        const int64_t orow = a.out_rows ? (int64_t)a.out_rows[mrow0 + r] : mrow0 + r;
+        if (orow < 0) continue;
+        const float4 w4 = *reinterpret_cast<const float4*>(a.ln_w + col), b4 = *reinterpret_cast<const float4*>(a.ln_b + col);
+        gt_store4<TO>(reinterpret_cast<TO*>(a.ln_out) + orow * a.ldo + col,
+                      make_float4((v[t].x - mu[t]) * rs[t] * w4.x + b4.x, (v[t].y - mu[t]) * rs[t] * w4.y + b4.y,
+                                  (v[t].z - mu[t]) * rs[t] * w4.z + b4.z, (v[t].w - mu[t]) * rs[t] * w4.w + b4.w));
+        if (wn == 0 && c4 == 0) {
+          a.ln_mean[orow] = mu[t];
+          a.ln_rstd[orow] = rs[t];
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       const int c = lane + t * 64;

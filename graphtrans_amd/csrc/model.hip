@@ -709,9 +709,19 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   // here and the bf16x6 kernel runs it: no pad pass over the node rows (modules/utils.py:5-29), no [N][d] intermediate
   c->fuse_rows = (!b.seq_desc && gt_linear_rows_ok(compute, GT_F32, tdt, m->g2t_w, N, d, c->Kc)) ? 1 : 0;
   void* g2t_out = P(c->o_hn);
+  // ... and norm_input (transformer_encoder.py:53-57) in the same epilogue when a token row fills one column block of the kernel
+  const bool fuse_nin = c->fuse_rows && m->nin_w && gt_linear_rows_layernorm_ok(d);
   if (c->fuse_rows) {
-    GT_TRY(gt_seq_token_rows(tdt, m->cls, graph_ptr, node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, P(c->o_tok), (int32_t*)P(c->o_rowmap), st));
-    GT_TRY(gt_linear_set_rows((const int32_t*)P(c->o_rowmap)));
+    int32_t* rmap = (int32_t*)P(c->o_rowmap);
+    if (fuse_nin) {
+      float* st0 = (float*)P(c->o_st0);
+      GT_TRY(gt_seq_token_rows_layernorm(tdt, m->cls, graph_ptr, node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, P(c->o_tok), rmap, m->nin_w,
+                                         m->nin_b, m->nin_eps, P(c->o_xin), st0, st0 + rows, st));
+      GT_TRY(gt_linear_set_rows_layernorm(rmap, m->nin_w, m->nin_b, m->nin_eps, P(c->o_xin), st0, st0 + rows));
+    } else {
+      GT_TRY(gt_seq_token_rows(tdt, m->cls, graph_ptr, node_graph, c->seq_desc, B, 1, m->with_cls ? 1 : 0, N, d, P(c->o_tok), rmap, st));
+      GT_TRY(gt_linear_set_rows(rmap));
+    }
     g2t_out = P(c->o_tok);
   }
   if (c->cat2) {
@@ -730,7 +740,9 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   if (!c->fuse_rows)
     GT_TRY(gt_seq_gather_cls32(tdt, P(c->o_hn), m->cls, graph_ptr, c->seq_desc, B, 1, c->max_npos, m->with_cls ? 1 : 0, d, P(c->o_tok), st));
   const void* cur = P(c->o_tok);
-  if (m->nin_w) {
+  if (fuse_nin) {
+    cur = P(c->o_xin);
+  } else if (m->nin_w) {
     GT_TRY(gt_layernorm_fwd(tdt, cur, nullptr, m->nin_w, m->nin_b, m->nin_eps, 0.f, 0, rows, d, P(c->o_xin), (float*)P(c->o_st0),
                             (float*)P(c->o_st0) + rows, st));
     cur = P(c->o_xin);

@@ -361,7 +361,9 @@ template <typename T>
 __global__ void __launch_bounds__(SEG_THREADS) k_seq_token_rows(const float* __restrict__ cls32, const int32_t* __restrict__ gptr,
                                                                 const int32_t* __restrict__ node_graph, const int32_t* __restrict__ desc,
                                                                 int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D,
-                                                                T* __restrict__ tokens, int32_t* __restrict__ rows) {
+                                                                T* __restrict__ tokens, int32_t* __restrict__ rows,
+                                                                const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps,
+                                                                T* __restrict__ ln_out, float* __restrict__ ln_mean, float* __restrict__ ln_rstd) {
   const int64_t C = D / 4;
   const int64_t t0 = (int64_t)blockIdx.x * SEG_THREADS + threadIdx.x, step = (int64_t)gridDim.x * SEG_THREADS;
   for (int64_t r = t0; r < N; r += step) {
@@ -370,56 +372,87 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seq_token_rows(const float* __r
     const int node0 = gptr[b + 1] - (d.w - with_cls);
     rows[r] = r >= node0 ? (int32_t)(d.x + (int64_t)(d.z + (int)r - node0) * row_stride) : -1;
   }
-  if (with_cls) {
+  if (!with_cls) return;
+  if (!ln_out) {
     for (int64_t i = t0; i < num_seqs * C; i += step) {
       const int64_t b = i / C, c = (i % C) * 4;
       const int4 d = *reinterpret_cast<const int4*>(desc + b * 4);
       gt_store4<T>(tokens + ((int64_t)d.x + (int64_t)(d.z + d.w - 1) * row_stride) * D + c, gt_load4<float>(cls32 + c));
     }
+    return;
   }
+  // with the LayerNorm of the token rows (norm_input): one wave per CLS row; the statistics of the STORED (T-rounded) row, two passes
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = t0 >> 6, nw = step >> 6;
+  for (int64_t b = w0; b < num_seqs; b += nw) {
+    const int4 d = *reinterpret_cast<const int4*>(desc + b * 4);
+    const int64_t row = (int64_t)d.x + (int64_t)(d.z + d.w - 1) * row_stride;
+    float s = 0.f;
+    for (int64_t c = lane; c < C; c += 64) {
+      gt_store4<T>(tokens + row * D + c * 4, gt_load4<float>(cls32 + c * 4));
+      const float4 v = gt_load4<T>(tokens + row * D + c * 4);   // (this lane's own store: what the LayerNorm kernels would read)
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+    const float mu = s / (float)D;
+    float q = 0.f;
+    for (int64_t c = lane; c < C; c += 64) {
+      const float4 v = gt_load4<T>(tokens + row * D + c * 4);
+      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) q += __shfl_xor(q, sh, 64);
+    const float rs = 1.0f / sqrtf(q / (float)D + ln_eps);
+    for (int64_t c = lane; c < C; c += 64) {
+      const float4 v = gt_load4<T>(tokens + row * D + c * 4);
+      const float4 w4 = *reinterpret_cast<const float4*>(ln_w + c * 4), b4 = *reinterpret_cast<const float4*>(ln_b + c * 4);
+      gt_store4<T>(ln_out + row * D + c * 4, make_float4((v.x - mu) * rs * w4.x + b4.x, (v.y - mu) * rs * w4.y + b4.y,
+                                                          (v.z - mu) * rs * w4.z + b4.z, (v.w - mu) * rs * w4.w + b4.w));
+    }
+    if (lane == 0) {
+      ln_mean[row] = mu;
+      ln_rstd[row] = rs;
+    }
+  }
+}
+static int seq_token_rows_impl(const char* fn, int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph,
+                               const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D, void* tokens,
+                               int32_t* rows, const float* ln_w, const float* ln_b, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd,
+                               gt_stream_t stream_) {
+  int rc = check(fn, dtype, D);
+  if (rc) return rc;
+  if (!(graph_ptr && node_graph && seq_desc && tokens && rows)) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
+  if (with_cls && !cls32) { gt_set_error("%s: with_cls needs the cls row", fn); return GT_ERR_INVALID_ARG; }
+  if (num_seqs == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  int64_t items = N > num_seqs * (D / 4) ? N : num_seqs * (D / 4);
+  if (ln_out && items < num_seqs * 64) items = num_seqs * 64;   // a wave per CLS row
+  dim3 grid((unsigned)(gt_cdiv(items, SEG_THREADS) < 1024 ? gt_cdiv(items, SEG_THREADS) : 1024));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_seq_token_rows<float>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
+                       with_cls, N, D, (float*)tokens, rows, ln_w, ln_b, ln_eps, (float*)ln_out, ln_mean, ln_rstd);
+  else
+    hipLaunchKernelGGL(k_seq_token_rows<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
+                       with_cls, N, D, (gt_bf16*)tokens, rows, ln_w, ln_b, ln_eps, (gt_bf16*)ln_out, ln_mean, ln_rstd);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
 }
 extern "C" int gt_seq_token_rows(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* seq_desc,
                                  int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D, void* tokens, int32_t* rows,
                                  gt_stream_t stream_) {
-  int rc = check("gt_seq_token_rows", dtype, D);
-  if (rc) return rc;
-  GT_CHECK_ARG(graph_ptr && node_graph && seq_desc && tokens && rows, "null buffer");
-  GT_CHECK_ARG(!with_cls || cls32, "with_cls needs the cls row");
-  if (num_seqs == 0) return GT_OK;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int64_t items = N > num_seqs * (D / 4) ? N : num_seqs * (D / 4);
-  dim3 grid((unsigned)(gt_cdiv(items, SEG_THREADS) < 1024 ? gt_cdiv(items, SEG_THREADS) : 1024));
-  if (dtype == GT_F32)
-    hipLaunchKernelGGL(k_seq_token_rows<float>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
-                       with_cls, N, D, (float*)tokens, rows);
-  else
-    hipLaunchKernelGGL(k_seq_token_rows<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride,
-                       with_cls, N, D, (gt_bf16*)tokens, rows);
-  GT_CHECK_LAUNCH();
-  return GT_OK;
+  return seq_token_rows_impl("gt_seq_token_rows", dtype, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D, tokens, rows,
+                             nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, stream_);
 }
-
-extern "C" int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_t* graph_ptr,
-                              const int32_t* node_graph, const int32_t* seq_desc, int64_t num_seqs,
-                              int64_t row_stride, int with_cls, int64_t N, int64_t D, void* h_out, void* cls_out,
-                              gt_stream_t stream_) {
-  int rc = check("gt_seq_scatter", dtype, D);
-  if (rc) return rc;
-  GT_CHECK_ARG(tokens && graph_ptr && node_graph && seq_desc && h_out, "null buffer");
-  if (num_seqs == 0) return GT_OK;
-  hipStream_t stream = (hipStream_t)stream_;
-  int64_t items = (N > num_seqs ? N : num_seqs) * (D / 4);
-  dim3 grid(flat_grid(items));
-  if (dtype == GT_F32)
-    hipLaunchKernelGGL(k_seq_scatter<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)tokens,
-                       (const float*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
-                       (float*)h_out, (float*)cls_out);
-  else
-    hipLaunchKernelGGL(k_seq_scatter<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)tokens,
-                       (const gt_bf16*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
-                       (gt_bf16*)h_out, (gt_bf16*)cls_out);
-  GT_CHECK_LAUNCH();
-  return GT_OK;
+// ... whose CLS rows also get the LayerNorm of gt_linear_set_rows_layernorm (the node rows get it in the GEMM's epilogue)
+extern "C" int gt_seq_token_rows_layernorm(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph,
+                                           const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D,
+                                           void* tokens, int32_t* rows, const float* ln_w, const float* ln_b, float ln_eps, void* ln_out,
+                                           float* ln_mean, float* ln_rstd, gt_stream_t stream_) {
+  GT_CHECK_ARG(ln_w && ln_b && ln_out && ln_mean && ln_rstd, "null LayerNorm buffer");
+  return seq_token_rows_impl("gt_seq_token_rows_layernorm", dtype, cls32, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
+                             tokens, rows, ln_w, ln_b, ln_eps, ln_out, ln_mean, ln_rstd, stream_);
 }
 
 extern "C" size_t gt_segment_sum_workspace_bytes(int64_t N, int64_t D) {

@@ -503,6 +503,13 @@ int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, int64_t N, in
  * rows = gt_seq_token_rows.  Only the fp32-accurate big-M path with bound weight images takes it: ask gt_linear_rows_ok. */
 int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K);
 int gt_linear_set_rows(const int32_t* rows);
+/* ... with LayerNorm(ln_w, ln_b, eps) of every stored row in the same epilogue (forward only; `norm_input` behind gnn2transformer,
+ * modules/transformer_encoder.py:53-57): ln_out (storage type / pitch of y) = the normalised row, ln_mean / ln_rstd = its statistics
+ * (what gt_layernorm_fwd saves for gt_layernorm_bwd), all at the row the output goes to.  N must fill one column block of the
+ * kernel (gt_linear_rows_layernorm_ok: 128, 160, ...). */
+int gt_linear_rows_layernorm_ok(int64_t N);
+int gt_linear_set_rows_layernorm(const int32_t* rows, const float* ln_w, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                                 float* ln_rstd);
 int gt_linear_fwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
                        const float* weight, const float* bias, void* y, int64_t M, int64_t N, int64_t ldy, gt_stream_t stream);
 int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int64_t ldx1, const void* x2, int64_t K2, int64_t ldx2,
@@ -965,6 +972,12 @@ int gt_colsum_rows_f32(int dtype, const void* x, const int64_t* row_idx, int64_t
 int gt_seq_token_rows(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* seq_desc,
                       int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D, void* tokens, int32_t* rows,
                       gt_stream_t stream);
+/* ... whose CLS rows also get LayerNorm(ln_w, ln_b, eps): ln_out / ln_mean / ln_rstd as in gt_linear_set_rows_layernorm (which
+ * covers the node rows) */
+int gt_seq_token_rows_layernorm(int dtype, const float* cls32, const int32_t* graph_ptr, const int32_t* node_graph,
+                                const int32_t* seq_desc, int64_t num_seqs, int64_t row_stride, int with_cls, int64_t N, int64_t D,
+                                void* tokens, int32_t* rows, const float* ln_w, const float* ln_b, float ln_eps, void* ln_out,
+                                float* ln_mean, float* ln_rstd, gt_stream_t stream);
 
 /* Stand-alone dropout (F.dropout / nn.Dropout with no producing kernel to carry it: masked_transformer_encoder.py:54,75,
  * pna/pna_module.py:78): y[i] = keep(i, seed) ? x[i] / (1 - p) : 0 over n elements (n % 4 == 0; x == y allowed).  The same

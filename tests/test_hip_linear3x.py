@@ -414,3 +414,58 @@ def test_deferred_partial_sums_equal_the_immediate_reduces():
     _lib.launch("gt_defer_flush", st)
     _lib.launch("gt_defer_end")
     assert torch.equal(dw, ref[0][0]) and torch.equal(db, ref[0][1])
+
+
+@pytest.mark.parametrize("tok_dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("max_len,with_cls", [(1000, 1), (9, 1), (60, 0)])
+def test_row_map_with_layernorm_equals_gather_then_layernorm(tok_dtype, tol, max_len, with_cls):
+    """gt_linear_set_rows_layernorm + gt_seq_token_rows_layernorm (gnn2transformer + pad + CLS + norm_input as one GEMM,
+    models/gnn_transformer.py:92-96, modules/transformer_encoder.py:50-57) against gt_linear_fwd -> gt_seq_gather_cls32 ->
+    gt_layernorm_fwd: the un-normalised token rows bit for bit, the normalised rows / saved statistics to one rounding of the storage type."""
+    import numpy as np
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W3Images
+    lib = _lib.lib()
+    rng = np.random.default_rng(max_len + 7)
+    B, K, N = 33, 600, 128
+    sizes = rng.integers(1, 150, B)
+    Nn = int(sizes.sum())
+    assert Nn >= 1024 and lib.gt_linear_rows_layernorm_ok(N) == 1 and lib.gt_linear_rows_layernorm_ok(100) == 0
+    gptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    kept = np.minimum(sizes, min(int(sizes.max()), max_len))
+    kv = kept + with_cls
+    tok_ptr = np.concatenate([[0], np.cumsum(kv)])
+    desc = np.zeros((B, 4), np.int32)
+    desc[:, 0], desc[:, 1], desc[:, 3] = tok_ptr[:-1], kv, kv
+    rows = int(tok_ptr[-1])
+    d_gptr, d_desc = torch.tensor(gptr, device=DEV), torch.tensor(desc, device=DEV)
+    d_ng = torch.tensor(np.repeat(np.arange(B, dtype=np.int32), sizes), device=DEV)
+    torch.manual_seed(2)
+    x = torch.randn(Nn, K, device=DEV) * (0.5 + torch.rand(Nn, 1, device=DEV))
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    bias, cls = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    lw, lb = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.2
+    tcode = GT_BF16 if tok_dtype == torch.bfloat16 else GT_F32
+    imgs = W3Images([W])
+    imgs.build()
+    st = _stream()
+    with imgs.bound():
+        hn = torch.empty(Nn, N, dtype=tok_dtype, device=DEV)
+        _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(hn), Nn, N, K, K, N, 0, 0.0, 0, st)
+        tok_ref = torch.zeros(rows, N, dtype=tok_dtype, device=DEV)
+        _lib.launch("gt_seq_gather_cls32", tcode, _p(hn), _p(cls), _p(d_gptr), _p(d_desc), B, 1, int(kv.max()), with_cls, N, _p(tok_ref), st)
+        xin_ref = torch.empty_like(tok_ref)
+        mean_ref, rstd_ref = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        _lib.launch("gt_layernorm_fwd", tcode, _p(tok_ref), None, _p(lw), _p(lb), 1e-5, 0.0, 0, rows, N, _p(xin_ref), _p(mean_ref), _p(rstd_ref), st)
+        tok, xin = torch.zeros(rows, N, dtype=tok_dtype, device=DEV), torch.zeros(rows, N, dtype=tok_dtype, device=DEV)
+        mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        rmap = torch.empty(Nn, dtype=torch.int32, device=DEV)
+        _lib.launch("gt_seq_token_rows_layernorm", tcode, _p(cls) if with_cls else None, _p(d_gptr), _p(d_ng), _p(d_desc), B, 1, with_cls, Nn, N, _p(tok),
+                    _p(rmap), _p(lw), _p(lb), 1e-5, _p(xin), _p(mean), _p(rstd), st)
+        _lib.launch("gt_linear_set_rows_layernorm", _p(rmap), _p(lw), _p(lb), 1e-5, _p(xin), _p(mean), _p(rstd))
+        _lib.launch("gt_linear_fwd_ld2", GT_F32, tcode, GT_F32, _p(x), _p(W), _p(bias), _p(tok), Nn, N, K, K, N, 0, 0.0, 0, st)
+    assert torch.equal(tok, tok_ref)
+    assert rel(mean, mean_ref) < 1e-5 and rel(rstd, rstd_ref) < 1e-5
+    assert float((xin.float() - xin_ref.float()).abs().max()) <= tol * max(1.0, float(xin_ref.float().abs().max()))
+    assert rel(xin.float(), xin_ref.float()) < tol * 0.1
