@@ -455,6 +455,29 @@ extern "C" int gt_seq_token_rows_layernorm(int dtype, const float* cls32, const 
                              tokens, rows, ln_w, ln_b, ln_eps, ln_out, ln_mean, ln_rstd, stream_);
 }
 
+extern "C" int gt_seq_scatter(int dtype, const void* tokens, const void* base, const int32_t* graph_ptr,
+                              const int32_t* node_graph, const int32_t* seq_desc, int64_t num_seqs,
+                              int64_t row_stride, int with_cls, int64_t N, int64_t D, void* h_out, void* cls_out,
+                              gt_stream_t stream_) {
+  int rc = check("gt_seq_scatter", dtype, D);
+  if (rc) return rc;
+  GT_CHECK_ARG(tokens && graph_ptr && node_graph && seq_desc && h_out, "null buffer");
+  if (num_seqs == 0) return GT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  int64_t items = (N > num_seqs ? N : num_seqs) * (D / 4);
+  dim3 grid(flat_grid(items));
+  if (dtype == GT_F32)
+    hipLaunchKernelGGL(k_seq_scatter<float>, grid, dim3(SEG_THREADS), 0, stream, (const float*)tokens,
+                       (const float*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
+                       (float*)h_out, (float*)cls_out);
+  else
+    hipLaunchKernelGGL(k_seq_scatter<gt_bf16>, grid, dim3(SEG_THREADS), 0, stream, (const gt_bf16*)tokens,
+                       (const gt_bf16*)base, graph_ptr, node_graph, seq_desc, num_seqs, row_stride, with_cls, N, D,
+                       (gt_bf16*)h_out, (gt_bf16*)cls_out);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
 extern "C" size_t gt_segment_sum_workspace_bytes(int64_t N, int64_t D) {
   return (size_t)2 * gt_cdiv(N > 0 ? N : 1, SS_CH) * D * sizeof(float) + 256;
 }
