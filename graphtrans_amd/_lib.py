@@ -78,6 +78,8 @@ SIGNATURES = {
     "gt_defer_begin": (_i, [_p, _sz]),
     "gt_defer_take": (_p, [_sz]),
     "gt_defer_push": (_i, [_p, _i, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gt_defer_push_strided": (_i, [_p, _i, _i64, _i64, _p, _i64]),
+    "gt_defer_room": (_i, [_i]),
     "gt_defer_flush": (_i, [_p]),
     "gt_defer_end": (_i, []),
     "gt_linear_rows_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),

@@ -831,6 +831,16 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   a.conv = conv; a.K = (int)K; a.N = N; a.E = E; a.D = D; a.h = h; a.g = grad_out; a.ptr = out_ptr; a.nbr = out_dst;
   a.eid = out_eid; a.deg = deg; a.dis = dis; a.self_param = self_param; a.attr = edge_attr; a.w = edge_w;
   a.b = edge_b; a.dense = edge_dense; a.out = grad_h; a.d_dense = d_dense; a.partial = (float*)workspace;
+  // GCN inside a deferred-reduce section (gt_defer_begin: the whole-model backward): the block partials go to the section's arena
+  // (the caller's workspace is reused by the next layer) and their sums are queued below instead of launched
+  float* dpart = nullptr;
+  {
+    static const bool on = [] { const char* e = getenv("GT_AGG_DEFER"); return !e || atoi(e) != 0; }();   // (A/B knob)
+    const int jobs = (d_self ? 1 : 0) + (edge_mode == GT_EDGE_LINEAR ? (d_edge_w ? (int)K : 0) + (d_edge_b ? 1 : 0)
+                                                                      : (edge_mode == GT_EDGE_TABLES && d_edge_w ? 1 : 0));
+    if (on && conv == GT_CONV_GCN && jobs > 0 && gt_defer_room(jobs)) dpart = (float*)gt_defer_take(need);
+    if (dpart) a.partial = dpart;
+  }
   a.table_rows = (int)table_rows;
   if (edge_mode == GT_EDGE_TABLES)
     for (int k = 0; k < K; ++k) a.tab_off[k] = tab_off_host[k];
@@ -839,9 +849,23 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
                        : launch_edge<gt_bf16, true>(edge_mode, a, lds, &grid, stream);
   if (rc != GT_OK) return rc;
   ReduceArgs r{};
-  r.partial = (const float*)workspace; r.nblocks = grid; r.nslots = nslots; r.D = D; r.conv = conv; r.edge = edge_mode;
+  r.partial = a.partial; r.nblocks = grid; r.nslots = nslots; r.D = D; r.conv = conv; r.edge = edge_mode;
   r.K = (int)K; r.table_rows = (int)table_rows; r.d_self = d_self; r.d_w = d_edge_w; r.d_b = d_edge_b;
   int ctiles = (int)gt_cdiv(D, 64);
+  if (dpart) {   // the partials sit in the deferred-reduce section's arena: their sums join the section's one reduce launch
+    const int64_t pstride = (int64_t)nslots * D;
+    if (d_self) (void)(gt_defer_push(dpart, grid, D, pstride, d_self, nullptr, 0, 0, nullptr));
+    if (edge_mode == GT_EDGE_LINEAR) {
+      if (d_edge_w)
+        for (int k = 0; k < (int)K; ++k) (void)(gt_defer_push_strided(dpart + (int64_t)(1 + k) * D, grid, D, pstride, d_edge_w + k, K));
+      if (d_edge_b) (void)(gt_defer_push(dpart + (int64_t)(1 + K) * D, grid, D, pstride, d_edge_b, nullptr, 0, 0, nullptr));
+    } else if (edge_mode == GT_EDGE_TABLES && d_edge_w) {
+      // slots 1 .. table_rows of a block row are contiguous: one job over table_rows x D outputs, d_w[(slot - 1) * D + c]
+      (void)(gt_defer_push(dpart + D, grid, (int64_t)table_rows * D, pstride, d_edge_w, nullptr, 0, 0, nullptr));
+    }
+    GT_CHECK_LAUNCH();
+    return GT_OK;
+  }
   // the block partials only hold parameter gradients (root / eps, edge-encoder weights): their reduce goes to the overlap stream
   // when there is one -- the next kernel of the backward (the dX GEMM) does not wait for it
   hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, 0 /* forked while profiled too: the brackets then hold the gather kernel alone, under the schedule the step really runs */);

@@ -723,9 +723,10 @@ struct DeferJob {
   const float *part, *part2;   // part[s * stride + i], s < nparts
   float *out, *out2;
   int64_t len, len2, stride, stride2;
+  int64_t ostride;             // out[i * ostride] (1 = contiguous; the second array is always contiguous)
   int32_t nparts, block0;
 };
-constexpr int DEFER_MAX_JOBS = 48;   // 48 x 72 bytes of kernel arguments
+constexpr int DEFER_MAX_JOBS = 44;   // 44 x 80 bytes of kernel arguments
 struct DeferJobs {
   DeferJob j[DEFER_MAX_JOBS];
   int n;
@@ -756,7 +757,9 @@ __global__ void __launch_bounds__(256) k_defer_reduce(DeferJobs J) {
       for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(s + u) * st + i];
     }
     for (; s < q.nparts; ++s) acc[0] += p[(int64_t)s * st + i];
-    (second ? q.out2 : q.out)[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const float t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    if (second) q.out2[i] = t;
+    else q.out[i * q.ostride] = t;
   }
 }
 
@@ -1703,13 +1706,21 @@ extern "C" void* gt_defer_take(size_t bytes) {
   g_defer.used += need;
   return p;
 }
+extern "C" int gt_defer_room(int jobs) { return (g_defer.active && g_defer.jobs.n + jobs <= DEFER_MAX_JOBS) ? 1 : 0; }
+extern "C" int gt_defer_push_strided(const float* part, int nparts, int64_t len, int64_t stride, float* out, int64_t ostride) {
+  GT_CHECK_ARG(ostride >= 1, "bad output stride");
+  const int rc = gt_defer_push(part, nparts, len, stride, out, nullptr, 0, 0, nullptr);
+  if (rc) return rc;
+  g_defer.jobs.j[g_defer.jobs.n - 1].ostride = ostride;
+  return GT_OK;
+}
 extern "C" int gt_defer_push(const float* part, int nparts, int64_t len, int64_t stride, float* out, const float* part2, int64_t len2,
                              int64_t stride2, float* out2) {
   GT_CHECK_ARG(g_defer.active && g_defer.jobs.n < DEFER_MAX_JOBS, "no open section / job list full (a gt_defer_take came first?)");
   GT_CHECK_ARG(part && out && nparts >= 1 && len > 0 && (len2 == 0 || (part2 && out2)), "bad job");
   DeferJob& q = g_defer.jobs.j[g_defer.jobs.n++];
   q.part = part; q.part2 = len2 ? part2 : nullptr; q.out = out; q.out2 = len2 ? out2 : nullptr;
-  q.len = len; q.len2 = len2; q.stride = stride; q.stride2 = stride2; q.nparts = nparts;
+  q.len = len; q.len2 = len2; q.stride = stride; q.stride2 = stride2; q.nparts = nparts; q.ostride = 1;
   q.block0 = g_defer.blocks;
   const int64_t nb = gt_cdiv(len + len2, 256);
   g_defer.blocks += (int)(nb < 512 ? nb : 512);

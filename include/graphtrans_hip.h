@@ -575,6 +575,8 @@ int gt_defer_begin(void* arena, size_t bytes);
 void* gt_defer_take(size_t bytes);
 int gt_defer_push(const float* part, int nparts, int64_t len, int64_t stride, float* out, const float* part2, int64_t len2,
                   int64_t stride2, float* out2);
+int gt_defer_push_strided(const float* part, int nparts, int64_t len, int64_t stride, float* out, int64_t ostride);   /* out[i * ostride] */
+int gt_defer_room(int jobs);   /* 1 when a section is open and `jobs` more sums fit its list */
 int gt_defer_flush(gt_stream_t stream);
 int gt_defer_end(void);
 int gt_overlap_dw_sync(void);
