@@ -838,7 +838,9 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
     static const bool on = [] { const char* e = getenv("GT_AGG_DEFER"); return !e || atoi(e) != 0; }();   // (A/B knob)
     const int jobs = (d_self ? 1 : 0) + (edge_mode == GT_EDGE_LINEAR ? (d_edge_w ? (int)K : 0) + (d_edge_b ? 1 : 0)
                                                                       : (edge_mode == GT_EDGE_TABLES && d_edge_w ? 1 : 0));
-    if (on && conv == GT_CONV_GCN && jobs > 0 && gt_defer_room(jobs)) dpart = (float*)gt_defer_take(need);
+    // (small batches only: a step made of launches gains the five launches -- NCI1 +3 % --, at Code2's 31 k rows the arena copy of
+    // the partials is cold memory every layer where the workspace stays in the Infinity Cache: -1 %)
+    if (on && conv == GT_CONV_GCN && N <= 2048 && jobs > 0 && gt_defer_room(jobs)) dpart = (float*)gt_defer_take(need);
     if (dpart) a.partial = dpart;
   }
   a.table_rows = (int)table_rows;
