@@ -808,7 +808,11 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
   }
   // the sums over weight-gradient / LayerNorm partials of a stage: queued by their producers, ONE launch at the end of the stage
   // (section open across the stage calls like the overlap section; the arena is not reused inside one backward)
-  if (!c->stages_done) GT_TRY(gt_defer_begin(Q(c->q_defer), c->defer_bytes));
+  // (up to ~6 M node-row elements: where the step is made of launches it gains them -- Molpcba +1 %, NCI1 +2 %, PNA b128 +1.2 % --;
+  // at Code2 b256 (9.5 M) the arena copies of the partials are cold memory where the reused workspaces stay in the Infinity Cache:
+  // -0.9 %, so the big batches keep the immediate reduces)
+  static const int64_t defer_max = [] { const char* e = getenv("GT_DEFER_MAX_ELEMS"); return e ? (int64_t)atoll(e) : (int64_t)6000000; }();
+  if (!c->stages_done) GT_TRY(gt_defer_begin(N * D <= defer_max ? Q(c->q_defer) : nullptr, c->defer_bytes));
   guard.defer_abort = true;   // cleared on the successful way out
   auto flush = [&]() -> int {
     gt_stream_t fs = ov ? gt_overlap_dw_fork(st, 0) : st;   // behind everything queued on the main stream, on the overlap stream
