@@ -474,7 +474,8 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
       need += gt_linear_bwd_workspace_bytes(ec, e.rows, 3 * e.d_model, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.d_model) +
               gt_linear_bwd_workspace_bytes(ec, e.rows, e.ffn, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.ffn);
     }
-    c->defer_bytes = need + 64 * 256;
+    static const int64_t defer_max = [] { const char* e = getenv("GT_DEFER_MAX_ELEMS"); return e ? (int64_t)atoll(e) : (int64_t)6000000; }();
+    c->defer_bytes = N * D <= defer_max ? need + 64 * 256 : 0;   // (see gt_model_backward: the big batches keep the immediate reduces)
     c->q_defer = q.take(c->defer_bytes);
   }
   c->barena_bytes = std::max(q.off, (size_t)256);
@@ -811,8 +812,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
   // (up to ~6 M node-row elements: where the step is made of launches it gains them -- Molpcba +1 %, NCI1 +2 %, PNA b128 +1.2 % --;
   // at Code2 b256 (9.5 M) the arena copies of the partials are cold memory where the reused workspaces stay in the Infinity Cache:
   // -0.9 %, so the big batches keep the immediate reduces)
-  static const int64_t defer_max = [] { const char* e = getenv("GT_DEFER_MAX_ELEMS"); return e ? (int64_t)atoll(e) : (int64_t)6000000; }();
-  if (!c->stages_done) GT_TRY(gt_defer_begin(N * D <= defer_max ? Q(c->q_defer) : nullptr, c->defer_bytes));
+  if (!c->stages_done) GT_TRY(gt_defer_begin(c->defer_bytes ? Q(c->q_defer) : nullptr, c->defer_bytes));
   guard.defer_abort = true;   // cleared on the successful way out
   auto flush = [&]() -> int {
     gt_stream_t fs = ov ? gt_overlap_dw_fork(st, 0) : st;   // behind everything queued on the main stream, on the overlap stream
