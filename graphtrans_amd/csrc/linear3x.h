@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
         v[t] = gt_add4(gt_add4(v[t], e1[t]), e2[t]);
       }
     }
+    if constexpr (!GELU) {   // (the gelu instantiations have no registers left for it, and no caller)
     if (a.ln_out) {
       // ---- LayerNorm of the row in the same epilogue (Nout = NT x 16: the block holds whole rows, half in each column wave):
       // two-pass statistics like k_ln_fwd on the STORED values (TO rounding first), the halves meet through LDS.  Every lane's HT
@@ -416,6 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
           a.ln_rstd[orow] = rs[t];
         }
       }
+    }
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
