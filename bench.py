@@ -515,6 +515,14 @@ def precision_vs_oracle(workload, modes, device, graphs=None):
 # ---- one timed measurement ------------------------------------------------------------------------------------------
 def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
     """Build the model of `mode`, run opt.warmup + opt.steps steps, return (result dict for rank 0, model, args)."""
+    import gc
+    try:
+        return _measure(opt, mode, scaling, world, rank, device, want_kernels)
+    finally:
+        gc.unfreeze()   # _measure freezes the set-up heap after its warm-up: undone on every way out (a raise included)
+
+
+def _measure(opt, mode, scaling, world, rank, device, want_kernels):
     import torch.distributed as dist
 
     from graphtrans_amd import _lib
@@ -697,7 +705,6 @@ def measure(opt, mode, scaling, world, rank, device, want_kernels=True):
                 res["roofline"] = r
                 res["kernels"] = rep
     del optim, sync
-    gc.unfreeze()
     return res, model, args, per_gpu
 
 

@@ -1382,7 +1382,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     a.ymask = nullptr;   // the gate belongs to the dX output, not to dY: the weight gradient below reads dY as it is
     y_for_mask = nullptr;
   }
-  if (dx && !dx_done && !y_for_mask && heads_shape_ok(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) && workspace &&
+  // (shape matching alone must not route a general GEMM with per-call options here: k_heads_dx knows none of them)
+  if (dx && !dx_done && !y_for_mask && !g_opt.mul_mask && !g_opt.bns.part && !g_opt.gate_out && dropout_p == 0.f &&
+      heads_shape_ok(x_dtype, y_dtype, M, N, K, ldx, ldy, groups) && workspace &&
       workspace_bytes >= heads_dx_workspace_bytes(M, N)) {   // the prediction heads: the contraction is their 25 010 columns (linear_heads.h)
     HeadsArgs h{};
     h.w = weight; h.dy = (const float*)dy; h.M = M; h.N = N; h.ldx = ldx; h.ldy = ldy;

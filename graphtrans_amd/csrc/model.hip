@@ -97,7 +97,8 @@ inline gt_pna_layer* pna_static(const gt_model* m) { return (gt_pna_layer*)m->co
 
 int model_check(const char* fn, const gt_model* m) {
   if (!m) { gt_set_error("%s: null model", fn); return GT_ERR_INVALID_ARG; }
-  if (m->L < 1 || m->L > MAXL || m->n_enc < 0 || m->n_enc > MAXL || m->n_tables < 0 || m->n_tables > MAXT) {
+  // (n_enc == 0 is legal in the reference -- it pools the token rows themselves -- but not built here: the callers route it to the module path)
+  if (m->L < 1 || m->L > MAXL || m->n_enc < 1 || m->n_enc > MAXL || m->n_tables < 0 || m->n_tables > MAXT) {
     gt_set_error("%s: layer / table counts out of range", fn);
     return GT_ERR_INVALID_ARG;
   }
@@ -814,8 +815,11 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
   // -0.9 %, so the big batches keep the immediate reduces)
   if (!c->stages_done) GT_TRY(gt_defer_begin(c->defer_bytes ? Q(c->q_defer) : nullptr, c->defer_bytes));
   guard.defer_abort = true;   // cleared on the successful way out
-  auto flush = [&]() -> int {
+  // `behind`: an event of a stream OTHER than the main one whose producers queued partials too (the virtual-node update's weight
+  // gradients run on the second stream and the main stream joins that stream only in stage 4)
+  auto flush = [&](void* behind = nullptr) -> int {
     gt_stream_t fs = ov ? gt_overlap_dw_fork(st, 0) : st;   // behind everything queued on the main stream, on the overlap stream
+    if (behind) GT_TRY(gt_stream_wait_event(fs, behind));
     GT_TRY(gt_defer_flush(fs));
     if (fs != st) gt_overlap_dw_booked(Q(c->q_defer), c->defer_bytes);
     return GT_OK;
@@ -960,7 +964,8 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       GT_TRY(gt_segment_sum(GT_F32, d_vn_next, nullptr, b.ptr01, B, 1, D, G + m->off_vn_emb, vst));
       if (side) GT_TRY(gt_event_record(m->ev_vnemb, side));
     }
-    GT_TRY(flush());
+    // the virtual-node updates' weight-gradient GEMMs queued their partials from the second stream: the sum runs behind its tail
+    GT_TRY(flush((m->has_vn && side) ? m->ev_vnemb : nullptr));
     c->stages_done |= 2;
   }
 

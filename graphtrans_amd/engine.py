@@ -616,7 +616,6 @@ def invalidate(model):
         st.pop("params", None)
         st.pop("bn_sync", None)
         st.pop("bn_hook", None)
-        st.pop("ddp_rc", None)
 
 
 def _bn_sync_hook(model, plan):
@@ -651,8 +650,8 @@ def eligible(model, batched_data, perturb):
     # the fused node differentiates EVERY parameter and assigns `.grad` itself: any frozen parameter (epoch_callback's freeze_gnn,
     # or a user's requires_grad_(False) on any submodule), any tensor hook on a parameter and a DistributedDataParallel wrapper send
     # the model through the module path.  All three are looked at on EVERY call (a model may be wrapped or hooked after its first
-    # fused forward): flags and hooks by one pass over the parameters, the wrapper through the model's reference count -- wrapping
-    # adds a referrer, and only then the (slow) search through gc runs again.
+    # fused forward): flags and hooks by one pass over the parameters, the wrapper through a flag that torch's module-registration
+    # hook sets at the moment a DistributedDataParallel takes the model as its `.module` (`_note_ddp_wrapper`).
     st = state(model)
     plist = st.get("params")
     if plist is None:
@@ -662,12 +661,11 @@ def eligible(model, batched_data, perturb):
         if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
             return False
         flags.append(p.requires_grad)
-    rc = sys.getrefcount(model)
-    if st.get("ddp_rc") != rc:
-        st["ddp"] = wrapped_in_ddp(model)
-        st["ddp_rc"] = sys.getrefcount(model)
-    if st["ddp"]:
-        return False
+    w = st.get("ddp_wrapper")   # set by the module-registration hook below when a DistributedDataParallel adopts this model
+    if w is not None:
+        if w() is not None:
+            return False
+        st["ddp_wrapper"] = None   # the wrapper is gone
     key = (model.training, torch.is_grad_enabled(), tuple(flags))
     cache = st.setdefault("eligible", {})
     ok = cache.get(key)
@@ -719,21 +717,26 @@ def has_grad_hooks(model):
 
 
 def wrapped_in_ddp(model):
-    """True when `model` is the `.module` of a torch DistributedDataParallel instance.  DDP reduces gradients from hooks on the
+    """True when `model` is the `.module` of a live torch DistributedDataParallel instance.  DDP reduces gradients from hooks on the
     parameters' AccumulateGrad nodes (C++ side, invisible from here), which a node that assigns `.grad` directly never reaches:
     such a model runs the module-by-module path (autograd accumulates as usual), or -- the supported way -- uses
-    graphtrans_amd.dist.GradSync, whose all-reduce the fused backward issues itself.  Found through the wrapper that holds the
-    model (wrapper.__dict__['_modules']['module'] is model)."""
-    import gc
-    from torch.nn.parallel import DistributedDataParallel
-    for mods in gc.get_referrers(model):
-        if not isinstance(mods, dict) or mods.get("module") is not model:
-            continue
-        for wd in gc.get_referrers(mods):
-            if isinstance(wd, dict) and wd.get("_modules") is mods:
-                if any(isinstance(o, DistributedDataParallel) for o in gc.get_referrers(wd)):
-                    return True
-    return False
+    graphtrans_amd.dist.GradSync, whose all-reduce the fused backward issues itself."""
+    w = state(model).get("ddp_wrapper")
+    return w is not None and w() is not None
+
+
+def _note_ddp_wrapper(parent, name, child):
+    """torch.nn module-registration hook (fires on `parent.<name> = child`, i.e. inside DistributedDataParallel.__init__): remember
+    the wrapper -- weakly -- in the wrapped model's state.  Exact and free on the step (the previous detection compared
+    sys.getrefcount(model) between calls, which any extra reference -- a list, a closure, a debugger -- triggered or hid)."""
+    if name == "module" and isinstance(child, torch.nn.Module):
+        from torch.nn.parallel import DistributedDataParallel
+        if isinstance(parent, DistributedDataParallel):
+            state(child)["ddp_wrapper"] = weakref.ref(parent)
+    return None
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_note_ddp_wrapper)
 
 
 def _eligible_static(model):
@@ -1044,14 +1047,24 @@ class _FusedModel(torch.autograd.Function):
             else:
                 # data parallel: each stage completes one range of the flat buffer, which goes on the wire (asynchronously, on RCCL's
                 # stream) while the next stage runs: heads .. gnn2transformer | message passing | input encoder
-                for i, stage in enumerate((1, 2, 4)):
-                    _lib.check(lib.gt_model_backward(*args, stage, st), "gt_model_backward")
-                    if stage == 2 and plan.has_vn and plan.side is not None:
-                        _call("gt_stream_wait_event", st, plan.cm.ev_vnemb)   # d virtualnode_embedding was reduced on the second stream
-                    if stage != 4:
-                        _call("gt_overlap_dw_sync")   # (the last stage joins the weight-gradient stream itself)
-                    lo, hi = plan.ranges[i]
-                    sync.reduce_flat(flat, lo, hi)
+                # (the C side keeps its overlap and deferred-reduce sections open between the stage calls on this host thread: a raise
+                # from Python in between -- the collective, the BatchNorm hook -- must not leave them pointing at this step's arena)
+                staged_open = False
+                try:
+                    for i, stage in enumerate((1, 2, 4)):
+                        staged_open = stage != 4
+                        _lib.check(lib.gt_model_backward(*args, stage, st), "gt_model_backward")
+                        if stage == 2 and plan.has_vn and plan.side is not None:
+                            _call("gt_stream_wait_event", st, plan.cm.ev_vnemb)   # d virtualnode_embedding was reduced on the second stream
+                        if stage != 4:
+                            _call("gt_overlap_dw_sync")   # (the last stage joins the weight-gradient stream itself)
+                        lo, hi = plan.ranges[i]
+                        sync.reduce_flat(flat, lo, hi)
+                    staged_open = False
+                finally:
+                    if staged_open:
+                        lib.gt_defer_begin(None, 0)
+                        lib.gt_overlap_dw_end()
         finally:
             if hook is not None:
                 hook.uninstall()
