@@ -203,6 +203,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 
 #include "linear32.h"
 #include "linear3x.h"
+#include "linear3r.h"
 #include "linear1.h"
 #include "linear_small.h"
 #include "linear_heads.h"
@@ -1030,7 +1031,8 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     }
     {
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
-      if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
+      if (w.w3 && w3r_ok(x_dtype, y_dtype, w)) w3r_launch(stream, w);   // rows straight into fragments (linear3r.h)
+      else if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
       else w32_launch<false>(x_dtype, y_dtype, stream, w);
     }
     GT_CHECK_LAUNCH();
@@ -1306,7 +1308,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.out2 = g_cat2.dx2; w.out_split = g_cat2.split; w.ldo2 = g_cat2.ld2;
       }
       GtProfScope pk__(GT_PROF_GEMM_KERNEL, w3t ? "k_lin3[dx]" : "k_lin32[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
-      if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
+      if (w3t && w3r_ok(y_dtype, x_dtype, w)) w3r_launch(stream, w);
+      else if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
       else w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {

@@ -42,6 +42,7 @@ struct L32Args {
   int ncb;             // column blocks of NT n-tiles
   const void* w3;      // linear3x.h: the bf16x3 image of the weight (k_lin3), w is unused then
   int w3_ntp;          // its 16-row tiles per plane and k-step
+  int ntb;             // k_lin3r (linear3r.h): n-tiles per column block
   // k_lin3 only -- the JK = "cat" concatenation without a copy (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105):
   const void* a2;      // contraction columns [a_split, Kc) of the row operand come from this matrix (pitch lda2); null = none
   int64_t a_split, lda2;

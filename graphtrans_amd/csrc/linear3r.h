@@ -1,0 +1,305 @@
+// linear3r.h — k_lin3r: the bf16x6 GEMM (linear3x.h) with the ROW operand straight from global memory into MFMA fragments.
+// Included by linear.hip inside its anonymous namespace, after linear3x.h (same weight images, same L32Args).
+//
+// The reference op: GCNConv / GINConv's nn.Linear on the node rows (modules/conv.py:44,51) and its input gradient --
+// 31.6 k x 300 x 300 fp32 on Code2, five times per direction and step.
+//
+// Why a second kernel.  k_lin3 stages BOTH operands through the LDS: per 32-deep k-step a 64 x 160 block writes 12 KB of row
+// planes, DMAs 30 KB of weight planes and reads 84 KB of fragments for 240 MFMAs -- the LDS port is as busy as the matrix pipe
+// (15.8 against 15.4 us per CU on the Code2 shape), the row planes cost two barriers per k-step, and with N = 300 cut into two
+// column blocks every activation row is loaded and split twice.  Here
+//   * the activation rows never touch the LDS: lane (n, g) of a wave loads the 8 consecutive fp32 of row n, k-chunk g -- exactly its
+//     MFMA fragment slot -- as two 16-byte global loads (the 4 lane groups of a row cover 128 contiguous bytes), one k-step ahead,
+//     and splits them into the three bf16 planes in registers;
+//   * a block is 128 rows x ALL columns (<= 20 n-tiles): 8 waves = 4 row groups x 2 column halves, wave = 32 rows x NTW n-tiles
+//     (2 x NTW accumulator tiles: 80 VGPRs at NTW = 10, two waves per SIMD); the two column-half waves of a row group load the same
+//     rows (the second from L1);
+//   * only the weight planes live in the LDS: 3 x 2 NTW KB per k-step by LDS-DMA (global_load_lds_dwordx4, the image's tile order is
+//     the LDS order), two stages, ONE barrier per k-step, the next stage's DMA and row loads in flight under the whole k-step's
+//     120 MFMAs per wave;
+//   * LDS traffic per MFMA falls from 0.35 KB (k_lin3) to 0.25 KB and nothing is written by ds_write: 1 824 LDS cycles against
+//     3 648 matrix-pipe cycles per k-step and CU;
+//   * the epilogue stores straight from the accumulators: lane (n, g) owns 4 consecutive columns of row n per tile (16-byte stores,
+//     64 contiguous bytes per row and tile), bias / ReLU / two addends on the way.
+// Covered: fp32 rows in and out, no gate / dropout / GELU / row maps / LayerNorm epilogue / virtual concatenation (those keep k_lin3),
+// 8 < n-tiles per column block <= 20, M >= W3R_MIN_M (the grid is ceil(M / 128) x column blocks: below ~16 k rows k_lin3's 64-row
+// blocks fill the chip better).
+#pragma once
+
+#ifndef W3R_ABL
+#define W3R_ABL 0   // ablation mask of tools/gemm3r_probe (1 no DMA, 2 no row loads, 4 no MFMA, 8 no stores); 0 in the library
+#endif
+
+constexpr int64_t W3R_MIN_M = 12288;
+
+template <int NTW, int CH>
+__global__ void __launch_bounds__(256 * CH, CH) k_lin3r(L32Args a) {
+  constexpr int NTB = CH * NTW;               // n-tiles per LDS stage and plane
+  constexpr int NWV = 4 * CH;                 // waves: 4 row groups x CH column parts
+  constexpr int WSTAGE = 3 * NTB * 1024;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3r[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int rg = wid / CH, ch = wid % CH;
+  const int cb = blockIdx.y;
+  const int64_t m0 = (int64_t)blockIdx.x * 128 + rg * 32;
+  const int tile0 = cb * a.ntb;                                   // first image tile of this column block
+  const int ntl = a.w3_ntp - tile0 < NTB ? a.w3_ntp - tile0 : NTB;   // tiles the image holds for this stage (the rest of the stage is never stored from)
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(a.w3) + (int64_t)tile0 * 1024 + lane * 16;
+  const int64_t plane_stride = (int64_t)a.w3_ntp * 1024;
+
+  // ---- row operand: rows m0 + i*16 + n, floats [ks*32 + g*8, +8) ------------------------------------------------------------
+  const float* arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int64_t r = m0 + i * 16 + n;
+    r = r < a.M ? r : a.M - 1;
+    arow[i] = reinterpret_cast<const float*>(a.a) + r * a.lda;
+  }
+  float4 raw[2][2];
+  bool z0 = false, z1 = false;
+  auto load_rows = [&](int ks) {
+    const int64_t k = (int64_t)ks * 32 + g * 8;
+    z0 = k + 4 > a.Kc;
+    z1 = k + 8 > a.Kc;
+    const int64_t k0c = z0 ? a.Kc - 4 : k, k1c = z1 ? a.Kc - 4 : k + 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (W3R_ABL & 32) {   // (probe only: the same bytes per wave, lane-linear)
+        const float* base = reinterpret_cast<const float*>(a.a) + (m0 + i * 16 + (lane >> 3)) * a.lda + ks * 32 + (lane & 7) * 4;
+        raw[i][0] = *reinterpret_cast<const float4*>(base);
+        raw[i][1] = *reinterpret_cast<const float4*>(base + 8 * a.lda);
+      } else {
+        raw[i][0] = *reinterpret_cast<const float4*>(arow[i] + k0c);
+        raw[i][1] = *reinterpret_cast<const float4*>(arow[i] + k1c);
+      }
+    }
+  };
+  // planes of the current k-step (fa) and of the next one (fn) as 32-bit words: word e of plane p of row tile i = k-pair e of the chunk
+  uint32_t fa[2][3][4], fn[2][3][4];
+  auto split_pair = [&](uint32_t (&dst)[2][3][4], int i, int e) {   // k-pair e (0..3) of row tile i
+    const float4 u = e < 2 ? raw[i][0] : raw[i][1];
+    const bool z = e < 2 ? z0 : z1;
+    const float lo = z ? 0.f : ((e & 1) ? u.z : u.x), hi = z ? 0.f : ((e & 1) ? u.w : u.y);
+    w3_split_pair(lo, hi, dst[i][0][e], dst[i][1][e], dst[i][2][e]);
+  };
+  auto frag = [&](const uint32_t (&src)[2][3][4], int i, int p) {
+    return __builtin_bit_cast(bf16x8_t, make_uint4(src[i][p][0], src[i][p][1], src[i][p][2], src[i][p][3]));
+  };
+  // ---- weight planes: piece i = plane i / NTB, tile i % NTB -> LDS offset i KB of the stage; wave w takes pieces w, w + 8, ...
+  // Branch-free (the pieces are issued BETWEEN the MFMAs of a k-step, one basic block): a piece index past the stage's last one
+  // repeats the last piece (same bytes to the same place), a tile past the image's last one repeats the last tile (never stored from).
+  constexpr int NPIECE = (3 * NTB + NWV - 1) / NWV;   // per wave and k-step
+  auto dma_piece = [&](int ks, int buf, int q) {
+    const unsigned char* src = img + (int64_t)ks * 3 * plane_stride;
+    unsigned char* dstb = smem3r + buf * WSTAGE;
+    int i = q * NWV + wid;
+    i = i < 3 * NTB ? i : 3 * NTB - 1;
+    const int p = i / NTB, j = i % NTB;
+    const int js = j < ntl ? j : ntl - 1;
+    __builtin_amdgcn_global_load_lds((w3_glb_void*)(src + p * plane_stride + (int64_t)js * 1024), (w3_lds_void*)(dstb + i * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[2][NTW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nks = (int)((a.Kc + 31) / 32);
+  const int swz = ((g ^ (n >> 1)) & 3) << 4;
+  constexpr int NP = NTW / 2;   // tile pairs per wave
+
+  // One k-step = NP tile pairs x 24 MFMAs (6 products x 2 tiles x 2 row tiles), issued in groups of four.  The side work is placed BY
+  // HAND between the groups and fenced (sched_barrier): hipcc's scheduler otherwise reads a pair's fragments right in front of its
+  // MFMAs and waits for them, and issues the DMA pieces and the split in clumps during which the matrix pipe idles.
+  //   * in front of group q (0..5) of pair p: fragment read q of pair p + 1 (one ds_read_b128);
+  //   * MORE (a next stage exists): `raw` holds the NEXT k-step's rows, loaded during the previous k-step and complete since its
+  //     closing barrier (vmcnt(0)).  They are split FIRST -- 8 k-pairs of ~13 VALU instructions in front of groups 0, 2, 3, 5 of
+  //     pairs 0 and 1: hipcc guards the first use of a loaded register with s_waitcnt vmcnt(0), which costs nothing here and would
+  //     wait for every LDS-DMA piece in flight anywhere later in the k-step (measured: +0.9 us per k-step) --, then the rows of
+  //     k-step + 2 are loaded into the same registers (clamped to the last k-step: branch-free), and the DMA pieces of the next
+  //     stage ride in front of groups 1 and 4 from pair 0 on (an LDS-DMA piece costs 60-180 issue cycles: never two in a row).
+  auto kstep = [&](int ks, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    // (all four row loads are complete here; told to hipcc's wait-count pass in one piece -- it would otherwise place a vmcnt(0) in
+    // front of the second row tile's split, behind the first DMA piece)
+    if constexpr (MORE) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    const unsigned char* sW = smem3r + (ks & 1) * WSTAGE + (ch * NTW) * 1024 + n * 64 + swz;
+    bf16x8_t fw[2][2][3];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fw[0][jj][p] = *reinterpret_cast<const bf16x8_t*>(sW + (p * NTB + jj) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int cur = pr & 1, jp = 2 * pr;
+      // the six products, small terms first; each group touches the pair's 4 accumulators once
+      constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (pr + 1 < NP) fw[cur ^ 1][t / 3][t % 3] = *reinterpret_cast<const bf16x8_t*>(sW + ((t % 3) * NTB + jp + 2 + t / 3) * 1024);
+        if constexpr (MORE) {
+          if (pr < 2 && t != 1 && t != 4 && !(W3R_ABL & 16)) {
+            const int e8 = pr * 4 + (t == 0 ? 0 : t == 2 ? 1 : t == 3 ? 2 : 3);   // 0..7
+            split_pair(fn, e8 >> 2, e8 & 3);
+          }
+          if constexpr (!(W3R_ABL & 2)) {
+            if (pr == 2 && t == 0) load_rows(ks + 2 < nks ? ks + 2 : nks - 1);
+          }
+        }
+        if constexpr (MORE && !(W3R_ABL & 1)) {
+          if ((t == 1 || t == 4) && 2 * pr + (t == 4 ? 1 : 0) < NPIECE) dma_piece(ks + 1, (ks + 1) & 1, 2 * pr + (t == 4 ? 1 : 0));
+          if (pr == NP - 1 && t == 2) {   // (more pieces than 2 per pair: the rest here)
+#pragma unroll
+            for (int q = 2 * NP; q < NPIECE; ++q) dma_piece(ks + 1, (ks + 1) & 1, q);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (W3R_ABL & 4) acc[i][jp + jj][0] += __builtin_bit_cast(f32x4, fw[cur][jj][PW[t]])[0] * __builtin_bit_cast(f32x4, frag(fa, i, PA[t]))[0];
+            else acc[i][jp + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][jj][PW[t]], frag(fa, i, PA[t]), acc[i][jp + jj], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (MORE) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[i][p][e] = (W3R_ABL & 16) ? (fa[i][p][e] ^ __float_as_uint(raw[i][e & 1].x)) : fn[i][p][e];
+      __syncthreads();   // every wave has read stage ks & 1 and sees all of stage (ks + 1) & 1 (each wave waited for its own pieces)
+    }
+  };
+
+  if constexpr (!(W3R_ABL & 1)) {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) dma_piece(0, 0, q);
+  }
+  if constexpr (!(W3R_ABL & 2)) load_rows(0);
+  else { raw[0][0] = raw[0][1] = raw[1][0] = raw[1][1] = make_float4(1.f, 2.f, 3.f, 4.f); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_pair(fa, i, e);
+  if constexpr (!(W3R_ABL & 2)) load_rows(nks > 1 ? 1 : 0);
+  __syncthreads();   // (vmcnt(0) + barrier) the first stage's tiles of every wave are visible
+  for (int ks = 0; ks + 1 < nks; ++ks) kstep(ks, std::true_type{});
+  kstep(nks - 1, std::false_type{});
+
+  // ---- epilogue: acc[i][j][r] = C[row m0 + i*16 + n][column (tile0 + ch*NTW + j)*16 + g*4 + r] -------------------------------
+  // (loads in batches, addresses clamped instead of branched around: a branch per tile serialises its load behind a wait)
+  float* out = reinterpret_cast<float*>(a.out);
+  const float* add1 = reinterpret_cast<const float*>(a.add1);
+  const float* add2 = reinterpret_cast<const float*>(a.add2);
+  int64_t colv[NTW];
+  bool okc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int64_t col = (int64_t)(tile0 + ch * NTW + j) * 16 + g * 4;
+    okc[j] = ch * NTW + j < a.ntb && col < a.Nout;
+    colv[j] = okc[j] ? col : 0;
+  }
+  float4 bv[NTW];
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bv[j] = *reinterpret_cast<const float4*>(a.bias + colv[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + i * 16 + n;
+    const bool okm = m < a.M;
+    const int64_t mc = okm ? m : a.M - 1;
+    float4 v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      v[j] = gt_add4(make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]), bv[j]);
+      if (a.act == 1) v[j] = gt_relu4(v[j]);
+    }
+    if (add1) {
+      float4 e[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) e[j] = *reinterpret_cast<const float4*>(add1 + mc * a.ldo + colv[j]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) v[j] = gt_add4(v[j], e[j]);
+    }
+    if (add2) {
+      float4 e[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) e[j] = *reinterpret_cast<const float4*>(add2 + mc * a.ldo + colv[j]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) v[j] = gt_add4(v[j], e[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (okm && okc[j]) {
+        if constexpr (!(W3R_ABL & 8)) *reinterpret_cast<float4*>(out + m * a.ldo + colv[j]) = v[j];
+        else if (v[j].x == 12345.678f) *reinterpret_cast<float4*>(out + m * a.ldo + colv[j]) = v[j];
+      }
+    }
+  }
+}
+
+template <int NTW, int CH>
+void w3r_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
+  constexpr int LDS = 2 * 3 * CH * NTW * 1024;
+  static std::mutex mu;   // per instantiation: the > 64 KB dynamic-LDS opt-in is set once per device
+  static bool done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+      (void)hipFuncSetAttribute((const void*)(k_lin3r<NTW, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((k_lin3r<NTW, CH>), grid, dim3(256 * CH), LDS, stream, a);
+}
+
+// column blocks of the register-row kernel: as few as hold <= 20 tiles each; 0 = the shape is not covered
+static inline int w3r_ncb(int64_t Nout) {
+  const int64_t tiles = gt_cdiv(Nout, 16);
+  const int ncb = (int)gt_cdiv(tiles, 20);
+  const int64_t ntb = gt_cdiv(tiles, ncb);
+  return ntb > 8 ? ncb : 0;
+}
+
+static inline bool w3r_enabled() {
+  static const bool on = [] { const char* e = getenv("GT_LIN3R"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return on;
+}
+
+// the register-row kernel takes the call (MASK callers pass amask == null for an ungated dX)
+static inline bool w3r_ok(int ta, int to, const L32Args& a) {
+  if (!w3r_enabled() || ta != GT_F32 || to != GT_F32 || !a.w3) return false;
+  if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out || a.bn_part) return false;
+  if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias) & 15) != 0) return false;
+  if (a.M < W3R_MIN_M || a.Nout % 4 || a.Kc % 4 || a.Kc < 4 || a.lda % 4 || a.ldo % 4) return false;
+  return w3r_ncb(a.Nout) > 0;
+}
+
+static inline void w3r_launch(hipStream_t stream, L32Args& a) {
+  const int64_t tiles = gt_cdiv(a.Nout, 16);
+  a.ncb = w3r_ncb(a.Nout);
+  a.ntb = (int)gt_cdiv(tiles, a.ncb);
+  a.w3_ntp = (int)w3_ntp(a.Nout);
+  dim3 grid((unsigned)gt_cdiv(a.M, 128), (unsigned)a.ncb);
+#if defined(W3R_CH) && W3R_CH == 1   // (probe only: one wave per SIMD, every wave all columns -- measured slower, 43.8 against 39.8 us)
+  if (a.ntb > 16) w3r_launch_one<20, 1>(grid, stream, a);
+  else w3r_launch_one<16, 1>(grid, stream, a);
+#else
+  if (a.ntb > 16) w3r_launch_one<10, 2>(grid, stream, a);
+  else w3r_launch_one<8, 2>(grid, stream, a);
+#endif
+}
