@@ -102,6 +102,8 @@ SIGNATURES = {
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
     "gt_bn_sync_set": (_i, [_p, _p, _i]),
+    "gt_bn_coop_slots": (_i, [_p, _i]),
+    "gt_bn_coop_set": (_i, [_i]),
     "gt_linear_cat2_ok": (_i, [_i, _p, _i64, _i64, _i64, _i64]),
     "gt_linear_fwd_cat2": (_i, [_i, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p]),
     "gt_linear_bwd_cat2": (_i, [_i, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),

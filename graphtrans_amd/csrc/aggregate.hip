@@ -538,6 +538,15 @@ __global__ void __launch_bounds__(RED_WAVES * 64) k_agg_reduce(ReduceArgs r) {
     const float* p = r.partial + (int64_t)slot * r.D + c;
     const int64_t stride = (int64_t)r.nslots * r.D;
     int b = wid;
+    // (32 loads in flight first: the ~1000 partial rows of a Code2 backward are 126 per thread -- 4 round trips instead of 16;
+    // 40 -> ~12 us for the 20-block launch, which runs beside the dX GEMM on the overlap stream and took CU time from it)
+    for (; b + 31 * RED_WAVES < r.nblocks; b += 32 * RED_WAVES) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = p[(int64_t)(b + RED_WAVES * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc[u & 7] += v[u];
+    }
     for (; b + 7 * RED_WAVES < r.nblocks; b += 8 * RED_WAVES) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(b + RED_WAVES * u) * stride];

@@ -1340,7 +1340,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3));
         {
           GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-          if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
+          if (w3r_dw_ok(y_dtype, x_dtype, d)) w3r_launch_dw(grid3, stream, d);   // stages pipelined (linear3r.h)
+          else if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
           else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
           dw_reduce(stream, deferred, part3, s3, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
         }

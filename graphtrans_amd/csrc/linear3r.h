@@ -303,3 +303,303 @@ static inline void w3r_launch(hipStream_t stream, L32Args& a) {
   else w3r_launch_one<8, 2>(grid, stream, a);
 #endif
 }
+
+#ifndef W3RD_ABL
+#define W3RD_ABL 0   // ablation mask of tools/gemm3r_dw_probe (1 no MFMA, 2 no fragment reads, 4 no split / plane stores, 8 no row loads, 16 no partial stores); 0 in the library
+#endif
+// =====================================================================================================================================
+// k_lin3r_dw — dW[N][K] = dZ^T X, db = colsum(dZ) on the bf16 pipe (bf16x6), the k_lin3_dw tiling with the stages PIPELINED.
+// Reference: the weight gradient of GCNConv / GINConv's nn.Linear and of the encoder's linears in the fp32 mode (modules/conv.py:44,51,
+// modules/transformer_encoder.py:59), M = 31.6 k rows against N x K = 300 x 300 on Code2.
+//
+// k_lin3_dw (linear3x.h) runs a stage as load-wait -> split + ds_write (260 VALU, ~1 000 cycles, matrix pipe idle) -> barrier ->
+// transposed reads + 150 MFMAs (2 400 cycles) -> barrier with ONE wave per SIMD: 75 us in the Code2 step against 15 us of MFMA time,
+// 0.147 of the bf16x6 ceiling with its reduce (BENCH_r04).  Here, same block (160 x 160 outputs x an M range, 4 waves as 2 x 2, wave =
+// 5 x 5 accumulator tiles, 32 rows per stage, planes [m][column] read transposed by ds_read_b64_tr_b16):
+//   * TWO LDS stage buffers (2 x 63 KB): while the MFMAs of stage s read buffer s & 1, the rows of stage s + 1 -- in registers since
+//     the previous stage -- are split and written to the other buffer, one 16-byte chunk (26 VALU + 3 ds_write_b64) in front of every
+//     15th MFMA, placed by hand and fenced (sched_barrier) like k_lin3r's k-step; ONE barrier per stage;
+//   * TWO register sets of raw rows: the loads of stage s + 2 go out at the top of stage s and have the whole stage to land;
+//   * the dZ fragments of n-tile j + 1 are read while the 30 MFMAs of n-tile j run;
+//   * db: every thread's chunks sit in the same columns at every stage -- it keeps their running sums (20 VALU per stage) and the
+//     block folds them once at the end (k-block 0 only), instead of re-reading the planes from the LDS at every stage.
+// fp32 rows only (bf16 token-row gradients keep k_lin3_dw); same partials + fixed-order
+// k_split_reduce, bitwise reproducible.
+// PC: 8 waves, PRODUCER / CONSUMER -- waves 4..7 (one per SIMD) only load, split and store the next stage's planes, waves 0..3 only read
+// fragments and issue MFMAs.  Measured (tools/gemm3r_dw_probe, profiles/r05_probes/gemm3r_dw_ablations.txt): alone on the chip 54.0 us
+// against 55.5 us for the 4-wave form (69 us for k_lin3_dw) -- per 32-row stage the multiplying side alone needs 1.47 us, the staging
+// side alone 1.73 us (the split is ~45 instructions per 16-byte chunk), together 2.75 us: they do not overlap much better from two
+// waves per SIMD than from one.  IN THE TRAINING STEP the 8-wave form is the worse neighbour -- 512 threads x 247 registers + 126 KB
+// of LDS leave a CU nothing for the main stream's kernels: Code2 71.0 k graphs/s against 73.3 k for the 4-wave form (= k_lin3_dw's
+// 73.1-73.6 k: the weight gradients run beside the critical path, their duration does not enter the step).  The 4-wave form ships;
+// GT_LIN3R_DW_PC=1 selects this one.
+template <bool MASK, bool ROWS, bool PC>
+__global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwArgs a) {
+  constexpr int NCH = 5;                                   // 16-byte chunks of a [32][160] fp32 tile per thread: chunk c = tid + 256 i
+  constexpr int STAGE_EL = 6 * W3D_PLANE;                  // bf16 elements of one stage buffer: sZ[3] then sX[3]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3rd[];
+  gt_bf16* sbuf = reinterpret_cast<gt_bf16*>(smem3rd);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool producer = PC && wave >= 4;      // (wave-uniform)
+  const bool stager = !PC || producer;        // this wave loads / splits / stores the planes
+  const bool mather = !PC || !producer;       // this wave reads fragments and issues MFMAs
+  const int tid = (int)threadIdx.x & 255;     // chunk ownership (stagers) and patch ownership (mathers)
+  const int wid = wave & 3;
+  const int n = lane & 15, g = lane >> 4, wn = wid & 1, wk = wid >> 1;
+  int64_t split_;
+  int tile_;
+  {  // XCD-aware: the tiles of one M-split read the same dZ / X rows -> ids 8 apart (same XCD, same L2)
+    const int nt = a.nkb * a.nnb;
+    const int64_t b = blockIdx.x;
+    const int64_t group = b / (8 * nt);
+    const int r = (int)(b % (8 * nt));
+    tile_ = r / 8;
+    split_ = group * 8 + r % 8;
+  }
+  if (split_ >= a.splits) return;
+  const int kb = tile_ % a.nkb, nb = tile_ / a.nkb;
+  const int64_t n0 = (int64_t)nb * W3D_T, k0 = (int64_t)kb * W3D_T;
+  const int64_t mb = split_ * a.m_per_split;
+  const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
+  const float* dY = reinterpret_cast<const float*>(a.dy);
+  const float* Ym = reinterpret_cast<const float*>(a.ymask);
+  const bool has_mask = MASK && Ym != nullptr;
+  const float* X = reinterpret_cast<const float*>(a.x);
+
+  // chunk i of this thread: row cr[i] of the stage, columns cq[i] .. + 3 of the tile (the same at every stage)
+  int cr[NCH], cq[NCH];
+  bool zcol[NCH], xcol[NCH];   // the chunk's columns exist
+  int64_t zoff[NCH], xld[NCH];
+  const float* xsrc[NCH];   // the chunk's X column in row 0 of its matrix (columns [x_split, K) of a virtual concatenation live in x2)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + 256 * i;
+    cr[i] = c / 40;
+    cq[i] = (c % 40) * 4;
+    zcol[i] = n0 + cq[i] < a.N;
+    xcol[i] = k0 + cq[i] < a.K;
+    zoff[i] = (int64_t)cr[i] * a.ldy + (zcol[i] ? n0 + cq[i] : 0);
+    const int64_t col = xcol[i] ? k0 + cq[i] : 0;
+    const bool second = a.x2 && col >= a.x_split;
+    xld[i] = second ? a.ldx2 : a.ldx;
+    xsrc[i] = (second ? reinterpret_cast<const float*>(a.x2) + (col - a.x_split) : X + col) + (int64_t)cr[i] * xld[i];
+  }
+  struct Raw {
+    float4 z[NCH], x[NCH], m[MASK ? NCH : 1];
+    uint32_t none;   // dy_rows: bit i = chunk i's row of dY has no source (zeros)
+  };
+  auto load_stage = [&](Raw& R, int64_t m0) {   // rows m0 + cr[i]; rows past the range clamp to its last row (zeroed at split time)
+    R.none = 0;
+    if constexpr (W3RD_ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { R.z[i] = make_float4(1.f, 2.f, (float)m0, 4.f); R.x[i] = make_float4(4.f, 3.f, 2.f, (float)m0); }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int64_t rowc = m0 + cr[i] < me ? m0 : me - 1 - cr[i];
+      if constexpr (ROWS) {   // dY's rows through the row map: L32DwArgs::dy_rows
+        const int32_t t = a.dy_rows[rowc + cr[i]];
+        if (t < 0) R.none |= 1u << i;
+        R.z[i] = *reinterpret_cast<const float4*>(dY + (int64_t)(t < 0 ? 0 : t) * a.ldy + (zoff[i] - (int64_t)cr[i] * a.ldy));
+      } else
+      R.z[i] = *reinterpret_cast<const float4*>(dY + rowc * a.ldy + zoff[i]);
+      R.x[i] = *reinterpret_cast<const float4*>(xsrc[i] + rowc * xld[i]);
+      if constexpr (MASK) {
+        if (has_mask) R.m[i] = *reinterpret_cast<const float4*>(Ym + rowc * a.ldy + zoff[i]);
+      }
+    }
+  };
+  float4 dbs[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) dbs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // split one chunk of a raw stage into the planes of buffer `buf`: which = 0 dZ chunk i (gated, summed into db), 1 X chunk i
+  auto split_chunk = [&](const Raw& R, int64_t m0, int buf, int which, int i) {
+    gt_bf16* planes = sbuf + buf * STAGE_EL + which * 3 * W3D_PLANE;
+    const bool ok = m0 + cr[i] < me && (which ? xcol[i] : (zcol[i] && !((R.none >> i) & 1u)));
+    float4 v = which ? R.x[i] : R.z[i];
+    if constexpr (MASK) {
+      if (!which && has_mask) {
+        const float4 y = R.m[i];
+        v = make_float4(gt_gate(v.x, y.x, a.inv_keep), gt_gate(v.y, y.y, a.inv_keep), gt_gate(v.z, y.z, a.inv_keep), gt_gate(v.w, y.w, a.inv_keep));
+      }
+    }
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!which) dbs[i] = gt_add4(dbs[i], v);
+    if constexpr (W3RD_ABL & 4) return;
+    uint32_t p1[2], p2[2], p3[2];
+    w3_split_pair(v.x, v.y, p1[0], p2[0], p3[0]);
+    w3_split_pair(v.z, v.w, p1[1], p2[1], p3[1]);
+    gt_bf16* dst = planes + cr[i] * W3D_LD + cq[i];
+    *reinterpret_cast<uint2*>(dst) = make_uint2(p1[0], p1[1]);
+    *reinterpret_cast<uint2*>(dst + W3D_PLANE) = make_uint2(p2[0], p2[1]);
+    *reinterpret_cast<uint2*>(dst + 2 * W3D_PLANE) = make_uint2(p3[0], p3[1]);
+  };
+
+  const int64_t nst = mb < me ? (me - mb + 31) / 32 : 0;
+  const bool want_db = kb == 0 && a.dbpart != nullptr;   // (uniform)
+
+  // ---- the staging side: rows of stage s + 1 split into buffer (s + 1) & 1 while stage s is multiplied --------------------------
+  // PC: the whole life of waves 4..7 (their registers hold raw rows and the db sums, no accumulators); !PC: called chunk by chunk
+  // from between the MFMAs below.
+  auto db_fold = [&]() {   // (every wave of the block passes the two barriers)
+    __syncthreads();
+    float* sdb = reinterpret_cast<float*>(smem3rd);   // [32][160]
+    if (stager) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(sdb + cr[i] * W3D_T + cq[i]) = dbs[i];
+    }
+    __syncthreads();
+    if (stager && tid < W3D_T && n0 + tid < a.N) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) t += sdb[r * W3D_T + tid];
+      a.dbpart[(int64_t)split_ * a.N + n0 + tid] = t;
+    }
+  };
+  if constexpr (PC) {
+    if (producer) {
+      Raw RA;
+      if (nst > 0) {
+        load_stage(RA, mb);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) { split_chunk(RA, mb, 0, 0, i); split_chunk(RA, mb, 0, 1, i); }
+        load_stage(RA, nst > 1 ? mb + 32 : mb);
+      }
+      __syncthreads();
+      for (int64_t s = 0; s < nst; ++s) {
+        const int buf = (int)(s & 1);
+        const int64_t m1 = mb + (s + 1) * 32, m2 = mb + (s + 2) * 32;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {   // (a stage past the range: zeros into the idle buffer)
+          split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 0, i);
+          split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, i);
+        }
+        load_stage(RA, m2 < me ? m2 : (me > 32 ? me - 32 : mb));   // in flight across the barrier: these waves have the time
+        __syncthreads();
+      }
+      if (want_db) db_fold();
+      return;
+    }
+  }
+
+  // ---- the multiplying side ------------------------------------------------------------------------------------------------------
+  f32x4 acc[5][5];   // [n tile j][k tile i]
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Raw RA, RB;   // (!PC) RA: the stage that is split during the current stage; RB: the one after it, in flight
+  if constexpr (!PC) {
+    if (nst > 0) {
+      load_stage(RA, mb);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { split_chunk(RA, mb, 0, 0, i); split_chunk(RA, mb, 0, 1, i); }
+      load_stage(RA, nst > 1 ? mb + 32 : mb);
+    }
+  }
+  __syncthreads();
+  for (int64_t s = 0; s < nst; ++s) {
+    const int buf = (int)(s & 1);
+    const int64_t m1 = mb + (s + 1) * 32, m2 = mb + (s + 2) * 32;
+    if constexpr (!PC) load_stage(RB, m2 < me ? m2 : (me > 32 ? me - 32 : mb));
+    __builtin_amdgcn_sched_barrier(0);
+    const gt_bf16* sZ = sbuf + buf * STAGE_EL;
+    const gt_bf16* sX = sZ + 3 * W3D_PLANE;
+    auto fload = [&](const gt_bf16* pl, int col0) {
+      if constexpr (W3RD_ABL & 2) { Frag<gt_bf16> f; f.v = make_uint4((uint32_t)col0, (uint32_t)s, 3u, (uint32_t)lane); return f; }
+      else return frag_load_tr(pl, W3D_LD, 0, col0, n, g);
+    };
+    Frag<gt_bf16> fx[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fx[i][p] = fload(sX + p * W3D_PLANE, wk * 80 + i * 16);
+    Frag<gt_bf16> fz[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fz[0][p] = fload(sZ + p * W3D_PLANE, wn * 80);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int cur = j & 1;
+      constexpr int PZ[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        // side work in front of this group of 5 MFMAs: the next n-tile's fragments (t < 3); one wave per SIMD (!PC): one chunk of the
+        // next stage's split (t = 1, 4)
+        if (j + 1 < 5 && t < 3) fz[cur ^ 1][t] = fload(sZ + t * W3D_PLANE, wn * 80 + (j + 1) * 16);
+        if constexpr (!PC) {
+          if (t == 1) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 0, j);
+          if (t == 4) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          if constexpr (W3RD_ABL & 1) acc[j][i][0] += __uint_as_float(fz[cur][PZ[t]].v.x) * __uint_as_float(fx[i][PX[t]].v.y);
+          else acc[j][i] = mma(fz[cur][PZ[t]], fx[i][PX[t]], acc[j][i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (!PC) RA = RB;
+    __syncthreads();   // every wave has read buffer `buf` and the next stage's planes are complete in the other one
+  }
+
+  // acc[j][i][r] = C[row n0 + wn*80 + j*16 + g*4 + r][column k0 + wk*80 + i*16 + n] -> per-wave patch [16 n rows][80 k columns]
+  constexpr int PLD = 80 + 4;
+  float* patch = reinterpret_cast<float*>(smem3rd) + wid * 16 * PLD;
+  float* part = a.part + (int64_t)split_ * a.N * a.K;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(g * 4 + r) * PLD + i * 16 + n] = acc[j][i][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {   // 16 rows x 20 chunks = 320 chunks
+      const int c = lane + q * 64;
+      const int r = c / 20, c4 = (c % 20) * 4;
+      const int64_t row = n0 + wn * 80 + j * 16 + r, col = k0 + wk * 80 + c4;
+      if (row < a.N && col < a.K && (!(W3RD_ABL & 16) || patch[r * PLD + c4] == 12345.678f)) *reinterpret_cast<float4*>(part + row * a.K + col) = *reinterpret_cast<const float4*>(patch + r * PLD + c4);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (want_db) db_fold();
+}
+
+static inline bool w3r_dw_enabled() {
+  static const bool on = [] { const char* e = getenv("GT_LIN3R_DW"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return on;
+}
+// the pipelined kernel takes the call: fp32 operands, 16-byte aligned rows
+static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
+  if (!w3r_dw_enabled() || ty != GT_F32 || tx != GT_F32 || (a.dy_rows && a.ymask)) return false;
+  if (a.N % 4 || a.K % 4 || a.ldy % 4 || a.ldx % 4 || (a.x2 && (a.ldx2 % 4 || a.x_split % 4))) return false;
+  return (((uintptr_t)a.dy | (uintptr_t)a.x | (uintptr_t)a.ymask | (uintptr_t)a.x2) & 15) == 0;
+}
+static inline void w3r_launch_dw(dim3 grid, hipStream_t stream, const L32DwArgs& a) {
+  constexpr int LDS = 2 * 6 * W3D_PLANE * 2;
+  static std::mutex mu;
+  static bool done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+  }
+  static const bool one_wave = [] { const char* e = getenv("GT_LIN3R_DW_PC"); return !e || atoi(e) == 0; }();   // (A/B knob; see the kernel's header)
+  if (a.dy_rows) hipLaunchKernelGGL((k_lin3r_dw<false, true, true>), grid, dim3(512), LDS, stream, a);   // (w3r_dw_ok: no gate with a row map)
+  else if (a.ymask) hipLaunchKernelGGL((k_lin3r_dw<true, false, true>), grid, dim3(512), LDS, stream, a);
+  else if (one_wave) hipLaunchKernelGGL((k_lin3r_dw<false, false, false>), grid, dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((k_lin3r_dw<false, false, true>), grid, dim3(512), LDS, stream, a);
+}

@@ -64,6 +64,8 @@ struct Ctx {
   size_t o_h[MAXL + 1], o_x0, o_vn[MAXL], o_vn_saved[MAXL], o_conv_saved[MAXL], o_cat, o_hn, o_tok, o_xin, o_st0, o_xe[MAXL],
       o_enc_saved[MAXL], o_hgin, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
   size_t o_scales, q_dimg;
+  size_t o_coop;   // zeroed barrier slots of the one-launch BatchNorms (gt_bn_coop_slots): n_coop for the forward, n_coop for the backward
+  int n_coop;
   size_t o_graph_ptr, o_node_graph, o_in_ptr, o_out_ptr, o_idx, o_dd, o_status, o_prep_ws, o_lay, o_lay_meta;
   size_t ws_bytes, ws2_bytes, eplan_bytes, esort_ws_bytes, prep_ws_bytes, arena_bytes;
   int cat2, want_wt, esort, late_wait;
@@ -193,6 +195,7 @@ struct BindGuard {   // the bind tables are per host thread: always undone on th
     gt_w1_unbind();
     if (dw) gt_overlap_dw_end();
     if (defer_abort) (void)gt_defer_begin(nullptr, 0);
+    (void)gt_bn_coop_slots(nullptr, 0);
   }
 };
 
@@ -406,6 +409,8 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
     c->prep_ws_bytes = gt_graph_prep_workspace_bytes(N, E, B);
     c->o_prep_ws = a.take(c->prep_ws_bytes);
   }
+  c->n_coop = training ? 2 * L + 2 : 0;   // (GIN: two BatchNorms per layer)
+  c->o_coop = a.take((size_t)2 * c->n_coop * 64);
   if (c->lay_host) c->o_lay = a.take(c->lay_bytes);
   if (c->build_layout_dev) {
     const size_t nd = (size_t)B * 16, nl = (size_t)B * 8, nw = (size_t)std::max<int64_t>(c->num_work, 1) * 8;
@@ -504,6 +509,10 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   auto P = [&](size_t off) -> void* { return base + off; };
   BindGuard guard;
   GT_TRY(bind_images(m, c));
+  if (c->n_coop) {   // one clear per step for the grid barriers of every BatchNorm launch, forward and backward
+    if (hipMemsetAsync(P(c->o_coop), 0, (size_t)2 * c->n_coop * 64, (hipStream_t)st) != hipSuccess) { gt_set_error("gt_model_forward: clear failed"); return GT_ERR_LAUNCH; }
+    GT_TRY(gt_bn_coop_slots(P(c->o_coop), c->n_coop));
+  }
 
   // ---- graph structure (gt_graph_prep) beside the first kernels, on the prep stream
   gt_stream_t pst = c->use_prep ? m->st_prep : st;
@@ -895,6 +904,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     // ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l from its consumers other than
     // conv_l: the JK slab (l = 0) and the virtual-node update's pooling (l < L-1)
     void* dy = c->dy;
+    if (c->n_coop) GT_TRY(gt_bn_coop_slots((char*)P(c->o_coop) + (size_t)c->n_coop * 64, c->n_coop));
     if (!c->cat2 && m->jk_cat) {
       GT_TRY(gt_copy2d(Q(c->q_dA), D * 4, (char*)Q(c->q_d_rep) + D * 4, Kc * 4, D * 4, N, st));   // d h_list[-1]
       GT_TRY(gt_copy2d(Q(c->q_dJ), D * 4, Q(c->q_d_rep), Kc * 4, D * 4, N, st));                   // d h_list[0]

@@ -376,6 +376,15 @@ int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float
  * on `stream` (stream-ordered, no host sync required); returns 0 or an error.  The collective itself is the caller's. */
 typedef int (*gt_bn_sync_fn)(void* user, int kind, float* buf, int64_t n, gt_stream_t stream);
 int gt_bn_sync_set(gt_bn_sync_fn fn, void* user, int world);
+/* Training-mode BatchNorm over more than 1024 fp32 rows runs as ONE launch per direction (statistics, a grid-wide barrier, apply;
+ * csrc/norm_coop.h; replaces the three launches behind modules/gnn_module.py:84,204 and modules/conv.py:19).  The barrier's counter
+ * must be zero at launch: a per-thread pool of `n` zeroed 64-byte slots (64-byte aligned device memory, cleared by the caller --
+ * gt_model_forward clears one pool per step) serves the calls of this host thread in order; without a pool, or when it is used up,
+ * a call clears its own counter (one small memset in front of the launch).  slots = NULL drops the pool.  GT_BN_COOP=0 in the
+ * environment keeps the three-launch scheme. */
+int gt_bn_coop_slots(void* slots, int n);
+/* the scheme's process-wide switch: 1 on, 0 off (three launches), -1 = the environment's choice; returns the previous setting */
+int gt_bn_coop_set(int on);
 /* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
  * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
  * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */

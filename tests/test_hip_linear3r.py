@@ -86,3 +86,35 @@ def test_rows_past_m_and_columns_past_n_are_not_written():
     torch.cuda.synchronize()
     assert bool((wide[:, N:] == 7.0).all())
     assert float((wide[:, :N] - y64).abs().max()) <= 1e-4 * max(1.0, float(y64.abs().max()))
+
+
+DW_SHAPES = [(31598, 300, 300), (31598, 384, 128), (31598, 128, 512), (6700, 600, 300), (1500, 20, 132), (12289, 132, 68), (33, 300, 300)]
+
+
+@pytest.mark.parametrize("M,N,K", DW_SHAPES, ids=[f"{m}x{n}x{k}" for m, n, k in DW_SHAPES])
+def test_pipelined_weight_gradient(M, N, K):
+    """k_lin3r_dw (the stages of k_lin3_dw pipelined: two LDS buffers, the split of the next stage between the MFMAs of this one, db from
+    running column sums) without and with a ReLU gate + keep scale, against float64; bitwise reproducible"""
+    from graphtrans_amd.w3 import W3Images
+    from test_hip_linear3x import bwd_all
+    torch.manual_seed(M + 7 * N + K)
+    x = torch.randn(M, K, device=DEV) * (0.5 + torch.rand(M, 1, device=DEV))
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    w64, b64 = dy.double().t() @ x.double(), dy.double().sum(0)
+    wt, bt = dy.t() @ x, dy.sum(0)
+    _, w3, b3 = bwd_all(x, W, dy, None, imgs)
+    e3, et = rel(w3, w64), rel(wt, w64)
+    print(f"\ndW {M}x{N}x{K}: pipelined bf16x6 {e3:.2e}  torch fp32 {et:.2e};  db {rel(b3, b64):.2e} / {rel(bt, b64):.2e}")
+    assert e3 <= max(3 * et, 1e-6), (e3, et)
+    assert rel(b3, b64) <= max(3 * rel(bt, b64), 1e-6)
+    _, w3b, b3b = bwd_all(x, W, dy, None, imgs)
+    assert torch.equal(w3, w3b) and torch.equal(b3, b3b)
+    yf = torch.relu(torch.randn(M, N, device=DEV))
+    dz = (dy.double() * (yf > 0)) / 0.8
+    _, w3, b3 = bwd_all(x, W, dy, yf, imgs, p=0.2)
+    dzf = (dy * (yf > 0)) / 0.8
+    assert rel(w3, dz.t() @ x.double()) <= max(3 * rel(dzf.t() @ x, dz.t() @ x.double()), 1e-6)
+    assert rel(b3, dz.sum(0)) <= max(3 * rel(dzf.sum(0), dz.sum(0)), 1e-6)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 
 from graphtrans_amd.w3 import W3Images
-from test_hip_linear3x import dx_of, fwd
+from test_hip_linear3x import bwd_all, dx_of, fwd
 
 DEV = "cuda:0"
 
@@ -31,6 +31,8 @@ def timeit(fn, n=100):
 
 def main():
     tag = "k_lin3r" if os.environ.get("GT_LIN3R", "1") != "0" else "k_lin3 "
+    if tag == "k_lin3 ":
+        os.environ["GT_LIN3R_DW"] = "0"
     for M, N, K in [(31598, 300, 300), (131072, 256, 256), (16000, 272, 272), (31598, 600, 300), (31598, 300, 600), (12800, 300, 300)]:
         x = torch.randn(M, K, device=DEV)
         W = torch.randn(N, K, device=DEV) / K ** 0.5
@@ -43,10 +45,11 @@ def main():
         t = timeit(lambda: fwd(x, W, b, imgs))
         d = timeit(lambda: dx_of(x, W, dy, None, None, None, imgs))
         da = timeit(lambda: dx_of(x, W, dy, None, a1, None, imgs))
-        print(f"{tag} {M:7d} x {N:4d} x {K:4d}: fwd {t:6.1f} us ({fl / t / 1e6:6.1f} TF, {fl / t / 1e6 / 416.7:.3f} of bf16x6)  dX {d:6.1f} us  dX+addend {da:6.1f} us", flush=True)
+        dwt = timeit(lambda: bwd_all(x, W, dy, None, imgs), n=50)   # dX + dW + db + reduce
+        print(f"{tag} {M:7d} x {N:4d} x {K:4d}: fwd {t:6.1f} us ({fl / t / 1e6:6.1f} TF, {fl / t / 1e6 / 416.7:.3f} of bf16x6)  dX {d:6.1f} us  dX+addend {da:6.1f} us  dX+dW+db+reduce {dwt:6.1f} us (dW part ~{dwt - d:5.1f}, {fl / max(dwt - d, 1e-3) / 1e6 / 416.7:.3f})", flush=True)
 
 
 if __name__ == "__main__":
     main()
     if os.environ.get("GT_LIN3R") is None:
-        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GT_LIN3R="0"))
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GT_LIN3R="0", GT_LIN3R_DW="0"))

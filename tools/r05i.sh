@@ -1,0 +1,20 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05i; O=gpurun_out/r05i
+run() { n=$1; shift; e=$1; shift
+  env $e timeout 300 python bench.py --no-cpu-baseline --no-extra --no-kernel-timing --steps 100 "$@" > $O/$n.json 2>/dev/null
+  python -c "
+import json
+d=json.load(open('$O/$n.json')); print('$n', d['value'], d['ms_per_step'], d.get('host_enqueue_ms_per_step'))"
+}
+for i in 1 2; do
+run code2_new "GT_X=1"
+run code2_dw_old "GT_LIN3R_DW=0"
+run code2_dw_pc0 "GT_LIN3R_DW_PC=0"
+done
+run code2_fp32_new "GT_X=1" --mode fp32
+run code2_fp32_dw_old "GT_LIN3R_DW=0" --mode fp32
+run molpcba_new "GT_X=1" --workload molpcba
+run molpcba_dw_old "GT_LIN3R_DW=0" --workload molpcba
+run er_new "GT_X=1" --workload er --steps 30
+run er_dw_old "GT_LIN3R_DW=0" --workload er --steps 30
+timeout 1500 python -m pytest tests/test_hip_engine.py tests/test_hip_configs.py tests/test_hip_parity.py tests/test_hip_linear.py tests/test_hip_pna.py tests/test_hip_dp.py -x -q > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log
+tail -n 4 $O/tests.log
