@@ -104,6 +104,9 @@ SIGNATURES = {
     "gt_bn_sync_set": (_i, [_p, _p, _i]),
     "gt_bn_coop_slots": (_i, [_p, _i]),
     "gt_bn_coop_set": (_i, [_i]),
+    "gt_vn_update_bwd_dt0": (_p, [_p, _p]),
+    "gt_linear_bwd_bcast_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
+    "gt_linear_bwd_bcast": (_i, [_p, _p]),
     "gt_linear_cat2_ok": (_i, [_i, _p, _i64, _i64, _i64, _i64]),
     "gt_linear_fwd_cat2": (_i, [_i, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p]),
     "gt_linear_bwd_cat2": (_i, [_i, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),

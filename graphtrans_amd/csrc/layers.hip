@@ -506,7 +506,7 @@ extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void
 extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, const void* saved, const void* d_x_add,
                                 void* d_x, void* d_vn, float* grads, void* workspace, size_t workspace_bytes,
                                 gt_stream_t st) {
-  GT_CHECK_ARG(L && d_vn_out && saved && d_x && d_vn && grads && workspace, "null buffer");
+  GT_CHECK_ARG(L && d_vn_out && saved && d_vn && grads && workspace, "null buffer");   // d_x == NULL: see gt_vn_update_bwd_dt0
   const VnWork w = vn_work(L, workspace);
   if (workspace_bytes < w.bytes) { gt_set_error("gt_vn_update_bwd: workspace too small"); return GT_ERR_WORKSPACE; }
   const VnSaved s = vn_saved(L, const_cast<void*>(saved));
@@ -525,7 +525,7 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, defer ? nullptr : g.w1,
                        defer ? nullptr : g.b1, B, 2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   // d_x[n] = d_t0[graph(n)] (+ d_x_add[n]: gradient reaching x from its other consumers)
-  GT_TRY(gt_segment_bcast_add(GT_F32, d_x_add, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
+  if (d_x) GT_TRY(gt_segment_bcast_add(GT_F32, d_x_add, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
   if (L->residual)
     GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
   else
@@ -538,6 +538,13 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
                          2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   }
   return GT_OK;
+}
+
+// d_t0 [B][D] inside the workspace of a gt_vn_update_bwd call: with d_x == NULL that call does not broadcast d_t0 over the nodes
+// (an N x D pass) -- the caller adds d_t0[node_graph[n]] where d_x is consumed (gt_linear_bwd_bcast: the dX GEMM's epilogue).
+extern "C" const float* gt_vn_update_bwd_dt0(const gt_vn_update* L, void* workspace) {
+  if (!L || !workspace) return nullptr;
+  return (const float*)vn_work(L, workspace).d_t0;
 }
 
 // =================================================================================================

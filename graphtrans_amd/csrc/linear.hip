@@ -1109,6 +1109,8 @@ struct BwdCallOpts {
   const float* weight_t = nullptr;   // W^T [K][N] prepared by the caller (gt_linear_bwd_wt): no transpose launch
   BnStatsReq bns;                    // set by gt_linear_bwd_bnstats BEFORE the call it applies to
   bool gate_out = false;             // y_for_mask [M][ldx] gates the dX OUTPUT (gt_linear_bwd_gate_out), dY is used as it is
+  const float* bcast = nullptr;      // dX += bcast[bcast_idx[row]] (gt_linear_bwd_bcast), set BEFORE the call it applies to
+  const int32_t* bcast_idx = nullptr;
 };
 thread_local BwdCallOpts g_opt;
 struct BwdOptScope {   // whatever was set is dropped when the call it was meant for returns
@@ -1136,6 +1138,24 @@ extern "C" int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float
   GT_CHECK_ARG(bn_x && mean && rstd && w && b && part && ldx > 0, "null buffer");
   BnStatsReq& q = g_opt.bns;
   q.x = bn_x; q.ldx = ldx; q.mean = mean; q.rstd = rstd; q.w = w; q.b = b; q.relu = relu; q.part = part;
+  return GT_OK;
+}
+
+// The dX of the NEXT gt_linear_bwd* call on this thread gets a broadcast addend: dx[m] += rows[idx[m]] (rows [.][K] fp32, pitch = the
+// dX pitch; idx int32 [M]) -- the gradient that reaches every node of a graph from the virtual-node update, d_t0[batch[m]]
+// (modules/gnn_module.py:219), added in the dX GEMM's epilogue instead of being written out per node first.  Only the kernel with
+// the rows in registers does this (csrc/linear3r.h): ask gt_linear_bwd_bcast_ok first; the request is dropped after the next call.
+extern "C" int gt_linear_bwd_bcast_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
+  if (!w32_eligible(compute, x_dtype, M, 1) || x_dtype != GT_F32 || y_dtype != GT_F32 || !w3_lookup(weight, N, K, true)) return 0;
+  L32Args w{};
+  w.w3 = w3_lookup(weight, N, K, true);
+  w.M = M; w.Nout = K; w.Kc = N; w.lda = N; w.ldo = K;
+  return w3r_ok(GT_F32, GT_F32, w) ? 1 : 0;
+}
+extern "C" int gt_linear_bwd_bcast(const float* rows, const int32_t* idx) {
+  GT_CHECK_ARG((rows == nullptr) == (idx == nullptr), "rows and idx go together");
+  g_opt.bcast = rows;
+  g_opt.bcast_idx = idx;
   return GT_OK;
 }
 
@@ -1202,6 +1222,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
   BwdOptScope opt_scope__;   // the per-call options live for exactly this call
+  if (g_opt.bcast && dx && !gt_linear_bwd_bcast_ok(compute, x_dtype, y_dtype, weight, M, N, K)) {
+    gt_set_error("gt_linear_bwd_bcast: this call does not run on the register-row kernel (ask gt_linear_bwd_bcast_ok)");
+    return GT_ERR_UNSUPPORTED;
+  }
   const RowsTake rows__;
   GT_CHECK_ARG(!rows__.rows || (groups == 1 && !y_for_mask && !g_opt.bns.part && !rows__.ln.out && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)),
                "gt_linear_set_rows: this GEMM does not take a row map (ask gt_linear_rows_ok)");
@@ -1299,6 +1323,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         w.bn_relu = q.relu; w.bn_part = q.part;
       }
       w.w3 = w3t;
+      if (g_opt.bcast) {
+        w.add_bc = g_opt.bcast; w.add_bidx = g_opt.bcast_idx;
+        if (!w3t || !w3r_ok(y_dtype, x_dtype, w)) { gt_set_error("gt_linear_bwd_bcast: this call does not run on the register-row kernel (ask gt_linear_bwd_bcast_ok)"); return GT_ERR_UNSUPPORTED; }
+      }
       if (rows__.rows) {
         if (!w3t) { gt_set_error("gt_linear_set_rows: needs the bound image of W^T"); return GT_ERR_UNSUPPORTED; }
         w.a_rows = rows__.rows;

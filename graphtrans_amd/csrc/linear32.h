@@ -43,6 +43,10 @@ struct L32Args {
   const void* w3;      // linear3x.h: the bf16x3 image of the weight (k_lin3), w is unused then
   int w3_ntp;          // its 16-row tiles per plane and k-step
   int ntb;             // k_lin3r (linear3r.h): n-tiles per column block
+  // k_lin3r dX form only -- a BROADCAST addend: out[m] += add_bc[add_bidx[m]] (the virtual-node update's gradient d_t0[graph of node m],
+  // modules/gnn_module.py:219 backward, without materialising it per node): rows [.][ldo] fp32, int32 index per GEMM row
+  const float* add_bc;
+  const int32_t* add_bidx;
   // k_lin3 only -- the JK = "cat" concatenation without a copy (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105):
   const void* a2;      // contraction columns [a_split, Kc) of the row operand come from this matrix (pitch lda2); null = none
   int64_t a_split, lda2;

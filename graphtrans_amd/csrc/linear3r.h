@@ -240,6 +240,14 @@ __global__ void __launch_bounds__(256 * CH, CH) k_lin3r(L32Args a) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) v[j] = gt_add4(v[j], e[j]);
     }
+    if (a.add_bc) {   // + add_bc[add_bidx[row]]: a few hundred distinct rows, L2-resident
+      const float* bc = a.add_bc + (int64_t)a.add_bidx[mc] * a.ldo;
+      float4 e[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) e[j] = *reinterpret_cast<const float4*>(bc + colv[j]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) v[j] = gt_add4(v[j], e[j]);
+    }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       if (okm && okc[j]) {
@@ -284,7 +292,7 @@ static inline bool w3r_enabled() {
 static inline bool w3r_ok(int ta, int to, const L32Args& a) {
   if (!w3r_enabled() || ta != GT_F32 || to != GT_F32 || !a.w3) return false;
   if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out || a.bn_part) return false;
-  if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias) & 15) != 0) return false;
+  if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias | (uintptr_t)a.add_bc) & 15) != 0) return false;
   if (a.M < W3R_MIN_M || a.Nout % 4 || a.Kc % 4 || a.Kc < 4 || a.lda % 4 || a.ldo % 4) return false;
   return w3r_ncb(a.Nout) > 0;
 }

@@ -924,17 +924,24 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     for (int l = L - 1; l >= 0; --l) {
       const void* extra = (l == 0 && m->jk_cat) ? Q(c->q_dJ) : nullptr;
       const bool upd = m->has_vn && l < L - 1;
+      const float* dt0 = nullptr;   // the update's gradient per GRAPH, added per node in the dX GEMM's epilogue (no N x D broadcast pass)
       if (upd) {   // vn_{l+1} = update(x_l, vn_l): d x_l = pooled gradient (+ the JK slab at l = 0)
+        static const bool bc_on = [] { const char* e = getenv("GT_VN_BCAST_EPILOGUE"); return !e || atoi(e) != 0; }();   // (A/B knob)
+        const bool bc = bc_on && m->conv == GT_CONV_GCN && gt_linear_bwd_bcast_ok(compute, GT_F32, GT_F32, c->gcn[l].lin_w, N, D, D);
+        void* dxl = bc ? nullptr : Q(c->q_dC);
         if (side) {   // beside layer l's BatchNorm / aggregate backward; joined before its dX GEMM (ev_dx_wait)
           GT_TRY(gt_event_record(m->ev_dvn[l], st));
           GT_TRY(gt_stream_wait_event(side, m->ev_dvn[l]));
-          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, Q(c->q_dC), Q(c->q_dvn[2]), G + m->off_vn[l], Q(c->q_ws2),
+          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, dxl, Q(c->q_dvn[2]), G + m->off_vn[l], Q(c->q_ws2),
                                   c->ws2_bytes, side));
           if (!m->vn_defer_dw) GT_TRY(gt_event_record(m->ev_extra[l], side));
+          if (bc) dt0 = gt_vn_update_bwd_dt0(&c->vn[l], Q(c->q_ws2));
         } else {
-          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, Q(c->q_dC), Q(c->q_dvn[2]), G + m->off_vn[l], W(), ws_bytes, st));
+          void* vws = W();
+          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, dxl, Q(c->q_dvn[2]), G + m->off_vn[l], vws, ws_bytes, st));
+          if (bc) dt0 = gt_vn_update_bwd_dt0(&c->vn[l], vws);
         }
-        extra = Q(c->q_dC);
+        if (!bc) extra = Q(c->q_dC);
       }
       void* out = dy == Q(c->q_dA) ? Q(c->q_dB) : Q(c->q_dA);
       if (l == 0 && ov) gt_overlap_dw_urgent(1);   // layer 0's weight gradients are the last: nothing left to overlap them with
@@ -948,8 +955,10 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
         GT_TRY(gt_pna_layer_bwd(&g, c->xptr[l], dy, conv_saved(l), out, G + m->off_conv[l], W(), ws_bytes, st));
       } else if (m->conv == GT_CONV_GIN)
         GT_TRY(gt_gin_layer_bwd(&c->gin[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
-      else
+      else {
+        if (dt0) GT_TRY(gt_linear_bwd_bcast(dt0, c->node_graph));   // (consumed by the layer's one dX GEMM)
         GT_TRY(gt_gcn_layer_bwd(&c->gcn[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
+      }
       if (m->has_vn) {   // d vn_l = per-graph sum of d x_l (+ update l's pooled + residual inputs): off the main chain
         gt_stream_t vst = pool_on_side ? side : st;
         if (pool_on_side) {

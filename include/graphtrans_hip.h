@@ -487,6 +487,12 @@ int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, int64_t M);
 int64_t gt_linear_bwd_bnstats_rows(int64_t M);
 int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w, const float* b,
                           int relu, float* part);
+/* Broadcast addend of the NEXT gt_linear_bwd* call of this host thread: dx[m] += rows[idx[m]] (rows [.][K] fp32 at the dX pitch,
+ * idx int32 [M]) in the dX GEMM's epilogue -- the virtual-node update's gradient d_t0[batch[m]] (modules/gnn_module.py:219)
+ * without writing it out per node.  Only fp32 GEMMs with M >= 12288 on a bound W^T image take it: ask gt_linear_bwd_bcast_ok
+ * (1 = yes); a call that cannot honour a pending request fails with GT_ERR_UNSUPPORTED.  Dropped after the next call. */
+int gt_linear_bwd_bcast_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K);
+int gt_linear_bwd_bcast(const float* rows, const int32_t* idx);
 /* gt_linear_bwd with W^T [K][N] (fp32, gt_transpose) supplied by the caller, NULL = none: the exact-fp32 dX GEMM runs on the
  * transposed weight and otherwise transposes it in front of every call. */
 int gt_linear_bwd_wt(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const float* weight_t,
@@ -794,6 +800,10 @@ int gt_vn_update_fwd(const gt_vn_update* layer, const void* x, const void* vn, v
 /* d_x [N][D] = d(pooled)[graph(n)] (+ d_x_add [N][D] when not NULL), d_vn [B][D]. */
 int gt_vn_update_bwd(const gt_vn_update* layer, const void* d_vn_out, const void* saved, const void* d_x_add, void* d_x,
                      void* d_vn, float* grads, void* workspace, size_t workspace_bytes, gt_stream_t stream);
+/* d_t0 [B][D] (fp32) inside `workspace` of a gt_vn_update_bwd call.  With d_x == NULL that call skips its broadcast pass
+ * d_x[n] = d_t0[node_graph[n]] (+ d_x_add[n]) over the N node rows; the caller adds the rows where d_x is consumed -- in the
+ * epilogue of the layer's dX GEMM (gt_linear_bwd_bcast).  Valid until the workspace is reused. */
+const float* gt_vn_update_bwd_dt0(const gt_vn_update* L, void* workspace);
 
 /* PNA layer (modules/pna/pna_module.py:57-78 around PyG's PNAConv(towers = T, divide_input = True, no edge features); math stated
  * in-tree by modules/pna_layer.py:131-167, modules/pna/aggregators.py:11-34, modules/pna/scalers.py:10-31):

@@ -118,3 +118,46 @@ def test_pipelined_weight_gradient(M, N, K):
     dzf = (dy * (yf > 0)) / 0.8
     assert rel(w3, dz.t() @ x.double()) <= max(3 * rel(dzf.t() @ x, dz.t() @ x.double()), 1e-6)
     assert rel(b3, dz.sum(0)) <= max(3 * rel(dzf.sum(0), dz.sum(0)), 1e-6)
+
+
+def test_dx_broadcast_addend():
+    """gt_linear_bwd_bcast: dx[m] += rows[idx[m]] in the dX epilogue (the virtual-node update's gradient per graph,
+    modules/gnn_module.py:219 backward) against the materialised addend; a call that cannot take the request fails loudly"""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W3Images
+    L = _lib.lib()
+    torch.manual_seed(21)
+    M, N, K, B = 31598, 300, 300, 256
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV)
+    a1 = torch.randn(M, K, device=DEV)
+    rows = torch.randn(B, K, device=DEV)
+    idx = torch.sort(torch.randint(0, B, (M,), dtype=torch.int32)).values.to(DEV)
+    imgs = W3Images([W])
+    imgs.build()
+    x = torch.empty(M, K, device=DEV)
+    ws_bytes = L.gt_linear_bwd_workspace_bytes(0, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    p = lambda t: None if t is None else t.data_ptr()
+
+    def dx_call(add1, bc, m=M):
+        dx = torch.empty(m, K, device=DEV)
+        if bc:
+            _lib.launch("gt_linear_bwd_bcast", p(rows), p(idx))
+        _lib.launch("gt_linear_bwd_ld2", 0, 0, 0, None, p(W), p(dy), None, p(add1), None, p(dx), None, None, m, N, K, K, N, 0.0, p(ws), ws_bytes, _stream())
+        return dx
+
+    with imgs.bound():
+        assert L.gt_linear_bwd_bcast_ok(0, 0, 0, p(W), M, N, K) == 1
+        assert L.gt_linear_bwd_bcast_ok(0, 0, 0, p(W), 4096, N, K) == 0   # too few rows for the register-row kernel
+        got = dx_call(a1, True)
+        want = dx_call(a1 + rows[idx.long()], False)
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        got2 = dx_call(None, True)
+        ref = dy.double() @ W.double() + rows[idx.long()].double()
+        assert float((got2 - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        assert torch.equal(dx_call(None, False), dx_call(None, False))   # the request does not outlive its call
+        with pytest.raises(RuntimeError):
+            dx_call(None, True, m=4096)
+    assert L.gt_linear_bwd_bcast_ok(0, 0, 0, p(W), M, N, K) == 0   # nothing bound
