@@ -125,6 +125,7 @@ SIGNATURES = {
     "gt_dropout": (_i, [_i, _p, _p, _i64, _f, _u64, _p]),
     "gt_linear_bwd_bnstats_ok": (_i, [_i, _i, _i, _i64]),
     "gt_linear_bwd_bnstats_rows": (_i64, [_i64]),
+    "gt_linear_bwd_bnstats_rows_for": (_i64, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_bwd_bnstats": (_i, [_p, _i64, _p, _p, _p, _p, _i, _p]),
     "gt_batchnorm_bwd_parts": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "gt_overlap_dw_begin": (_i, [_p, _p]),

@@ -1133,6 +1133,26 @@ extern "C" int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, i
   return (w32_eligible(compute, x_dtype, M, 1) && x_dtype == GT_F32 && y_dtype == GT_F32) ? 1 : 0;
 }
 extern "C" int64_t gt_linear_bwd_bnstats_rows(int64_t M) { return gt_cdiv(M, W32_BM); }
+// the register-row bf16x6 kernel (linear3r.h) takes a dX call with BatchNorm statistics in its epilogue: one partial row per 128-row block
+// (only with GT_FUSE_BN=2 in the environment: measured slower than the separate partial pass -- Code2 74.0 k against 74.85 k graphs/s --,
+// and gt_linear_bwd_bnstats' documented partial layout is the exact kernel's 64-row tiles)
+static bool bns_on_rows_kernel(int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy) {
+  static const bool on = [] { const char* e = getenv("GT_FUSE_BN"); return e && atoi(e) == 2; }();
+  if (!on) return false;
+  const void* img = w3_lookup(weight, N, K, true);
+  if (!img || x_dtype != GT_F32 || y_dtype != GT_F32) return false;
+  L32Args w{};
+  w.w3 = img;
+  w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldo = ldx;
+  return w3r_ok(GT_F32, GT_F32, w);
+}
+// Partial rows the dX call (weight [N][K], M rows) would write for a gt_linear_bwd_bnstats request under the CURRENT bindings of this
+// thread: ceil(M / 128) when the register-row bf16x6 kernel takes it (a bound image of W^T, M >= 12288), else gt_linear_bwd_bnstats_rows(M)
+// (the exact-fp32 kernel); 0 = no kernel does it for this call.
+extern "C" int64_t gt_linear_bwd_bnstats_rows_for(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
+  if (!gt_linear_bwd_bnstats_ok(compute, x_dtype, y_dtype, M)) return 0;
+  return bns_on_rows_kernel(x_dtype, y_dtype, weight, M, N, K, K, N) ? gt_cdiv(M, 128) : gt_cdiv(M, W32_BM);
+}
 extern "C" int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w,
                                      const float* b, int relu, float* part) {
   GT_CHECK_ARG(bn_x && mean && rstd && w && b && part && ldx > 0, "null buffer");
@@ -1305,7 +1325,8 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       // W^T lives in the caller's workspace: a previous call's dW GEMM may still be running on the overlap stream with
       // its partials in the same workspace (callers hand ONE workspace to consecutive GEMMs, e.g. the four of an encoder
       // layer) -> wait for the forks that used this range (those on other workspaces keep running).
-      const void* w3t = (g_opt.bns.part || (y_dtype != GT_F32 && N % 8)) ? nullptr : w3_lookup(weight, N, K, true);
+      const void* w3t = (y_dtype != GT_F32 && N % 8) ? nullptr : w3_lookup(weight, N, K, true);
+      if (w3t && g_opt.bns.part && !bns_on_rows_kernel(x_dtype, y_dtype, weight, M, N, K, ldx, ldy)) w3t = nullptr;   // the exact kernel's epilogue then
       if (w3t) {
         wt = nullptr;   // the bound image of W^T: k_lin3, no transpose
       } else if (g_opt.weight_t) {

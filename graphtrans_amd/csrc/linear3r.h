@@ -215,6 +215,13 @@ __global__ void __launch_bounds__(256 * CH, CH) k_lin3r(L32Args a) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // BNS (dX form): this dX is the dy of a BatchNorm further down the backward pass (gt_linear_bwd_bnstats): the block also writes
+  // bn_part[block][0][Nout] = sum_rows dy', [1][Nout] = sum_rows dy' xhat over its 128 rows -- k_bn_bwd_partial's second pass over dy
+  // and the BatchNorm input happens here, on the values in the registers
+  const bool bns = a.bn_part != nullptr;
+  float4 s0[NTW], s1[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) s0[j] = s1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int64_t m = m0 + i * 16 + n;
@@ -255,6 +262,52 @@ __global__ void __launch_bounds__(256 * CH, CH) k_lin3r(L32Args a) {
         else if (v[j].x == 12345.678f) *reinterpret_cast<float4*>(out + m * a.ldo + colv[j]) = v[j];
       }
     }
+    if (bns) {
+      float4 xr[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) xr[j] = *reinterpret_cast<const float4*>(a.bn_x + mc * a.bn_ldx + colv[j]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const float4 mu = *reinterpret_cast<const float4*>(a.bn_mean + colv[j]), rs = *reinterpret_cast<const float4*>(a.bn_rstd + colv[j]);
+        const float4 xh = make_float4((xr[j].x - mu.x) * rs.x, (xr[j].y - mu.y) * rs.y, (xr[j].z - mu.z) * rs.z, (xr[j].w - mu.w) * rs.w);
+        float4 gg = (okm && okc[j]) ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bn_relu) {
+          const float4 ww = *reinterpret_cast<const float4*>(a.bn_w + colv[j]), bb = *reinterpret_cast<const float4*>(a.bn_b + colv[j]);
+          gg = make_float4(xh.x * ww.x + bb.x > 0.f ? gg.x : 0.f, xh.y * ww.y + bb.y > 0.f ? gg.y : 0.f, xh.z * ww.z + bb.z > 0.f ? gg.z : 0.f,
+                           xh.w * ww.w + bb.w > 0.f ? gg.w : 0.f);
+        }
+        s0[j] = gt_add4(s0[j], gg);
+        s1[j] = make_float4(fmaf(gg.x, xh.x, s1[j].x), fmaf(gg.y, xh.y, s1[j].y), fmaf(gg.z, xh.z, s1[j].z), fmaf(gg.w, xh.w, s1[j].w));
+      }
+    }
+  }
+  if (bns) {   // (uniform) sum over the 16 rows of a lane group (fixed butterfly), then over the four row groups through the LDS
+    __syncthreads();   // every wave is past its last fragment read: the stage buffers become scratch
+    float* sb = reinterpret_cast<float*>(smem3r);   // [2][4 row groups][NTB * 16 columns]
+    constexpr int NC = NTB * 16;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      float t[8] = {s0[j].x, s0[j].y, s0[j].z, s0[j].w, s1[j].x, s1[j].y, s1[j].z, s1[j].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) t[e] += __shfl_xor(t[e], o, 64);
+      }
+      if (n == 0) {
+        const int cl = (ch * NTW + j) * 16 + g * 4;
+        *reinterpret_cast<float4*>(sb + (0 * 4 + rg) * NC + cl) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4*>(sb + (1 * 4 + rg) * NC + cl) = make_float4(t[4], t[5], t[6], t[7]);
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * NC; c += 256 * CH) {
+      const int which = c / NC, cl = c % NC;
+      const int64_t col = (int64_t)tile0 * 16 + cl;
+      if (cl < a.ntb * 16 && col < a.Nout) {
+        const float* q = sb + which * 4 * NC + cl;
+        a.bn_part[((int64_t)blockIdx.x * 2 + which) * a.Nout + col] = (q[0] + q[NC]) + (q[2 * NC] + q[3 * NC]);
+      }
+    }
   }
 }
 
@@ -291,7 +344,8 @@ static inline bool w3r_enabled() {
 // the register-row kernel takes the call (MASK callers pass amask == null for an ungated dX)
 static inline bool w3r_ok(int ta, int to, const L32Args& a) {
   if (!w3r_enabled() || ta != GT_F32 || to != GT_F32 || !a.w3) return false;
-  if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out || a.bn_part) return false;
+  if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out) return false;
+  if (a.bn_part && (a.bn_ldx % 4 || (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mean | (uintptr_t)a.bn_rstd | (uintptr_t)a.bn_w | (uintptr_t)a.bn_b) & 15))) return false;
   if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias | (uintptr_t)a.add_bc) & 15) != 0) return false;
   if (a.M < W3R_MIN_M || a.Nout % 4 || a.Kc % 4 || a.Kc < 4 || a.lda % 4 || a.ldo % 4) return false;
   return w3r_ncb(a.Nout) > 0;

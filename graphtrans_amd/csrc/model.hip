@@ -456,10 +456,26 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   static const bool fuse_bn_on = [] { const char* e = getenv("GT_FUSE_BN"); return !e || atoi(e) != 0; }();   // (A/B knob)
   // (not beyond 64 k rows: the statistics ride in the EXACT-fp32 dX kernel -- at the Erdos-Renyi stress' 131 k x 256 x 256 that GEMM is
   // 219 us against 116 us for the bf16x6 kernel + a 50-us partial pass: 17.6 k -> 17.9 k graphs/s without)
-  if (fuse_bn_on && N <= 65536 && !b->sync_bn && !m->has_vn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f &&
+  if (fuse_bn_on && L > 1 && !b->sync_bn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f &&
       gt_linear_bwd_bnstats_ok(c->compute, GT_F32, GT_F32, N)) {
-    c->fuse_bn = 1;
-    c->bn_rows = (int)gt_linear_bwd_bnstats_rows(N);
+    // which kernel will run the layers' dX GEMMs: the register-row bf16x6 kernel (bound images, N >= 12288: one partial row per 128
+    // rows, any N, with or without a virtual node -- its epilogue holds the complete d x_l, virtual-node rows included) or the
+    // exact-fp32 one (64-row tiles; without a virtual node and up to 64 k rows only, see above)
+    int64_t rows = gt_linear_bwd_bnstats_rows(N);
+    bool on_rows_kernel = false;
+    if (b->use_w3) {
+      BindGuard guard;
+      GT_TRY(bind_images(m, c));
+      rows = gt_linear_bwd_bnstats_rows_for(c->compute, GT_F32, GT_F32, c->gcn[1].lin_w, N, D, D);
+      on_rows_kernel = rows != gt_linear_bwd_bnstats_rows(N);
+    }
+    // (the register-row kernel answers only with GT_FUSE_BN=2 -- measured r5, Code2 b256: statistics in its epilogue 74.0 k graphs/s,
+    // the separate partial pass 74.85 k; ER 19.07 k against 19.14 k: the epilogue's second row read + 320 lane shuffles per wave
+    // cost more than the 23-us pass they replace)
+    if (rows > 0 && (on_rows_kernel || (!m->has_vn && N <= 65536))) {
+      c->fuse_bn = 1;
+      c->bn_rows = (int)rows;
+    }
   }
   for (int l = 0; l + 1 < L; ++l) c->q_bnpart[l] = q.take(c->fuse_bn ? (size_t)c->bn_rows * 2 * D * 4 : 0);
   c->heads_ws_bytes = gt_linear_bwd_workspace_bytes(c->compute, B, m->Nh, d);

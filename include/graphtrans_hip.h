@@ -485,6 +485,9 @@ int gt_overlap_dw_begin(gt_stream_t main_stream, gt_stream_t side_stream);
  * over dy and the BatchNorm input.  Only where gt_linear_bwd_bnstats_ok(...) says so (exact-fp32 path, fp32 rows, M >= 1024). */
 int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, int64_t M);
 int64_t gt_linear_bwd_bnstats_rows(int64_t M);
+/* ... under the current image bindings of this thread: ceil(M / 128) when the register-row bf16x6 kernel (csrc/linear3r.h) takes the
+ * call (bound image of W^T, fp32 rows, M >= 12288), else gt_linear_bwd_bnstats_rows(M); 0 = unsupported */
+int64_t gt_linear_bwd_bnstats_rows_for(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K);
 int gt_linear_bwd_bnstats(const float* bn_x, int64_t ldx, const float* mean, const float* rstd, const float* w, const float* b,
                           int relu, float* part);
 /* Broadcast addend of the NEXT gt_linear_bwd* call of this host thread: dx[m] += rows[idx[m]] (rows [.][K] fp32 at the dX pitch,
