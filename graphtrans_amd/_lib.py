@@ -135,6 +135,8 @@ SIGNATURES = {
     "gt_overlap_dw_fork": (_p, [_p, C.c_uint]),
     "gt_overlap_dw_booked": (None, [_p, _sz]),
     "gt_overlap_dw_end": (_i, []),
+    "gt_overlap_dw_hold": (_i, []),
+    "gt_overlap_dw_unhold": (_i, []),
     "gt_linear_fwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_fwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_grouped_workspace_bytes": (_sz, [_i, _i64, _i64, _i64, _i]),

@@ -157,3 +157,9 @@ __device__ __forceinline__ float4 gt_fma4(float4 a, float s, float4 c) {
 __device__ __forceinline__ float4 gt_relu4(float4 a) {
   return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
 }
+
+// ---- held forks of the weight-gradient overlap section (csrc/linear.hip; C++ linkage: the queued work is a closure) ----------------
+#include <functional>
+// true = `fn` was queued and will run on the overlap stream at gt_overlap_dw_unhold (booked under `workspace`); false = no hold is open
+// on `stream` (or the launch profiler brackets `prof_category`): the caller launches / forks as before
+bool gt_overlap_dw_defer(gt_stream_t stream, std::function<int(hipStream_t)> fn, const void* workspace, size_t bytes, unsigned prof_category);

@@ -675,6 +675,17 @@ struct DwOverlap {
   bool urgent = false;       // the forks from here on are the last of the backward: the optimizer waits for them
   DwPending ring[DW_RING];   // forks since the last full join, oldest first (the side stream runs them in this order)
   int n = 0;
+  // HELD forks (gt_overlap_dw_hold / _unhold): a fork costs the main stream an event record (~3 us of its timeline, ~5 with the other
+  // stream's wait: tools/event_cost_probe.hip) -- a layer's backward forked 4-6 times.  While a hold is open the side work is queued
+  // instead and ONE record at the unhold orders all of it behind the main stream (nobody waits for it: it produces parameter
+  // gradients; starting it a few kernels later costs nothing).
+  int hold = 0;
+  struct Held {
+    std::function<int(hipStream_t)> fn;
+    const void* ws;
+    size_t bytes;
+  };
+  std::vector<Held> held;
 };
 thread_local DwOverlap g_dw;
 
@@ -1111,6 +1122,7 @@ struct BwdCallOpts {
   bool gate_out = false;             // y_for_mask [M][ldx] gates the dX OUTPUT (gt_linear_bwd_gate_out), dY is used as it is
   const float* bcast = nullptr;      // dX += bcast[bcast_idx[row]] (gt_linear_bwd_bcast), set BEFORE the call it applies to
   const int32_t* bcast_idx = nullptr;
+  bool as_fork = false;              // a dW-only call replayed on the overlap stream by gt_overlap_dw_unhold: sized like a forked one
 };
 thread_local BwdCallOpts g_opt;
 struct BwdOptScope {   // whatever was set is dropped when the call it was meant for returns
@@ -1241,6 +1253,32 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
+  if (g_dw.active && g_dw.hold > 0 && (hipStream_t)stream_ == g_dw.main && dweight && (dx || g_opt.fork_dw_only) && workspace && workspace_bytes &&
+      !g_opt.as_fork && !(gt_prof_mask() & GT_PROF_LINEAR)) {
+    // forks are held: the dX part now, the dW part (with this call's options and one-call requests) when the hold is released
+    const BwdCallOpts opts = g_opt;
+    const int32_t* rows = g_rows;
+    const RowsLn rows_ln = g_rows_ln;
+    const Cat2Req cat2 = g_cat2;
+    int rc = GT_OK;
+    if (dx) {
+      rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, nullptr, nullptr, M, N, K, ldx, ldy, groups,
+                                 x_group_stride, y_group_stride, dropout_p, workspace, workspace_bytes, stream_);
+    } else {
+      g_opt = BwdCallOpts{}; g_rows = nullptr; g_rows_ln = RowsLn{}; g_cat2 = Cat2Req{};
+    }
+    if (rc) return rc;
+    auto fn = [=](hipStream_t side) -> int {
+      g_opt = opts;
+      g_opt.fork_dw_only = false; g_opt.as_fork = true; g_opt.bcast = nullptr; g_opt.bcast_idx = nullptr; g_opt.bns = BnStatsReq{};
+      g_rows = rows; g_rows_ln = rows_ln; g_cat2 = cat2;
+      g_cat2.dx2 = nullptr;
+      return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, nullptr, nullptr, nullptr, dweight, dbias, M, N, K, ldx, ldy,
+                                   groups, x_group_stride, y_group_stride, dropout_p, workspace, workspace_bytes, (gt_stream_t)side);
+    };
+    if (!gt_overlap_dw_defer(stream_, fn, workspace, workspace_bytes, GT_PROF_LINEAR)) return fn((hipStream_t)stream_);
+    return GT_OK;
+  }
   BwdOptScope opt_scope__;   // the per-call options live for exactly this call
   if (g_opt.bcast && dx && !gt_linear_bwd_bcast_ok(compute, x_dtype, y_dtype, weight, M, N, K)) {
     gt_set_error("gt_linear_bwd_bcast: this call does not run on the register-row kernel (ask gt_linear_bwd_bcast_ok)");
@@ -1316,7 +1354,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     }
     const int nt = w32_pick_nt(N);
     const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
-    const bool will_fork = g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR);
+    const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR)) || (g_opt.as_fork && dweight);
     const int splits = w32_dw_splits(M, nkb, nnb, will_fork && !g_dw.urgent);
     float* part = reinterpret_cast<float*>(workspace);
     float* wt = part + (size_t)w32_dw_splits(M, nkb, nnb, false) * (size_t)(N * K + N) + 64;   // behind the larger partial area
@@ -1362,7 +1400,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       else w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
-      const bool forked = will_fork;
+      const bool forked = will_fork && !g_opt.as_fork;   // (replayed from a hold: already on the overlap stream, booked by the unhold)
       if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
@@ -1814,6 +1852,8 @@ extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
   g_dw.active = true;
   g_dw.urgent = false;
   g_dw.n = 0;
+  g_dw.hold = 0;
+  g_dw.held.clear();
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_sync(void) {
@@ -1835,6 +1875,35 @@ extern "C" gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned prof_cate
 extern "C" void gt_overlap_dw_booked(const void* workspace, size_t bytes) {
   if (g_dw.active) dw_forked(workspace, bytes);
 }
+// Side work for the overlap stream while forks are held: true = queued (runs at gt_overlap_dw_unhold on the overlap stream, booked under
+// `workspace`), false = no hold open on this stream: the caller forks as before.  (C++ linkage: declared in gt_common.h.)
+bool gt_overlap_dw_defer(gt_stream_t stream, std::function<int(hipStream_t)> fn, const void* workspace, size_t bytes, unsigned prof_category) {
+  if (!g_dw.active || g_dw.hold <= 0 || (hipStream_t)stream != g_dw.main || (gt_prof_mask() & prof_category)) return false;
+  g_dw.held.push_back(DwOverlap::Held{std::move(fn), workspace, bytes});
+  return true;
+}
+extern "C" int gt_overlap_dw_hold(void) {
+  // OFF unless asked for (GT_HOLD_FORKS=1): measured r5 it LOSES in the step -- Code2 74.2 k against 74.5 k graphs/s, fp32 mode 51.7 k
+  // against 52.7 k, Molpcba 95.0 k against 96.4 k -- although a record + wait pair costs the main stream ~5 us in isolation
+  // (tools/event_cost_probe.hip): the weight-gradient GEMMs then start a layer late and pile up behind the step's last layers
+  static const bool on = [] { const char* e = getenv("GT_HOLD_FORKS"); return e && atoi(e) != 0; }();
+  if (g_dw.active && on) ++g_dw.hold;
+  return GT_OK;
+}
+extern "C" int gt_overlap_dw_unhold(void) {
+  if (!g_dw.active || g_dw.hold <= 0) return GT_OK;
+  if (--g_dw.hold > 0 || g_dw.held.empty()) return GT_OK;
+  (void)hipEventRecord(g_dw.ev_fork, g_dw.main);
+  (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+  int rc = GT_OK;
+  std::vector<DwOverlap::Held> work;
+  work.swap(g_dw.held);
+  for (auto& h : work) {
+    if (rc == GT_OK) rc = h.fn(g_dw.side);
+    dw_forked(h.ws, h.bytes);   // (one event per entry on the side stream: the ring's release logic stays as it is)
+  }
+  return rc;
+}
 extern "C" int gt_overlap_dw_urgent(int on) {
   g_dw.urgent = on != 0;
   return GT_OK;
@@ -1844,6 +1913,8 @@ extern "C" int gt_overlap_dw_release(const void* workspace, size_t bytes) {
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_end(void) {
+  g_dw.hold = g_dw.hold > 0 ? 1 : 0;
+  (void)gt_overlap_dw_unhold();   // (a hold left open by an error path: its work still runs)
   const int rc = gt_overlap_dw_sync();
   g_dw.active = false;
   return rc;

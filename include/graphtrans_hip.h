@@ -607,6 +607,15 @@ int gt_overlap_dw_urgent(int on);
  * overlap section -- else `stream`; a launch sent there is booked under the workspace it reads (gt_overlap_dw_release). */
 gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned profiler_category /* GT_PROF_* of the caller, 0 = none */);
 void gt_overlap_dw_booked(const void* workspace, size_t bytes);
+/* Held forks.  Every fork costs the main stream an event record (~3 us of its timeline, ~5 with the overlap stream's wait:
+ * tools/event_cost_probe.hip) and a layer's backward forks 4-6 times.  Between gt_overlap_dw_hold() and the matching
+ * gt_overlap_dw_unhold() (they nest; same host thread, inside an overlap section) the weight-gradient parts of gt_linear_bwd*
+ * calls on the main stream, LayerNorm backward's column finish and the aggregate backward's partial reduce are QUEUED instead;
+ * the outermost unhold orders the overlap stream behind the main stream ONCE and issues them there in order.  The composite
+ * layer entry points (gt_gcn_layer_bwd, gt_gin_layer_bwd, gt_encoder_layer_bwd, gt_encoder_layer_pooled_bwd) hold their forks.
+ * Everything queued reads buffers the caller keeps alive until gt_overlap_dw_release / _sync says otherwise, as for plain forks. */
+int gt_overlap_dw_hold(void);
+int gt_overlap_dw_unhold(void);
 int gt_overlap_dw_end(void);
 
 int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,

@@ -266,7 +266,7 @@ def test_one_launch_batchnorm_against_the_three_launch_scheme(rows, D):
     def run(on):
         prev = L.gt_bn_coop_set(on)
         try:
-            ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+            ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)   # (zeroed: shapes beyond one round of register rows keep the three launches)
             rm, rv = torch.zeros(D, device=DEV), torch.ones(D, device=DEV)
             y, dx = torch.empty_like(x), torch.empty_like(x)
             mean, rstd, dw, db = (torch.empty(D, device=DEV) for _ in range(4))
