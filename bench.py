@@ -447,7 +447,8 @@ def precision_vs_oracle(workload, modes, device, graphs=None):
     (oracle/noise.py): `worst_vs_oracle_noise` is the largest such ratio -- an ill-conditioned gradient (GINConv.eps) has a
     large error AND a large noise floor, a wrong kernel a large ratio.  Since r4 the perturbation covers the activations
     and activation gradients the mode rounds as well (reference_math's storage taps).  Same metric as tests/test_hip_configs.py,
-    which bounds the ratio by 4 (measured worst: 2.8)."""
+    which bounds the ratio by 4 ON THIS SAMPLE too (measured worst: 2.0; the noise is the maximum over four perturbation seeds since r5 --
+    over two it under-estimated a heavy-tailed response: GINConv.eps read 7 x)."""
     from graphtrans_amd import ops as gt_ops
     from oracle import noise as on
     from oracle import reference_math as rm
@@ -502,7 +503,7 @@ def precision_vs_oracle(workload, modes, device, graphs=None):
         out[mode] = dict(loss_rel_err=float(f"{abs(float(loss) - l64v) / abs(l64v):.3e}"), grad_rel_l2_worst=float(f"{errs[worst]:.3e}"),
                          grad_rel_l2_worst_param=worst, grad_rel_l2_median=float(f"{vals[len(vals) // 2]:.3e}"), tensors=len(errs))
         if mode != "fp32":
-            floor = on.lowp_noise({k: v.detach() for k, v in sd64.items()}, oargs, b64, rm.gnn_transformer, loss_of, g64, mode, seeds=(11, 12))
+            floor = on.lowp_noise({k: v.detach() for k, v in sd64.items()}, oargs, b64, rm.gnn_transformer, loss_of, g64, mode)
             ratio = {k: errs[k] / max(floor[k], 2.5e-4) for k in errs}
             wr = max(ratio, key=ratio.get)
             out[mode].update(worst_vs_oracle_noise=float(f"{ratio[wr]:.3g}"), worst_vs_oracle_noise_param=wr,

@@ -54,7 +54,7 @@ class _RoundLike(torch.autograd.Function):
         return g * (1.0 + ctx.rel * (2.0 * torch.rand(g.shape, generator=ctx.gen, dtype=g.dtype) - 1.0)), None, None
 
 
-def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12), rel=BF16_EPS, activations=True):
+def lowp_noise(sd64, oargs, batch, fwd, loss_of, ref_g64, mode, seeds=(11, 12, 13, 14), rel=BF16_EPS, activations=True):
     """-> {gradient key: max over seeds of ||g_perturbed - g64|| / ||g64||}.  sd64: float64 state dict (leaf tensors),
     fwd: oracle.reference_math.gnn_transformer / pna_transformer, loss_of(outputs) -> scalar.  activations: also perturb the
     activations the mode rounds (and their gradients) through reference_math's storage taps."""

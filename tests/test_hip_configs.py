@@ -288,12 +288,37 @@ def test_c5_encoder_hd64_n513_vs_oracle(dtype):
 # whose exact gradient is not ~0 (||g64|| >= 1e-3 of the largest tensor norm per element count; the Linear biases in
 # front of a train-mode BatchNorm have an exactly-zero gradient).  "fp32" additionally goes through check_grads;
 # the reduced-precision modes are held to the stated bounds on the worst and the median tensor.
+LOWP_FACTOR, LOWP_FLOOR = 4.0, 2.5e-4   # floor: only a guard against a vanishing noise estimate (r4: the noise model rounds activations and their gradients too)
+# elementwise logit error / largest logit: bf16 token rows round every stored activation to 2^-9 relative, four post-norm layers deep
+X
+# Since r5 the reduced-precision modes carry NO blanket bound on the worst / median gradient tensor (a blanket 0.2 / 0.8 can
+# hide a wrong tensor): every tensor is held to its own oracle-noise bound (check_lowp_grads), the logits to an elementwise bound
+# relative to the largest logit, and the same criterion runs on bench.py's own sample (test_bench_precision_sample_is_held_to_the_same_bound).
 BOUNDS = {
-    "fp32": dict(loss=1e-5, worst=2e-2, median=1e-3),
-    "mixed": dict(loss=5e-4, worst=2e-1, median=3e-2),
-    "bf16": dict(loss=2e-3, worst=8e-1, median=1.5e-1),
+    "fp32": dict(loss=1e-5, worst=2e-2, median=1e-3, logits=1e-4),
+    "mixed": dict(loss=5e-4, logits=LOGIT_MIXED),
+    "bf16": dict(loss=2e-3, logits=LOGIT_BF16),
 }
 MODES = {"fp32": (torch.float32, torch.float32), "mixed": (torch.float32, torch.bfloat16), "bf16": (torch.bfloat16, torch.bfloat16)}
+
+
+@pytest.mark.parametrize("workload", ["code2", "molpcba"])
+def test_bench_precision_sample_is_held_to_the_same_bound(workload):
+    """bench.py's "precision_vs_oracle" sample (24 graphs, seed 7 / batch 5, dropout 0) through bench.py's OWN code, held to the bound
+    of check_lowp_grads: every gradient tensor of the reduced-precision modes within LOWP_FACTOR x the oracle's bf16-noise of that
+    tensor (the bench sample showed 7 x on GINConv.eps where this file's 64-graph sample passed at 4 x -- the noise
+    estimate was a maximum over two perturbation seeds of a heavy-tailed response; it is taken over four seeds now, here and in
+    bench.py, see oracle/noise.py)."""
+    import bench
+
+    rep = bench.precision_vs_oracle(workload, ["fp32", "mixed", "bf16"], DEV)
+    for mode in ("mixed", "bf16"):
+        r = rep[mode]
+        print(f"\n[bench sample {workload} {mode}] loss rel err {r['loss_rel_err']:.2e}; worst tensor {r['grad_rel_l2_worst_param']} "
+              f"{r['grad_rel_l2_worst']:.2e}; worst vs oracle noise {r['worst_vs_oracle_noise']} ({r['worst_vs_oracle_noise_param']})")
+        assert r["loss_rel_err"] <= BOUNDS[mode]["loss"], r
+        assert r["worst_vs_oracle_noise"] <= LOWP_FACTOR, r
+    assert rep["fp32"]["loss_rel_err"] <= BOUNDS["fp32"]["loss"] and rep["fp32"]["grad_rel_l2_worst"] <= BOUNDS["fp32"]["worst"], rep["fp32"]
 
 
 def precision_report(grads, loss, ref64, loss64):
@@ -320,7 +345,7 @@ def test_fused_precision_modes_vs_oracle(workload, graphs, mode):
         kw.update(gnn_type="gin", max_seq_len=None)
     args = _args(**kw)
     model, b, oloss, hloss = build(workload, args, graphs, 5)
-    _, ref_loss64, ref_g64 = oracle_run(model, args, b, oloss, torch.float64)
+    ref_out64, ref_loss64, ref_g64 = oracle_run(model, args, b, oloss, torch.float64)
     noise = fp32_noise(model, args, b, oloss, ref_g64) if mode == "fp32" else None
     ops.set_matmul_dtype(matmul)
     try:
@@ -334,15 +359,20 @@ def test_fused_precision_modes_vs_oracle(workload, graphs, mode):
           "worst: " + ", ".join(f"{k} {e:.1e}" for k, e in rep["worst4"]))
     bound = BOUNDS[mode]
     assert rep["loss_rel_err"] <= bound["loss"], rep
-    assert rep["grad_rel_l2_worst"] <= bound["worst"], rep
-    assert rep["grad_rel_l2_median"] <= bound["median"], rep
+    # the logits, element by element, relative to the largest logit (they are O(1..10): the fp32 mode is the plain 1e-4)
+    refs = [o.detach() for o in (ref_out64 if isinstance(ref_out64, (list, tuple)) else [ref_out64])]
+    top = max(float(r.abs().max()) for r in refs)
+    lerr = max(float((o.double() - r).abs().max()) for o, r in zip(outs, refs)) / max(top, 1.0)
+    print(f"[{workload} {mode}] logits: max elementwise error {lerr:.2e} of the largest logit ({top:.2f}); bound {bound['logits']:g}")
+    assert lerr <= bound["logits"], (lerr, bound["logits"])
     if mode == "fp32":
+        assert rep["grad_rel_l2_worst"] <= bound["worst"], rep
+        assert rep["grad_rel_l2_median"] <= bound["median"], rep
         check_grads(grads, ref_g64, noise, what=f"{workload} fp32")
     else:
         check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=f"{workload} {mode}")
 
 
-LOWP_FACTOR, LOWP_FLOOR = 4.0, 2.5e-4   # floor: only a guard against a vanishing noise estimate (r4: the noise model rounds activations and their gradients too)
 
 
 def check_lowp_grads(model, args, b, oloss, grads, ref_g64, mode, what=""):

@@ -21,7 +21,8 @@ def test_linear_fwd_bwd(M, N, K, mode, act):
     from graphtrans_amd import ops
 
     if mode == "bf16" and (K % 8 or N % 8):
-        pytest.skip("bf16 storage needs 16-byte rows (K, N multiples of 8); such shapes go to torch's GEMM")
+        pytest.skip("bf16 storage needs 16-byte rows (K, N multiples of 8): the kernels reject other shapes (ops.linear has no "
+                    "fallback GEMM), and no bf16-storage GEMM of the path has one")
     torch.manual_seed(0)
     x = torch.randn(M, K)
     w = torch.randn(N, K) / K ** 0.5
