@@ -290,7 +290,7 @@ def test_c5_encoder_hd64_n513_vs_oracle(dtype):
 # the reduced-precision modes are held to the stated bounds on the worst and the median tensor.
 LOWP_FACTOR, LOWP_FLOOR = 4.0, 2.5e-4   # floor: only a guard against a vanishing noise estimate (r4: the noise model rounds activations and their gradients too)
 # elementwise logit error / largest logit: bf16 token rows round every stored activation to 2^-9 relative, four post-norm layers deep
-X
+LOGIT_MIXED, LOGIT_BF16 = 1.5e-2, 1e-1   # measured r5: mixed 5.7e-3 (Code2) / 4.6e-3 (Molpcba), bf16 4.2e-2 / 2.1e-2 -> ~2.5 x the measured value
 # Since r5 the reduced-precision modes carry NO blanket bound on the worst / median gradient tensor (a blanket 0.2 / 0.8 can
 # hide a wrong tensor): every tensor is held to its own oracle-noise bound (check_lowp_grads), the logits to an elementwise bound
 # relative to the largest logit, and the same criterion runs on bench.py's own sample (test_bench_precision_sample_is_held_to_the_same_bound).
