@@ -310,24 +310,40 @@ extern "C" int gt_seq_gather_cls32(int dtype, const void* h, const float* cls32,
                          with_cls, D, tokens, nullptr, stream_);
 }
 
-// out[c] = sum over rows of x[r][c], fp32, fixed order: 4 row groups x (dim / 4) column chunks per block pass
+// out[c] = sum over rows of x[r][c], fp32, fixed order: (256 / CW) row groups x CW column chunks per block pass, CW = 16 / 32 / 64 by
+// the row width; a thread takes every (256 / CW)-th row, 8 rows (index, then row) in flight.  (r5: with 64 chunk columns fixed, the
+// CLS-row gradient of a d = 128 encoder -- 256 rows through row_idx -- ran on 128 threads as 64 chained index -> row round trips:
+// 37 us of the main stream for 64 KB, profiles/r05 timeline; now ~5.)
 template <typename T>
 __global__ void __launch_bounds__(256) k_colsum_f32(const T* __restrict__ x, const int64_t* __restrict__ row_idx, int64_t rows, int64_t D,
                                                     float* __restrict__ out) {
   __shared__ float4 part[256];
   const int64_t C = D / 4;
-  const int groups = 256 / 64;   // 64 column chunks per pass
-  const int g = threadIdx.x / 64, cl = threadIdx.x % 64;
-  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < C; c0 += (int64_t)gridDim.x * 64) {
+  const int CW = C >= 64 ? 64 : (C >= 32 ? 32 : 16);
+  const int groups = 256 / CW;
+  const int g = threadIdx.x / CW, cl = threadIdx.x % CW;
+  for (int64_t c0 = (int64_t)blockIdx.x * CW; c0 < C; c0 += (int64_t)gridDim.x * CW) {
     const int64_t c = c0 + cl;
     float4 acc = gt_zero4();
-    if (c < C)
-      for (int64_t r = g; r < rows; r += groups) acc = gt_add4(acc, gt_load4<T>(x + (row_idx ? row_idx[r] : r) * D + c * 4));
+    if (c < C) {
+      int64_t r = g;
+      for (; r + 7 * groups < rows; r += 8 * groups) {
+        int64_t idx[8];
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = row_idx ? row_idx[r + u * groups] : r + u * groups;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gt_load4<T>(x + idx[u] * D + c * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = gt_add4(acc, v[u]);
+      }
+      for (; r < rows; r += groups) acc = gt_add4(acc, gt_load4<T>(x + (row_idx ? row_idx[r] : r) * D + c * 4));
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c < C) {
       float4 s = part[cl];
-      for (int k = 1; k < groups; ++k) s = gt_add4(s, part[k * 64 + cl]);
+      for (int k = 1; k < groups; ++k) s = gt_add4(s, part[k * CW + cl]);
       gt_store4<float>(out + c * 4, s);
     }
     __syncthreads();
@@ -339,7 +355,8 @@ static int colsum_impl(const char* fn, int dtype, const void* x, const int64_t* 
   if (rc) return rc;
   if (!(x && out)) { gt_set_error("%s: null buffer", fn); return GT_ERR_INVALID_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
-  dim3 grid((unsigned)gt_cdiv(D / 4, 64));
+  const int64_t C = D / 4;
+  dim3 grid((unsigned)gt_cdiv(C, C >= 64 ? 64 : (C >= 32 ? 32 : 16)));
   if (dtype == GT_F32) hipLaunchKernelGGL(k_colsum_f32<float>, grid, dim3(256), 0, stream, (const float*)x, row_idx, rows, D, out);
   else hipLaunchKernelGGL(k_colsum_f32<gt_bf16>, grid, dim3(256), 0, stream, (const gt_bf16*)x, row_idx, rows, D, out);
   GT_CHECK_LAUNCH();
