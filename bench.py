@@ -272,7 +272,7 @@ def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
     inside the timed region, under the schedule the un-profiled steps run: the weight-gradient GEMMs are bracketed ON the
     overlap stream).  -> per kernel roofline dicts, keyed like rocprofv3's kernel names so that every `frac` can be
     recomputed from profiles/*_kernel_stats.csv: achieved = algorithmic flops | bytes / average duration.
-      k_lin3[fwd|dx], k_lin3_dw+reduce   fp32-accurate GEMM on the bf16 pipe, six bf16 MFMAs per product: peak = 2500 / 6 = 416.7 TFLOP/s
+      k_lin3[fwd|dx], k_lin3r[fwd|dx] (rows straight into fragments, r5), k_lin3_dw+reduce, k_lin3r_dw+reduce   fp32-accurate GEMM on the bf16 pipe, six bf16 MFMAs per product: peak = 2500 / 6 = 416.7 TFLOP/s
       k_lin32[..], k_lin32_dw+reduce   exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): peak 157.3 TFLOP/s
       k_linear_*          bf16 MFMA on skinny shapes (M ~ 3e4, K, N <= 600): HBM-bound, priced on algorithmic bytes
       k_small_*           short-M GEMMs (one row per graph): latency-bound, reported against the fp32 MFMA peak for scale"""

@@ -1063,8 +1063,9 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
       }
     }
     {
-      GtProfScope pk__(GT_PROF_GEMM_KERNEL, w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
-      if (w.w3 && w3r_ok(x_dtype, y_dtype, w)) w3r_launch(stream, w);   // rows straight into fragments (linear3r.h)
+      const bool on_rows_kernel = w.w3 && w3r_ok(x_dtype, y_dtype, w);
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, on_rows_kernel ? "k_lin3r[fwd]" : (w.w3 ? "k_lin3[fwd]" : "k_lin32[fwd]"), stream, {M, N, K, x_dtype, y_dtype, compute});
+      if (on_rows_kernel) w3r_launch(stream, w);   // rows straight into fragments (linear3r.h)
       else if (w.w3) w3_launch<false>(x_dtype, y_dtype, stream, w);
       else w32_launch<false>(x_dtype, y_dtype, stream, w);
     }
@@ -1417,8 +1418,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         if (!w3t || dx_add1 || dx_add2) { gt_set_error("gt_linear_bwd_cat2: needs a bound weight image and no addends"); return GT_ERR_UNSUPPORTED; }
         w.out2 = g_cat2.dx2; w.out_split = g_cat2.split; w.ldo2 = g_cat2.ld2;
       }
-      GtProfScope pk__(GT_PROF_GEMM_KERNEL, w3t ? "k_lin3[dx]" : "k_lin32[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
-      if (w3t && w3r_ok(y_dtype, x_dtype, w)) w3r_launch(stream, w);
+      const bool on_rows_kernel = w3t && w3r_ok(y_dtype, x_dtype, w);
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, on_rows_kernel ? "k_lin3r[dx]" : (w3t ? "k_lin3[dx]" : "k_lin32[dx]"), stream, {M, N, K, x_dtype, y_dtype, compute});
+      if (on_rows_kernel) w3r_launch(stream, w);
       else if (w3t) w3_launch<true>(y_dtype, x_dtype, stream, w);
       else w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
@@ -1450,8 +1452,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         d.m_per_split = gt_cdiv(gt_cdiv(M, s3), 32) * 32;
         dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3));
         {
-          GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-          if (w3r_dw_ok(y_dtype, x_dtype, d)) w3r_launch_dw(grid3, stream, d);   // stages pipelined (linear3r.h)
+          const bool pipelined = w3r_dw_ok(y_dtype, x_dtype, d);
+          GtProfScope pk__(GT_PROF_GEMM_KERNEL, pipelined ? "k_lin3r_dw+reduce" : "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+          if (pipelined) w3r_launch_dw(grid3, stream, d);   // stages pipelined (linear3r.h)
           else if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
           else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
           dw_reduce(stream, deferred, part3, s3, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);

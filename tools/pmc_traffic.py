@@ -19,6 +19,10 @@ ENTRY = {
     # GEMM kernels one by one (bench.py kernel_report keys = the C-side kernel-level profiler names, GT_PROF_GEMM_KERNEL)
     "k_lin3[fwd]": ((r"k_lin3<[^>]*, false, (?:false|true)>",), r"k_lin3<[^>]*, false, (?:false|true)>"),
     "k_lin3[dx]": ((r"k_lin3<[^>]*, true, false>",), r"k_lin3<[^>]*, true, false>"),
+    # k_lin3r (rows straight into fragments, r5): forward and dX are ONE instantiation -- their launches are pooled, both keys get the average
+    "k_lin3r[fwd]": ((r"k_lin3r<",), r"k_lin3r<"),
+    "k_lin3r[dx]": ((r"k_lin3r<",), r"k_lin3r<"),
+    "k_lin3r_dw+reduce": ((r"k_lin3r_dw<",), r"k_lin3r_dw<"),
     "k_lin32[fwd]": ((r"k_lin32<[^>]*?, \d+, false,",), r"k_lin32<[^>]*?, \d+, false,"),
     "k_lin32[dx]": ((r"k_lin32<[^>]*?, \d+, true,", r"k_transpose32"), r"k_lin32<[^>]*?, \d+, true,"),
     # weight-stationary encoder GEMMs: forward and dX share instantiations (k_lin1<KS, NTW, LN>), so the plain ones are pooled
