@@ -9,16 +9,18 @@ tag=${1:-r02a}
 shift || true
 modes=${@:-mixed bf16}
 mkdir -p gpurun_out/$tag
-for w in code2 molpcba er; do
+for w in code2 molpcba er code2-pna; do
   for m in $modes; do
     [ $w = er ] && [ $m != mixed ] && continue   # the stress workload: the headline mode only
+    [ $w = code2-pna ] && [ $m != mixed ] && continue
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_${w}_${m}_$c
       timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_${w}_${m}_$c -o res -- python bench.py --workload $w --mode $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_${w}_${m}_$c.log 2>&1 || true
     done
     f=$(find /tmp/pmc_${w}_${m}_FETCH_SIZE -name "*.db" | head -1)
     wr=$(find /tmp/pmc_${w}_${m}_WRITE_SIZE -name "*.db" | head -1)
-    python tools/pmc_traffic.py $f $wr $w $m 256 gpurun_out/$tag/${tag}_${w}_${m} || true
+    per=256; [ $w = code2-pna ] && per=128   # (graphs per batch of the workload's bench line)
+    python tools/pmc_traffic.py $f $wr $w $m $per gpurun_out/$tag/${tag}_${w}_${m} || true
   done
 done
 # HBM traffic of the aggregate kernels on the stress batch (BASELINE configs[4]: the bandwidth proof; on Code2 the re-gathers hit L2)

@@ -33,6 +33,10 @@ ENTRY = {
     "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dx[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>",), r"k_linear_dx<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dw+reduce[bf16]": ((r"k_linear_dw<[^>]*" + BF16 + r">",), r"k_linear_dw<[^>]*" + BF16 + r">"),
+    # the round-1 tiled kernels in exact fp32: what PNA's grouped tower GEMMs still run on
+    "k_linear_fwd[fp32]": ((r"k_linear_fwd<[^>]*float, \d+>",), r"k_linear_fwd<[^>]*float, \d+>"),
+    "k_linear_dx[fp32]": ((r"k_linear_dx<[^>]*float, \d+>",), r"k_linear_dx<[^>]*float, \d+>"),
+    "k_linear_dw+reduce[fp32]": ((r"k_linear_dw<[^>]*float>",), r"k_linear_dw<[^>]*float>"),
     "k_dw16+reduce[bf16]": ((r"k_dw16\(",), r"k_dw16\("),   # LDS-DMA ring dW of the encoder linears (its k_split_reduce: reported on its own)
     "k_split_reduce": ((r"k_split_reduce",), r"k_split_reduce"),
     "gt_aggregate_fwd": ((r"k_aggw?_fwd<",), r"k_aggw?_fwd<"),
