@@ -860,6 +860,12 @@ constexpr int64_t W32_MIN_M = 1024;   // below this the grid of 64-row blocks ca
 bool w32_eligible(int compute, int x_dtype, int64_t M, int groups) {
   return compute == GT_F32 && x_dtype == GT_F32 && groups == 1 && M >= W32_MIN_M;
 }
+// grouped launches of the bf16x6 kernel (k_lin3, blockIdx.y = group): fp32 rows in and out, 16-byte chunks of every row
+bool g3_eligible(int compute, int x_dtype, int y_dtype, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy) {
+  static const bool on = [] { const char* e = getenv("GT_LIN3_GROUPED"); return !(e && e[0] == '0'); }();
+  return on && compute == GT_F32 && x_dtype == GT_F32 && y_dtype == GT_F32 && M >= W32_MIN_M && N % 4 == 0 && K % 4 == 0 && ldx % 4 == 0 &&
+         ldy % 4 == 0;
+}
 
 template <typename TA, typename TO, bool MASK, bool GELU = false, bool BNS = false>
 void w32_launch_nt(int nt, dim3 grid, hipStream_t stream, const L32Args& a) {
@@ -1041,6 +1047,22 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
     }
     GT_CHECK_LAUNCH();
     return GT_OK;
+  }
+  if (groups > 1 && g3_eligible(compute, x_dtype, y_dtype, M, N, K, ldx, ldy) && act != 2 && !g_cat2.x2) {
+    // grouped big-M fp32 GEMMs whose group weights all have bound images (the towers of PNAConv): k_lin3 with blockIdx.y = group
+    int64_t spacing = 0;
+    if (const void* img = w3_lookup_grouped(weight, N, K, groups, false, &spacing)) {
+      L32Args w{};
+      w.a = x; w.bias = bias; w.out = y; w.M = M; w.Nout = N; w.Kc = K; w.lda = ldx; w.ldw = K; w.ldo = ldy;
+      w.act = act; w.inv_keep = a.inv_keep; w.thr = a.thr; w.s0 = a.s0; w.s1 = a.s1;
+      w.w3 = img; w.groups = groups; w.g_a = x_group_stride; w.g_o = y_group_stride; w.g_img = spacing; w.g_b = (int)N;
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
+        w3_launch<false>(x_dtype, y_dtype, stream, w);
+      }
+      GT_CHECK_LAUNCH();
+      return GT_OK;
+    }
   }
   if (w32_eligible(compute, x_dtype, M, groups) && (act != 2 || (x_dtype == GT_F32 && y_dtype == GT_F32))) {
     L32Args w{};
@@ -1371,6 +1393,72 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
+  bool dx_done = false;
+  if (dx && groups > 1 && g3_eligible(compute, x_dtype, y_dtype, M, N, K, ldx, ldy) && !g_opt.bns.part && !g_opt.bcast && !g_opt.gate_out &&
+      !g_cat2.dx2 && !rows__.rows) {
+    // dX of a grouped big-M fp32 GEMM on the bound images of the groups' W^T (k_lin3, blockIdx.y = group)
+    int64_t spacing = 0;
+    if (const void* img = w3_lookup_grouped(weight, N, K, groups, true, &spacing)) {
+      L32Args w{};
+      w.a = dy; w.amask = y_for_mask; w.out = dx; w.add1 = dx_add1; w.add2 = dx_add2;
+      w.M = M; w.Nout = K; w.Kc = N; w.lda = ldy; w.ldw = N; w.ldo = ldx; w.inv_keep = a.inv_keep;
+      w.w3 = img; w.groups = groups; w.g_a = y_group_stride; w.g_o = x_group_stride; w.g_img = spacing;
+      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
+      w3_launch<true>(y_dtype, x_dtype, stream, w);
+      dx_done = true;
+    }
+  }
+  static const bool g3_dw_on = [] { const char* e = getenv("GT_LIN3_GROUPED_DW"); return !(e && e[0] == '0'); }();   // (A/B knob)
+  if (g3_dw_on && dweight && groups > 1 && g3_eligible(compute, x_dtype, y_dtype, M, N, K, ldx, ldy) && !g_cat2.x2 && !rows__.rows && workspace &&
+      workspace_bytes >= need) {
+    // the groups' weight gradients on the pipelined bf16x6 kernel (k_lin3r_dw, blockIdx.y = group) when their weights are bound
+    int64_t spacing = 0;
+    L32DwArgs d{};
+    d.dy = dy; d.ymask = y_for_mask; d.x = x; d.inv_keep = a.inv_keep;
+    d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx;
+    d.groups = groups; d.g_y = y_group_stride; d.g_x = x_group_stride;
+    if (w3_lookup_grouped(weight, N, K, groups, false, &spacing) && w3r_dw_ok(y_dtype, x_dtype, d)) {
+      const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && !(gt_prof_mask() & GT_PROF_LINEAR)) || g_opt.as_fork;
+      const bool forked = will_fork && !g_opt.as_fork;
+      if (forked) {
+        (void)hipEventRecord(g_dw.ev_fork, stream);
+        (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
+        dw_run_queued();
+        stream = g_dw.side;
+      }
+      const int shape = w3r_dw_pick_shape(N, K);
+      const int nkb3 = (int)gt_cdiv(K, w3r_dw_xt(shape)), nnb3 = (int)gt_cdiv(N, w3r_dw_zt(shape));
+      int s3 = w3_dw_splits(M, nkb3 * nnb3 * groups);
+      const int cap = w32_dw_splits(M, (int)gt_cdiv(K, 64), (int)gt_cdiv(gt_cdiv(N, 16), w32_pick_nt(N)), false);   // a group's share of the workspace holds this many partial copies
+      if (s3 > cap) s3 = cap;
+      const int64_t per = (int64_t)s3 * (N * K + N);
+      // (reduced right behind the GEMM, not deferred to the end of the backward: the PNA driver gathers the image gradients before that)
+      const bool deferred = false;
+      float* base = reinterpret_cast<float*>(workspace);
+      d.g_part = deferred ? per : a.g_part;
+      d.part = base; d.dbpart = dbias ? base + (int64_t)s3 * N * K : nullptr;
+      d.splits = s3; d.nkb = nkb3; d.nnb = nnb3;
+      d.m_per_split = gt_cdiv(gt_cdiv(M, s3), 32) * 32;
+      dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3), (unsigned)groups);
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3r_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
+        w3r_launch_dw(grid3, stream, d, shape);
+        if (deferred) {
+          for (int g = 0; g < groups; ++g)
+            (void)gt_defer_push(base + g * per, s3, N * K, N * K, dweight + (int64_t)g * N * K, dbias ? base + g * per + (int64_t)s3 * N * K : nullptr,
+                                dbias ? N : 0, dbias ? N : 0, dbias ? dbias + (int64_t)g * N : nullptr);
+        } else {
+          const int64_t len = N * K, len2 = dbias ? N : 0;
+          const int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
+          hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)base, s3, len, dweight, (const float*)d.dbpart,
+                             len2, dbias, d.g_part);
+        }
+      }
+      if (forked) dw_forked(workspace, workspace_bytes);
+      dweight = nullptr; dbias = nullptr;   // done
+      if (!dx || dx_done) { GT_CHECK_LAUNCH(); return GT_OK; }
+    }
+  }
   if (w32_eligible(compute, x_dtype, M, groups)) {
     if (!workspace || workspace_bytes < need) {
       gt_set_error("gt_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -1480,7 +1568,6 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
-  bool dx_done = false;
   if (dx && x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && groups == 1 && M >= W1_MIN_M && (!y_for_mask || g_opt.gate_out)) {
     // dX = dY W on the bound image of W^T (linear1.h); a gate here applies to the OUTPUT columns (gt_linear_bwd_gate_out)
     if (const void* img = w1_lookup(weight, N, K, true)) {
@@ -1666,7 +1753,7 @@ extern "C" int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int6
 extern "C" size_t gt_w3_image_bytes(int64_t rows, int64_t contraction) {
   return rows > 0 && contraction > 0 ? w3_image_bytes(rows, contraction) : 0;
 }
-// Builds `n` images in as few launches as the kernel-argument table allows (24 jobs each).  Job i: weight[i] is the fp32 matrix
+// Builds `n` images in as few launches as the kernel-argument table allows (64 jobs each).  Job i: weight[i] is the fp32 matrix
 // [N[i]][K[i]] (row pitch K[i]); transposed[i] == 0 -> image of W (rows N, contraction K) for the forward, != 0 -> image of W^T (rows K,
 // contraction N) for the dX GEMM; image[i] has gt_w3_image_bytes(rows, contraction) bytes, 1024-byte aligned.
 extern "C" int gt_w3_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,

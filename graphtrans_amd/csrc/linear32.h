@@ -47,6 +47,11 @@ struct L32Args {
   // modules/gnn_module.py:219 backward, without materialising it per node): rows [.][ldo] fp32, int32 index per GEMM row
   const float* add_bc;
   const int32_t* add_bidx;
+  // k_lin3 only -- a GROUPED launch (blockIdx.y = group, e.g. the towers of PNAConv, modules/pna/pna_module.py:116-133): group g reads
+  // a / amask + g * g_a elements, the image w3 + g * g_img bytes, bias + g * g_b, and writes out (add1 / add2 alike) + g * g_o elements
+  int groups;          // 0 / 1 = one GEMM
+  int g_b;
+  int64_t g_a, g_o, g_img;
   // k_lin3 only -- the JK = "cat" concatenation without a copy (torch.cat([h_list[0], h_list[-1]], 1), modules/gnn_module.py:104-105):
   const void* a2;      // contraction columns [a_split, Kc) of the row operand come from this matrix (pitch lda2); null = none
   int64_t a_split, lda2;
@@ -365,6 +370,10 @@ struct L32DwArgs {
   const void* x2;      // columns [x_split, K) of X come from this matrix (pitch ldx2); null = none
   int64_t x_split, ldx2;
   const int32_t* dy_rows;   // k_lin3_dw only: row m of dY is row dy_rows[m] of `dy` (zeros when < 0); see L32Args
+  // k_lin3r_dw only -- a GROUPED launch (blockIdx.y = group): group g reads dy / ymask + g * g_y and x + g * g_x elements and writes
+  // its partials g * g_part floats behind part / dbpart
+  int groups;               // 0 / 1 = one GEMM
+  int64_t g_y, g_x, g_part;
 };
 
 template <typename TY, typename TX, int NT, bool MASK>

@@ -344,7 +344,7 @@ static inline bool w3r_enabled() {
 // the register-row kernel takes the call (MASK callers pass amask == null for an ungated dX)
 static inline bool w3r_ok(int ta, int to, const L32Args& a) {
   if (!w3r_enabled() || ta != GT_F32 || to != GT_F32 || !a.w3) return false;
-  if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out) return false;
+  if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out || a.groups > 1) return false;
   if (a.bn_part && (a.bn_ldx % 4 || (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mean | (uintptr_t)a.bn_rstd | (uintptr_t)a.bn_w | (uintptr_t)a.bn_b) & 15))) return false;
   if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias | (uintptr_t)a.add_bc) & 15) != 0) return false;
   if (a.M < W3R_MIN_M || a.Nout % 4 || a.Kc % 4 || a.Kc < 4 || a.lda % 4 || a.ldo % 4) return false;
@@ -395,10 +395,14 @@ static inline void w3r_launch(hipStream_t stream, L32Args& a) {
 // of LDS leave a CU nothing for the main stream's kernels: Code2 71.0 k graphs/s against 73.3 k for the 4-wave form (= k_lin3_dw's
 // 73.1-73.6 k: the weight gradients run beside the critical path, their duration does not enter the step).  The 4-wave form ships;
 // GT_LIN3R_DW_PC=1 selects this one.
-template <bool MASK, bool ROWS, bool PC>
+// TN x TK: accumulator tiles per wave -> block = 32 TN x 32 TK outputs (5 x 5: 160 x 160; 7 x 4: 224 x 128 for the PNA towers' 204 x 340)
+template <bool MASK, bool ROWS, bool PC, int TN = 5, int TK = 5>
 __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwArgs a) {
-  constexpr int NCH = 5;                                   // 16-byte chunks of a [32][160] fp32 tile per thread: chunk c = tid + 256 i
-  constexpr int STAGE_EL = 6 * W3D_PLANE;                  // bf16 elements of one stage buffer: sZ[3] then sX[3]
+  static_assert(TK <= TN && TN <= 7, "one X chunk per n-tile of the MFMA loop at most");
+  constexpr int ZT = 32 * TN, XT = 32 * TK;                // the block's extents along N and K
+  constexpr int LDZ = ZT + 8, LDX = XT + 8, PLZ = 32 * LDZ, PLX = 32 * LDX;   // plane pitches / sizes (bf16 elements)
+  constexpr int NCZ = TN, NCX = TK;                        // 16-byte chunks of the [32][ZT] / [32][XT] fp32 tiles per thread: chunk c = tid + 256 i
+  constexpr int STAGE_EL = 3 * PLZ + 3 * PLX;              // bf16 elements of one stage buffer: sZ[3] then sX[3]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3rd[];
   gt_bf16* sbuf = reinterpret_cast<gt_bf16*>(smem3rd);
   const int lane = threadIdx.x & 63;
@@ -421,65 +425,87 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
   }
   if (split_ >= a.splits) return;
   const int kb = tile_ % a.nkb, nb = tile_ / a.nkb;
-  const int64_t n0 = (int64_t)nb * W3D_T, k0 = (int64_t)kb * W3D_T;
+  const int64_t n0 = (int64_t)nb * ZT, k0 = (int64_t)kb * XT;
   const int64_t mb = split_ * a.m_per_split;
   const int64_t me = mb + a.m_per_split < a.M ? mb + a.m_per_split : a.M;
+  if (a.groups > 1) {   // grouped launch: this block's group has its own operands and partials (uniform pointer arithmetic)
+    const int64_t gi = blockIdx.y;
+    a.dy = reinterpret_cast<const float*>(a.dy) + gi * a.g_y;
+    if (a.ymask) a.ymask = reinterpret_cast<const float*>(a.ymask) + gi * a.g_y;
+    a.x = reinterpret_cast<const float*>(a.x) + gi * a.g_x;
+    a.part += gi * a.g_part;
+    if (a.dbpart) a.dbpart += gi * a.g_part;
+  }
   const float* dY = reinterpret_cast<const float*>(a.dy);
   const float* Ym = reinterpret_cast<const float*>(a.ymask);
   const bool has_mask = MASK && Ym != nullptr;
   const float* X = reinterpret_cast<const float*>(a.x);
 
   // chunk i of this thread: row cr[i] of the stage, columns cq[i] .. + 3 of the tile (the same at every stage)
-  int cr[NCH], cq[NCH];
-  bool zcol[NCH], xcol[NCH];   // the chunk's columns exist
-  int64_t zoff[NCH], xld[NCH];
-  const float* xsrc[NCH];   // the chunk's X column in row 0 of its matrix (columns [x_split, K) of a virtual concatenation live in x2)
+  int crz[NCZ], cqz[NCZ], crx[NCX], cqx[NCX];
+  bool zcol[NCZ], xcol[NCX];   // the chunk's columns exist
+  int64_t zoff[NCZ], xld[NCX];
+  const float* xsrc[NCX];   // the chunk's X column in row 0 of its matrix (columns [x_split, K) of a virtual concatenation live in x2)
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
+  for (int i = 0; i < NCZ; ++i) {
     const int c = tid + 256 * i;
-    cr[i] = c / 40;
-    cq[i] = (c % 40) * 4;
-    zcol[i] = n0 + cq[i] < a.N;
-    xcol[i] = k0 + cq[i] < a.K;
-    zoff[i] = (int64_t)cr[i] * a.ldy + (zcol[i] ? n0 + cq[i] : 0);
-    const int64_t col = xcol[i] ? k0 + cq[i] : 0;
+    crz[i] = c / (ZT / 4);
+    cqz[i] = (c % (ZT / 4)) * 4;
+    zcol[i] = n0 + cqz[i] < a.N;
+    zoff[i] = (int64_t)crz[i] * a.ldy + (zcol[i] ? n0 + cqz[i] : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NCX; ++i) {
+    const int c = tid + 256 * i;
+    crx[i] = c / (XT / 4);
+    cqx[i] = (c % (XT / 4)) * 4;
+    xcol[i] = k0 + cqx[i] < a.K;
+    const int64_t col = xcol[i] ? k0 + cqx[i] : 0;
     const bool second = a.x2 && col >= a.x_split;
     xld[i] = second ? a.ldx2 : a.ldx;
-    xsrc[i] = (second ? reinterpret_cast<const float*>(a.x2) + (col - a.x_split) : X + col) + (int64_t)cr[i] * xld[i];
+    xsrc[i] = (second ? reinterpret_cast<const float*>(a.x2) + (col - a.x_split) : X + col) + (int64_t)crx[i] * xld[i];
   }
   struct Raw {
-    float4 z[NCH], x[NCH], m[MASK ? NCH : 1];
+    float4 z[NCZ], x[NCX], m[MASK ? NCZ : 1];
     uint32_t none;   // dy_rows: bit i = chunk i's row of dY has no source (zeros)
   };
   auto load_stage = [&](Raw& R, int64_t m0) {   // rows m0 + cr[i]; rows past the range clamp to its last row (zeroed at split time)
     R.none = 0;
     if constexpr (W3RD_ABL & 8) {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) { R.z[i] = make_float4(1.f, 2.f, (float)m0, 4.f); R.x[i] = make_float4(4.f, 3.f, 2.f, (float)m0); }
+      for (int i = 0; i < NCZ; ++i) R.z[i] = make_float4(1.f, 2.f, (float)m0, 4.f);
+#pragma unroll
+      for (int i = 0; i < NCX; ++i) R.x[i] = make_float4(4.f, 3.f, 2.f, (float)m0);
       return;
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int64_t rowc = m0 + cr[i] < me ? m0 : me - 1 - cr[i];
+    for (int i = 0; i < NCZ; ++i) {
+      const int64_t rowc = m0 + crz[i] < me ? m0 : me - 1 - crz[i];
       if constexpr (ROWS) {   // dY's rows through the row map: L32DwArgs::dy_rows
-        const int32_t t = a.dy_rows[rowc + cr[i]];
+        const int32_t t = a.dy_rows[rowc + crz[i]];
         if (t < 0) R.none |= 1u << i;
-        R.z[i] = *reinterpret_cast<const float4*>(dY + (int64_t)(t < 0 ? 0 : t) * a.ldy + (zoff[i] - (int64_t)cr[i] * a.ldy));
+        R.z[i] = *reinterpret_cast<const float4*>(dY + (int64_t)(t < 0 ? 0 : t) * a.ldy + (zoff[i] - (int64_t)crz[i] * a.ldy));
       } else
       R.z[i] = *reinterpret_cast<const float4*>(dY + rowc * a.ldy + zoff[i]);
-      R.x[i] = *reinterpret_cast<const float4*>(xsrc[i] + rowc * xld[i]);
       if constexpr (MASK) {
         if (has_mask) R.m[i] = *reinterpret_cast<const float4*>(Ym + rowc * a.ldy + zoff[i]);
       }
     }
-  };
-  float4 dbs[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) dbs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NCX; ++i) {
+      const int64_t rowc = m0 + crx[i] < me ? m0 : me - 1 - crx[i];
+      R.x[i] = *reinterpret_cast<const float4*>(xsrc[i] + rowc * xld[i]);
+    }
+  };
+  float4 dbs[NCZ];
+#pragma unroll
+  for (int i = 0; i < NCZ; ++i) dbs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // split one chunk of a raw stage into the planes of buffer `buf`: which = 0 dZ chunk i (gated, summed into db), 1 X chunk i
   auto split_chunk = [&](const Raw& R, int64_t m0, int buf, int which, int i) {
-    gt_bf16* planes = sbuf + buf * STAGE_EL + which * 3 * W3D_PLANE;
-    const bool ok = m0 + cr[i] < me && (which ? xcol[i] : (zcol[i] && !((R.none >> i) & 1u)));
+    gt_bf16* planes = sbuf + buf * STAGE_EL + which * 3 * PLZ;
+    const int cr_ = which ? crx[i] : crz[i], cq_ = which ? cqx[i] : cqz[i];
+    const int pl_ = which ? PLX : PLZ;
+    const bool ok = m0 + cr_ < me && (which ? xcol[i] : (zcol[i] && !((R.none >> i) & 1u)));
     float4 v = which ? R.x[i] : R.z[i];
     if constexpr (MASK) {
       if (!which && has_mask) {
@@ -493,10 +519,10 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
     uint32_t p1[2], p2[2], p3[2];
     w3_split_pair(v.x, v.y, p1[0], p2[0], p3[0]);
     w3_split_pair(v.z, v.w, p1[1], p2[1], p3[1]);
-    gt_bf16* dst = planes + cr[i] * W3D_LD + cq[i];
+    gt_bf16* dst = planes + cr_ * (which ? LDX : LDZ) + cq_;
     *reinterpret_cast<uint2*>(dst) = make_uint2(p1[0], p1[1]);
-    *reinterpret_cast<uint2*>(dst + W3D_PLANE) = make_uint2(p2[0], p2[1]);
-    *reinterpret_cast<uint2*>(dst + 2 * W3D_PLANE) = make_uint2(p3[0], p3[1]);
+    *reinterpret_cast<uint2*>(dst + pl_) = make_uint2(p2[0], p2[1]);
+    *reinterpret_cast<uint2*>(dst + 2 * pl_) = make_uint2(p3[0], p3[1]);
   };
 
   const int64_t nst = mb < me ? (me - mb + 31) / 32 : 0;
@@ -507,16 +533,16 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
   // from between the MFMAs below.
   auto db_fold = [&]() {   // (every wave of the block passes the two barriers)
     __syncthreads();
-    float* sdb = reinterpret_cast<float*>(smem3rd);   // [32][160]
+    float* sdb = reinterpret_cast<float*>(smem3rd);   // [32][ZT]
     if (stager) {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(sdb + cr[i] * W3D_T + cq[i]) = dbs[i];
+      for (int i = 0; i < NCZ; ++i) *reinterpret_cast<float4*>(sdb + crz[i] * ZT + cqz[i]) = dbs[i];
     }
     __syncthreads();
-    if (stager && tid < W3D_T && n0 + tid < a.N) {
+    if (stager && tid < ZT && n0 + tid < a.N) {
       float t = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) t += sdb[r * W3D_T + tid];
+      for (int r = 0; r < 32; ++r) t += sdb[r * ZT + tid];
       a.dbpart[(int64_t)split_ * a.N + n0 + tid] = t;
     }
   };
@@ -526,7 +552,7 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
       if (nst > 0) {
         load_stage(RA, mb);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) { split_chunk(RA, mb, 0, 0, i); split_chunk(RA, mb, 0, 1, i); }
+        for (int i = 0; i < NCZ; ++i) { split_chunk(RA, mb, 0, 0, i); if (i < NCX) split_chunk(RA, mb, 0, 1, i); }
         load_stage(RA, nst > 1 ? mb + 32 : mb);
       }
       __syncthreads();
@@ -534,9 +560,9 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
         const int buf = (int)(s & 1);
         const int64_t m1 = mb + (s + 1) * 32, m2 = mb + (s + 2) * 32;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {   // (a stage past the range: zeros into the idle buffer)
+        for (int i = 0; i < NCZ; ++i) {   // (a stage past the range: zeros into the idle buffer)
           split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 0, i);
-          split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, i);
+          if (i < NCX) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, i);
         }
         load_stage(RA, m2 < me ? m2 : (me > 32 ? me - 32 : mb));   // in flight across the barrier: these waves have the time
         __syncthreads();
@@ -547,17 +573,17 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
   }
 
   // ---- the multiplying side ------------------------------------------------------------------------------------------------------
-  f32x4 acc[5][5];   // [n tile j][k tile i]
+  f32x4 acc[TN][TK];   // [n tile j][k tile i]
 #pragma unroll
-  for (int j = 0; j < 5; ++j)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TK; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   Raw RA, RB;   // (!PC) RA: the stage that is split during the current stage; RB: the one after it, in flight
   if constexpr (!PC) {
     if (nst > 0) {
       load_stage(RA, mb);
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) { split_chunk(RA, mb, 0, 0, i); split_chunk(RA, mb, 0, 1, i); }
+      for (int i = 0; i < NCZ; ++i) { split_chunk(RA, mb, 0, 0, i); if (i < NCX) split_chunk(RA, mb, 0, 1, i); }
       load_stage(RA, nst > 1 ? mb + 32 : mb);
     }
   }
@@ -568,36 +594,36 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
     if constexpr (!PC) load_stage(RB, m2 < me ? m2 : (me > 32 ? me - 32 : mb));
     __builtin_amdgcn_sched_barrier(0);
     const gt_bf16* sZ = sbuf + buf * STAGE_EL;
-    const gt_bf16* sX = sZ + 3 * W3D_PLANE;
-    auto fload = [&](const gt_bf16* pl, int col0) {
+    const gt_bf16* sX = sZ + 3 * PLZ;
+    auto fload = [&](const gt_bf16* pl, int ld, int col0) {
       if constexpr (W3RD_ABL & 2) { Frag<gt_bf16> f; f.v = make_uint4((uint32_t)col0, (uint32_t)s, 3u, (uint32_t)lane); return f; }
-      else return frag_load_tr(pl, W3D_LD, 0, col0, n, g);
+      else return frag_load_tr(pl, ld, 0, col0, n, g);
     };
-    Frag<gt_bf16> fx[5][3];
+    Frag<gt_bf16> fx[TK][3];
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < TK; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fx[i][p] = fload(sX + p * W3D_PLANE, wk * 80 + i * 16);
+      for (int p = 0; p < 3; ++p) fx[i][p] = fload(sX + p * PLX, LDX, wk * 16 * TK + i * 16);
     Frag<gt_bf16> fz[2][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) fz[0][p] = fload(sZ + p * W3D_PLANE, wn * 80);
+    for (int p = 0; p < 3; ++p) fz[0][p] = fload(sZ + p * PLZ, LDZ, wn * 16 * TN);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int cur = j & 1;
       constexpr int PZ[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
         // side work in front of this group of 5 MFMAs: the next n-tile's fragments (t < 3); one wave per SIMD (!PC): one chunk of the
         // next stage's split (t = 1, 4)
-        if (j + 1 < 5 && t < 3) fz[cur ^ 1][t] = fload(sZ + t * W3D_PLANE, wn * 80 + (j + 1) * 16);
+        if (j + 1 < TN && t < 3) fz[cur ^ 1][t] = fload(sZ + t * PLZ, LDZ, wn * 16 * TN + (j + 1) * 16);
         if constexpr (!PC) {
           if (t == 1) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 0, j);
-          if (t == 4) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, j);
+          if (t == 4 && j < NCX) split_chunk(RA, m1 < me ? m1 : me, buf ^ 1, 1, j);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < TK; ++i) {
           if constexpr (W3RD_ABL & 1) acc[j][i][0] += __uint_as_float(fz[cur][PZ[t]].v.x) * __uint_as_float(fx[i][PX[t]].v.y);
           else acc[j][i] = mma(fz[cur][PZ[t]], fx[i][PX[t]], acc[j][i]);
         }
@@ -609,22 +635,22 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
   }
 
   // acc[j][i][r] = C[row n0 + wn*80 + j*16 + g*4 + r][column k0 + wk*80 + i*16 + n] -> per-wave patch [16 n rows][80 k columns]
-  constexpr int PLD = 80 + 4;
+  constexpr int PLD = 16 * TK + 4;
   float* patch = reinterpret_cast<float*>(smem3rd) + wid * 16 * PLD;
   float* part = a.part + (int64_t)split_ * a.N * a.K;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < TN; ++j) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < TK; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) patch[(g * 4 + r) * PLD + i * 16 + n] = acc[j][i][r];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {   // 16 rows x 20 chunks = 320 chunks
+    for (int q = 0; q < TK; ++q) {   // 16 rows x 4 TK chunks
       const int c = lane + q * 64;
-      const int r = c / 20, c4 = (c % 20) * 4;
-      const int64_t row = n0 + wn * 80 + j * 16 + r, col = k0 + wk * 80 + c4;
+      const int r = c / (4 * TK), c4 = (c % (4 * TK)) * 4;
+      const int64_t row = n0 + wn * 16 * TN + j * 16 + r, col = k0 + wk * 16 * TK + c4;
       if (row < a.N && col < a.K && (!(W3RD_ABL & 16) || patch[r * PLD + c4] == 12345.678f)) *reinterpret_cast<float4*>(part + row * a.K + col) = *reinterpret_cast<const float4*>(patch + r * PLD + c4);
     }
     __builtin_amdgcn_wave_barrier();
@@ -639,11 +665,43 @@ static inline bool w3r_dw_enabled() {
 }
 // the pipelined kernel takes the call: fp32 operands, 16-byte aligned rows
 static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
-  if (!w3r_dw_enabled() || ty != GT_F32 || tx != GT_F32 || (a.dy_rows && a.ymask)) return false;
+  if (!w3r_dw_enabled() || ty != GT_F32 || tx != GT_F32 || (a.dy_rows && a.ymask) || (a.groups > 1 && (a.dy_rows || a.x2))) return false;
   if (a.N % 4 || a.K % 4 || a.ldy % 4 || a.ldx % 4 || (a.x2 && (a.ldx2 % 4 || a.x_split % 4))) return false;
   return (((uintptr_t)a.dy | (uintptr_t)a.x | (uintptr_t)a.ymask | (uintptr_t)a.x2) & 15) == 0;
 }
-static inline void w3r_launch_dw(dim3 grid, hipStream_t stream, const L32DwArgs& a) {
+// block shapes of k_lin3r_dw: 0 = 160 x 160 (5 x 5 tiles per wave), 1 = 224 x 128 (7 x 4: the PNA towers' 204 x 340 post-Linear
+// pads to 224 x 384 instead of 320 x 480)
+static inline int w3r_dw_zt(int shape) { return shape == 1 ? 224 : 160; }
+static inline int w3r_dw_xt(int shape) { return shape == 1 ? 128 : 160; }
+static inline int w3r_dw_pick_shape(int64_t N, int64_t K) {   // least padded area, ties -> 0
+  int best = 0;
+  int64_t area = -1;
+  for (int sh = 0; sh < 2; ++sh) {
+    const int64_t ar = gt_cdiv(N, w3r_dw_zt(sh)) * w3r_dw_zt(sh) * gt_cdiv(K, w3r_dw_xt(sh)) * w3r_dw_xt(sh);
+    if (area < 0 || ar < area) { area = ar; best = sh; }
+  }
+  return best;
+}
+template <int TN, int TK>
+static inline void w3r_launch_dw_shape(dim3 grid, hipStream_t stream, const L32DwArgs& a) {
+  constexpr int LDS = 2 * 2 * (3 * 32 * (32 * TN + 8) + 3 * 32 * (32 * TK + 8));
+  static std::mutex mu;
+  static bool done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<true, false, false, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, false, false, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+  }
+  if (a.ymask) hipLaunchKernelGGL((k_lin3r_dw<true, false, false, TN, TK>), grid, dim3(256), LDS, stream, a);
+  else hipLaunchKernelGGL((k_lin3r_dw<false, false, false, TN, TK>), grid, dim3(256), LDS, stream, a);
+}
+static inline void w3r_launch_dw(dim3 grid, hipStream_t stream, const L32DwArgs& a, int shape = 0) {
+  if (shape == 1) { w3r_launch_dw_shape<7, 4>(grid, stream, a); return; }   // (no row map there: w3r_dw_ok with groups)
   constexpr int LDS = 2 * 6 * W3D_PLANE * 2;
   static std::mutex mu;
   static bool done[16] = {false};

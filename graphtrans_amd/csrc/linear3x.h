@@ -49,7 +49,7 @@ struct W3Job {
   int ntp, ksteps;
   int block0;       // first block of this job
 };
-constexpr int W3_MAX_JOBS = 24;
+constexpr int W3_MAX_JOBS = 64;   // (3 KB of kernel arguments)
 struct W3Jobs {
   W3Job j[W3_MAX_JOBS];
   int n;
@@ -119,6 +119,16 @@ __global__ void __launch_bounds__(256, 2) k_lin3(L32Args a) {
   }
   const int64_t m0 = mt * BM;
   if (m0 >= a.M) return;
+  if (a.groups > 1) {   // grouped launch: this block's group has its own operands (uniform pointer arithmetic)
+    const int64_t gi = blockIdx.y;
+    a.a = reinterpret_cast<const TA*>(a.a) + gi * a.g_a;
+    if (a.amask) a.amask = reinterpret_cast<const TA*>(a.amask) + gi * a.g_a;
+    a.w3 = reinterpret_cast<const unsigned char*>(a.w3) + gi * a.g_img;
+    if (a.bias) a.bias += gi * a.g_b;
+    if (a.add1) a.add1 = reinterpret_cast<const TO*>(a.add1) + gi * a.g_o;
+    if (a.add2) a.add2 = reinterpret_cast<const TO*>(a.add2) + gi * a.g_o;
+    a.out = reinterpret_cast<TO*>(a.out) + gi * a.g_o;
+  }
   const int64_t n0 = (int64_t)cb * NT * 16;
   const TA* A = reinterpret_cast<const TA*>(a.a);
   const TA* Am = reinterpret_cast<const TA*>(a.amask);
@@ -475,8 +485,9 @@ void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
   const int nt = w3_pick_nt(a.Nout);
   a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
   a.w3_ntp = (int)w3_ntp(a.Nout);
-  const int mt = w3_pick_mt(a.M, a.ncb);
-  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, 32 * mt), 8) * 8 * a.ncb));
+  const int ng = a.groups > 1 ? a.groups : 1;
+  const int mt = w3_pick_mt(a.M, a.ncb * ng);
+  dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, 32 * mt), 8) * 8 * a.ncb), (unsigned)ng);
 #define GT_W3_MT(TA_, TO_, NT_, GELU_)                                                             \
   do {                                                                                             \
     if (mt == 4) w3_launch_one<TA_, TO_, NT_, 4, W3_WB_MT4, MASK, GELU_>(grid, stream, a);                 \
@@ -718,4 +729,15 @@ static inline const void* w3_lookup(const float* w, int64_t N, int64_t K, bool t
   for (int i = 0; i < g_w3.n; ++i)
     if (g_w3.e[i].w == w && g_w3.e[i].N == N && g_w3.e[i].K == K) return transposed ? g_w3.e[i].img_t : g_w3.e[i].img_fwd;
   return nullptr;
+}
+// `groups` weights [N][K] back to back from w, every one bound, their images evenly spaced: the first image and the spacing in bytes
+static inline const void* w3_lookup_grouped(const float* w, int64_t N, int64_t K, int groups, bool transposed, int64_t* spacing) {
+  const unsigned char* i0 = (const unsigned char*)w3_lookup(w, N, K, transposed);
+  if (!i0 || groups < 2) { *spacing = 0; return i0; }
+  const unsigned char* i1 = (const unsigned char*)w3_lookup(w + N * K, N, K, transposed);
+  if (!i1) return nullptr;
+  *spacing = (int64_t)(i1 - i0);
+  for (int g = 2; g < groups; ++g)
+    if ((const unsigned char*)w3_lookup(w + (int64_t)g * N * K, N, K, transposed) != i0 + (int64_t)g * *spacing) return nullptr;
+  return i0;
 }

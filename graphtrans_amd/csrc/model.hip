@@ -579,6 +579,8 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
     }
   }
   for (int i = 0; i < nenc; ++i) { c->enc[i].seq_desc = c->seq_desc; c->enc[i].work_items = c->work_items; }
+  if (m->conv == GT_CONV_PNA)   // the towers' re-stacked weights (the optimizer changed them: one launch for all layers); their
+    GT_TRY(gt_gather_f32(m->pna_img, m->pna_src, m->pna_map, m->pna_n_img, st));   // bf16x3 images are built from these just below
   // ---- weight images (the weights changed since the last step: one launch each)
   if (b.use_w3) {
     const gt_image_set& s = b.use_w3 == 2 ? m->w3_enc : m->w3;
@@ -608,8 +610,6 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
       g.out_ptr = out_ptr; g.out_dst = out_dst; g.out_eid = out_eid;
     }
   }
-  if (m->conv == GT_CONV_PNA)   // the towers' re-stacked weight images (the optimizer changed the weights: one launch for all layers)
-    GT_TRY(gt_gather_f32(m->pna_img, m->pna_src, m->pna_map, m->pna_n_img, st));
   for (int l = 0; l < nvn; ++l) { c->vn[l].graph_ptr = graph_ptr; c->vn[l].node_graph = node_graph; }
 
   gt_stream_t side = m->has_vn ? m->st_vn : nullptr;

@@ -164,6 +164,7 @@ def _image_set(imgs):
     return s
 
 
+PNA_TOWER_IMAGES = os.environ.get("GT_PNA_TOWER_IMAGES", "1") != "0"   # bf16x3 images of the PNA tower weights (grouped k_lin3)
 W_MAX_BOUND = 64   # W3_MAX_BOUND / W1_MAX_BOUND of the library's bind tables
 
 
@@ -561,6 +562,17 @@ class _Plan:
             desc.bn_w, desc.bn_b = bn.weight.data_ptr(), bn.bias.data_ptr()
             desc.bn_rm, desc.bn_rv, desc.bn_nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
             desc.bn_momentum, desc.bn_eps = float(bn.momentum), float(bn.eps)
+        # the towers' re-stacked matrices get bf16x3 images too (grouped k_lin3: the T GEMMs of a tower stack in one launch on the
+        # bf16 matrix pipe at fp32 accuracy); views of pna_img, whose contents the driver gathers before it builds the images
+        self.pna_tower_views = []
+        if PNA_TOWER_IMAGES:
+            for l in range(L):
+                for j, (rows_, cols_) in ((0, (2 * F, F)), (2, (S * F, 5 * F))):
+                    o0 = int(cm.pna_img_off[l][j])
+                    for t in range(T):
+                        v = self.pna_img[o0 + t * rows_ * cols_:o0 + (t + 1) * rows_ * cols_].view(rows_, cols_)
+                        self.pna_tower_views.append(v)
+            self.w3_weights.extend(self.pna_tower_views)
         cm.off_pna_src = self.total
         for p, o_ in tower_params:
             self.params.append((p, self.total + o_))

@@ -534,7 +534,7 @@ int gt_linear_bwd_cat2(int y_dtype, int compute, const void* x1, int64_t K1, int
                        const float* weight, const void* dy, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2, float* dweight,
                        float* dbias, int64_t M, int64_t N, int64_t ldy, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 size_t gt_w3_image_bytes(int64_t rows, int64_t contraction);
-/* n images in one launch per 24 jobs: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (forward), != 0 -> image of
+/* n images in one launch per 64 jobs: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (forward), != 0 -> image of
  * W^T (dX form); image[i]: gt_w3_image_bytes(rows, contraction) bytes, 1024-byte aligned. */
 int gt_w3_images(int n, const float* const* weight, const int64_t* N, const int64_t* K, const int* transposed,
                  void* const* image, gt_stream_t stream);

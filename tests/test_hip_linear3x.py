@@ -469,3 +469,44 @@ def test_row_map_with_layernorm_equals_gather_then_layernorm(tok_dtype, tol, max
     assert rel(mean, mean_ref) < 1e-5 and rel(rstd, rstd_ref) < 1e-5
     assert float((xin.float() - xin_ref.float()).abs().max()) <= tol * max(1.0, float(xin_ref.float().abs().max()))
     assert rel(xin.float(), xin_ref.float()) < tol * 0.1
+
+
+@pytest.mark.parametrize("M,T,K,N", [(15945, 4, 68, 136), (15945, 4, 340, 204), (1500, 3, 36, 20), (4097, 2, 100, 324)])
+def test_grouped_towers_on_bound_images(M, T, K, N):
+    """gt_linear_fwd_grouped / gt_linear_bwd_grouped with every tower weight bound (PNAConv's pre / post tower stacks,
+    modules/pna/pna_module.py:116-133, at the Code2-PNA shapes): k_lin3 with blockIdx.y = tower, column slices in and out, bias, the two
+    dX addends; held to the float64 evaluation like the one-group kernel, and the weight gradient to the exact kernel's bits."""
+    from graphtrans_amd import _lib, w3
+    from graphtrans_amd.graph import _stream
+    torch.manual_seed(M + K)
+    x = torch.randn(M, T * K, device=DEV)
+    W = (torch.randn(T, N, K, device=DEV) / K ** 0.5).contiguous()
+    b = torch.randn(T, N, device=DEV)
+    dy = torch.randn(M, T * N, device=DEV)
+    a1, a2 = torch.randn(M, T * K, device=DEV), torch.randn(M, T * K, device=DEV)
+    imgs = w3.W3Images([W[t] for t in range(T)])
+    imgs.build()
+    ws_bytes = _lib.lib().gt_linear_bwd_grouped_workspace_bytes(GT_F32, M, N, K, T)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=DEV)
+
+    def run():
+        y = torch.empty(M, T * N, device=DEV)
+        dx = torch.empty(M, T * K, device=DEV)
+        dw, db = torch.empty(T, N, K, device=DEV), torch.empty(T, N, device=DEV)
+        _lib.launch("gt_linear_fwd_grouped", GT_F32, GT_F32, GT_F32, _p(x), _p(W), _p(b), _p(y), M, N, K, T * K, T * N, T, K, N, 0, 0.0, 0, _stream())
+        _lib.launch("gt_linear_bwd_grouped", GT_F32, GT_F32, GT_F32, _p(x), _p(W), _p(dy), None, _p(a1), _p(a2), _p(dx), _p(dw), _p(db),
+                    M, N, K, T * K, T * N, T, K, N, 0.0, _p(ws), ws_bytes, _stream())
+        torch.cuda.synchronize()
+        return y, dx, dw, db
+
+    y0, dx0, dw0, db0 = run()            # exact-fp32 tiled kernels
+    with imgs.bound():
+        y1, dx1, dw1, db1 = run()        # grouped bf16x6
+    xd, Wd = x.double().view(M, T, K), W.double()
+    yr = (torch.einsum("mtk,tnk->mtn", xd, Wd) + b.double()).reshape(M, T * N)
+    dxr = torch.einsum("mtn,tnk->mtk", dy.double().view(M, T, N), Wd).reshape(M, T * K) + a1.double() + a2.double()
+    assert rel(y1, yr) <= 4e-7 and rel(dx1, dxr) <= 4e-7
+    assert rel(y1, yr) <= 2.0 * rel(y0, yr) + 1e-7 and rel(dx1, dxr) <= 2.0 * rel(dx0, dxr) + 1e-7
+    assert float((y1.double() - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    dwr = torch.einsum("mtn,mtk->tnk", dy.double().view(M, T, N), xd)
+    assert rel(dw1, dwr) <= 1e-6 and rel(db1, dy.double().view(M, T, N).sum(0)) <= 1e-6
