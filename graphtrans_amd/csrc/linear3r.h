@@ -674,6 +674,8 @@ static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
 static inline int w3r_dw_zt(int shape) { return shape == 1 ? 224 : 160; }
 static inline int w3r_dw_xt(int shape) { return shape == 1 ? 128 : 160; }
 static inline int w3r_dw_pick_shape(int64_t N, int64_t K) {   // least padded area, ties -> 0
+  static const int forced = [] { const char* e = getenv("GT_LIN3R_DW_SHAPE"); return e ? atoi(e) : -1; }();   // (A/B knob)
+  if (forced >= 0) return forced ? 1 : 0;
   int best = 0;
   int64_t area = -1;
   for (int sh = 0; sh < 2; ++sh) {

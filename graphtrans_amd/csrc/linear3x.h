@@ -687,7 +687,12 @@ __global__ void __launch_bounds__(256, 1) k_lin3_dw(L32DwArgs a) {
 }
 
 static inline int w3_dw_splits(int64_t M, int tiles) {
-  int64_t s = 256 / (tiles > 0 ? tiles : 1);          // one block per CU: the kernel runs on the overlap stream beside the dX chain
+  // one block per CU (the kernel runs on the overlap stream beside the dX chain) -- and per XCD: block b runs on XCD b % 8 and the
+  // kernels give the tiles of a split ids 8 apart, so XCD x gets the splits = x (mod 8); with 21 splits x 12 tiles (the PNA towers)
+  // five XCDs got 36 blocks for their 32 CUs and the launch took two rounds (6.4 us per stage against 3.1: tools/gemm3r_dw_pna_probe).
+  // Whole groups of 8 splits, at most 32 blocks per XCD.
+  if (tiles < 1) tiles = 1;
+  int64_t s = tiles <= 32 ? 8 * (32 / tiles) : 256 / tiles;
   const int64_t maxs = gt_cdiv(M, 32 * 8);           // at least 8 stages per split
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
