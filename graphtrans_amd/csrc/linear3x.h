@@ -692,7 +692,8 @@ static inline int w3_dw_splits(int64_t M, int tiles) {
   // five XCDs got 36 blocks for their 32 CUs and the launch took two rounds (6.4 us per stage against 3.1: tools/gemm3r_dw_pna_probe).
   // Whole groups of 8 splits, at most 32 blocks per XCD.
   if (tiles < 1) tiles = 1;
-  int64_t s = tiles <= 32 ? 8 * (32 / tiles) : 256 / tiles;
+  static const int per_xcd = [] { const char* e = getenv("GT_DW3_XCD_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 32; }();   // (A/B knob)
+  int64_t s = tiles <= per_xcd ? 8 * (per_xcd / tiles) : (8 * per_xcd) / tiles;
   const int64_t maxs = gt_cdiv(M, 32 * 8);           // at least 8 stages per split
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
