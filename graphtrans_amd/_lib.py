@@ -76,6 +76,7 @@ SIGNATURES = {
     "gt_seq_token_rows_layernorm": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p, _p, _f, _p, _p, _p, _p]),
     "gt_seq_token_rows": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
     "gt_defer_begin": (_i, [_p, _sz]),
+    "gt_defer_limit": (_i, [_sz]),
     "gt_defer_take": (_p, [_sz]),
     "gt_defer_push": (_i, [_p, _i, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gt_defer_push_strided": (_i, [_p, _i, _i64, _i64, _p, _i64]),

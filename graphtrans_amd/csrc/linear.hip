@@ -769,6 +769,7 @@ struct DeferState {
   bool active = false;
   char* arena = nullptr;
   size_t cap = 0, used = 0;
+  size_t max_take = 0;   // gt_defer_limit: requests above this many bytes are refused (0 = no limit)
   DeferJobs jobs{};
   int blocks = 0;
 };
@@ -1903,12 +1904,19 @@ extern "C" int gt_defer_begin(void* arena, size_t bytes) {
   g_defer.arena = (char*)arena;
   g_defer.cap = bytes;
   g_defer.used = 0;
+  g_defer.max_take = 0;
   g_defer.jobs.n = 0;
   g_defer.blocks = 0;
   return GT_OK;
 }
+// Only partial buffers of at most `max_take_bytes` join the open section (0 = every size): the big batches keep the weight-gradient
+// GEMMs' immediate reduces (their partials stay in the reused, cache-resident workspaces) and defer the LayerNorms' column sums
+extern "C" int gt_defer_limit(size_t max_take_bytes) {
+  g_defer.max_take = max_take_bytes;
+  return GT_OK;
+}
 extern "C" void* gt_defer_take(size_t bytes) {
-  if (!g_defer.active || g_defer.jobs.n >= DEFER_MAX_JOBS) return nullptr;
+  if (!g_defer.active || g_defer.jobs.n >= DEFER_MAX_JOBS || (g_defer.max_take && bytes > g_defer.max_take)) return nullptr;
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (g_defer.used + need > g_defer.cap) return nullptr;
   void* p = g_defer.arena + g_defer.used;

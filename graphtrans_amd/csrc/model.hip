@@ -81,7 +81,7 @@ struct Ctx {
   int64_t e_str[MAXT + 1], e_clamp[MAXT + 1], e_rows[MAXT + 1];
   // backward arena
   size_t q_d_hgin, q_dyp;
-  size_t q_defer, defer_bytes;   // the arena of the backward's deferred partial-sum reduces (gt_defer_begin)
+  size_t q_defer, defer_bytes, defer_small;   // defer_small: only partial buffers up to this size join the section (0 = all)   // the arena of the backward's deferred partial-sum reduces (gt_defer_begin)
   size_t q_d_hg, q_dtok[2], q_d_hn, q_d_cls, q_d_rep, q_dA, q_dB, q_dC, q_dJ, q_dvn[4], q_ne_dw, q_bnpart[MAXL], q_heads_ws,
       q_ws[2], q_ws2, q_ws3;
   size_t bws_bytes, heads_ws_bytes, seg_ws_bytes, barena_bytes;
@@ -497,7 +497,10 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
               gt_linear_bwd_workspace_bytes(ec, e.rows, e.ffn, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.ffn);
     }
     static const int64_t defer_max = [] { const char* e = getenv("GT_DEFER_MAX_ELEMS"); return e ? (int64_t)atoll(e) : (int64_t)6000000; }();
-    c->defer_bytes = N * D <= defer_max ? need + 64 * 256 : 0;   // (see gt_model_backward: the big batches keep the immediate reduces)
+    // (see gt_model_backward: the big batches keep the GEMMs' immediate reduces and defer the LayerNorms' column sums only)
+    static const bool small_too = [] { const char* e = getenv("GT_DEFER_LN_ONLY"); return !e || atoi(e) != 0; }();   // (A/B knob)
+    c->defer_small = N * D > defer_max && small_too && nenc > 0 ? ln_ws : 0;
+    c->defer_bytes = N * D <= defer_max ? need + 64 * 256 : (c->defer_small ? (size_t)(2 * nenc + 2) * (ln_ws + 256) + 64 * 256 : 0);
     c->q_defer = q.take(c->defer_bytes);
   }
   c->barena_bytes = std::max(q.off, (size_t)256);
@@ -838,7 +841,10 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
   // (up to ~6 M node-row elements: where the step is made of launches it gains them -- Molpcba +1 %, NCI1 +2 %, PNA b128 +1.2 % --;
   // at Code2 b256 (9.5 M) the arena copies of the partials are cold memory where the reused workspaces stay in the Infinity Cache:
   // -0.9 %, so the big batches keep the immediate reduces)
-  if (!c->stages_done) GT_TRY(gt_defer_begin(c->defer_bytes ? Q(c->q_defer) : nullptr, c->defer_bytes));
+  if (!c->stages_done) {
+    GT_TRY(gt_defer_begin(c->defer_bytes ? Q(c->q_defer) : nullptr, c->defer_bytes));
+    if (c->defer_bytes && c->defer_small) GT_TRY(gt_defer_limit(c->defer_small));
+  }
   guard.defer_abort = true;   // cleared on the successful way out
   // `behind`: an event of a stream OTHER than the main one whose producers queued partials too (the virtual-node update's weight
   // gradients run on the second stream and the main stream joins that stream only in stage 4)

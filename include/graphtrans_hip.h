@@ -590,6 +590,7 @@ int gt_linear_bwd_mul_dw_forked(int x_dtype, int y_dtype, int compute, const voi
  * section, or when the arena / the job list is full, every call reduces on the spot as before.  (take / push are what the
  * library's own producers call; listed for completeness.) */
 int gt_defer_begin(void* arena, size_t bytes);
+int gt_defer_limit(size_t max_take_bytes);   /* only partial buffers up to this size join the open section (0 = every size) */
 void* gt_defer_take(size_t bytes);
 int gt_defer_push(const float* part, int nparts, int64_t len, int64_t stride, float* out, const float* part2, int64_t len2,
                   int64_t stride2, float* out2);
