@@ -120,6 +120,10 @@ SIGNATURES = {
     "gt_w1_bind": (_i, [_i, _p, _p, _p, _p, _p]),
     "gt_w1_unbind": (_i, []),
     "gt_linear_layernorm_fwd_ok": (_i, [_i, _i, _p, _i64, _i64, _i64]),
+    "gt_linear_bwd_dx_layernorm_ok": (_i, [_i, _i, _p, _i64, _i64, _i64]),
+    "gt_linear_bwd_dx_layernorm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gt_linear_bwd_dx_layernorm": (_i, [_i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f, _u64, _p, _p, _p, _p, _p, _sz, _p]),
+    "gt_layernorm_bwd_finish": (_i, [_p, _i, _i64, _p, _p, _p]),
     "gt_linear_layernorm_fwd": (_i, [_i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _f, _f, C.c_uint64, _p, _p, _p, _p]),
     "gt_linear_bwd_gate_out_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_bwd_gate_out": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _sz, _p]),

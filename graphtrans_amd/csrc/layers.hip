@@ -305,11 +305,20 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
   GT_TRY(gt_layernorm_bwd(t, s.f2, s.x1, dy, L->n2_w, s.st2, s.st2 + R, p, L->seed ^ 0x14057B7EF767814FULL, R, d, w.d_f2,
                           w.d_x1, g.n2_w, g.n2_b, w.ln_ws, w.ln_ws_bytes, st));
   // f2 = f1 W2^T + b2 ; f1 = drop(act(x1 W1^T + b1)) ; d_x1 += ...
+  bool norm1_done = false;
   if (gt_linear_bwd_gate_out_ok(t, t, c, L->l2_w, R, d, F)) {
     // weight-stationary path (linear1.h): linear2's dX GEMM writes the GATED gradient dZ1 = (dF2 W2) * act'(.) * dropout scale, the
     // tensor both GEMMs of linear1's backward read (the tiled kernels gate d_f1 while they stage it, twice)
     GT_TRY(gt_linear_bwd_gate_out(t, t, c, s.f1, L->l2_w, w.d_f2, L->act == 1 ? s.g1 : s.f1, nullptr, nullptr, w.d_f1, g.l2_w, g.l2_b, R, d, F,
                                   F, d, L->act == 1 ? -1.f : p, w.lin_ws, w.lin_ws_bytes, st));
+    if (gt_linear_bwd_dx_layernorm_ok(t, c, L->l1_w, R, F, d) && w.ln_ws_bytes >= gt_linear_bwd_dx_layernorm_workspace_bytes(R, F, d)) {
+      // linear1's dX GEMM ends in norm1's backward (x1 = LN1(x + drop(a))): d_x1 + dZ1 W1 never reaches memory (linear1.h, LNB epilogue)
+      // (the weight gradient is forked BEHIND the dX launch, as gt_linear_bwd does: beside it, it slowed the critical kernel)
+      GT_TRY(gt_linear_bwd_dx_layernorm(t, c, L->l1_w, w.d_f1, w.d_x1, nullptr, R, F, d, s.a, x, L->n1_w, s.st1, s.st1 + R, p,
+                                        L->seed ^ 0x5851F42D4C957F2DULL, w.d_a, dx, g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
+      GT_TRY(gt_linear_bwd_dw_forked(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, g.l1_w, g.l1_b, R, F, d, d, F, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+      norm1_done = true;
+    } else
     GT_TRY(gt_linear_bwd(t, t, c, s.x1, L->l1_w, w.d_f1, nullptr, w.d_x1, nullptr, w.d_x1, g.l1_w, g.l1_b, R, F, d, 0.f, w.lin_ws,
                          w.lin_ws_bytes, st));
   } else {
@@ -323,8 +332,9 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
                            w.lin_ws_bytes, st));
   }
   // x1 = LN1(x + drop(a))
-  GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
-                          g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
+  if (!norm1_done)
+    GT_TRY(gt_layernorm_bwd(t, s.a, x, w.d_x1, L->n1_w, s.st1, s.st1 + R, p, L->seed ^ 0x5851F42D4C957F2DULL, R, d, w.d_a, dx,
+                            g.n1_w, g.n1_b, w.ln_ws1, w.ln_ws_bytes, st));
   // a = ctx Wo^T + bo
   GT_TRY(gt_linear_bwd(t, t, c, s.ctx, L->out_w, w.d_a, nullptr, nullptr, nullptr, w.d_ctx, g.out_w, g.out_b, R, d, d, 0.f,
                        w.lin_ws, w.lin_ws_bytes, st));

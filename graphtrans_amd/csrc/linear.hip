@@ -1897,6 +1897,67 @@ extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, co
   return GT_OK;
 }
 
+// dX of a Linear whose OUTPUT gradient is at once the gradient of the LayerNorm below it (post-norm nn.TransformerEncoderLayer backward,
+// modules/transformer_encoder.py:28-32: linear1's dX + the residual gradient -> norm1's backward; in_proj's dX + the residual gradient
+// -> the previous layer's norm2): g = dY W (+ add1 + add2) never reaches memory, the GEMM's epilogue holds whole rows and runs
+// gt_layernorm_bwd's arithmetic on them -- d_sub = d(sub-layer output), d_resid = d(residual branch), and the LayerNorm's weight / bias
+// gradient through block partials in `workspace` (or the open deferred-reduce section).  weight [N][K], K = the LayerNorm dim.
+// Only on the weight-stationary path: gt_linear_bwd_dx_layernorm_ok says so (callers fall back to gt_linear_bwd + gt_layernorm_bwd).
+extern "C" int gt_linear_bwd_dx_layernorm_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
+  static const bool on = [] { const char* e = getenv("GT_W1_LNB"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return !on ? 0 : (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_lnb_covered(K, N) && w1_lookup(weight, N, K, true)) ? 1 : 0;
+}
+extern "C" size_t gt_linear_bwd_dx_layernorm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return (size_t)w1_grid_blocks(M, K, N) * 2 * (size_t)K * sizeof(float) + 256;
+}
+extern "C" int gt_linear_bwd_dx_layernorm(int dtype, int compute, const float* weight, const void* dy, const void* dx_add1, const void* dx_add2,
+                                          int64_t M, int64_t N, int64_t K, const void* ln_x, const void* ln_resid, const float* ln_weight,
+                                          const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed, void* d_sub,
+                                          void* d_resid, float* ln_dweight, float* ln_dbias, void* workspace, size_t workspace_bytes,
+                                          gt_stream_t stream_) {
+  GT_CHECK_ARG(weight && dy && ln_x && ln_weight && save_mean && save_rstd && ln_dweight && ln_dbias, "null buffer");
+  GT_CHECK_ARG(d_sub || d_resid, "nothing to compute");
+  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
+  if (!gt_linear_bwd_dx_layernorm_ok(dtype, compute, weight, M, N, K)) {
+    gt_set_error("gt_linear_bwd_dx_layernorm: not covered (ask gt_linear_bwd_dx_layernorm_ok)");
+    return GT_ERR_UNSUPPORTED;
+  }
+  if (M == 0) {
+    (void)hipMemsetAsync(ln_dweight, 0, (size_t)K * sizeof(float), (hipStream_t)stream_);
+    (void)hipMemsetAsync(ln_dbias, 0, (size_t)K * sizeof(float), (hipStream_t)stream_);
+    return GT_OK;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int blocks = w1_grid_blocks(M, K, N);
+  const size_t pbytes = (size_t)blocks * 2 * (size_t)K * sizeof(float);
+  float* part = (float*)gt_defer_take(pbytes);   // inside a deferred-reduce section: the column sums join its one launch
+  const bool deferred = part != nullptr;
+  if (!deferred) {
+    if (!workspace || workspace_bytes < pbytes) { gt_set_error("gt_linear_bwd_dx_layernorm: workspace too small"); return GT_ERR_WORKSPACE; }
+    if (g_dw.active && stream == g_dw.main) dw_release(workspace, workspace_bytes);   // a forked GEMM may still read partials there
+    part = (float*)workspace;
+  }
+  LinArgs d{};
+  fill_drop(d, dropout_p, seed);
+  L1Args l{};
+  l.a = (const gt_bf16*)dy; l.img = (const unsigned char*)w1_lookup(weight, N, K, true);
+  l.add1 = (const gt_bf16*)dx_add1; l.add2 = (const gt_bf16*)dx_add2;
+  l.M = M; l.lda = N; l.ldo = K; l.N = (int)K; l.K = (int)N;
+  l.lnb_x = (const gt_bf16*)ln_x; l.ln_resid = (const gt_bf16*)ln_resid; l.ln_w = ln_weight;
+  l.ln_mean = const_cast<float*>(save_mean); l.ln_rstd = const_cast<float*>(save_rstd);
+  l.ln_inv_keep = d.inv_keep; l.ln_thr = d.thr; l.ln_s0 = d.s0; l.ln_s1 = d.s1;
+  l.lnb_dsub = (gt_bf16*)d_sub; l.lnb_dresid = (gt_bf16*)d_resid; l.lnb_part = part;
+  bool ok;
+  {
+    GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[dx+lnb]", stream, {M, N, K, dtype, dtype, compute});
+    ok = w1_launch(stream, l);
+  }
+  if (!ok) { gt_set_error("gt_linear_bwd_dx_layernorm: launch set-up failed"); return GT_ERR_LAUNCH; }
+  GT_CHECK_LAUNCH();
+  if (deferred) return gt_defer_push(part, blocks, K, 2 * K, ln_dweight, part + K, K, 2 * K, ln_dbias);
+  return gt_layernorm_bwd_finish(part, blocks, K, ln_dweight, ln_dbias, stream_);
+}
+
 // ---- overlap section -------------------------------------------------------------------------------
 extern "C" int gt_defer_begin(void* arena, size_t bytes) {
   static const bool on = [] { const char* e = getenv("GT_DEFER_REDUCE"); return !e || atoi(e) != 0; }();   // (A/B knob)

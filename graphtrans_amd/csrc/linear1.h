@@ -77,6 +77,14 @@ struct L1Args {
   float* ln_rstd;
   float ln_eps, ln_inv_keep;
   uint32_t ln_thr, ln_s0, ln_s1;
+  // LNB instantiations (dX form, one column block = the whole row): g = acc (+ add1 + add2), rounded to bf16, is the gradient of
+  // LayerNorm(ln_resid + dropout(lnb_x)) (statistics ln_mean / ln_rstd, weight ln_w, dropout ln_thr / ln_s0 / ln_s1 / ln_inv_keep): the
+  // epilogue writes lnb_dresid = dz and lnb_dsub = dz * dropout mask instead of g, and the block's partial column sums of g * xhat and
+  // g into lnb_part[block][2][N] (k_ln_bwd_finish / the deferred reduce sum them: the LayerNorm's weight / bias gradient)
+  const gt_bf16* lnb_x;       // [M][ldo] the sub-layer output the forward normalised (before dropout)
+  gt_bf16* lnb_dsub;          // [M][ldo] or null
+  gt_bf16* lnb_dresid;        // [M][ldo] or null
+  float* lnb_part;
   int ncb;                    // column blocks of 64 * NTW columns
   int sgroups;                // row-tile groups in flight: grid = 8 * ncb * sgroups
   int row_tiles;              // ceil(M / 64)
@@ -100,7 +108,7 @@ __device__ __forceinline__ void w1_merge(float& mean, float& m2, float mean_b, f
 }
 
 // KS = K / 32 k-steps (K % 128 == 0), NTW = n-tiles per wave (column block = 4 * NTW * 16 columns)
-template <int KS, int NTW, bool LN = false>
+template <int KS, int NTW, int LN = 0>   // LN: 0 plain epilogue, 1 LayerNorm forward, 2 LayerNorm backward (LNB)
 __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   constexpr int KCH = KS / 4;                 // 128-deep chunks per row tile
   constexpr int PLD = w1_patch_ld<NTW>();
@@ -128,7 +136,19 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
   const int first_tile = sg * 8 + xcd;
   const int my_tiles = first_tile < a.row_tiles ? (a.row_tiles - first_tile + tile_stride - 1) / tile_stride : 0;
   const int nchunks = my_tiles * KCH;
-  if (nchunks == 0) return;
+  if (nchunks == 0) {
+    if constexpr (LN == 2) {   // (its partial row is summed with the others)
+      if (tid < 2 * NTW * 64) a.lnb_part[(int64_t)blockIdx.x * 2 * NTW * 64 + tid] = 0.f;
+    }
+    return;
+  }
+  // LNB: this thread's running column sums of g * xhat and g (its 8 columns are the same in every tile) live in a private LDS column
+  // [16][512] behind the patches (as registers they spilled beside the 128 weight registers of KS = 16)
+  float* lacc = reinterpret_cast<float*>(smem1 + w1_lds_bytes<NTW>()) + tid;
+  if constexpr (LN == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e * W1_THREADS] = 0.f;
+  }
 
   // staging: thread -> 2 x 16 bytes of a chunk: p = tid + q * 512 -> row p / 16, 16-byte column p % 16 (a wave reads 4 whole rows).
   // (plain values, no lambdas writing captured registers: those end up in scratch)
@@ -186,7 +206,138 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
     if (kc == KCH - 1) {
       // ---- epilogue of this row tile: per wave, 2 m-tiles x (NTW x 16) columns through the wave's patch
       const int tile = first_tile + t * tile_stride;
-      if constexpr (LN) {
+      if constexpr (LN == 2) {
+        // ---- LayerNorm-BACKWARD epilogue (k_ln_bwd_d128's arithmetic on the rows this block holds): phase A per wave -- g = bf16(acc +
+        // addends), xhat recomputed from the saved sub-layer output / residual / statistics, the wave's row sums of g * w and g * w * xhat
+        // over its NTW x 16 columns -> LDS --, block barrier, phase B: dz = rstd * (g w - mean(g w) - xhat * mean(g w xhat))
+        constexpr int CPR = NTW * 2, NCH = 16 * CPR, NQ = NCH / 64;
+        static_assert(NCH % 64 == 0, "LNB epilogue: whole waves of chunks");
+        constexpr float INV_D = 1.0f / (float)(NTW * 64);
+        // (one m-tile at a time, a block barrier each: holding both m-tiles' g / xhat rows across ONE barrier spilled at KS = 16)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float gk[NQ][8], xk[NQ][8], rk[NQ];
+          uint32_t kp[NQ];
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            *reinterpret_cast<float4*>(patch + n * PLD + j * 16 + g * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ch = lane + q * 64;
+            const int r = ch / CPR, c8 = (ch % CPR) * 8;
+            int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
+            const bool live = m < a.M;
+            if (!live) m = a.M - 1;   // (tail rows compute on a valid row, store nothing and add nothing to the column sums)
+            const int col = col0 + c8;
+            const int64_t o = m * a.ldo + col;
+            const uint4 sx = *reinterpret_cast<const uint4*>(a.lnb_x + o);
+            const uint4 sr = a.ln_resid ? *reinterpret_cast<const uint4*>(a.ln_resid + o) : make_uint4(0, 0, 0, 0);
+            const float mu = a.ln_mean[m], rs = a.ln_rstd[m];
+            float v[8];
+            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(patch + r * PLD + c8);
+            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(patch + r * PLD + c8 + 4);
+            if (a.add1) {
+              const uint4 ad = *reinterpret_cast<const uint4*>(a.add1 + o);
+              const uint32_t u[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] += __uint_as_float(u[e] << 16);
+                v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+              }
+            }
+            if (a.add2) {
+              const uint4 ad = *reinterpret_cast<const uint4*>(a.add2 + o);
+              const uint32_t u[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] += __uint_as_float(u[e] << 16);
+                v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+              }
+            }
+            {   // the LayerNorm backward sees the gradient as the stand-alone pair of kernels hands it over: rounded to bf16
+              const uint32_t u[4] = {gt_pack_bf16(v[0], v[1]), gt_pack_bf16(v[2], v[3]), gt_pack_bf16(v[4], v[5]), gt_pack_bf16(v[6], v[7])};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(u[e] << 16);
+                v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+              }
+            }
+            float x[8], rr[8];
+            {
+              const uint32_t ux[4] = {sx.x, sx.y, sx.z, sx.w}, ur[4] = {sr.x, sr.y, sr.z, sr.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                x[2 * e] = __uint_as_float(ux[e] << 16); x[2 * e + 1] = __uint_as_float(ux[e] & 0xffff0000u);
+                rr[2 * e] = __uint_as_float(ur[e] << 16); rr[2 * e + 1] = __uint_as_float(ur[e] & 0xffff0000u);
+              }
+            }
+            uint32_t keep = 0xffu;
+            if (a.ln_thr) {
+              keep = 0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const bool k = lin_hash(a.ln_s0, a.ln_s1, (uint32_t)m, (uint32_t)(col + e)) >= a.ln_thr;
+                keep |= k ? (1u << e) : 0u;
+                x[e] = k ? x[e] * a.ln_inv_keep : 0.f;
+              }
+            }
+            const float4 w0 = *reinterpret_cast<const float4*>(a.ln_w + col), w1 = *reinterpret_cast<const float4*>(a.ln_w + col + 4);
+            const float gw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float cnt = live ? 1.f : 0.f;
+            float gg[8], xh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              xh[e] = ((x[e] + rr[e]) - mu) * rs;
+              gg[e] = v[e] * gw[e];
+              lacc[(8 + e) * W1_THREADS] = fmaf(v[e], cnt, lacc[(8 + e) * W1_THREADS]);
+              lacc[e * W1_THREADS] = fmaf(v[e] * cnt, xh[e], lacc[e * W1_THREADS]);
+              gk[q][e] = gg[e];
+              xk[q][e] = xh[e];
+            }
+            kp[q] = keep;
+            rk[q] = rs;
+            float s1 = ((gg[0] + gg[1]) + (gg[2] + gg[3])) + ((gg[4] + gg[5]) + (gg[6] + gg[7]));
+            float s2 = ((gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3])) + ((gg[4] * xh[4] + gg[5] * xh[5]) + (gg[6] * xh[6] + gg[7] * xh[7]));
+#pragma unroll
+            for (int sh = 1; sh < CPR; sh <<= 1) {   // the CPR adjacent lanes of a row
+              s1 += __shfl_xor(s1, sh, 64);
+              s2 += __shfl_xor(s2, sh, 64);
+            }
+            if ((ch % CPR) == 0) rowstat[(wm * 32 + i * 16 + r) * 4 + wn] = make_float2(s1, s2);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int ch = lane + q * 64;
+            const int r = ch / CPR, c8 = (ch % CPR) * 8;
+            const int64_t m = (int64_t)tile * W1_TM + wm * 32 + i * 16 + r;
+            const float2* rsp = rowstat + (wm * 32 + i * 16 + r) * 4;
+            const float2 p0 = rsp[0], p1 = rsp[1], p2 = rsp[2], p3 = rsp[3];
+            const float m1 = ((p0.x + p1.x) + (p2.x + p3.x)) * INV_D, m2 = ((p0.y + p1.y) + (p2.y + p3.y)) * INV_D;
+            if (m < a.M) {
+              const int64_t o = m * a.ldo + col0 + c8;
+              float dz[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) dz[e] = rk[q] * (gk[q][e] - m1 - xk[q][e] * m2);
+              if (a.lnb_dresid)
+                *reinterpret_cast<uint4*>(a.lnb_dresid + o) =
+                    make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+              if (a.lnb_dsub) {
+                if (a.ln_thr) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) dz[e] = ((kp[q] >> e) & 1u) ? dz[e] * a.ln_inv_keep : 0.f;
+                }
+                *reinterpret_cast<uint4*>(a.lnb_dsub + o) =
+                    make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+              }
+            }
+          }
+        }
+      } else if constexpr (LN == 1) {
         // ---- LayerNorm epilogue: phase A per wave (a = bf16(acc + bias) stored; z = resid + dropout(a) kept in registers; the wave's
         // (mean, M2) over its NTW x 16 columns of every row -> LDS), block barrier, phase B (merge the 4 column waves, normalise, store)
         constexpr int CPR = NTW * 2, NCH = 16 * CPR, NQ = NCH / 64;
@@ -365,6 +516,33 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
     }
   }
 #undef W1_CHUNK_PTR
+  if constexpr (LN == 2) {
+    // ---- the block's partial of the LayerNorm weight / bias gradient: lanes with the same lane % CPR hold the same 8 columns (16 row
+    // lanes) -> lanes 0 .. CPR-1 of every wave -> the two row halves of a column quarter through LDS -> lnb_part[block][2][N]
+    constexpr int CPR = NTW * 2, NC = NTW * 64;
+    float lnb_w[8], lnb_b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lnb_w[e] = lacc[e * W1_THREADS]; lnb_b[e] = lacc[(8 + e) * W1_THREADS]; }
+    __syncthreads();   // (sred below aliases the stages, which the last tile's slower waves may still read)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int sh = CPR; sh < 64; sh <<= 1) {
+        lnb_w[e] += __shfl_xor(lnb_w[e], sh, 64);
+        lnb_b[e] += __shfl_xor(lnb_b[e], sh, 64);
+      }
+    }
+    float* sred = reinterpret_cast<float*>(smem1);   // [2 row halves][2][NC] (the stages are idle: the tile loop ended behind a barrier)
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sred[(wm * 2 + 0) * NC + col0 + lane * 8 + e] = lnb_w[e];
+        sred[(wm * 2 + 1) * NC + col0 + lane * 8 + e] = lnb_b[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * NC) a.lnb_part[(int64_t)blockIdx.x * 2 * NC + tid] = sred[tid] + sred[2 * NC + tid];
+  }
 }
 
 // ---- shapes ---------------------------------------------------------------------------------------------------------
@@ -383,13 +561,13 @@ static inline int w1_pick_ntw(int64_t R, int64_t C) {
   return 0;
 }
 
-template <int KS, int NTW, bool LN = false>
+template <int KS, int NTW, int LN = 0>
 static inline bool w1_launch_one(dim3 grid, hipStream_t stream, const L1Args& a) {
   static std::mutex mu;
   static bool set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  constexpr size_t lds = w1_lds_bytes<NTW>();
+  constexpr size_t lds = w1_lds_bytes<NTW>() + (LN == 2 ? 16 * W1_THREADS * sizeof(float) : 0);
   if (dev >= 0 && dev < 64) {
     std::lock_guard<std::mutex> lk(mu);
     if (!set[dev]) {
@@ -406,6 +584,22 @@ static inline bool w1_ln_covered(int64_t N, int64_t K) {
   const int ntw = w1_pick_ntw(N, K), ks = (int)(K / 32);
   return ntw && N == 64 * ntw && ((ntw == 2 && (ks == 4 || ks == 8 || ks == 16)) || (ntw == 4 && ks == 8));
 }
+// LayerNorm-backward epilogue: 128-column rows out of a 128 / 384 / 512-deep contraction (d_model = 128: out_proj^T-free shapes of the
+// encoder layer -- linear1's dX (512 -> 128) and in_proj's dX (384 -> 128))
+static inline bool w1_lnb_covered(int64_t N, int64_t K) {   // N = output columns (the LayerNorm dim), K = contraction
+  return N == 128 && (K == 128 || K == 384 || K == 512) && w1_pick_ntw(N, K) == 2;
+}
+// blocks of the launch for M rows and N output columns (the LNB partial rows: one per block)
+static inline int w1_grid_blocks(int64_t M, int64_t N, int64_t K) {
+  const int ntw = w1_pick_ntw(N, K);
+  if (!ntw || M <= 0) return 0;
+  const int ncb = (int)(N / (64 * ntw));
+  int sgroups = 32 / ncb;
+  if (sgroups < 1) sgroups = 1;
+  const int need = (int)gt_cdiv(gt_cdiv(M, W1_TM), 8);
+  if (sgroups > need) sgroups = need;
+  return 8 * ncb * sgroups;
+}
 static inline bool w1_launch(hipStream_t stream, L1Args& a) {
   const int ntw = w1_pick_ntw(a.N, a.K);
   if (!ntw || a.M <= 0) return false;
@@ -420,9 +614,16 @@ static inline bool w1_launch(hipStream_t stream, L1Args& a) {
   const int ks = a.K / 32;
   if (a.ln_out) {   // LayerNorm epilogue: the row must lie in ONE column block
     if (a.ncb != 1) return false;
-#define GT_W1_LN_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_, true>(grid, stream, a)
+#define GT_W1_LN_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_, 1>(grid, stream, a)
     GT_W1_LN_CASE(4, 2); GT_W1_LN_CASE(8, 2); GT_W1_LN_CASE(16, 2); GT_W1_LN_CASE(8, 4);
 #undef GT_W1_LN_CASE
+    return false;
+  }
+  if (a.lnb_part) {   // LayerNorm-backward epilogue (dX form): the row in ONE column block of 128 columns
+    if (a.ncb != 1) return false;
+    if (ks == 12 && ntw == 2) return w1_launch_one<12, 2, 2>(grid, stream, a);
+    if (ks == 16 && ntw == 2) return w1_launch_one<16, 2, 2>(grid, stream, a);
+    if (ks == 4 && ntw == 2) return w1_launch_one<4, 2, 2>(grid, stream, a);
     return false;
   }
 #define GT_W1_CASE(KS_, NTW_) if (ks == KS_ && ntw == NTW_) return w1_launch_one<KS_, NTW_>(grid, stream, a)

@@ -1312,6 +1312,16 @@ extern "C" size_t gt_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
   return (size_t)LN_BWD_BLOCKS * 2 * dim * sizeof(float) + 256;
 }
 
+// dweight[c] = sum_b part[b][0][c], dbias[c] = sum_b part[b][1][c] over `nblk` block partials [2][dim] (k_ln_bwd_finish: the fixed
+// order of gt_layernorm_bwd's own finish); for producers of such partials outside this file (linear1.h's LayerNorm-backward epilogue)
+extern "C" int gt_layernorm_bwd_finish(const float* part, int nblk, int64_t dim, float* dweight, float* dbias, gt_stream_t stream_) {
+  GT_CHECK_ARG(part && nblk >= 1 && dim >= 1 && dweight && dbias, "bad arguments");
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, (hipStream_t)stream_, part, nblk, dim,
+                     dweight, dbias);
+  GT_CHECK_LAUNCH();
+  return GT_OK;
+}
+
 extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy, const float* weight,
                                 const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed,
                                 int64_t rows, int64_t dim, void* dx, void* dresid, float* dweight, float* dbias,

@@ -412,6 +412,8 @@ int gt_layernorm_bwd(int dtype, const void* x, const void* resid, const void* dy
                      const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed, int64_t rows,
                      int64_t dim, void* dx, void* dresid, float* dweight, float* dbias, void* workspace,
                      size_t workspace_bytes, gt_stream_t stream);
+/* the column finish over `nblk` block partials [2][dim] (dweight partial | dbias partial per block), gt_layernorm_bwd's own fixed order */
+int gt_layernorm_bwd_finish(const float* part, int nblk, int64_t dim, float* dweight, float* dbias, gt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nn.Linear on the matrix cores with fused bias / ReLU / dropout, forward and backward.
@@ -565,6 +567,18 @@ int gt_linear_layernorm_fwd_ok(int dtype, int compute, const float* weight, int6
 int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, const float* weight, const float* bias, void* a_out, int64_t M,
                             int64_t N, int64_t K, const void* resid, const float* ln_weight, const float* ln_bias, float eps,
                             float dropout_p, uint64_t seed, void* y, float* save_mean, float* save_rstd, gt_stream_t stream);
+/* dX of a Linear (weight [N][K]) whose output gradient g = dy W + add1 + add2 is the gradient of the LayerNorm below it,
+ * ln_out = LayerNorm(ln_resid + dropout(ln_x)) over K columns (post-norm encoder layer backward: linear1's dX -> norm1, in_proj's dX ->
+ * the previous layer's norm2; modules/transformer_encoder.py:28-32), in ONE launch: g is rounded to bf16 as the two-call form stores it
+ * and never written; d_sub = d ln_x and d_resid (either may be NULL) and the LayerNorm's weight / bias gradients are what
+ * gt_linear_bwd (dX only) + gt_layernorm_bwd would produce (row sums in a different order).  `workspace`:
+ * gt_linear_bwd_dx_layernorm_workspace_bytes.  Only with a bound image of W^T, bf16 rows, K = 128: gt_linear_bwd_dx_layernorm_ok. */
+int gt_linear_bwd_dx_layernorm_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K);
+size_t gt_linear_bwd_dx_layernorm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gt_linear_bwd_dx_layernorm(int dtype, int compute, const float* weight, const void* dy, const void* dx_add1, const void* dx_add2,
+                               int64_t M, int64_t N, int64_t K, const void* ln_x, const void* ln_resid, const float* ln_weight,
+                               const float* save_mean, const float* save_rstd, float dropout_p, uint64_t seed, void* d_sub, void* d_resid,
+                               float* ln_dweight, float* ln_dbias, void* workspace, size_t workspace_bytes, gt_stream_t stream);
 /* gt_linear_bwd_ld2 with the activation gate on the dX OUTPUT: dx = gate(dy W, y_or_mul) + add1 + add2, where y_or_mul [M][ldx] is
  * the forward output of the layer below (dropout_p >= 0: * 1[y > 0] / (1 - p)) or a saved multiplier (dropout_p < 0).  dW / db use
  * dy as it is.  The encoder layer's backward writes dZ1 = d(linear1 output) straight out of linear2's dX GEMM this way (the tensor

@@ -196,6 +196,62 @@ def test_gemm_with_layernorm_epilogue_equals_the_two_kernels(M, N, K, p):
         assert rel(mu1, z.mean(1)) < 1e-5 and rel(rs1, 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,p,resid,adds", [(31598, 512, 128, 0.3, True, 1), (31598, 384, 128, 0.3, True, 1), (31598, 128, 128, 0.0, True, 2),
+                                                   (4099, 512, 128, 0.3, False, 0), (61, 384, 128, 0.3, True, 1)],
+                         ids=["linear1", "in_proj", "out_proj-shape", "no-resid", "tiny"])
+def test_dx_gemm_with_layernorm_backward_epilogue_equals_the_two_kernels(M, N, K, p, resid, adds):
+    """gt_linear_bwd_dx_layernorm (g = dY W + addends never stored; d_sub, d_resid and the LayerNorm weight / bias gradients out of the
+    GEMM's epilogue) against gt_linear_bwd_ld2 (dX) + gt_layernorm_bwd on the stored bf16 g (post-norm encoder layer backward,
+    modules/transformer_encoder.py:28-32), same dropout mask; row sums in another order: <= a bf16 ulp on the rows, 1e-4 on the sums."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W1Images
+    lib = _lib.lib()
+    torch.manual_seed(M + N)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    dy = torch.randn(M, N, device=DEV).to(BF)
+    a1 = torch.randn(M, K, device=DEV).to(BF) if adds >= 1 else None
+    a2 = torch.randn(M, K, device=DEV).to(BF) if adds >= 2 else None
+    sub = torch.randn(M, K, device=DEV).to(BF)                       # the sub-layer output the forward normalised
+    res = (2.0 * torch.randn(M, K, device=DEV)).to(BF) if resid else None
+    gam = 1.0 + 0.1 * torch.randn(K, device=DEV)
+    seed = 0x0FEDCBA987654321
+    mu, rs = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    y = torch.empty(M, K, dtype=BF, device=DEV)
+    _lib.launch("gt_layernorm_fwd", GT_BF16, _p(sub), _p(res), _p(gam), _p(torch.zeros(K, device=DEV)), 1e-5, p, seed, M, K, _p(y), _p(mu), _p(rs), _stream())
+    imgs = W1Images([W])
+    imgs.build()
+    assert lib.gt_linear_bwd_dx_layernorm_ok(GT_BF16, GT_BF16, _p(W), M, N, K) == 0   # unbound
+    ds1, dr1 = torch.empty(M, K, dtype=BF, device=DEV), torch.empty(M, K, dtype=BF, device=DEV)
+    dg1, db1 = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
+    ws_bytes = int(lib.gt_linear_bwd_dx_layernorm_workspace_bytes(M, N, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    with imgs.bound():
+        assert lib.gt_linear_bwd_dx_layernorm_ok(GT_BF16, GT_BF16, _p(W), M, N, K) == 1
+        _lib.launch("gt_linear_bwd_dx_layernorm", GT_BF16, GT_BF16, _p(W), _p(dy), _p(a1), _p(a2), M, N, K, _p(sub), _p(res), _p(gam), _p(mu), _p(rs),
+                    p, seed, _p(ds1), _p(dr1), _p(dg1), _p(db1), _p(ws), ws_bytes, _stream())
+        g = bwd(None, W, dy, None, a1, a2, imgs)           # the same weight-stationary dX GEMM, g stored
+    ds0, dr0 = torch.empty(M, K, dtype=BF, device=DEV), torch.empty(M, K, dtype=BF, device=DEV)
+    dg0, db0 = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
+    lws_bytes = int(lib.gt_layernorm_bwd_workspace_bytes(M, K))
+    lws = torch.empty(lws_bytes, dtype=torch.uint8, device=DEV)
+    _lib.launch("gt_layernorm_bwd", GT_BF16, _p(sub), _p(res), _p(g), _p(gam), _p(mu), _p(rs), p, seed, M, K, _p(ds0), _p(dr0), _p(dg0), _p(db0),
+                _p(lws), lws_bytes, _stream())
+    torch.cuda.synchronize()
+    for got, want in ((dr1, dr0), (ds1, ds0)):
+        assert float((got.float() - want.float()).abs().max()) <= 2 ** -7 * float(want.float().abs().max()) and rel(got, want) < 1e-3
+    assert rel(dg1, dg0) < 1e-4 and rel(db1, db0) < 1e-4
+    if p > 0:
+        assert bool(((ds1 == 0) == (ds0 == 0)).all())     # the same dropout mask
+    # only d_resid (norm_input's use: no sub-layer gradient)
+    dr2 = torch.empty(M, K, dtype=BF, device=DEV)
+    with imgs.bound():
+        _lib.launch("gt_linear_bwd_dx_layernorm", GT_BF16, GT_BF16, _p(W), _p(dy), _p(a1), _p(a2), M, N, K, _p(sub), _p(res), _p(gam), _p(mu), _p(rs),
+                    p, seed, None, _p(dr2), _p(dg1), _p(db1), _p(ws), ws_bytes, _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dr2, dr1)
+
+
 @pytest.mark.parametrize("M,N,K", [(31598, 384, 128), (31598, 128, 128), (31598, 512, 128), (31598, 128, 512), (20011, 1024, 256), (5003, 72, 200), (1024, 136, 8),
                                     (1025, 128, 128)], ids=lambda v: str(v))
 def test_bf16_weight_gradient(M, N, K):
