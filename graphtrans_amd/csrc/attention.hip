@@ -20,6 +20,8 @@
 //
 // dtype GT_BF16: v_mfma_f32_16x16x32_bf16, operands bf16, accumulate fp32.
 // dtype GT_F32 : v_mfma_f32_16x16x4_f32 x8 per 32-deep step: exact fp32 (fma chain), the parity mode.
+#include <cstdlib>
+#include <cstring>
 #include "gt_common.h"
 #include "mfma_frag.h"
 
@@ -180,24 +182,80 @@ struct TilePair {
     fa = ok ? frag_load(pa + (int64_t)pos0 * sa) : frag_zero<T>();
     fb = ok ? frag_load(pb + (int64_t)pos0 * sb) : frag_zero<T>();
   }
-  __device__ __forceinline__ void store(T* sA, T* sB) const {
+  template <typename TO>
+  __device__ __forceinline__ void store(typename TO::LT* sA, typename TO::LT* sB) const {
     if (has) {
-      frag_store_lds(sA + r * LD + col, fa);
-      frag_store_lds(sB + r * LD + col, fb);
+      TO::store(sA, r, col, fa);
+      TO::store(sB, r, col, fb);
     }
   }
+};
+
+// What a kernel does with its LDS tiles and MFMA operands, by storage type T and arithmetic:
+//   plain (SP = false): tiles of T, operands Frag<T>, products by mma (bf16 MFMA; for fp32 rows the exact v_mfma_f32_16x16x4_f32 chains);
+//   SP (fp32 rows, head dims 32 / 64): fp32-accurate products on the bf16 pipe ("bf16x6", mfma_frag.h: the arithmetic of the fp32
+//     contract mode's GEMMs).  A tile is split ONCE, when it is staged, into three bf16 planes [plane][TILE][HDP + 8] -- so the row
+//     fragments are three ds_read_b128 and the transposed ones come from ds_read_b64_tr_b16 like the bf16 kernels' (the fp32 tiles'
+//     transposed fragment was eight strided ds_read_b32) --, the per-query / per-key register operands (Q, dO, K, V) once at load
+//     time, the softmax weights / score gradients once per step.
+template <typename T, int HD, bool SP>
+struct TileOps {
+  using LT = T;
+  using Op = Frag<T>;
+  static constexpr int LD = Lds<HD, T>::LD;
+  static constexpr int ELEMS = TILE * LD;
+  static __device__ __forceinline__ Op reg(const Frag<T>& f) { return f; }
+  static __device__ __forceinline__ Op from(const float* x) { return frag_from_f32<T>(x); }
+  static __device__ __forceinline__ Op row(const LT* tile, int r, int c) { return frag_load(tile + r * LD + c); }
+  static __device__ __forceinline__ Op tr(const LT* tile, int col0, int n, int g) { return frag_load_tr(tile, LD, 0, col0, n, g); }
+  static __device__ __forceinline__ void store(LT* tile, int r, int c, const Frag<T>& f) { frag_store_lds(tile + r * LD + c, f); }
+  static __device__ __forceinline__ f32x4 mm(const Op& a, const Op& b, f32x4 c) { return mma(a, b, c); }
+};
+template <int HD>
+struct TileOps<float, HD, true> {
+  static_assert(HD >= 32, "whole 32-deep steps");
+  using LT = gt_bf16;
+  using Op = Frag3;
+  static constexpr int LD = HD + 8;             // bf16 elements per row of a plane
+  static constexpr int PLANE = TILE * LD;
+  static constexpr int ELEMS = 3 * PLANE;
+  static __device__ __forceinline__ Op reg(const Frag<float>& f) { return frag_split3(f); }
+  static __device__ __forceinline__ Op from(const float* x) { return frag_split3(frag_from_f32<float>(x)); }
+  static __device__ __forceinline__ Op row(const LT* tile, int r, int c) {
+    Op o;
+    o.p1 = *reinterpret_cast<const uint4*>(tile + r * LD + c);
+    o.p2 = *reinterpret_cast<const uint4*>(tile + PLANE + r * LD + c);
+    o.p3 = *reinterpret_cast<const uint4*>(tile + 2 * PLANE + r * LD + c);
+    return o;
+  }
+  static __device__ __forceinline__ Op tr(const LT* tile, int col0, int n, int g) {
+    Op o;
+    o.p1 = frag_load_tr(tile, LD, 0, col0, n, g).v;
+    o.p2 = frag_load_tr(tile + PLANE, LD, 0, col0, n, g).v;
+    o.p3 = frag_load_tr(tile + 2 * PLANE, LD, 0, col0, n, g).v;
+    return o;
+  }
+  static __device__ __forceinline__ void store(LT* tile, int r, int c, const Frag<float>& f) {
+    const Op o = frag_split3(f);
+    *reinterpret_cast<uint4*>(tile + r * LD + c) = o.p1;
+    *reinterpret_cast<uint4*>(tile + PLANE + r * LD + c) = o.p2;
+    *reinterpret_cast<uint4*>(tile + 2 * PLANE + r * LD + c) = o.p3;
+  }
+  static __device__ __forceinline__ f32x4 mm(const Op& a, const Op& b, f32x4 c) { return mma3(a, b, c); }
 };
 
 // =================================================================================================
 // forward
 // =================================================================================================
-template <typename T, int HD, bool DENSE>
+template <typename T, int HD, bool DENSE, bool SP = false>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
-  constexpr int LD = Lds<HD, T>::LD;
+  using TO = TileOps<T, HD, SP>;
+  using LT = typename TO::LT;
+  using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;  // 32-deep steps over head_dim
   constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
-  __shared__ __attribute__((aligned(16))) T sKb[2][TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sVb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) LT sKb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sVb[2][TO::ELEMS];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -213,14 +271,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
   const int64_t qrow = row0 + (int64_t)qp * a.row_stride;
 
-  Frag<T> bq[KK];
+  Op bq[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
-    bq[kk] = frag_load_head<T, HD>(qkv + qrow * ld3 + head * HD, kk * 32 + g * 8, qvalid);
-  zero_pad_cols<T, HD>(sKb[0]);
-  zero_pad_cols<T, HD>(sVb[0]);
-  zero_pad_cols<T, HD>(sKb[1]);
-  zero_pad_cols<T, HD>(sVb[1]);
+    bq[kk] = TO::reg(frag_load_head<T, HD>(qkv + qrow * ld3 + head * HD, kk * 32 + g * 8, qvalid));
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[1]);
 
   float m = -INFINITY, lsum = 0.f;
   f32x4 acc[DT];
@@ -238,14 +296,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();   // the zero fill above and the first store touch the same rows
   stg.load(k_first, kv_off, kv_end);
-  stg.store(sKb[0], sVb[0]);
+  stg.template store<TO>(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
   for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
     const bool more = k0 + TILE < kv_end;
     if (more) stg.load(k0 + TILE, kv_off, kv_end);
-    const T* sK = sKb[cur];
-    const T* sV = sVb[cur];
+    const LT* sK = sKb[cur];
+    const LT* sV = sVb[cur];
     // S^T: two 16-key tiles; row m of tile t <-> key (m>>2)*8 + t*4 + (m&3)
     float s[8];
 #pragma unroll
@@ -253,7 +311,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       const int krow = (n >> 2) * 8 + t * 4 + (n & 3);
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) c = mma(frag_load(sK + krow * LD + kk * 32 + g * 8), bq[kk], c);
+      for (int kk = 0; kk < KK; ++kk) c = TO::mm(TO::row(sK, krow, kk * 32 + g * 8), bq[kk], c);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[t * 4 + r] = c[r];
     }
@@ -304,14 +362,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
         p[i + 1] = h >= thr16 ? p[i + 1] : 0.f;      // == (h >> 16) >= thr
       }
     }
-    const Frag<T> bp = frag_from_f32<T>(p);
+    const Op bp = TO::from(p);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       f32x4 o = acc[dt];
       o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-      acc[dt] = mma(frag_load_tr(sV, LD, 0, dt * 16, n, g), bp, o);
+      acc[dt] = TO::mm(TO::tr(sV, dt * 16, n, g), bp, o);
     }
-    if (more) stg.store(sKb[cur ^ 1], sVb[cur ^ 1]);
+    if (more) stg.template store<TO>(sKb[cur ^ 1], sVb[cur ^ 1]);
     __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16, 64);
@@ -334,13 +392,15 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 // =================================================================================================
 // backward, pass 1: delta = rowsum(dO * O) and dQ      (block = 64 queries, loop over key tiles)
 // =================================================================================================
-template <typename T, int HD, bool DENSE>
+template <typename T, int HD, bool DENSE, bool SP = false>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
-  constexpr int LD = Lds<HD, T>::LD;
+  using TO = TileOps<T, HD, SP>;
+  using LT = typename TO::LT;
+  using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  __shared__ __attribute__((aligned(16))) T sKb[2][TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sVb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) LT sKb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sVb[2][TO::ELEMS];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -358,13 +418,13 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const T* ctx = reinterpret_cast<const T*>(a.ctx);
   const int64_t qrow = row0 + (int64_t)qp * a.row_stride;
 
-  Frag<T> bq[KK], bdo[KK];
+  Op bq[KK], bdo[KK];
   float delta = 0.f;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
     if (qvalid && kk * 32 + g * 8 < HD) {
-      bq[kk] = frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8);
-      bdo[kk] = frag_load(dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8);
+      bq[kk] = TO::reg(frag_load(qkv + qrow * ld3 + head * HD + kk * 32 + g * 8));
+      bdo[kk] = TO::reg(frag_load(dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8));
       // delta partial over this lane's 8 dims
       const T* po = ctx + qrow * a.d_model + head * HD + kk * 32 + g * 8;
       const T* pd = dctx + qrow * a.d_model + head * HD + kk * 32 + g * 8;
@@ -372,8 +432,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
       delta += o0.x * d0.x + o0.y * d0.y + o0.z * d0.z + o0.w * d0.w + o1.x * d1.x + o1.y * d1.y + o1.z * d1.z +
                o1.w * d1.w;
     } else {
-      bq[kk] = frag_zero<T>();
-      bdo[kk] = frag_zero<T>();
+      bq[kk] = TO::reg(frag_zero<T>());
+      bdo[kk] = TO::reg(frag_zero<T>());
     }
   }
   delta += __shfl_xor(delta, 16, 64);
@@ -383,10 +443,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const float negl = -(lse + logl);
   const uint32_t thr16 = a.drop_thr << 16;
   if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
-  zero_pad_cols<T, HD>(sKb[0]);
-  zero_pad_cols<T, HD>(sVb[0]);
-  zero_pad_cols<T, HD>(sKb[1]);
-  zero_pad_cols<T, HD>(sVb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[1]);
 
   f32x4 acc[DT];
 #pragma unroll
@@ -401,14 +461,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();
   stg.load(k_first, kv_off, kv_end);
-  stg.store(sKb[0], sVb[0]);
+  stg.template store<TO>(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
   for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
     const bool more = k0 + TILE < kv_end;
     if (more) stg.load(k0 + TILE, kv_off, kv_end);
-    const T* sK = sKb[cur];
-    const T* sV = sVb[cur];
+    const LT* sK = sKb[cur];
+    const LT* sV = sVb[cur];
     float ds[8];
     const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
     bool full_tile = false;
@@ -419,8 +479,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
       const int krow = (n >> 2) * 8 + t * 4 + (n & 3);
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        c = mma(frag_load(sK + krow * LD + kk * 32 + g * 8), bq[kk], c);
-        dp = mma(frag_load(sV + krow * LD + kk * 32 + g * 8), bdo[kk], dp);
+        c = TO::mm(TO::row(sK, krow, kk * 32 + g * 8), bq[kk], c);
+        dp = TO::mm(TO::row(sV, krow, kk * 32 + g * 8), bdo[kk], dp);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -446,10 +506,10 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
         }
       }
     }
-    const Frag<T> bds = frag_from_f32<T>(ds);
+    const Op bds = TO::from(ds);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] = mma(frag_load_tr(sK, LD, 0, dt * 16, n, g), bds, acc[dt]);
-    if (more) stg.store(sKb[cur ^ 1], sVb[cur ^ 1]);
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = TO::mm(TO::tr(sK, dt * 16, n, g), bds, acc[dt]);
+    if (more) stg.template store<TO>(sKb[cur ^ 1], sVb[cur ^ 1]);
     __syncthreads();
   }
   if (!qvalid) return;
@@ -465,13 +525,15 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
 // =================================================================================================
 // backward, pass 2: dK, dV                              (block = 64 keys, loop over query tiles)
 // =================================================================================================
-template <typename T, int HD, bool DENSE>
+template <typename T, int HD, bool DENSE, bool SP = false>
 __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
-  constexpr int LD = Lds<HD, T>::LD;
+  using TO = TileOps<T, HD, SP>;
+  using LT = typename TO::LT;
+  using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  __shared__ __attribute__((aligned(16))) T sQb[2][TILE * LD];
-  __shared__ __attribute__((aligned(16))) T sDOb[2][TILE * LD];
+  __shared__ __attribute__((aligned(16))) LT sQb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sDOb[2][TO::ELEMS];
   __shared__ float sAux[2][3 * TILE];   // per query of the tile: running max, log2(sum), delta
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
@@ -490,16 +552,16 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   const T* dctx = reinterpret_cast<const T*>(a.d_ctx);
   const int64_t krow = row0 + (int64_t)kp * a.row_stride;
 
-  Frag<T> bk[KK], bv[KK];
+  Op bk[KK], bv[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    bk[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + a.d_model + head * HD, kk * 32 + g * 8, kvalid);
-    bv[kk] = frag_load_head<T, HD>(qkv + krow * ld3 + 2 * a.d_model + head * HD, kk * 32 + g * 8, kvalid);
+    bk[kk] = TO::reg(frag_load_head<T, HD>(qkv + krow * ld3 + a.d_model + head * HD, kk * 32 + g * 8, kvalid));
+    bv[kk] = TO::reg(frag_load_head<T, HD>(qkv + krow * ld3 + 2 * a.d_model + head * HD, kk * 32 + g * 8, kvalid));
   }
-  zero_pad_cols<T, HD>(sQb[0]);
-  zero_pad_cols<T, HD>(sDOb[0]);
-  zero_pad_cols<T, HD>(sQb[1]);
-  zero_pad_cols<T, HD>(sDOb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sQb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sDOb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sQb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sDOb[1]);
   f32x4 dk[DT], dv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -534,7 +596,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   if (any_valid) {
     stg.load(q_begin, 0, npos);
     load_aux(q_begin);
-    stg.store(sQb[0], sDOb[0]);
+    stg.template store<TO>(sQb[0], sDOb[0]);
     if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
   }
   __syncthreads();
@@ -545,8 +607,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
       stg.load(q0 + TILE, 0, npos);
       load_aux(q0 + TILE);
     }
-    const T* sQ = sQb[cur];
-    const T* sDO = sDOb[cur];
+    const LT* sQ = sQb[cur];
+    const LT* sDO = sDOb[cur];
     const float* sLse = sAux[cur];
     const float* sLogl = sAux[cur] + TILE;
     const float* sDelta = sAux[cur] + 2 * TILE;
@@ -560,8 +622,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
       const int qr = (n >> 2) * 8 + t * 4 + (n & 3);
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        c = mma(frag_load(sQ + qr * LD + kk * 32 + g * 8), bk[kk], c);
-        dp = mma(frag_load(sDO + qr * LD + kk * 32 + g * 8), bv[kk], dp);
+        c = TO::mm(TO::row(sQ, qr, kk * 32 + g * 8), bk[kk], c);
+        dp = TO::mm(TO::row(sDO, qr, kk * 32 + g * 8), bv[kk], dp);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -591,15 +653,15 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
         ds[i] = filled ? 0.f : p * dd;
       }
     }
-    const Frag<T> bp = frag_from_f32<T>(pd);
-    const Frag<T> bds = frag_from_f32<T>(ds);
+    const Op bp = TO::from(pd);
+    const Op bds = TO::from(ds);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      dv[dt] = mma(frag_load_tr(sDO, LD, 0, dt * 16, n, g), bp, dv[dt]);
-      dk[dt] = mma(frag_load_tr(sQ, LD, 0, dt * 16, n, g), bds, dk[dt]);
+      dv[dt] = TO::mm(TO::tr(sDO, dt * 16, n, g), bp, dv[dt]);
+      dk[dt] = TO::mm(TO::tr(sQ, dt * 16, n, g), bds, dk[dt]);
     }
     if (more) {
-      stg.store(sQb[cur ^ 1], sDOb[cur ^ 1]);
+      stg.template store<TO>(sQb[cur ^ 1], sDOb[cur ^ 1]);
       if (threadIdx.x < 3 * TILE) sAux[cur ^ 1][threadIdx.x] = aux_v;
     }
     __syncthreads();
@@ -647,6 +709,18 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
   return a;
 }
 
+// fp32 rows: bf16x6 products unless GT_F32_GEMM=exact (the switch of the fp32 GEMMs: the exact MFMA chains stay the parity yardstick)
+// or GT_ATTN_F32_SPLIT=0
+bool attn_f32_split() {
+  static const bool on = [] {
+    const char* g = getenv("GT_F32_GEMM");
+    const char* e = getenv("GT_ATTN_F32_SPLIT");
+    if (e) return atoi(e) != 0;
+    return !(g && strcmp(g, "exact") == 0);
+  }();
+  return on;
+}
+
 }  // namespace
 
 static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
@@ -675,7 +749,10 @@ static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, floa
     if (dense_launch) hipLaunchKernelGGL((k_attn_fwd<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a);  \
     else hipLaunchKernelGGL((k_attn_fwd<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);              \
   } while (0)
-  if (dtype == GT_F32) {
+  if (dtype == GT_F32 && !dense_launch && attn_f32_split() && (hd == 32 || hd == 64)) {   // bf16x6 products (TileOps<float, HD, true>)
+    if (hd == 32) hipLaunchKernelGGL((k_attn_fwd<float, 32, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((k_attn_fwd<float, 64, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+  } else if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
     else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
   } else {
@@ -743,7 +820,15 @@ static int attn_bwd_impl(int pooled, int dtype, const void* qkv, const void* ctx
       hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);\
     }                                                                                           \
   } while (0)
-  if (dtype == GT_F32) {
+  if (dtype == GT_F32 && !dense_launch && attn_f32_split() && (hd == 32 || hd == 64)) {   // bf16x6 products (TileOps<float, HD, true>)
+    if (hd == 32) {
+      hipLaunchKernelGGL((k_attn_bwd_dq<float, 32, false, true>), grid_q, dim3(ATT_THREADS), 0, stream, aq);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<float, 32, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((k_attn_bwd_dq<float, 64, false, true>), grid_q, dim3(ATT_THREADS), 0, stream, aq);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<float, 64, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    }
+  } else if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
     else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
   } else {

@@ -119,6 +119,35 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b,
   return c;
 }
 
+// ---- fp32-accurate product on the bf16 pipe ("bf16x6", as linear3x.h): both 8-slot fp32 fragments split EXACTLY into three bf16
+// planes (8 + 8 + 8 significand bits), the six products of order <= 2^-16 kept, small terms first.  6 x 16 cycles instead of the
+// 8 dependent v_mfma_f32_16x16x4_f32 (8 x 32 cycles) of the exact form, at ~14 VALU per split pair.
+struct Frag3 {
+  uint4 p1, p2, p3;
+};
+__device__ __forceinline__ Frag3 frag_split3(const Frag<float>& f) {
+  Frag3 r;
+  uint32_t u1[4], u2[4], u3[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float lo = f.v[2 * q], hi = f.v[2 * q + 1];
+    u1[q] = gt_pack_bf16(lo, hi);
+    const float rl = lo - __uint_as_float(u1[q] << 16), rh = hi - __uint_as_float(u1[q] & 0xffff0000u);   // exact
+    u2[q] = gt_pack_bf16(rl, rh);
+    u3[q] = gt_pack_bf16(rl - __uint_as_float(u2[q] << 16), rh - __uint_as_float(u2[q] & 0xffff0000u));
+  }
+  r.p1 = make_uint4(u1[0], u1[1], u1[2], u1[3]);
+  r.p2 = make_uint4(u2[0], u2[1], u2[2], u2[3]);
+  r.p3 = make_uint4(u3[0], u3[1], u3[2], u3[3]);
+  return r;
+}
+__device__ __forceinline__ f32x4 mma3(const Frag3& a, const Frag3& b, f32x4 c) {
+#define GT_MMA3(X, Y) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.X), __builtin_bit_cast(bf16x8_t, b.Y), c, 0, 0, 0)
+  GT_MMA3(p3, p1); GT_MMA3(p1, p3); GT_MMA3(p2, p2); GT_MMA3(p2, p1); GT_MMA3(p1, p2); GT_MMA3(p1, p1);
+#undef GT_MMA3
+  return c;
+}
+
 template <typename T>
 __device__ __forceinline__ void store4(T* p, f32x4 v) {
   gt_store4<T>(p, make_float4(v[0], v[1], v[2], v[3]));
