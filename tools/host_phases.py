@@ -13,7 +13,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 dev = torch.device("cuda:0")
 matmul_dtype, dtype = bench.MODES["mixed"]
 gt_ops.set_matmul_dtype(matmul_dtype)
-per_gpu = {"nci1": 32, "code2-pna": 128}.get(wl, 256)
+per_gpu = int(sys.argv[3]) if len(sys.argv) > 3 else {"nci1": 32, "code2-pna": 128}.get(wl, 256)
 torch.manual_seed(1234)
 args, model, gen, loss_fn, name = bench.build(wl, dtype, dev, per_gpu)
 model.train()
