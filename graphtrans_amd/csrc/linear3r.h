@@ -671,6 +671,8 @@ static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
 }
 // block shapes of k_lin3r_dw: 0 = 160 x 160 (5 x 5 tiles per wave), 1 = 224 x 128 (7 x 4: the PNA towers' 204 x 340 post-Linear
 // pads to 224 x 384 instead of 320 x 480)
+// (a 224 x 96 shape -- 7 x 3 tiles, 126 KB of LDS and 372 registers, so that a 30-KB block of the main stream fits beside it -- measured the
+// same as 224 x 128 on Code2-PNA: 33.7-33.9 k graphs/s both; not kept)
 static inline int w3r_dw_zt(int shape) { return shape == 1 ? 224 : 160; }
 static inline int w3r_dw_xt(int shape) { return shape == 1 ? 128 : 160; }
 static inline int w3r_dw_pick_shape(int64_t N, int64_t K) {   // least padded area, ties -> 0

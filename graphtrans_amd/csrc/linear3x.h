@@ -475,6 +475,10 @@ void w3_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
 #endif
 // rows per block: 128 (one W buffer, two blocks per CU: every W byte feeds twice the MFMAs -- at 64 rows the kernel asks the L2 for
 // 40 B / cycle / CU at the MFMA rate) when that still gives the chip >= 384 blocks, else 64 (two W buffers)
+static inline bool w3_small_lds() {
+  static const bool on = [] { const char* e = getenv("GT_LIN3_SMALL_LDS"); return !e || atoi(e) != 0; }();   // (A/B knob)
+  return on;
+}
 static inline int w3_pick_mt(int64_t M, int ncb) {
   if (W3_FORCE_MT) return W3_FORCE_MT;
   return gt_cdiv(M, 128) * ncb >= 384 ? 4 : 2;
@@ -482,6 +486,17 @@ static inline int w3_pick_mt(int64_t M, int ncb) {
 
 template <bool MASK>
 void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
+  if (a.groups > 1 && a.Nout <= 96 && ta == GT_F32 && to == GT_F32 && a.act != 2 && w3_small_lds()) {
+    // a grouped launch of narrow GEMMs (the PNA pre stack's dX: 136 -> 68 columns per tower): 6 n-tiles, 64 rows, one W buffer =
+    // 30 KB of LDS and 107 registers instead of 48 KB and 185 -- it runs beside the post stack's weight-gradient kernel (138 KB of LDS on
+    // 192 CUs), where five of these blocks fit on a free CU against three: 126 -> 99 us in the step (24 us alone), Code2-PNA 33.0 ->
+    // 33.9 k graphs/s.  The image was built for >= 8 tiles per plane: its first 6 are what this kernel reads.
+    a.ncb = 1;
+    a.w3_ntp = (int)w3_ntp(a.Nout);
+    dim3 grid((unsigned)(gt_cdiv(gt_cdiv(a.M, 64), 8) * 8), (unsigned)a.groups);
+    w3_launch_one<float, float, 6, 2, 1, MASK, false>(grid, stream, a);
+    return;
+  }
   const int nt = w3_pick_nt(a.Nout);
   a.ncb = (int)gt_cdiv(gt_cdiv(a.Nout, 16), nt);
   a.w3_ntp = (int)w3_ntp(a.Nout);
