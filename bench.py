@@ -22,17 +22,18 @@ Precision modes (`config.mode`):
          -- what BASELINE.json's north_star sanctions;
   bf16:  bf16 MFMA for every GEMM (fp32 storage and master weights on the GNN side);
   fp32:  fp32-accurate GEMMs everywhere (fp32 token rows).
-Rank 0 prints ONE JSON line with the contract keys plus
-  "roofline":     the dominant hand-written kernel (largest total HIP-event time inside the timed region): algorithmic
+Rank 0 prints ONE JSON line of at most 4 KB (compact_line) with the contract keys plus
+  "roofline":     the dominant hand-written kernel, named as rocprofv3 names it (the kernel family with the largest total
+                  HIP-event time inside the timed region; forward and dX launches of one kernel are one family): algorithmic
                   bytes|flops per launch (SURVEY.md 8d formulas) / average launch time; "traffic" = PMC bytes of the same
                   build (profiles/*_pmc_traffic.json, attached only when its build id matches the sources that run),
-  "kernels":      the same for every timed C-ABI entry point,
-  "modes":        value / ms_per_step / roofline of the other precision modes measured in the same process (N = 1),
-  "strong_scaling": (N > 1) the same step on a GLOBAL batch of 256 graphs split over the N ranks,
-  "precision_vs_oracle": per reported mode, loss and gradient errors of the fused path against the float64 oracle on a
-                  24-graph sample at the real dims (N = 1),
   "cpu_baseline": the CPU oracle (oracle/reference_math.py, kind "port") timed on this box's host cores on a bounded
-                  sample of the same workload (rank 0, N = 1 only).
+                  sample of the same workload (rank 0, N = 1 only),
+  "value_fp32_contract" / "ms_per_step_fp32_contract": the same step in the fp32 mode (the mode that meets north_star's
+                  1e-4), "value_bf16": the all-bf16 mode, "precision_vs_oracle": three numbers per mode,
+  "strong_scaling" / "weak_scaling": (N > 1) value + ms_per_step of the other scaling of the same step,
+  "report":       path of bench_report.json -- the FULL record (every timed kernel's roofline, the other modes' kernels,
+                  aggregate_stress, collate, the precision report's details, notes), written next to this script.
 """
 import argparse
 import json
@@ -267,17 +268,34 @@ def _w3_enabled():
     return bool(w3.ENABLED)
 
 
-def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None):
-    """records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the stream each launch goes to, recorded
+POOLED = ("k_lin3r", "k_lin1")   # one template instantiation serves forward and dX: ONE kernel name in rocprofv3's table
+
+
+def pooled_name(name):
+    """`k_lin3r[fwd]` / `k_lin3r[dx]` -> `k_lin3r` (rocprofv3: k_lin3r<10,2> for both); `k_lin1[fwd]` / `k_lin1[dx]` -> `k_lin1`;
+    the epilogue variants (`[fwd+ln]`, `[dx+lnb]`: other template modes) and every other kernel keep their names"""
+    for k in POOLED:
+        for d in ("[fwd]", "[dx]"):
+            if name == k + d:
+                return k
+    return name
+
+
+def kernel_report(records, attn_flops_fwd, dtype, matmul_dtype=None, pool=False):
+    """pool=True: forward and dX launches of one kernel instantiation form one entry (pooled_name) -- the table the
+    dominant kernel of the line's "roofline" is picked from, comparable with rocprofv3's per-kernel rows.
+    records: [(name, ms, dims6)] from the C-side launch profiler (HIP events on the stream each launch goes to, recorded
     inside the timed region, under the schedule the un-profiled steps run: the weight-gradient GEMMs are bracketed ON the
     overlap stream).  -> per kernel roofline dicts, keyed like rocprofv3's kernel names so that every `frac` can be
     recomputed from profiles/*_kernel_stats.csv: achieved = algorithmic flops | bytes / average duration.
-      k_lin3[fwd|dx], k_lin3r[fwd|dx] (rows straight into fragments, r5), k_lin3_dw+reduce, k_lin3r_dw+reduce   fp32-accurate GEMM on the bf16 pipe, six bf16 MFMAs per product: peak = 2500 / 6 = 416.7 TFLOP/s
-      k_lin32[..], k_lin32_dw+reduce   exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): peak 157.3 TFLOP/s
+      k_lin3[fwd|dx], k_lin3r[fwd|dx] (rows straight into fragments, r5), k_lin3_dw, k_lin3r_dw (the GEMM kernel alone since r6: its reduce is k_split_reduce's own rocprofv3 row)   fp32-accurate GEMM on the bf16 pipe, six bf16 MFMAs per product: peak = 2500 / 6 = 416.7 TFLOP/s
+      k_lin32[..], k_lin32_dw   exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): peak 157.3 TFLOP/s
       k_linear_*          bf16 MFMA on skinny shapes (M ~ 3e4, K, N <= 600): HBM-bound, priced on algorithmic bytes
       k_small_*           short-M GEMMs (one row per graph): latency-bound, reported against the fp32 MFMA peak for scale"""
     groups = {}
     for name, ms, dims in records:
+        if pool:
+            name = pooled_name(name)
         if name.startswith("k_"):
             tag = "" if name.startswith(("k_lin3", "k_lin32")) else ("[fp32" if dims[5] == 0 else "[bf16") + (",rows=graphs]" if dims[0] <= 1024 else "]")
             name = name + tag
@@ -396,6 +414,7 @@ def cpu_baseline(workload, model, args, budget_s=24.0, full_graphs=256):
                     note="the full batch of the GPU line, one timed pass without warm-up")
     torch.set_num_threads(threads)
     return dict(value=round(graphs / t, 2), unit="graphs/s", cores=threads, kind="port", full_batch=full,
+                sample_short=f"oracle/reference_math.py fwd+loss+bwd fp32, {graphs}-graph seed-0 {what} batch, median of {n} iter(s), {threads} of {cores} threads",
                 sample=f"oracle/reference_math.py fwd+loss+bwd fp32 (dropout at config rates) on a {graphs}-graph seed-0 {what} "
                        f"batch, median of {n} timed iteration(s) on {threads} threads; padded layout like the reference (S = max "
                        f"nodes of the sample); host has {cores} logical cores (more threads are slower: profiles/r02_cpu_sweep.json)",
@@ -485,7 +504,7 @@ def precision_vs_oracle(workload, modes, device, graphs=None):
                 l64.backward()
             finally:
                 torch.set_default_dtype(torch.float32)
-            ref = (float(l64), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, sd, b64)
+            ref = (float(l64.detach()), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, sd, b64)
         model = model.to(device).train()
         bd = attach_sizes(b).to(device)
         loss = loss_fn(model(bd), bd)
@@ -660,7 +679,10 @@ def _measure(opt, mode, scaling, world, rank, device, want_kernels):
                            "bf16 MFMA GEMMs" if matmul_dtype == torch.bfloat16 else
                            ("fp32-accurate GEMMs: bf16x6 on the bf16 matrix pipe for the big-M linears (three-way bf16 split of both operands, six products, "
                             "fp32 accumulation), exact-fp32 MFMA for the short-M ones" if _w3_enabled() else "exact-fp32 MFMA GEMMs")),
-                       "transformer_dtype": "%s token rows, %s MFMA (encoder layers)" % (("bf16", "bf16") if dtype == torch.bfloat16 else ("fp32", "bf16" if matmul_dtype == torch.bfloat16 else "exact-fp32")),
+                       "transformer_dtype": "%s token rows, %s (encoder layers)" % (
+                           ("bf16", "bf16 MFMA") if dtype == torch.bfloat16 else
+                           ("fp32", "bf16 MFMA" if matmul_dtype == torch.bfloat16 else
+                            ("fp32-accurate products on the bf16 pipe (bf16x6: GEMMs and attention)" if _w3_enabled() else "exact-fp32 MFMA"))),
                        "dropout": {"gnn": args.gnn_dropout, "transformer": args.transformer_dropout},
                        "batchnorm": "synchronised over the ranks (statistics of the global batch)" if sync_bn else "per-rank statistics",
                        "interpreter": "gc.freeze() after warm-up (set-up heap out of the cyclic collector's full passes)"},
@@ -699,14 +721,122 @@ def _measure(opt, mode, scaling, world, rank, device, want_kernels):
                 elif k.split("[")[0] in tr and sum(1 for q in rep if q.split("[")[0] == k.split("[")[0]) == 1:
                     rep[k]["traffic"] = tr[k.split("[")[0]]
             if rep:
-                dom = max(rep, key=lambda k: rep[k]["total_ms"])
-                r = dict(rep[dom])
+                fam = kernel_report(records, float(np.mean(fl)), dtype, matmul_dtype, pool=True)
+                dom = max(fam, key=lambda k: fam[k]["total_ms"])
+                r = dict(fam[dom])
                 r["kernel"] = dom
+                def base_tag(k):   # "k_lin1[dx][bf16]" -> ("k_lin1[dx]", "[bf16]"): the dtype / rows tag kernel_report appends
+                    for t in ("[bf16", "[fp32"):
+                        if t in k:
+                            return k[:k.index(t)], k[k.index(t):]
+                    return k, ""
+                members = [k for k in rep if k != dom and pooled_name(base_tag(k)[0]) + base_tag(k)[1] == dom]
+                if dom in rep:
+                    r["traffic"] = rep[dom]["traffic"]
+                elif members:   # a pooled family: call-weighted mean of its members' PMC bytes (or the pooled PMC row itself)
+                    r["members"] = members
+                    pooled_key = base_tag(dom)[0] + "[fwd|dx]" + base_tag(dom)[1]
+                    tv = [(rep[m]["traffic"], rep[m]["calls"]) for m in members]
+                    if dom in tr or pooled_key in tr:
+                        r["traffic"] = tr.get(dom, tr.get(pooled_key))
+                    elif all(t is not None for t, _ in tv):
+                        r["traffic"] = int(sum(t * c for t, c in tv) / sum(c for _, c in tv))
+                r["timing"] = "HIP events on the launch stream, every 24th timed step"
                 r["traffic_source"] = note
                 res["roofline"] = r
                 res["kernels"] = rep
     del optim, sync
     return res, model, args, per_gpu
+
+
+LINE_LIMIT = 4096   # the driver keeps the tail of stdout: the one JSON line must fit with room to spare (21 KB -> parsed: null)
+REPORT_NAME = "bench_report.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_line(res, report_path=None):
+    """The ONE line rank 0 prints: the contract keys, `config` (workload + mode + sizes, no prose), `roofline` of the dominant
+    kernel, `cpu_baseline` as numbers, the fp32-contract / bf16 values, three precision numbers per mode, the other scaling for
+    N > 1 and the path of the full report.  Everything else of `res` lives in bench_report.json.  Never longer than LINE_LIMIT
+    bytes: optional blocks are dropped from the back until it fits (tests/test_bench_line.py)."""
+    line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = res.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "mode", "graphs_per_gpu", "global_batch", "avg_nodes_per_batch", "avg_edges_per_batch", "parallelism", "step"))
+    if isinstance(line["config"].get("parallelism"), str):
+        line["config"]["parallelism"] = line["config"]["parallelism"].split(" ")[0]
+    rf = res.get("roofline")
+    if rf:
+        line["roofline"] = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "calls", "algorithmic_flops", "algorithmic_bytes"))
+        line["roofline"]["traffic"] = rf.get("traffic")
+        src = str(rf.get("traffic_source", ""))
+        line["roofline"]["traffic_source"] = src if len(src) <= 120 else src[:117] + "..."
+    cb = res.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "s_per_step"))
+        c["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:160]
+        if cb.get("full_batch"):
+            c["full_batch_value"] = cb["full_batch"].get("value")
+        if cb.get("one_thread"):
+            c["one_thread_value"] = cb["one_thread"].get("value")
+        line["cpu_baseline"] = c
+    optional = []   # (key, value) in the order they are dropped LAST .. FIRST when the line would not fit
+    modes = dict(res.get("modes") or {})
+    if cfg.get("mode") in ("mixed", "bf16", "fp32"):
+        modes[cfg["mode"]] = {"value": res.get("value"), "ms_per_step": res.get("ms_per_step")}
+    if "fp32" in modes:
+        line["value_fp32_contract"] = modes["fp32"].get("value")
+        line["ms_per_step_fp32_contract"] = modes["fp32"].get("ms_per_step")
+    if "bf16" in modes:
+        line["value_bf16"] = modes["bf16"].get("value")
+    if "mixed" in modes and cfg.get("mode") != "mixed":
+        line["value_mixed"] = modes["mixed"].get("value")
+    pv = res.get("precision_vs_oracle")
+    if isinstance(pv, dict):
+        optional.append(("precision_vs_oracle", {m: _pick(v, ("loss_rel_err", "grad_rel_l2_worst", "grad_rel_l2_median"))
+                                                 for m, v in pv.items() if isinstance(v, dict)} if "error" not in pv else {"error": str(pv["error"])[:200]}))
+    for k in ("strong_scaling", "weak_scaling"):
+        if k in res:
+            optional.append((k, _pick(res[k], ("value", "ms_per_step", "graphs_per_gpu", "global_batch", "error")) |
+                             ({"per_rank_batchnorm_value": res[k]["per_rank_batchnorm"].get("value")} if isinstance(res[k].get("per_rank_batchnorm"), dict) else {})))
+    if "data_parallel" in res:
+        optional.append(("data_parallel", _pick(res["data_parallel"], ("backend", "ranks", "rccl_ranks", "grad_allreduce_mb_per_step", "grad_allreduce_collectives_per_step"))))
+    ag = res.get("aggregate_stress")
+    if isinstance(ag, dict) and "gt_aggregate_fwd" in ag:
+        optional.append(("aggregate_stress", {"N": ag.get("N"), "E": ag.get("E"), "D": ag.get("D"),
+                                              "fwd_frac_hbm": ag["gt_aggregate_fwd"].get("frac"), "fwd_us": ag["gt_aggregate_fwd"].get("avg_us"),
+                                              "bwd_frac_hbm": (ag.get("gt_aggregate_bwd") or {}).get("frac"), "bwd_us": (ag.get("gt_aggregate_bwd") or {}).get("avg_us")}))
+    optional.append(("host_enqueue_ms_per_step_idle_device", res.get("host_enqueue_ms_per_step_idle_device")))
+    optional.append(("launches_per_step", res.get("launches_per_step")))
+    if report_path:
+        line["report"] = report_path
+    for k, v in optional:
+        if v is not None:
+            line[k] = v
+    text = json.dumps(line)
+    while len(text) > LINE_LIMIT and optional:   # never reached on real records; the contract keys, roofline and cpu_baseline always stay
+        k, _ = optional.pop()
+        line.pop(k, None)
+        text = json.dumps(line)
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError("bench line of %d bytes even without the optional blocks" % len(text))
+    return text
+
+
+def emit(res, path=None):
+    """bench_report.json (the full record; --report PATH) next to this script, then the compact line as the LAST line of stdout"""
+    shown = path or REPORT_NAME
+    path = path or os.path.join(REPO, REPORT_NAME)
+    try:
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError as e:
+        shown = "not written: %r" % (e,)
+    sys.stdout.flush()
+    print(compact_line(res, shown), flush=True)
 
 
 def self_spawn(opt):
@@ -742,6 +872,7 @@ def main():
     ap.add_argument("--no-sync-bn", action="store_true", help="strong scaling with per-rank BatchNorm statistics (default: synchronised)")
     ap.add_argument("--no-optimizer", action="store_true", help="time zero+fwd+loss+bwd(+allreduce) only")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--report", default=None, help="where the full record goes (default: bench_report.json next to this script)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check only (runs without a GPU): rendezvous, barrier, max-over-ranks reduction and the "
                          "JSON line with value 0 -- what tests/test_dist_gloo.py uses to cover `--gpus N` self-spawn on gloo")
@@ -858,11 +989,12 @@ def main():
                 full = cpu_baseline_full(opt.workload, model, args)
                 b = full["best"]
                 res["cpu_baseline"] = dict(value=b["graphs_per_s"], unit="graphs/s", cores=b["threads"], kind="port",
+                                           s_per_step=b["s_per_step"], one_thread={"value": full["one_thread"]["graphs_per_s"]},
                                            sample=f"oracle/reference_math.py fwd+loss+bwd fp32, full {full['graphs']}-graph batch, median of "
                                                   f"{b['timed_iterations']} after 2 warm-ups, best of the thread counts below", full=full)
             else:
                 res["cpu_baseline"] = cpu_baseline(opt.workload, model, args, full_graphs=per_gpu)
-        print(json.dumps(res))
+        emit(res, opt.report)
     if world > 1:
         import torch.distributed as dist
         try:

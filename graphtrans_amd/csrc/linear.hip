@@ -1425,8 +1425,9 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
         dw_run_queued();
-        stream = g_dw.side;
       }
+      // (a local: a dX that falls through to the generic kernels below must stay on the caller's stream -- ADVICE r5)
+      hipStream_t dw_stream = forked ? g_dw.side : stream;
       const int shape = w3r_dw_pick_shape(N, K);
       const int nkb3 = (int)gt_cdiv(K, w3r_dw_xt(shape)), nnb3 = (int)gt_cdiv(N, w3r_dw_zt(shape));
       int s3 = w3_dw_splits(M, nkb3 * nnb3 * groups);
@@ -1442,8 +1443,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       d.m_per_split = gt_cdiv(gt_cdiv(M, s3), 32) * 32;
       dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3), (unsigned)groups);
       {
-        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3r_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-        w3r_launch_dw(grid3, stream, d, shape);
+        {   // (the bracket holds the GEMM kernel alone: one rocprofv3 row; its fixed-order reduce is k_split_reduce's row)
+          GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin3r_dw", dw_stream, {M, N, K, x_dtype, y_dtype, compute});
+          w3r_launch_dw(grid3, dw_stream, d, shape);
+        }
         if (deferred) {
           for (int g = 0; g < groups; ++g)
             (void)gt_defer_push(base + g * per, s3, N * K, N * K, dweight + (int64_t)g * N * K, dbias ? base + g * per + (int64_t)s3 * N * K : nullptr,
@@ -1451,7 +1454,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         } else {
           const int64_t len = N * K, len2 = dbias ? N : 0;
           const int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
-          hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)base, s3, len, dweight, (const float*)d.dbpart,
+          hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, dw_stream, (const float*)base, s3, len, dweight, (const float*)d.dbpart,
                              len2, dbias, d.g_part);
         }
       }
@@ -1542,10 +1545,12 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
         dim3 grid3((unsigned)(gt_cdiv(s3, 8) * 8 * nkb3 * nnb3));
         {
           const bool pipelined = w3r_dw_ok(y_dtype, x_dtype, d);
-          GtProfScope pk__(GT_PROF_GEMM_KERNEL, pipelined ? "k_lin3r_dw+reduce" : "k_lin3_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-          if (pipelined) w3r_launch_dw(grid3, stream, d);   // stages pipelined (linear3r.h)
-          else if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
-          else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
+          {
+            GtProfScope pk__(GT_PROF_GEMM_KERNEL, pipelined ? "k_lin3r_dw" : "k_lin3_dw", stream, {M, N, K, x_dtype, y_dtype, compute});
+            if (pipelined) w3r_launch_dw(grid3, stream, d);   // stages pipelined (linear3r.h)
+            else if (y_dtype == GT_F32) w3_launch_dw<float, float>(grid3, stream, d);
+            else w3_launch_dw<gt_bf16, float>(grid3, stream, d);
+          }
           dw_reduce(stream, deferred, part3, s3, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
         }
         if (forked) dw_forked(workspace, workspace_bytes);
@@ -1559,9 +1564,11 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       d.m_per_split = gt_cdiv(gt_cdiv(M, splits), 16) * 16;
       dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * nkb * nnb));
       {
-        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin32_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-        if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
-        else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
+        {
+          GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin32_dw", stream, {M, N, K, x_dtype, y_dtype, compute});
+          if (y_dtype == GT_F32) w32_launch_dw_nt<float, float>(nt, grid, stream, d);
+          else w32_launch_dw_nt<gt_bf16, float>(nt, grid, stream, d);
+        }
         dw_reduce(stream, deferred, part2w, splits, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
       }
       if (forked) dw_forked(workspace, workspace_bytes);
@@ -1668,8 +1675,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       d.ntx = (int)(N / D16_T);
       d.ntiles = d.ntx * (int)(K / D16_T);
       {
-        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_dw16+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-        hipLaunchKernelGGL(k_dw16, dim3((unsigned)(gt_cdiv(d.splits, 8) * 8 * d.ntiles)), dim3(256), 0, stream, d);
+        {
+          GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_dw16", stream, {M, N, K, x_dtype, y_dtype, compute});
+          hipLaunchKernelGGL(k_dw16, dim3((unsigned)(gt_cdiv(d.splits, 8) * 8 * d.ntiles)), dim3(256), 0, stream, d);
+        }
         dw_reduce(stream, deferred, d.part, d.splits, N * K, dweight, d.dbpart, dbias ? N : 0, dbias);
       }
       if (forked) dw_forked(workspace, workspace_bytes);
@@ -1686,8 +1695,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     dim3 grid((unsigned)(gt_cdiv(splits, 8) * 8 * a.ntiles), (unsigned)groups);
     const int t0 = y_dtype, t1 = x_dtype;
     {
-      GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_linear_dw+reduce", stream, {M, N, K, x_dtype, y_dtype, compute});
-      GT_LIN_DISPATCH(k_linear_dw, grid, a);
+      {
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_linear_dw", stream, {M, N, K, x_dtype, y_dtype, compute});
+        GT_LIN_DISPATCH(k_linear_dw, grid, a);
+      }
       const int64_t len = N * K, len2 = dbias ? N : 0;
       int rg = (int)(gt_cdiv(len + len2, 256) < 2048 ? gt_cdiv(len + len2, 256) : 2048);
       hipLaunchKernelGGL(k_split_reduce, dim3(rg, groups), dim3(256), 0, stream, (const float*)workspace, splits, len, dweight,

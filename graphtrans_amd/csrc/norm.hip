@@ -304,7 +304,6 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
   }
 }
 
-#include "norm_coop.h"
 
 // ---- few rows (the virtual-node MLP normalises B = 256 graph rows, modules/gnn_module.py:161-170): ONE launch
 // per direction instead of three.  A block owns 32 columns x all rows (8 row lanes); statistics and apply in
@@ -523,13 +522,8 @@ float* bn_sync_buf(void* workspace, int64_t rows, int64_t dim) {
 }
 
 int part_blocks(int64_t N) {
-  static const int max_part = [] {   // experiment knob (GT_BN_MAX_PART), read once
-    const char* e = getenv("GT_BN_MAX_PART");
-    const int v = e ? atoi(e) : 0;
-    return v >= 32 && v <= 4096 ? v : MAX_PART;
-  }();
   int64_t b = gt_cdiv(N, 32);
-  return (int)(b < 1 ? 1 : (b > max_part ? max_part : b));
+  return (int)(b < 1 ? 1 : (b > MAX_PART ? MAX_PART : b));
 }
 int flat_blocks(int64_t items) {
   int64_t g = gt_cdiv(items, NT * 2);
@@ -910,12 +904,11 @@ template <typename T, bool BWD>
 void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
   const int64_t D = a.D;
   if constexpr (BWD && sizeof(T) == 2) {
-    static const bool d128 = [] { const char* e = getenv("GT_LN_BWD_D128"); return !e || atoi(e) != 0; }();   // (A/B knob)
-    if (D == 128 && d128) {
+    if (D == 128) {
       hipLaunchKernelGGL((k_ln_bwd_d128<1024, 128>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
       return;
     }
-    if (D == 256 && d128) {   // the same scheme at 32 lanes per row (the Erdos-Renyi stress: d_model 256, 131 k token rows)
+    if (D == 256) {   // the same scheme at 32 lanes per row (the Erdos-Renyi stress: d_model 256, 131 k token rows)
       hipLaunchKernelGGL((k_ln_bwd_d128<1024, 256>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 256 * 4, stream, a);
       return;
     }
@@ -1021,25 +1014,6 @@ extern "C" int gt_batchnorm_fwd_bcast(int dtype, const void* x, const float* wei
     if (!workspace || workspace_bytes < gt_batchnorm_workspace_bytes(rows, dim)) {
       gt_set_error("gt_batchnorm_fwd: workspace too small");
       return GT_ERR_WORKSPACE;
-    }
-    {   // one launch: statistics, grid barrier, apply (norm_coop.h)
-      int RB, CS;
-      int64_t rows_per;
-      if (!sync && co_plan(dtype, rows, dim, &RB, &CS, &rows_per) && co_workspace_need(RB, CS) <= workspace_bytes) {
-        if (bcast && ev_bcast_ready) {
-          rc = gt_stream_wait_event(stream_, ev_bcast_ready);
-          if (rc) return rc;
-        }
-        BnCoopArgs c{};
-        c.x = (const float*)x; c.out = (float*)y; c.w = weight; c.b = bias; c.resid = (const float*)resid;
-        c.bcast = (const float*)bcast; c.bidx = bcast_index; c.mean = save_mean; c.rstd = save_rstd;
-        c.rmean = running_mean; c.rvar = running_var; c.nbt = num_batches_tracked;
-        c.part = (float*)workspace; c.ctr = co_counter(workspace, workspace_bytes, stream);
-        c.N = rows; c.D = dim; c.rows_per = rows_per; c.RB = RB; c.CS = CS; c.relu = relu; c.momentum = momentum; c.eps = eps; c.drop = drop;
-        co_launch<false>(c, stream);
-        GT_CHECK_LAUNCH();
-        return GT_OK;
-      }
     }
     float* part = (float*)workspace;
     size_t lds = rowlane_lds(dim, 2);
@@ -1154,20 +1128,6 @@ extern "C" int gt_batchnorm_bwd(int dtype, const void* x, const void* dy, const 
     GT_CHECK_LAUNCH();
     return GT_OK;
   }
-  {   // one launch: the two column sums, grid barrier, apply (norm_coop.h; training mode: the sums enter dx)
-    int RB, CS;
-    int64_t rows_per;
-    if (training && co_plan(dtype, rows, dim, &RB, &CS, &rows_per) && co_workspace_need(RB, CS) <= workspace_bytes) {
-      BnCoopArgs c{};
-      c.x = (const float*)x; c.dy = (const float*)dy; c.out = (float*)dx; c.w = weight; c.b = bias;
-      c.mean = const_cast<float*>(save_mean); c.rstd = const_cast<float*>(save_rstd); c.dweight = dweight; c.dbias = dbias;
-      c.part = (float*)workspace; c.ctr = co_counter(workspace, workspace_bytes, stream);
-      c.N = rows; c.D = dim; c.rows_per = rows_per; c.RB = RB; c.CS = CS; c.relu = relu; c.drop = drop;
-      co_launch<true>(c, stream);
-      GT_CHECK_LAUNCH();
-      return GT_OK;
-    }
-  }
   if (dtype == GT_F32) {
     hipLaunchKernelGGL(k_bn_bwd_partial<float>, dim3(nb), dim3(NT), lds, stream, (const float*)x, (const float*)dy,
                        weight, bias, save_mean, save_rstd, relu, drop, rows, dim, part);
@@ -1257,24 +1217,6 @@ extern "C" int gt_batchnorm_bwd_apply(int dtype, const void* x, const void* dy, 
                        weight, bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (gt_bf16*)dx, (const float*)nullptr);
   GT_CHECK_LAUNCH();
   return GT_OK;
-}
-
-// Per host thread: a pool of ZEROED 64-byte counter slots for the one-launch BatchNorm's grid barrier (norm_coop.h); every call takes
-// the next one.  Without a pool (or when it is used up) a call clears its own counter with a small memset in front of its launch.
-// slots == NULL drops the pool.
-extern "C" int gt_bn_coop_slots(void* slots, int n) {
-  GT_CHECK_ARG(n >= 0 && (!slots || ((uintptr_t)slots & 63) == 0), "slots: 64-byte aligned, n >= 0");
-  g_co_slots.base = slots ? (uint32_t*)slots : nullptr;
-  g_co_slots.n = slots ? n : 0;
-  g_co_slots.next = 0;
-  return GT_OK;
-}
-
-// Process-wide switch of the one-launch scheme: 1 on, 0 off, -1 back to the environment's choice; returns the previous setting.
-extern "C" int gt_bn_coop_set(int on) {
-  const int prev = g_co_on;
-  g_co_on = on < 0 ? -1 : (on ? 1 : 0);
-  return prev;
 }
 
 // Per host thread: every training-mode BatchNorm call of this thread exchanges its statistics through `fn` (contract above);

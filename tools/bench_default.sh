@@ -1,9 +1,11 @@
 # usage (GPU box): bash tools/bench_default.sh <tag>  -- the driver's command line (python bench.py, all defaults) with its wall time
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/${1:-r04q}; mkdir -p $O
-t0=$(date +%s); python bench.py > $O/bench_default.json 2> $O/bench_default.err; t1=$(date +%s); echo "wall $((t1-t0)) s"
+t0=$(date +%s); python bench.py --report $O/bench_default_report.json > $O/bench_default.json 2> $O/bench_default.err; t1=$(date +%s); echo "wall $((t1-t0)) s"
 python - <<PY
 import json
-d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+line=open("$O/bench_default.json").read().strip().splitlines()[-1]
+print("line bytes", len(line)); json.loads(line)
+d=json.load(open("$O/bench_default_report.json"))
 print(d["metric"], d["value"], d["ms_per_step"], d["dtype"], d["scaling"])
 print("roofline", d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"].get("traffic"))
 print("modes", {k:(v["value"],v["ms_per_step"]) for k,v in d["modes"].items()})

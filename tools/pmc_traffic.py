@@ -13,31 +13,33 @@ import sys
 
 # bench.py kernel-report key -> (regexes over the demangled kernel names it launches, regex of the kernel whose call count
 # = the entry point's call count).  k_split_reduce (the fixed-order reduce of the dW partials) is shared by the fp32 and
-# bf16 GEMM paths and is reported on its own.
+# bf16 GEMM paths and is reported on its own (r6: bench.py's brackets hold the GEMM kernel alone as well).
 BF16 = r"unsigned short"
 ENTRY = {
     # GEMM kernels one by one (bench.py kernel_report keys = the C-side kernel-level profiler names, GT_PROF_GEMM_KERNEL)
     "k_lin3[fwd]": ((r"k_lin3<[^>]*, false, (?:false|true)>",), r"k_lin3<[^>]*, false, (?:false|true)>"),
     "k_lin3[dx]": ((r"k_lin3<[^>]*, true, false>",), r"k_lin3<[^>]*, true, false>"),
     # k_lin3r (rows straight into fragments, r5): forward and dX are ONE instantiation -- their launches are pooled, both keys get the average
+    "k_lin3r": ((r"k_lin3r<",), r"k_lin3r<"),        # (bench.py's pooled family = rocprofv3's one row)
     "k_lin3r[fwd]": ((r"k_lin3r<",), r"k_lin3r<"),
     "k_lin3r[dx]": ((r"k_lin3r<",), r"k_lin3r<"),
-    "k_lin3r_dw+reduce": ((r"k_lin3r_dw<",), r"k_lin3r_dw<"),
+    "k_lin3r_dw": ((r"k_lin3r_dw<",), r"k_lin3r_dw<"),
     "k_lin32[fwd]": ((r"k_lin32<[^>]*?, \d+, false,",), r"k_lin32<[^>]*?, \d+, false,"),
     "k_lin32[dx]": ((r"k_lin32<[^>]*?, \d+, true,", r"k_transpose32"), r"k_lin32<[^>]*?, \d+, true,"),
     # weight-stationary encoder GEMMs: forward and dX share instantiations (k_lin1<KS, NTW, LN>), so the plain ones are pooled
     "k_lin1[fwd+ln][bf16]": ((r"k_lin1<\d+, \d+, (?:true|1)>",), r"k_lin1<\d+, \d+, (?:true|1)>"),
+    "k_lin1[bf16]": ((r"k_lin1<\d+, \d+, (?:false|0)>",), r"k_lin1<\d+, \d+, (?:false|0)>"),   # (bench.py's pooled family)
     "k_lin1[fwd|dx][bf16]": ((r"k_lin1<\d+, \d+, (?:false|0)>",), r"k_lin1<\d+, \d+, (?:false|0)>"),
-    "k_lin3_dw+reduce": ((r"k_lin3_dw<",), r"k_lin3_dw<"),     # (its k_split_reduce launches are shared with the other dW kernels: reported on their own)
-    "k_lin32_dw+reduce": ((r"k_lin32_dw<",), r"k_lin32_dw<"),   # (its k_split_reduce launches are shared with the bf16 path: reported on their own)
+    "k_lin3_dw": ((r"k_lin3_dw<",), r"k_lin3_dw<"),     # (its k_split_reduce launches are shared with the other dW kernels: reported on their own)
+    "k_lin32_dw": ((r"k_lin32_dw<",), r"k_lin32_dw<"),   # (its k_split_reduce launches are shared with the bf16 path: reported on their own)
     "k_linear_fwd[bf16]": ((r"k_linear_fwd<[^>]*" + BF16 + r", \d+>",), r"k_linear_fwd<[^>]*" + BF16 + r", \d+>"),
     "k_linear_dx[bf16]": ((r"k_linear_dx<[^>]*" + BF16 + r", \d+>",), r"k_linear_dx<[^>]*" + BF16 + r", \d+>"),
-    "k_linear_dw+reduce[bf16]": ((r"k_linear_dw<[^>]*" + BF16 + r">",), r"k_linear_dw<[^>]*" + BF16 + r">"),
+    "k_linear_dw[bf16]": ((r"k_linear_dw<[^>]*" + BF16 + r">",), r"k_linear_dw<[^>]*" + BF16 + r">"),
     # the round-1 tiled kernels in exact fp32: what PNA's grouped tower GEMMs still run on
     "k_linear_fwd[fp32]": ((r"k_linear_fwd<[^>]*float, \d+>",), r"k_linear_fwd<[^>]*float, \d+>"),
     "k_linear_dx[fp32]": ((r"k_linear_dx<[^>]*float, \d+>",), r"k_linear_dx<[^>]*float, \d+>"),
-    "k_linear_dw+reduce[fp32]": ((r"k_linear_dw<[^>]*float>",), r"k_linear_dw<[^>]*float>"),
-    "k_dw16+reduce[bf16]": ((r"k_dw16\(",), r"k_dw16\("),   # LDS-DMA ring dW of the encoder linears (its k_split_reduce: reported on its own)
+    "k_linear_dw[fp32]": ((r"k_linear_dw<[^>]*float>",), r"k_linear_dw<[^>]*float>"),
+    "k_dw16[bf16]": ((r"k_dw16\(",), r"k_dw16\("),   # LDS-DMA ring dW of the encoder linears (its k_split_reduce: reported on its own)
     "k_split_reduce": ((r"k_split_reduce",), r"k_split_reduce"),
     "gt_aggregate_fwd": ((r"k_aggw?_fwd<",), r"k_aggw?_fwd<"),
     "gt_aggregate_bwd": ((r"k_aggw?_bwd<",), r"k_aggw?_bwd<"),   # (the gather kernel: its parameter-partials reduce, k_agg_reduce, runs on the overlap stream)

@@ -8,20 +8,20 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
 bash tools/pmc_round.sh $TAG mixed bf16 > gpurun_out/$TAG/pmc.log 2>&1 || true
 cp gpurun_out/$TAG/${TAG}_*_pmc_traffic.json profiles/ 2>/dev/null || true   # picked up by bench.py below (same build id)
-python bench.py > gpurun_out/$TAG/bench_code2.json 2> gpurun_out/$TAG/bench_code2.err
-python bench.py --workload molpcba > gpurun_out/$TAG/bench_molpcba.json 2> gpurun_out/$TAG/bench_molpcba.err
-python bench.py --workload nci1 --no-extra > gpurun_out/$TAG/bench_nci1.json 2> gpurun_out/$TAG/bench_nci1.err
-python bench.py --workload er --steps 20 --warmup 5 --no-extra > gpurun_out/$TAG/bench_er.json 2> gpurun_out/$TAG/bench_er.err
-python bench.py --workload er --steps 20 --warmup 5 --no-extra --mode bf16 --no-cpu-baseline > gpurun_out/$TAG/bench_er_bf16.json 2> gpurun_out/$TAG/bench_er_bf16.err
-python bench.py --workload code2-pna --no-extra > gpurun_out/$TAG/bench_code2pna.json 2> gpurun_out/$TAG/bench_code2pna.err
-python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 > gpurun_out/$TAG/bench_code2_mixed_clean.json 2>/dev/null
-python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --mode bf16 > gpurun_out/$TAG/bench_code2_bf16_clean.json 2>/dev/null
+python bench.py --report gpurun_out/$TAG/report_code2.json > gpurun_out/$TAG/bench_code2.json 2> gpurun_out/$TAG/bench_code2.err
+python bench.py --workload molpcba --report gpurun_out/$TAG/report_molpcba.json > gpurun_out/$TAG/bench_molpcba.json 2> gpurun_out/$TAG/bench_molpcba.err
+python bench.py --workload nci1 --no-extra --report gpurun_out/$TAG/report_nci1.json > gpurun_out/$TAG/bench_nci1.json 2> gpurun_out/$TAG/bench_nci1.err
+python bench.py --workload er --steps 20 --warmup 5 --no-extra --report gpurun_out/$TAG/report_er.json > gpurun_out/$TAG/bench_er.json 2> gpurun_out/$TAG/bench_er.err
+python bench.py --workload er --steps 20 --warmup 5 --no-extra --mode bf16 --no-cpu-baseline --report gpurun_out/$TAG/report_er_bf16.json > gpurun_out/$TAG/bench_er_bf16.json 2> gpurun_out/$TAG/bench_er_bf16.err
+python bench.py --workload code2-pna --no-extra --report gpurun_out/$TAG/report_code2pna.json > gpurun_out/$TAG/bench_code2pna.json 2> gpurun_out/$TAG/bench_code2pna.err
+python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --report gpurun_out/$TAG/report_code2_mixed_clean.json > gpurun_out/$TAG/bench_code2_mixed_clean.json 2>/dev/null
+python bench.py --no-kernel-timing --no-cpu-baseline --no-extra --steps 100 --mode bf16 --report gpurun_out/$TAG/report_code2_bf16_clean.json > gpurun_out/$TAG/bench_code2_bf16_clean.json 2>/dev/null
 # the per-rank shape of the global batch of 256 split over 8 GPUs (strong scaling), on one GPU
-python bench.py --batch 32 --no-cpu-baseline --no-extra > gpurun_out/$TAG/bench_code2_b32.json 2> gpurun_out/$TAG/bench_code2_b32.err
+python bench.py --batch 32 --no-cpu-baseline --no-extra --report gpurun_out/$TAG/report_code2_b32.json > gpurun_out/$TAG/bench_code2_b32.json 2> gpurun_out/$TAG/bench_code2_b32.err
 # clean lines (no kernel brackets, no CPU baseline) of the other workloads
 for w in molpcba nci1 code2-pna er; do
   S=100; [ $w = er ] && S=20
-  python bench.py --workload $w --steps $S --warmup 10 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$TAG/bench_${w}_clean.json 2>/dev/null
+  python bench.py --workload $w --steps $S --warmup 10 --no-cpu-baseline --no-kernel-timing --no-extra --report gpurun_out/$TAG/report_${w}_clean.json > gpurun_out/$TAG/bench_${w}_clean.json 2>/dev/null
 done
 for m in mixed bf16; do
   for w in code2 molpcba er code2-pna nci1; do
