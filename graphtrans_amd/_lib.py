@@ -29,6 +29,8 @@ _d = C.c_double
 SIGNATURES = {
     "gt_version": (_i, []),
     "gt_last_error": (C.c_char_p, []),
+    "gt_option_set": (_i, [C.c_char_p, _i]),
+    "gt_option_get": (_i, [C.c_char_p]),
     "gt_profile_enable": (_i, [C.c_uint]),
     "gt_profile_resume": (_i, [C.c_uint]),
     "gt_profile_count": (_i64, []),
@@ -103,8 +105,6 @@ SIGNATURES = {
     "gt_linear_bwd_wt": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p, _sz, _p]),
     "gt_transpose": (_i, [_p, _p, _i64, _i64, _p]),
     "gt_bn_sync_set": (_i, [_p, _p, _i]),
-    "gt_bn_coop_slots": (_i, [_p, _i]),
-    "gt_bn_coop_set": (_i, [_i]),
     "gt_vn_update_bwd_dt0": (_p, [_p, _p]),
     "gt_linear_bwd_bcast_ok": (_i, [_i, _i, _i, _p, _i64, _i64, _i64]),
     "gt_linear_bwd_bcast": (_i, [_p, _p]),
@@ -140,8 +140,6 @@ SIGNATURES = {
     "gt_overlap_dw_fork": (_p, [_p, C.c_uint]),
     "gt_overlap_dw_booked": (None, [_p, _sz]),
     "gt_overlap_dw_end": (_i, []),
-    "gt_overlap_dw_hold": (_i, []),
-    "gt_overlap_dw_unhold": (_i, []),
     "gt_linear_fwd_ld2": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_fwd_grouped": (_i, [_i, _i, _i, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i, _f, _u64, _p]),
     "gt_linear_bwd_grouped_workspace_bytes": (_sz, [_i, _i64, _i64, _i64, _i]),
@@ -232,6 +230,8 @@ def lib():
             fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("GT_F32_GEMM", "split") == "exact":   # the parity yardstick everywhere: w3.ENABLED keeps the GEMMs' images
+            h.gt_option_set(b"attn_f32_exact", 1)               # unbound, this keeps attention on the exact fp32 MFMA chains
         _lib = h
     return _lib
 
@@ -260,6 +260,21 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+def option_set(name, value):
+    """named runtime option (include/graphtrans_hip.h "Named runtime options") -> the previous value"""
+    rc = lib().gt_option_set(name.encode(), int(value))
+    if rc < 0:
+        check(rc, "gt_option_set")
+    return rc
+
+
+def option_get(name):
+    rc = lib().gt_option_get(name.encode())
+    if rc < 0:
+        check(rc, "gt_option_get")
+    return rc
 
 
 def profile_enable(mask):

@@ -844,12 +844,11 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   // (the caller's workspace is reused by the next layer) and their sums are queued below instead of launched
   float* dpart = nullptr;
   {
-    static const bool on = [] { const char* e = getenv("GT_AGG_DEFER"); return !e || atoi(e) != 0; }();   // (A/B knob)
     const int jobs = (d_self ? 1 : 0) + (edge_mode == GT_EDGE_LINEAR ? (d_edge_w ? (int)K : 0) + (d_edge_b ? 1 : 0)
                                                                       : (edge_mode == GT_EDGE_TABLES && d_edge_w ? 1 : 0));
     // (small batches only: a step made of launches gains the five launches -- NCI1 +3 % --, at Code2's 31 k rows the arena copy of
     // the partials is cold memory every layer where the workspace stays in the Infinity Cache: -1 %)
-    if (on && conv == GT_CONV_GCN && N <= 2048 && jobs > 0 && gt_defer_room(jobs)) dpart = (float*)gt_defer_take(need);
+    if (conv == GT_CONV_GCN && N <= 2048 && jobs > 0 && gt_defer_room(jobs)) dpart = (float*)gt_defer_take(need);
     if (dpart) a.partial = dpart;
   }
   a.table_rows = (int)table_rows;
@@ -879,18 +878,6 @@ extern "C" int gt_aggregate_bwd(int conv, int edge_mode, int dtype, const void* 
   }
   // the block partials only hold parameter gradients (root / eps, edge-encoder weights): their reduce goes to the overlap stream
   // when there is one -- the next kernel of the backward (the dX GEMM) does not wait for it
-  {   // the caller holds its forks (a layer's backward): the reduce joins the layer's one fork
-    const bool eps = conv == GT_CONV_GIN && d_self;
-    const int ct = ctiles, ns = nslots;
-    if (gt_overlap_dw_defer(stream_, [=](hipStream_t side) -> int {
-          hipLaunchKernelGGL(k_agg_reduce, dim3(ct, ns), dim3(RED_WAVES * 64), 0, side, r);
-          if (eps) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, side, d_self, ct);
-          return GT_OK;
-        }, workspace, workspace_bytes, 0)) {
-      GT_CHECK_LAUNCH();
-      return GT_OK;
-    }
-  }
   hipStream_t rstream = (hipStream_t)gt_overlap_dw_fork(stream_, 0 /* forked while profiled too: the brackets then hold the gather kernel alone, under the schedule the step really runs */);
   hipLaunchKernelGGL(k_agg_reduce, dim3(ctiles, nslots), dim3(RED_WAVES * 64), 0, rstream, r);
   if (conv == GT_CONV_GIN && d_self) hipLaunchKernelGGL(k_eps_finish, dim3(1), dim3(64), 0, rstream, d_self, ctiles);

@@ -709,17 +709,9 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
   return a;
 }
 
-// fp32 rows: bf16x6 products unless GT_F32_GEMM=exact (the switch of the fp32 GEMMs: the exact MFMA chains stay the parity yardstick)
-// or GT_ATTN_F32_SPLIT=0
-bool attn_f32_split() {
-  static const bool on = [] {
-    const char* g = getenv("GT_F32_GEMM");
-    const char* e = getenv("GT_ATTN_F32_SPLIT");
-    if (e) return atoi(e) != 0;
-    return !(g && strcmp(g, "exact") == 0);
-  }();
-  return on;
-}
+// fp32 rows: bf16x6 products unless gt_option_set("attn_f32_exact", 1) -- the exact v_mfma_f32_16x16x4_f32 chains stay the parity
+// yardstick (graphtrans_amd/w3.py sets it together with the exact fp32 GEMMs: GT_F32_GEMM=exact; tests/test_hip_options.py)
+bool attn_f32_split() { return !gt_opt(GT_OPT_ATTN_F32_EXACT); }
 
 }  // namespace
 

@@ -60,6 +60,29 @@ void gt_prof_end(int64_t id, hipStream_t stream) {
   if ((size_t)id < g_prof.size()) (void)hipEventRecord(g_prof[id].e1, stream);
 }
 
+// ---- named runtime options ----------------------------------------------------------------------------------------------------
+namespace {
+std::atomic<int> g_options[GT_OPT_COUNT];   // zero-initialised = every default
+const char* const OPTION_NAMES[GT_OPT_COUNT] = {"attn_f32_exact", "bnstats_rows_kernel"};
+int option_id(const char* name) {
+  if (name)
+    for (int i = 0; i < GT_OPT_COUNT; ++i)
+      if (strcmp(name, OPTION_NAMES[i]) == 0) return i;
+  return -1;
+}
+}  // namespace
+int gt_opt(int id) { return g_options[id].load(std::memory_order_relaxed); }
+extern "C" int gt_option_set(const char* name, int value) {
+  const int id = option_id(name);
+  if (id < 0) { gt_set_error("gt_option_set: unknown option '%s'", name ? name : "(null)"); return GT_ERR_INVALID_ARG; }
+  return g_options[id].exchange(value != 0 ? 1 : 0);
+}
+extern "C" int gt_option_get(const char* name) {
+  const int id = option_id(name);
+  if (id < 0) { gt_set_error("gt_option_get: unknown option '%s'", name ? name : "(null)"); return GT_ERR_INVALID_ARG; }
+  return gt_opt(id);
+}
+
 extern "C" int gt_profile_enable(unsigned mask) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (mask) {

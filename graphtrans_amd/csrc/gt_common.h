@@ -62,6 +62,10 @@ enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF
        // category times the schedule the un-profiled step runs -- bench.py's roofline uses it
        GT_PROF_GEMM_KERNEL = 32 };
 unsigned gt_prof_mask();
+// named runtime options (gt_option_set / gt_option_get, csrc/common.hip): alternative implementations that stay in the library as
+// TESTED yardsticks (tests/test_hip_options.py runs each non-default value against the oracle).  Process-wide, read at every call.
+enum { GT_OPT_ATTN_F32_EXACT = 0, GT_OPT_BNSTATS_ROWS_KERNEL = 1, GT_OPT_COUNT };
+int gt_opt(int id);
 int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims);
 void gt_prof_end(int64_t id, hipStream_t stream);
 struct GtProfScope {
@@ -158,8 +162,3 @@ __device__ __forceinline__ float4 gt_relu4(float4 a) {
   return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
 }
 
-// ---- held forks of the weight-gradient overlap section (csrc/linear.hip; C++ linkage: the queued work is a closure) ----------------
-#include <functional>
-// true = `fn` was queued and will run on the overlap stream at gt_overlap_dw_unhold (booked under `workspace`); false = no hold is open
-// on `stream` (or the launch profiler brackets `prof_category`): the caller launches / forks as before
-bool gt_overlap_dw_defer(gt_stream_t stream, std::function<int(hipStream_t)> fn, const void* workspace, size_t bytes, unsigned prof_category);

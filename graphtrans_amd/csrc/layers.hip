@@ -24,13 +24,6 @@ struct Bump {
 };
 
 size_t elt(int dtype) { return dtype == GT_BF16 ? 2 : 4; }
-// a layer's backward forks its weight-gradient work ONCE: queued while this lives, issued when it dies (gt_overlap_dw_hold)
-struct ForkHold {
-  bool open = true;
-  ForkHold() { (void)gt_overlap_dw_hold(); }
-  int release() { open = false; return gt_overlap_dw_unhold(); }   // the layer's last statement: a failing queued launch is the layer's failure
-  ~ForkHold() { if (open) (void)gt_overlap_dw_unhold(); }
-};
 
 #define GT_TRY(call)            \
   do {                          \
@@ -289,7 +282,6 @@ extern "C" int gt_encoder_layer_fwd(const gt_encoder_layer* L, const void* x, vo
 
 extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, const void* dy, const void* saved, void* dx,
                                     float* grads, void* workspace, size_t workspace_bytes, gt_stream_t st) {
-  ForkHold fork_hold__;
   GT_TRY(enc_check("gt_encoder_layer_bwd", L));
   GT_CHECK_ARG(x && dy && saved && dx && grads && workspace, "null buffer");
   const EncWork w = enc_work(L, workspace);
@@ -346,7 +338,7 @@ extern "C" int gt_encoder_layer_bwd(const gt_encoder_layer* L, const void* x, co
                                  w.lin_ws_bytes, st));
   GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, dx, nullptr, dx, nullptr, nullptr, R, 3 * d, d, 0.f, w.lin_ws,
                        w.lin_ws_bytes, st));
-  return fork_hold__.release();
+  return GT_OK;
 }
 
 // ---------------------------------------------------------------- GIN layer
@@ -464,7 +456,6 @@ extern "C" int gt_gcn_layer_fwd(const gt_gcn_layer* L, const void* h_in, const v
 extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void* dy, const void* dx_extra,
                                 const void* saved, void* d_h_in, void* d_vn, float* grads, void* workspace,
                                 size_t workspace_bytes, gt_stream_t st) {
-  ForkHold fork_hold__;
   GT_TRY(gcn_check("gt_gcn_layer_bwd", L));
   GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
   const GcnWork w = gcn_work(L, workspace);   // d_vn may be NULL: the caller pools d_h_in itself (e.g. on another stream)
@@ -488,11 +479,13 @@ extern "C" int gt_gcn_layer_bwd(const gt_gcn_layer* L, const void* x, const void
     GT_TRY(gt_linear_bwd_bnstats((const float*)ps.agg, L->D, ps.stats, ps.stats + L->D, L->prev_bn_w, L->prev_bn_b, L->prev_relu,
                                  L->prev_bn_part));
   }
+  // (the broadcast request is consumed -- or dropped -- by the very next gt_linear_bwd* call of this thread: this one)
+  if (L->dx_bcast) GT_TRY(gt_linear_bwd_bcast(L->dx_bcast, L->dx_bcast_idx));
   GT_TRY(gt_linear_bwd_wt(GT_F32, GT_F32, L->compute, x, L->lin_w, L->lin_wt, w.d_lin, nullptr, dx_extra, L->residual ? dy : nullptr,
                           d_h_in, g.lin_w, g.lin_b, L->N, L->D, L->D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
   if (L->has_vn && d_vn)
     GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, L->N, L->B, L->D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
-  return fork_hold__.release();
+  return GT_OK;
 }
 
 // =================================================================================================
@@ -610,7 +603,6 @@ extern "C" int gt_gin_layer_fwd(const gt_gin_layer* L, const void* h_in, const v
 extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void* dy, const void* dx_extra,
                                 const void* saved, void* d_h_in, void* d_vn, float* grads, void* workspace,
                                 size_t workspace_bytes, gt_stream_t st) {
-  ForkHold fork_hold__;
   GT_TRY(gin_check("gt_gin_layer_bwd", L));
   GT_CHECK_ARG(x && dy && saved && d_h_in && grads && workspace, "null buffer");
   const GinWork w = gin_work(L, workspace);   // d_vn may be NULL: the caller pools d_h_in itself
@@ -640,7 +632,7 @@ extern "C" int gt_gin_layer_bwd(const gt_gin_layer* L, const void* x, const void
     GT_TRY(gt_add3((const float*)w.d_x, e1, e2, N * D, (float*)d_h_in, st));
   }
   if (L->has_vn && d_vn) GT_TRY(gt_segment_sum_ws(GT_F32, d_h_in, nullptr, L->graph_ptr, N, L->B, D, d_vn, w.seg_ws, w.seg_ws_bytes, st));
-  return fork_hold__.release();
+  return GT_OK;
 }
 
 // =================================================================================================
@@ -752,7 +744,6 @@ extern "C" int gt_encoder_layer_pooled_fwd(const gt_encoder_layer* L, const void
 extern "C" int gt_encoder_layer_pooled_bwd(const gt_encoder_layer* L, const void* x, const int64_t* pool_rows, const void* dy_pool,
                                            const void* saved, void* dx, float* grads, void* workspace, size_t workspace_bytes,
                                            gt_stream_t st) {
-  ForkHold fork_hold__;
   GT_TRY(enc_check("gt_encoder_layer_pooled_bwd", L));
   GT_CHECK_ARG(x && pool_rows && dy_pool && saved && dx && grads && workspace, "null buffer");
   const EncPoolWork w = encp_work(L, workspace);
@@ -800,7 +791,7 @@ extern "C" int gt_encoder_layer_pooled_bwd(const gt_encoder_layer* L, const void
   GT_TRY(gt_linear_bwd(t, t, c, x, L->in_w, w.d_qkv, nullptr, nullptr, nullptr, dx, nullptr, nullptr, R, 3 * d, d, 0.f, w.lin_ws_in,
                        w.lin_ws_in_bytes, st));
   GT_TRY(gt_rows_add(t, w.d_xp, pool_rows, B, d, dx, st));
-  return fork_hold__.release();
+  return GT_OK;
 }
 
 // =================================================================================================

@@ -675,43 +675,12 @@ struct DwOverlap {
   bool urgent = false;       // the forks from here on are the last of the backward: the optimizer waits for them
   DwPending ring[DW_RING];   // forks since the last full join, oldest first (the side stream runs them in this order)
   int n = 0;
-  // HELD forks (gt_overlap_dw_hold / _unhold): a fork costs the main stream an event record (~3 us of its timeline, ~5 with the other
-  // stream's wait: tools/event_cost_probe.hip) -- a layer's backward forked 4-6 times.  While a hold is open the side work is queued
-  // instead and ONE record at the unhold orders all of it behind the main stream (nobody waits for it: it produces parameter
-  // gradients; starting it a few kernels later costs nothing).
-  int hold = 0;
-  struct Held {
-    std::function<int(hipStream_t)> fn;
-    const void* ws;
-    size_t bytes;
-  };
-  std::vector<Held> held;
 };
 thread_local DwOverlap g_dw;
 
 void dw_forked(const void* workspace, size_t bytes);
-// Side work queued by gt_overlap_dw_defer rides on the NEXT fork: right behind a fork's record + wait the overlap stream is ordered
-// behind everything the queued launches depend on (they were queued earlier), so they cost the main stream nothing -- no launch, no
-// event of their own (the LayerNorm backward's 5-us column finish sat on the main stream between two GEMMs, 10 per Code2 step).
-void dw_run_queued() {
-  if (g_dw.hold > 0 || g_dw.held.empty()) return;
-  std::vector<DwOverlap::Held> work;
-  work.swap(g_dw.held);
-  for (auto& h : work) {
-    (void)h.fn(g_dw.side);
-    dw_forked(h.ws, h.bytes);
-  }
-}
-// ... and before the main stream joins or releases anything, with a fork of their own
-void dw_flush_queued() {
-  if (g_dw.hold > 0 || g_dw.held.empty()) return;
-  (void)hipEventRecord(g_dw.ev_fork, g_dw.main);
-  (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-  dw_run_queued();
-}
 // main waits for the side stream; nothing is pending afterwards
 void dw_join_all() {
-  dw_flush_queued();
   (void)hipEventRecord(g_dw.ev_join, g_dw.side);
   (void)hipStreamWaitEvent(g_dw.main, g_dw.ev_join, 0);
   g_dw.n = 0;
@@ -719,7 +688,6 @@ void dw_join_all() {
 // main waits for the forked dW GEMMs whose workspace overlaps [p, p + bytes) -- and, the side stream being in order, for
 // everything forked before them; later forks on other workspaces keep running
 void dw_release(const void* p, size_t bytes) {
-  if (g_dw.active) dw_flush_queued();
   if (!g_dw.active || !g_dw.n) return;
   const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
   int last = -1;
@@ -863,8 +831,7 @@ bool w32_eligible(int compute, int x_dtype, int64_t M, int groups) {
 }
 // grouped launches of the bf16x6 kernel (k_lin3, blockIdx.y = group): fp32 rows in and out, 16-byte chunks of every row
 bool g3_eligible(int compute, int x_dtype, int y_dtype, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy) {
-  static const bool on = [] { const char* e = getenv("GT_LIN3_GROUPED"); return !(e && e[0] == '0'); }();
-  return on && compute == GT_F32 && x_dtype == GT_F32 && y_dtype == GT_F32 && M >= W32_MIN_M && N % 4 == 0 && K % 4 == 0 && ldx % 4 == 0 &&
+  return compute == GT_F32 && x_dtype == GT_F32 && y_dtype == GT_F32 && M >= W32_MIN_M && N % 4 == 0 && K % 4 == 0 && ldx % 4 == 0 &&
          ldy % 4 == 0;
 }
 
@@ -1168,7 +1135,6 @@ struct BwdCallOpts {
   bool gate_out = false;             // y_for_mask [M][ldx] gates the dX OUTPUT (gt_linear_bwd_gate_out), dY is used as it is
   const float* bcast = nullptr;      // dX += bcast[bcast_idx[row]] (gt_linear_bwd_bcast), set BEFORE the call it applies to
   const int32_t* bcast_idx = nullptr;
-  bool as_fork = false;              // a dW-only call replayed on the overlap stream by gt_overlap_dw_unhold: sized like a forked one
 };
 thread_local BwdCallOpts g_opt;
 struct BwdOptScope {   // whatever was set is dropped when the call it was meant for returns
@@ -1192,11 +1158,11 @@ extern "C" int gt_linear_bwd_bnstats_ok(int compute, int x_dtype, int y_dtype, i
 }
 extern "C" int64_t gt_linear_bwd_bnstats_rows(int64_t M) { return gt_cdiv(M, W32_BM); }
 // the register-row bf16x6 kernel (linear3r.h) takes a dX call with BatchNorm statistics in its epilogue: one partial row per 128-row block
-// (only with GT_FUSE_BN=2 in the environment: measured slower than the separate partial pass -- Code2 74.0 k against 74.85 k graphs/s --,
-// and gt_linear_bwd_bnstats' documented partial layout is the exact kernel's 64-row tiles)
+// (only with gt_option_set("bnstats_rows_kernel", 1): measured slower than the separate partial pass -- Code2 74.0 k against 74.85 k
+// graphs/s, round 5 -- and gt_linear_bwd_bnstats' documented partial layout is the exact kernel's 64-row tiles; kept as a tested
+// alternative, tests/test_hip_options.py)
 static bool bns_on_rows_kernel(int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy) {
-  static const bool on = [] { const char* e = getenv("GT_FUSE_BN"); return e && atoi(e) == 2; }();
-  if (!on) return false;
+  if (!gt_opt(GT_OPT_BNSTATS_ROWS_KERNEL)) return false;
   const void* img = w3_lookup(weight, N, K, true);
   if (!img || x_dtype != GT_F32 || y_dtype != GT_F32) return false;
   L32Args w{};
@@ -1299,32 +1265,6 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
                                      float* dbias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups,
                                      int64_t x_group_stride, int64_t y_group_stride, float dropout_p, void* workspace,
                                      size_t workspace_bytes, gt_stream_t stream_) {
-  if (g_dw.active && g_dw.hold > 0 && (hipStream_t)stream_ == g_dw.main && dweight && (dx || g_opt.fork_dw_only) && workspace && workspace_bytes &&
-      !g_opt.as_fork && !(gt_prof_mask() & GT_PROF_LINEAR)) {
-    // forks are held: the dX part now, the dW part (with this call's options and one-call requests) when the hold is released
-    const BwdCallOpts opts = g_opt;
-    const int32_t* rows = g_rows;
-    const RowsLn rows_ln = g_rows_ln;
-    const Cat2Req cat2 = g_cat2;
-    int rc = GT_OK;
-    if (dx) {
-      rc = gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, dx_add1, dx_add2, dx, nullptr, nullptr, M, N, K, ldx, ldy, groups,
-                                 x_group_stride, y_group_stride, dropout_p, workspace, workspace_bytes, stream_);
-    } else {
-      g_opt = BwdCallOpts{}; g_rows = nullptr; g_rows_ln = RowsLn{}; g_cat2 = Cat2Req{};
-    }
-    if (rc) return rc;
-    auto fn = [=](hipStream_t side) -> int {
-      g_opt = opts;
-      g_opt.fork_dw_only = false; g_opt.as_fork = true; g_opt.bcast = nullptr; g_opt.bcast_idx = nullptr; g_opt.bns = BnStatsReq{};
-      g_rows = rows; g_rows_ln = rows_ln; g_cat2 = cat2;
-      g_cat2.dx2 = nullptr;
-      return gt_linear_bwd_grouped(x_dtype, y_dtype, compute, x, weight, dy, y_for_mask, nullptr, nullptr, nullptr, dweight, dbias, M, N, K, ldx, ldy,
-                                   groups, x_group_stride, y_group_stride, dropout_p, workspace, workspace_bytes, (gt_stream_t)side);
-    };
-    if (!gt_overlap_dw_defer(stream_, fn, workspace, workspace_bytes, GT_PROF_LINEAR)) return fn((hipStream_t)stream_);
-    return GT_OK;
-  }
   BwdOptScope opt_scope__;   // the per-call options live for exactly this call
   if (g_opt.bcast && dx && !gt_linear_bwd_bcast_ok(compute, x_dtype, y_dtype, weight, M, N, K)) {
     gt_set_error("gt_linear_bwd_bcast: this call does not run on the register-row kernel (ask gt_linear_bwd_bcast_ok)");
@@ -1381,7 +1321,6 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
         stream = g_dw.side;
       }
       sa.out = dweight; sa.db = dbias;
@@ -1409,8 +1348,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       dx_done = true;
     }
   }
-  static const bool g3_dw_on = [] { const char* e = getenv("GT_LIN3_GROUPED_DW"); return !(e && e[0] == '0'); }();   // (A/B knob)
-  if (g3_dw_on && dweight && groups > 1 && g3_eligible(compute, x_dtype, y_dtype, M, N, K, ldx, ldy) && !g_cat2.x2 && !rows__.rows && workspace &&
+  if (dweight && groups > 1 && g3_eligible(compute, x_dtype, y_dtype, M, N, K, ldx, ldy) && !g_cat2.x2 && !rows__.rows && workspace &&
       workspace_bytes >= need) {
     // the groups' weight gradients on the pipelined bf16x6 kernel (k_lin3r_dw, blockIdx.y = group) when their weights are bound
     int64_t spacing = 0;
@@ -1419,12 +1357,11 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     d.M = M; d.N = N; d.K = K; d.ldy = ldy; d.ldx = ldx;
     d.groups = groups; d.g_y = y_group_stride; d.g_x = x_group_stride;
     if (w3_lookup_grouped(weight, N, K, groups, false, &spacing) && w3r_dw_ok(y_dtype, x_dtype, d)) {
-      const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && !(gt_prof_mask() & GT_PROF_LINEAR)) || g_opt.as_fork;
-      const bool forked = will_fork && !g_opt.as_fork;
+      const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && !(gt_prof_mask() & GT_PROF_LINEAR));
+      const bool forked = will_fork;
       if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
       }
       // (a local: a dX that falls through to the generic kernels below must stay on the caller's stream -- ADVICE r5)
       hipStream_t dw_stream = forked ? g_dw.side : stream;
@@ -1470,7 +1407,7 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     }
     const int nt = w32_pick_nt(N);
     const int nkb = (int)gt_cdiv(K, 64), nnb = (int)gt_cdiv(gt_cdiv(N, 16), nt);
-    const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR)) || (g_opt.as_fork && dweight);
+    const bool will_fork = (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && dweight && !(gt_prof_mask() & GT_PROF_LINEAR));
     const int splits = w32_dw_splits(M, nkb, nnb, will_fork && !g_dw.urgent);
     float* part = reinterpret_cast<float*>(workspace);
     float* wt = part + (size_t)w32_dw_splits(M, nkb, nnb, false) * (size_t)(N * K + N) + 64;   // behind the larger partial area
@@ -1517,11 +1454,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       else w32_launch<true>(y_dtype, x_dtype, stream, w);
     }
     if (dweight) {
-      const bool forked = will_fork && !g_opt.as_fork;   // (replayed from a hold: already on the overlap stream, booked by the unhold)
+      const bool forked = will_fork;
       if (forked) {
         (void)hipEventRecord(g_dw.ev_fork, stream);
         (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
         stream = g_dw.side;
       }
       L32DwArgs d{};
@@ -1632,7 +1568,6 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (forked) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
       stream = g_dw.side;
     }
     SmallArgs sa{};
@@ -1660,7 +1595,6 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
     if (g_dw.active && stream == g_dw.main && (dx || g_opt.fork_dw_only) && a.splits <= 1 && !(gt_prof_mask() & GT_PROF_LINEAR)) {
       (void)hipEventRecord(g_dw.ev_fork, stream);
       (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
       stream = g_dw.side;
       forked = true;
     }
@@ -1719,8 +1653,7 @@ extern "C" int gt_linear_cat2_ok(int compute, const float* weight, int64_t M, in
 // ---- a row map on the output (forward) / on dY (backward): gnn2transformer writing and reading the Transformer's token rows in place
 // (models/gnn_transformer.py:92-96, modules/utils.py:5-29: no pad / unpad pass over the node rows) -----------------------------------
 extern "C" int gt_linear_rows_ok(int compute, int x_dtype, int y_dtype, const float* weight, int64_t M, int64_t N, int64_t K) {
-  static const bool on = [] { const char* e = getenv("GT_LINEAR_ROWS"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return (on && rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)) ? 1 : 0;
+  return (rows_eligible(compute, x_dtype, y_dtype, weight, M, N, K)) ? 1 : 0;
 }
 extern "C" int gt_linear_set_rows(const int32_t* rows) {
   g_rows = rows;
@@ -1876,8 +1809,7 @@ extern "C" int gt_linear_bwd_gate_out(int x_dtype, int y_dtype, int compute, con
 // modules/transformer_encoder.py:28-32).  Only on the weight-stationary path: gt_linear_layernorm_fwd_ok says so (callers fall back to
 // the two calls).
 extern "C" int gt_linear_layernorm_fwd_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
-  static const bool on = [] { const char* e = getenv("GT_W1_LN"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return !on ? 0 : (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_ln_covered(N, K) && w1_lookup(weight, N, K, false)) ? 1 : 0;
+  return (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_ln_covered(N, K) && w1_lookup(weight, N, K, false)) ? 1 : 0;
 }
 extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, const float* weight, const float* bias, void* a_out,
                                        int64_t M, int64_t N, int64_t K, const void* resid, const float* ln_weight, const float* ln_bias,
@@ -1915,8 +1847,7 @@ extern "C" int gt_linear_layernorm_fwd(int dtype, int compute, const void* x, co
 // gradient through block partials in `workspace` (or the open deferred-reduce section).  weight [N][K], K = the LayerNorm dim.
 // Only on the weight-stationary path: gt_linear_bwd_dx_layernorm_ok says so (callers fall back to gt_linear_bwd + gt_layernorm_bwd).
 extern "C" int gt_linear_bwd_dx_layernorm_ok(int dtype, int compute, const float* weight, int64_t M, int64_t N, int64_t K) {
-  static const bool on = [] { const char* e = getenv("GT_W1_LNB"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return !on ? 0 : (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_lnb_covered(K, N) && w1_lookup(weight, N, K, true)) ? 1 : 0;
+  return (dtype == GT_BF16 && compute == GT_BF16 && M >= W1_MIN_M && w1_lnb_covered(K, N) && w1_lookup(weight, N, K, true)) ? 1 : 0;
 }
 extern "C" size_t gt_linear_bwd_dx_layernorm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return (size_t)w1_grid_blocks(M, K, N) * 2 * (size_t)K * sizeof(float) + 256;
@@ -1971,8 +1902,7 @@ extern "C" int gt_linear_bwd_dx_layernorm(int dtype, int compute, const float* w
 
 // ---- overlap section -------------------------------------------------------------------------------
 extern "C" int gt_defer_begin(void* arena, size_t bytes) {
-  static const bool on = [] { const char* e = getenv("GT_DEFER_REDUCE"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  g_defer.active = on && arena && bytes > 0;
+  g_defer.active = arena && bytes > 0;
   g_defer.arena = (char*)arena;
   g_defer.cap = bytes;
   g_defer.used = 0;
@@ -2048,8 +1978,6 @@ extern "C" int gt_overlap_dw_begin(gt_stream_t main_, gt_stream_t side_) {
   g_dw.active = true;
   g_dw.urgent = false;
   g_dw.n = 0;
-  g_dw.hold = 0;
-  g_dw.held.clear();
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_sync(void) {
@@ -2066,44 +1994,10 @@ extern "C" gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned prof_cate
   if (!g_dw.active || (hipStream_t)stream != g_dw.main || (gt_prof_mask() & prof_category)) return stream;
   (void)hipEventRecord(g_dw.ev_fork, g_dw.main);
   (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-        dw_run_queued();
   return (gt_stream_t)g_dw.side;
 }
 extern "C" void gt_overlap_dw_booked(const void* workspace, size_t bytes) {
   if (g_dw.active) dw_forked(workspace, bytes);
-}
-// Side work for the overlap stream while forks are held: true = queued (runs at gt_overlap_dw_unhold on the overlap stream, booked under
-// `workspace`), false = no hold open on this stream: the caller forks as before.  (C++ linkage: declared in gt_common.h.)
-bool gt_overlap_dw_defer(gt_stream_t stream, std::function<int(hipStream_t)> fn, const void* workspace, size_t bytes, unsigned prof_category) {
-  // (GT_FORK_PIGGYBACK=1: LayerNorm backward's column finishes leave the main stream and ride on the next fork; measured r5 within the
-  // noise -- Code2 74.10 k against 74.33 k graphs/s, fp32 mode 52.6 k against 52.3 k, Molpcba 95.2 k against 95.0 k -- so off)
-  static const bool piggy = [] { const char* e = getenv("GT_FORK_PIGGYBACK"); return e && atoi(e) != 0; }();
-  if (!g_dw.active || (hipStream_t)stream != g_dw.main || (gt_prof_mask() & prof_category)) return false;
-  if (g_dw.hold <= 0 && (!piggy || prof_category == 0)) return false;   // (category 0: the aggregate backward's reduce keeps its own fork)
-  g_dw.held.push_back(DwOverlap::Held{std::move(fn), workspace, bytes});
-  return true;
-}
-extern "C" int gt_overlap_dw_hold(void) {
-  // OFF unless asked for (GT_HOLD_FORKS=1): measured r5 it LOSES in the step -- Code2 74.2 k against 74.5 k graphs/s, fp32 mode 51.7 k
-  // against 52.7 k, Molpcba 95.0 k against 96.4 k -- although a record + wait pair costs the main stream ~5 us in isolation
-  // (tools/event_cost_probe.hip): the weight-gradient GEMMs then start a layer late and pile up behind the step's last layers
-  static const bool on = [] { const char* e = getenv("GT_HOLD_FORKS"); return e && atoi(e) != 0; }();
-  if (g_dw.active && on) ++g_dw.hold;
-  return GT_OK;
-}
-extern "C" int gt_overlap_dw_unhold(void) {
-  if (!g_dw.active || g_dw.hold <= 0) return GT_OK;
-  if (--g_dw.hold > 0 || g_dw.held.empty()) return GT_OK;
-  (void)hipEventRecord(g_dw.ev_fork, g_dw.main);
-  (void)hipStreamWaitEvent(g_dw.side, g_dw.ev_fork, 0);
-  int rc = GT_OK;
-  std::vector<DwOverlap::Held> work;
-  work.swap(g_dw.held);
-  for (auto& h : work) {
-    if (rc == GT_OK) rc = h.fn(g_dw.side);
-    dw_forked(h.ws, h.bytes);   // (one event per entry on the side stream: the ring's release logic stays as it is)
-  }
-  return rc;
 }
 extern "C" int gt_overlap_dw_urgent(int on) {
   g_dw.urgent = on != 0;
@@ -2114,8 +2008,6 @@ extern "C" int gt_overlap_dw_release(const void* workspace, size_t bytes) {
   return GT_OK;
 }
 extern "C" int gt_overlap_dw_end(void) {
-  g_dw.hold = g_dw.hold > 0 ? 1 : 0;
-  (void)gt_overlap_dw_unhold();   // (a hold left open by an error path: its work still runs)
   const int rc = gt_overlap_dw_sync();
   g_dw.active = false;
   return rc;

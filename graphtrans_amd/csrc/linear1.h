@@ -553,11 +553,10 @@ static inline int w1_pick_ntw(int64_t R, int64_t C) {
   static const int cand[6][5] = {{4, 6, 4, 2, 0}, {8, 4, 2, 0, 0}, {12, 2, 0, 0, 0}, {16, 2, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   // (K = 768 / 1024 with ONE n-tile per wave -- the ER shapes 256 x 1024, 256 x 768 -- measured slower than the tiled kernels: not covered)
   // (NTW = 8 for 512 columns x K = 128 measured no faster than two column blocks of NTW = 4 and needs all 256 registers)
-  static const int max_ntw = [] { const char* e = getenv("GT_W1_MAX_NTW"); return e ? atoi(e) : 8; }();   // (A/B knob)
   for (int i = 0; i < 6; ++i)
     if (cand[i][0] == ks)
       for (int j = 1; j < 5 && cand[i][j]; ++j)
-        if (q % cand[i][j] == 0 && cand[i][j] <= max_ntw) return cand[i][j];
+        if (q % cand[i][j] == 0) return cand[i][j];
   return 0;
 }
 

@@ -336,14 +336,9 @@ static inline int w3r_ncb(int64_t Nout) {
   return ntb > 8 ? ncb : 0;
 }
 
-static inline bool w3r_enabled() {
-  static const bool on = [] { const char* e = getenv("GT_LIN3R"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
-
 // the register-row kernel takes the call (MASK callers pass amask == null for an ungated dX)
 static inline bool w3r_ok(int ta, int to, const L32Args& a) {
-  if (!w3r_enabled() || ta != GT_F32 || to != GT_F32 || !a.w3) return false;
+  if (ta != GT_F32 || to != GT_F32 || !a.w3) return false;
   if (a.amask || a.gout || a.thr || a.act > 1 || a.a2 || a.out2 || a.out_rows || a.a_rows || a.ln_out || a.groups > 1) return false;
   if (a.bn_part && (a.bn_ldx % 4 || (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mean | (uintptr_t)a.bn_rstd | (uintptr_t)a.bn_w | (uintptr_t)a.bn_b) & 15))) return false;
   if ((((uintptr_t)a.a | (uintptr_t)a.out | (uintptr_t)a.add1 | (uintptr_t)a.add2 | (uintptr_t)a.bias | (uintptr_t)a.add_bc) & 15) != 0) return false;
@@ -659,13 +654,9 @@ __global__ void __launch_bounds__(PC ? 512 : 256, PC ? 2 : 1) k_lin3r_dw(L32DwAr
   if (want_db) db_fold();
 }
 
-static inline bool w3r_dw_enabled() {
-  static const bool on = [] { const char* e = getenv("GT_LIN3R_DW"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
 // the pipelined kernel takes the call: fp32 operands, 16-byte aligned rows
 static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
-  if (!w3r_dw_enabled() || ty != GT_F32 || tx != GT_F32 || (a.dy_rows && a.ymask) || (a.groups > 1 && (a.dy_rows || a.x2))) return false;
+  if (ty != GT_F32 || tx != GT_F32 || (a.dy_rows && a.ymask) || (a.groups > 1 && (a.dy_rows || a.x2))) return false;
   if (a.N % 4 || a.K % 4 || a.ldy % 4 || a.ldx % 4 || (a.x2 && (a.ldx2 % 4 || a.x_split % 4))) return false;
   return (((uintptr_t)a.dy | (uintptr_t)a.x | (uintptr_t)a.ymask | (uintptr_t)a.x2) & 15) == 0;
 }
@@ -676,8 +667,6 @@ static inline bool w3r_dw_ok(int ty, int tx, const L32DwArgs& a) {
 static inline int w3r_dw_zt(int shape) { return shape == 1 ? 224 : 160; }
 static inline int w3r_dw_xt(int shape) { return shape == 1 ? 128 : 160; }
 static inline int w3r_dw_pick_shape(int64_t N, int64_t K) {   // least padded area, ties -> 0
-  static const int forced = [] { const char* e = getenv("GT_LIN3R_DW_SHAPE"); return e ? atoi(e) : -1; }();   // (A/B knob)
-  if (forced >= 0) return forced ? 1 : 0;
   int best = 0;
   int64_t area = -1;
   for (int sh = 0; sh < 2; ++sh) {
@@ -715,15 +704,12 @@ static inline void w3r_launch_dw(dim3 grid, hipStream_t stream, const L32DwArgs&
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= 16 || !done[dev]) {
       (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)(k_lin3r_dw<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (dev >= 0 && dev < 16) done[dev] = true;
     }
   }
-  static const bool one_wave = [] { const char* e = getenv("GT_LIN3R_DW_PC"); return !e || atoi(e) == 0; }();   // (A/B knob; see the kernel's header)
   if (a.dy_rows) hipLaunchKernelGGL((k_lin3r_dw<false, true, true>), grid, dim3(512), LDS, stream, a);   // (w3r_dw_ok: no gate with a row map)
   else if (a.ymask) hipLaunchKernelGGL((k_lin3r_dw<true, false, true>), grid, dim3(512), LDS, stream, a);
-  else if (one_wave) hipLaunchKernelGGL((k_lin3r_dw<false, false, false>), grid, dim3(256), LDS, stream, a);
-  else hipLaunchKernelGGL((k_lin3r_dw<false, false, true>), grid, dim3(512), LDS, stream, a);
+  else hipLaunchKernelGGL((k_lin3r_dw<false, false, false>), grid, dim3(256), LDS, stream, a);   // (the 8-wave producer / consumer form of this case: 3 % slower in the step, see the kernel's header)
 }

@@ -475,10 +475,6 @@ void w3_launch_one(dim3 grid, hipStream_t stream, const L32Args& a) {
 #endif
 // rows per block: 128 (one W buffer, two blocks per CU: every W byte feeds twice the MFMAs -- at 64 rows the kernel asks the L2 for
 // 40 B / cycle / CU at the MFMA rate) when that still gives the chip >= 384 blocks, else 64 (two W buffers)
-static inline bool w3_small_lds() {
-  static const bool on = [] { const char* e = getenv("GT_LIN3_SMALL_LDS"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
 static inline int w3_pick_mt(int64_t M, int ncb) {
   if (W3_FORCE_MT) return W3_FORCE_MT;
   return gt_cdiv(M, 128) * ncb >= 384 ? 4 : 2;
@@ -486,7 +482,7 @@ static inline int w3_pick_mt(int64_t M, int ncb) {
 
 template <bool MASK>
 void w3_launch(int ta, int to, hipStream_t stream, L32Args& a) {
-  if (a.groups > 1 && a.Nout <= 96 && ta == GT_F32 && to == GT_F32 && a.act != 2 && w3_small_lds()) {
+  if (a.groups > 1 && a.Nout <= 96 && ta == GT_F32 && to == GT_F32 && a.act != 2) {
     // a grouped launch of narrow GEMMs (the PNA pre stack's dX: 136 -> 68 columns per tower): 6 n-tiles, 64 rows, one W buffer =
     // 30 KB of LDS and 107 registers instead of 48 KB and 185 -- it runs beside the post stack's weight-gradient kernel (138 KB of LDS on
     // 192 CUs), where five of these blocks fit on a free CU against three: 126 -> 99 us in the step (24 us alone), Code2-PNA 33.0 ->
@@ -707,7 +703,7 @@ static inline int w3_dw_splits(int64_t M, int tiles) {
   // five XCDs got 36 blocks for their 32 CUs and the launch took two rounds (6.4 us per stage against 3.1: tools/gemm3r_dw_pna_probe).
   // Whole groups of 8 splits, at most 32 blocks per XCD.
   if (tiles < 1) tiles = 1;
-  static const int per_xcd = [] { const char* e = getenv("GT_DW3_XCD_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 32; }();   // (A/B knob)
+  constexpr int per_xcd = 32;
   int64_t s = tiles <= per_xcd ? 8 * (per_xcd / tiles) : (8 * per_xcd) / tiles;
   const int64_t maxs = gt_cdiv(M, 32 * 8);           // at least 8 stages per split
   if (s > maxs) s = maxs;

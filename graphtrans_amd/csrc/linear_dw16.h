@@ -191,25 +191,18 @@ __global__ void __launch_bounds__(256) k_dw16(Dw16Args a) {
 
 #undef D16_TR
 
-static inline bool dw16_on() {
-  static const bool on = [] { const char* e = getenv("GT_DW16"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on;
-}
-static inline int dw16_blocks() {
-  static const int v = [] { const char* e = getenv("GT_DW16_BLOCKS"); const int b = e ? atoi(e) : 256; return b < 8 ? 8 : b; }();   // (A/B knob)
-  return v;
-}
+constexpr int D16_BLOCKS = 256;   // one block per CU
 // bf16 rows on both sides, whole 128 x 128 tiles, 16-byte aligned rows, enough rows to fill the ring
 static inline bool dw16_ok(int x_dtype, int y_dtype, int compute, const void* x, const void* dy, const void* ymask, int64_t M, int64_t N,
                            int64_t K, int64_t ldx, int64_t ldy, int groups) {
-  return dw16_on() && x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && groups == 1 && !ymask && M >= 1024 &&
+  return x_dtype == GT_BF16 && y_dtype == GT_BF16 && compute == GT_BF16 && groups == 1 && !ymask && M >= 1024 &&
          N % D16_T == 0 && K % D16_T == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0;
 }
 static inline int dw16_splits(int64_t M, int64_t N, int64_t K, int cap) {
   const int64_t tiles = (N / D16_T) * (K / D16_T);
   // two blocks per CU (2 x 64 KB of LDS) once the contraction is long enough that the doubled partials stay small beside the operands:
   // at M = 131 k (the Erdos-Renyi stress) 512 blocks run the N or K = 1024 shapes in 125-133 us against 174-185 us (tools/dw16_bench.py)
-  const int64_t target = (M >= 65536 && !getenv("GT_DW16_BLOCKS")) ? 2 * dw16_blocks() : dw16_blocks();
+  const int64_t target = M >= 65536 ? 2 * D16_BLOCKS : D16_BLOCKS;
   int64_t s = target / tiles;
   const int64_t maxs = gt_cdiv(M, 4 * D16_ROWS);   // at least four stages per split
   if (s > maxs) s = maxs;

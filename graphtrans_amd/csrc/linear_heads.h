@@ -27,8 +27,7 @@ constexpr int HD_K = 128;          // d_model of the heads' input
 constexpr int HD_LDW = HD_K + 4;   // LDS row pitch of a W slab (2-way conflicts on the transposed reads: 32 reads against 128 MFMAs)
 
 static inline bool heads_shape_ok(int x_dtype, int y_dtype, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int groups) {
-  static const bool on = [] { const char* e = getenv("GT_HEADS_KERNELS"); return !e || atoi(e) != 0; }();   // (A/B knob)
-  return on && groups == 1 && x_dtype == GT_F32 && y_dtype == GT_F32 && K == HD_K && N >= 4096 && M > 0 && M <= 4096 && ldx % 4 == 0 &&
+  return groups == 1 && x_dtype == GT_F32 && y_dtype == GT_F32 && K == HD_K && N >= 4096 && M > 0 && M <= 4096 && ldx % 4 == 0 &&
          ldy % 4 == 0;
 }
 static inline int heads_dx_blocks(int64_t N) {

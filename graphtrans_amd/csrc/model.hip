@@ -64,8 +64,6 @@ struct Ctx {
   size_t o_h[MAXL + 1], o_x0, o_vn[MAXL], o_vn_saved[MAXL], o_conv_saved[MAXL], o_cat, o_hn, o_tok, o_xin, o_st0, o_xe[MAXL],
       o_enc_saved[MAXL], o_hgin, o_sto, o_eplan, o_esort_ws, o_ne_x, o_ne_w, o_hg, o_ws, o_ws2, o_wt[MAXL], o_g2t_wt;
   size_t o_scales, q_dimg;
-  size_t o_coop;   // zeroed barrier slots of the one-launch BatchNorms (gt_bn_coop_slots): n_coop for the forward, n_coop for the backward
-  int n_coop;
   size_t o_graph_ptr, o_node_graph, o_in_ptr, o_out_ptr, o_idx, o_dd, o_status, o_prep_ws, o_lay, o_lay_meta;
   size_t ws_bytes, ws2_bytes, eplan_bytes, esort_ws_bytes, prep_ws_bytes, arena_bytes;
   int cat2, want_wt, esort, late_wait;
@@ -195,7 +193,6 @@ struct BindGuard {   // the bind tables are per host thread: always undone on th
     gt_w1_unbind();
     if (dw) gt_overlap_dw_end();
     if (defer_abort) (void)gt_defer_begin(nullptr, 0);
-    (void)gt_bn_coop_slots(nullptr, 0);
   }
 };
 
@@ -290,6 +287,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
       g.vn_next = nullptr; g.ev_vn_next = nullptr; g.lin_wt = nullptr;
       g.prev_saved = nullptr; g.prev_bn_w = g.prev_bn_b = nullptr; g.prev_bn_part = nullptr; g.bn_part_in = nullptr;
       g.prev_relu = 0; g.bn_nparts_in = 0; g.ev_graph_ready = nullptr;
+      g.dx_bcast = nullptr; g.dx_bcast_idx = nullptr;
     } else if (m->conv == GT_CONV_PNA) {
       gt_pna_layer& g = c->pna[l];
       g = pna_static(m)[l];
@@ -409,8 +407,6 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
     c->prep_ws_bytes = gt_graph_prep_workspace_bytes(N, E, B);
     c->o_prep_ws = a.take(c->prep_ws_bytes);
   }
-  c->n_coop = training ? 2 * L + 2 : 0;   // (GIN: two BatchNorms per layer)
-  c->o_coop = a.take((size_t)2 * c->n_coop * 64);
   if (c->lay_host) c->o_lay = a.take(c->lay_bytes);
   if (c->build_layout_dev) {
     const size_t nd = (size_t)B * 16, nl = (size_t)B * 8, nw = (size_t)std::max<int64_t>(c->num_work, 1) * 8;
@@ -453,10 +449,9 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
   // BatchNorm-backward statistics summed in the dX epilogue of the layer above (GCN, exact-fp32 GEMMs, no GNN dropout, no virtual node)
   c->fuse_bn = 0;
   c->bn_rows = 0;
-  static const bool fuse_bn_on = [] { const char* e = getenv("GT_FUSE_BN"); return !e || atoi(e) != 0; }();   // (A/B knob)
   // (not beyond 64 k rows: the statistics ride in the EXACT-fp32 dX kernel -- at the Erdos-Renyi stress' 131 k x 256 x 256 that GEMM is
   // 219 us against 116 us for the bf16x6 kernel + a 50-us partial pass: 17.6 k -> 17.9 k graphs/s without)
-  if (fuse_bn_on && L > 1 && !b->sync_bn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f &&
+  if (L > 1 && !b->sync_bn && m->conv == GT_CONV_GCN && training && c->gcn[0].dropout_p == 0.f &&
       gt_linear_bwd_bnstats_ok(c->compute, GT_F32, GT_F32, N)) {
     // which kernel will run the layers' dX GEMMs: the register-row bf16x6 kernel (bound images, N >= 12288: one partial row per 128
     // rows, any N, with or without a virtual node -- its epilogue holds the complete d x_l, virtual-node rows included) or the
@@ -469,7 +464,7 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
       rows = gt_linear_bwd_bnstats_rows_for(c->compute, GT_F32, GT_F32, c->gcn[1].lin_w, N, D, D);
       on_rows_kernel = rows != gt_linear_bwd_bnstats_rows(N);
     }
-    // (the register-row kernel answers only with GT_FUSE_BN=2 -- measured r5, Code2 b256: statistics in its epilogue 74.0 k graphs/s,
+    // (the register-row kernel answers only with gt_option_set("bnstats_rows_kernel", 1) -- measured r5, Code2 b256: statistics in its epilogue 74.0 k graphs/s,
     // the separate partial pass 74.85 k; ER 19.07 k against 19.14 k: the epilogue's second row read + 320 lane shuffles per wave
     // cost more than the 23-us pass they replace)
     if (rows > 0 && (on_rows_kernel || (!m->has_vn && N <= 65536))) {
@@ -496,10 +491,9 @@ extern "C" int gt_model_prepare(const gt_model* m, const gt_model_batch* b, void
       need += gt_linear_bwd_workspace_bytes(ec, e.rows, 3 * e.d_model, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.d_model) +
               gt_linear_bwd_workspace_bytes(ec, e.rows, e.ffn, e.d_model) + gt_linear_bwd_workspace_bytes(ec, e.rows, e.d_model, e.ffn);
     }
-    static const int64_t defer_max = [] { const char* e = getenv("GT_DEFER_MAX_ELEMS"); return e ? (int64_t)atoll(e) : (int64_t)6000000; }();
+    constexpr int64_t defer_max = 6000000;
     // (see gt_model_backward: the big batches keep the GEMMs' immediate reduces and defer the LayerNorms' column sums only)
-    static const bool small_too = [] { const char* e = getenv("GT_DEFER_LN_ONLY"); return !e || atoi(e) != 0; }();   // (A/B knob)
-    c->defer_small = N * D > defer_max && small_too && nenc > 0 ? ln_ws : 0;
+    c->defer_small = N * D > defer_max && nenc > 0 ? ln_ws : 0;
     c->defer_bytes = N * D <= defer_max ? need + 64 * 256 : (c->defer_small ? (size_t)(2 * nenc + 2) * (ln_ws + 256) + 64 * 256 : 0);
     c->q_defer = q.take(c->defer_bytes);
   }
@@ -528,10 +522,6 @@ extern "C" int gt_model_forward(const gt_model* m, void* ctx_, void* arena, floa
   auto P = [&](size_t off) -> void* { return base + off; };
   BindGuard guard;
   GT_TRY(bind_images(m, c));
-  if (c->n_coop) {   // one clear per step for the grid barriers of every BatchNorm launch, forward and backward
-    if (hipMemsetAsync(P(c->o_coop), 0, (size_t)2 * c->n_coop * 64, (hipStream_t)st) != hipSuccess) { gt_set_error("gt_model_forward: clear failed"); return GT_ERR_LAUNCH; }
-    GT_TRY(gt_bn_coop_slots(P(c->o_coop), c->n_coop));
-  }
 
   // ---- graph structure (gt_graph_prep) beside the first kernels, on the prep stream
   gt_stream_t pst = c->use_prep ? m->st_prep : st;
@@ -926,7 +916,6 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     // ---- message passing, last layer first.  dy = d h_list[l+1]; "extra" = gradient reaching x_l from its consumers other than
     // conv_l: the JK slab (l = 0) and the virtual-node update's pooling (l < L-1)
     void* dy = c->dy;
-    if (c->n_coop) GT_TRY(gt_bn_coop_slots((char*)P(c->o_coop) + (size_t)c->n_coop * 64, c->n_coop));
     if (!c->cat2 && m->jk_cat) {
       GT_TRY(gt_copy2d(Q(c->q_dA), D * 4, (char*)Q(c->q_d_rep) + D * 4, Kc * 4, D * 4, N, st));   // d h_list[-1]
       GT_TRY(gt_copy2d(Q(c->q_dJ), D * 4, Q(c->q_d_rep), Kc * 4, D * 4, N, st));                   // d h_list[0]
@@ -948,8 +937,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       const bool upd = m->has_vn && l < L - 1;
       const float* dt0 = nullptr;   // the update's gradient per GRAPH, added per node in the dX GEMM's epilogue (no N x D broadcast pass)
       if (upd) {   // vn_{l+1} = update(x_l, vn_l): d x_l = pooled gradient (+ the JK slab at l = 0)
-        static const bool bc_on = [] { const char* e = getenv("GT_VN_BCAST_EPILOGUE"); return !e || atoi(e) != 0; }();   // (A/B knob)
-        const bool bc = bc_on && m->conv == GT_CONV_GCN && gt_linear_bwd_bcast_ok(compute, GT_F32, GT_F32, c->gcn[l].lin_w, N, D, D);
+        const bool bc = m->conv == GT_CONV_GCN && gt_linear_bwd_bcast_ok(compute, GT_F32, GT_F32, c->gcn[l].lin_w, N, D, D);
         void* dxl = bc ? nullptr : Q(c->q_dC);
         if (side) {   // beside layer l's BatchNorm / aggregate backward; joined before its dX GEMM (ev_dx_wait)
           GT_TRY(gt_event_record(m->ev_dvn[l], st));
@@ -978,7 +966,8 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       } else if (m->conv == GT_CONV_GIN)
         GT_TRY(gt_gin_layer_bwd(&c->gin[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
       else {
-        if (dt0) GT_TRY(gt_linear_bwd_bcast(dt0, c->node_graph));   // (consumed by the layer's one dX GEMM)
+        c->gcn[l].dx_bcast = dt0;   // (requested inside the layer, right in front of its one dX GEMM)
+        c->gcn[l].dx_bcast_idx = dt0 ? c->node_graph : nullptr;
         GT_TRY(gt_gcn_layer_bwd(&c->gcn[l], c->xptr[l], dy, extra, conv_saved(l), out, d_vn, G + m->off_conv[l], W(), ws_bytes, st));
       }
       if (m->has_vn) {   // d vn_l = per-graph sum of d x_l (+ update l's pooled + residual inputs): off the main chain

@@ -1299,25 +1299,9 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   }
   // d gamma / d beta are parameter gradients, nothing on the critical path reads them -- but their 5-us column finish stays on the
   // caller's stream: forking it onto the overlap stream costs the caller's queue an event record now and a wait when the workspace is
-  // handed on, two queue packets for one, and measured 0.5 % slower end to end on Code2 (GT_LN_FINISH_FORK=1: the forked form)
-  // ... unless the caller holds its forks (gt_overlap_dw_hold: a layer's backward): then the finish joins the layer's ONE fork for free
-  {
-    const int64_t fdim = dim;
-    const int fgrid = grid;
-    const float* fpart = (const float*)workspace;
-    if (gt_overlap_dw_defer(stream_, [=](hipStream_t side) -> int {
-          hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(fdim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, side, fpart, fgrid, fdim, dweight, dbias);
-          return GT_OK;
-        }, workspace, workspace_bytes, GT_PROF_NORM)) {
-      GT_CHECK_LAUNCH();
-      return GT_OK;
-    }
-  }
-  static const bool finish_fork = [] { const char* e = getenv("GT_LN_FINISH_FORK"); return e && atoi(e) != 0; }();   // (A/B knob)
-  hipStream_t fstream = finish_fork ? (hipStream_t)gt_overlap_dw_fork(stream_, GT_PROF_NORM) : stream;
-  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, fstream, (const float*)workspace, grid,
+  // handed on, two queue packets for one, and measured 0.5 % slower end to end on Code2 (profiles/LOG.md, round 5)
+  hipLaunchKernelGGL(k_ln_bwd_finish, dim3((unsigned)gt_cdiv(dim, FIN_COLS)), dim3(FIN_COLS * FINK_LANES), 0, stream, (const float*)workspace, grid,
                      dim, dweight, dbias);
-  if (fstream != stream) gt_overlap_dw_booked(workspace, workspace_bytes);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

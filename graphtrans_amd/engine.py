@@ -572,7 +572,15 @@ class _Plan:
                     for t in range(T):
                         v = self.pna_img[o0 + t * rows_ * cols_:o0 + (t + 1) * rows_ * cols_].view(rows_, cols_)
                         self.pna_tower_views.append(v)
-            self.w3_weights.extend(self.pna_tower_views)
+            # the bind table holds W_MAX_BOUND weights: when the tower views would overflow it they are the ones left out (the towers
+            # then run the exact-fp32 tiled kernels) -- NOT every image of the model (the whole set silently fell back)
+            if len(self.w3_weights) + len(self.pna_tower_views) + 2 <= W_MAX_BOUND:   # (+ gnn2transformer, + a Linear node encoder)
+                self.w3_weights.extend(self.pna_tower_views)
+            else:
+                import warnings
+                warnings.warn("graphtrans_amd: %d PNA tower matrices do not fit the library's %d-entry weight-image table beside the "
+                              "model's other weights: the towers run on the exact-fp32 kernels" % (len(self.pna_tower_views), W_MAX_BOUND))
+                self.pna_tower_views = []
         cm.off_pna_src = self.total
         for p, o_ in tower_params:
             self.params.append((p, self.total + o_))

@@ -36,7 +36,8 @@ class GcnLayerDesc(C.Structure):
                                    "bn_rm", "bn_rv", "bn_nbt", "ev_x_ready", "ev_dx_wait")] + \
                [("seed", C.c_uint64), ("dropout_p", C.c_float), ("x_has_vn", C.c_int32), ("vn_next", _fp), ("ev_vn_next", _fp),
                 ("lin_wt", _fp), ("prev_saved", _fp), ("prev_bn_w", _fp), ("prev_bn_b", _fp), ("prev_bn_part", _fp),
-                ("bn_part_in", _fp), ("prev_relu", C.c_int32), ("bn_nparts_in", C.c_int32), ("ev_graph_ready", _fp)]
+                ("bn_part_in", _fp), ("prev_relu", C.c_int32), ("bn_nparts_in", C.c_int32), ("ev_graph_ready", _fp),
+                ("dx_bcast", _fp), ("dx_bcast_idx", _fp)]
 
 
 class GinLayerDesc(C.Structure):

@@ -18,7 +18,18 @@ from . import _lib
 from .graph import _stream
 
 # GT_F32_GEMM=exact keeps the exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32) everywhere: the parity yardstick
+# (the GEMMs by not binding images, attention through the library's "attn_f32_exact" option -- set_exact() does both at run time)
 ENABLED = os.environ.get("GT_F32_GEMM", "split") != "exact"
+
+
+def set_exact(on):
+    """exact-fp32 MFMA everywhere (True) or fp32-accurate bf16x6 products (False, the default); -> the previous setting.  Models built
+    before the call keep the images they hold: engine.plan() reads ENABLED when a plan is made."""
+    global ENABLED
+    prev = not ENABLED
+    ENABLED = not on
+    _lib.option_set("attn_f32_exact", 1 if on else 0)
+    return prev
 
 # Images are a cache of the weights: torch's in-place ops bump a parameter's `_version`, kernels that write parameters through raw
 # pointers (optim.FusedAdamW) do not -- they call weights_changed() instead; holders compare (versions, EPOCH).

@@ -62,6 +62,15 @@ void gt_event_destroy(void* event);
 int gt_event_record(void* event, gt_stream_t stream);
 int gt_stream_wait_event(gt_stream_t stream, void* event);
 
+/* Named runtime options: alternative implementations kept in the library as tested yardsticks (tests/test_hip_options.py runs each
+ * non-default value against the oracle).  Process-wide, read at every call.  gt_option_set returns the previous value (0 / 1) or a
+ * negative status for an unknown name.
+ *   "attn_f32_exact"       1: fp32 token rows run attention on the exact v_mfma_f32_16x16x4_f32 chains instead of bf16x6 products
+ *   "bnstats_rows_kernel"  1: a gt_linear_bwd_bnstats request is also taken by the register-row bf16x6 dX kernel (one partial row per
+ *                             128 rows; measured slower than the separate partial pass, off by default) */
+int gt_option_set(const char* name, int value);
+int gt_option_get(const char* name);
+
 /* Opt-in launch profiler: HIP events on the launch stream around the selected entry points
  * (mask: 1 aggregate, 2 attention, 4 linear).  gt_profile_enable(mask != 0) clears old records and
  * starts recording, (0) stops; after a device synchronisation gt_profile_get returns the entry
@@ -376,15 +385,6 @@ int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float
  * on `stream` (stream-ordered, no host sync required); returns 0 or an error.  The collective itself is the caller's. */
 typedef int (*gt_bn_sync_fn)(void* user, int kind, float* buf, int64_t n, gt_stream_t stream);
 int gt_bn_sync_set(gt_bn_sync_fn fn, void* user, int world);
-/* Training-mode BatchNorm over more than 1024 fp32 rows runs as ONE launch per direction (statistics, a grid-wide barrier, apply;
- * csrc/norm_coop.h; replaces the three launches behind modules/gnn_module.py:84,204 and modules/conv.py:19).  The barrier's counter
- * must be zero at launch: a per-thread pool of `n` zeroed 64-byte slots (64-byte aligned device memory, cleared by the caller --
- * gt_model_forward clears one pool per step) serves the calls of this host thread in order; without a pool, or when it is used up,
- * a call clears its own counter (one small memset in front of the launch).  slots = NULL drops the pool.  GT_BN_COOP=0 in the
- * environment keeps the three-launch scheme. */
-int gt_bn_coop_slots(void* slots, int n);
-/* the scheme's process-wide switch: 1 on, 0 off (three launches), -1 = the environment's choice; returns the previous setting */
-int gt_bn_coop_set(int on);
 /* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
  * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
  * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */
@@ -622,15 +622,6 @@ int gt_overlap_dw_urgent(int on);
  * overlap section -- else `stream`; a launch sent there is booked under the workspace it reads (gt_overlap_dw_release). */
 gt_stream_t gt_overlap_dw_fork(gt_stream_t stream, unsigned profiler_category /* GT_PROF_* of the caller, 0 = none */);
 void gt_overlap_dw_booked(const void* workspace, size_t bytes);
-/* Held forks.  Every fork costs the main stream an event record (~3 us of its timeline, ~5 with the overlap stream's wait:
- * tools/event_cost_probe.hip) and a layer's backward forks 4-6 times.  Between gt_overlap_dw_hold() and the matching
- * gt_overlap_dw_unhold() (they nest; same host thread, inside an overlap section) the weight-gradient parts of gt_linear_bwd*
- * calls on the main stream, LayerNorm backward's column finish and the aggregate backward's partial reduce are QUEUED instead;
- * the outermost unhold orders the overlap stream behind the main stream ONCE and issues them there in order.  The composite
- * layer entry points (gt_gcn_layer_bwd, gt_gin_layer_bwd, gt_encoder_layer_bwd, gt_encoder_layer_pooled_bwd) hold their forks.
- * Everything queued reads buffers the caller keeps alive until gt_overlap_dw_release / _sync says otherwise, as for plain forks. */
-int gt_overlap_dw_hold(void);
-int gt_overlap_dw_unhold(void);
 int gt_overlap_dw_end(void);
 
 int gt_linear_bwd_ld2(int x_dtype, int y_dtype, int compute, const void* x, const float* weight, const void* dy,
@@ -760,6 +751,11 @@ typedef struct gt_gcn_layer {  /* x = h_in [+ vn[batch]]; y = BN(GCNConv(x)) [re
    * another stream (gt_graph_prep beside the input embedding and this layer's GEMM); the forward waits for it between its linear
    * and its aggregate.  NULL = the arrays are ready on `stream`. */
   void* ev_graph_ready;
+  /* backward only, optional: d_h_in[n] += dx_bcast[dx_bcast_idx[n]] in the dX GEMM's epilogue (the virtual-node update's gradient per
+   * GRAPH, modules/gnn_module.py:199,219: no N x D broadcast pass).  The caller asks gt_linear_bwd_bcast_ok first; the request is made
+   * right in front of the layer's one dX GEMM and never outlives the call. */
+  const float* dx_bcast;
+  const int32_t* dx_bcast_idx;
 } gt_gcn_layer;
 size_t gt_gcn_layer_saved_bytes(const gt_gcn_layer* layer);
 size_t gt_gcn_layer_workspace_bytes(const gt_gcn_layer* layer);

@@ -177,8 +177,7 @@ def _bn_keep_mask(rows, D, p, seed):
 
 
 
-# (> 1024 rows: the one-launch scheme of csrc/norm_coop.h -- Code2's shape with ~10 graphs per block, 8000 tiny graphs (the staged
-# broadcast rows do not cover a block's graphs: indices and rows from memory), rows beyond a block's registers)
+# (> 1024 rows: Code2's shape with ~10 graphs per block, 8000 tiny graphs, wide and narrow rows)
 @pytest.mark.parametrize("rows,D,B", [(1500, 300, 40), (6611, 600, 256), (8192, 128, 7), (31598, 300, 256), (20000, 300, 8000), (46000, 64, 900)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
@@ -244,54 +243,3 @@ def test_batchnorm_mid_rows_full_epilogue(rows, D, B, relu):
     assert_close(db.cpu().double(), br.grad, atol=1e-4, rtol=1e-4, what="db")
 
 
-@pytest.mark.parametrize("rows,D", [(31598, 300), (6611, 600), (1025, 36), (45000, 128), (2049, 2048)])
-def test_one_launch_batchnorm_against_the_three_launch_scheme(rows, D):
-    """csrc/norm_coop.h (statistics, grid barrier, apply in ONE launch per direction) against the three-launch scheme on the same
-    call: same function, different summation order -> 1e-5; bitwise identical from run to run; the barrier's give-up flag stays 0."""
-    import ctypes as C
-    from graphtrans_amd import _lib
-    L = _lib.lib()
-    torch.manual_seed(rows + D)
-    p, seed, eps, mom = 0.1, 7, 1e-5, 0.1
-    x = (torch.randn(rows, D) * 1.5 + torch.linspace(-20, 20, D)).to(DEV)
-    w, b = (torch.rand(D) + 0.5).to(DEV), (torch.randn(D) * 0.2).to(DEV)
-    B = max(rows // 120, 2)
-    vn = torch.randn(B, D, device=DEV)
-    idx = torch.sort(torch.randint(0, B, (rows,), dtype=torch.int32)).values.to(DEV)
-    g = torch.randn(rows, D, device=DEV)
-    wsb = L.gt_batchnorm_workspace_bytes(rows, D)
-    ptr = lambda t: C.c_void_p(t.data_ptr())
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def run(on):
-        prev = L.gt_bn_coop_set(on)
-        try:
-            ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)   # (zeroed: shapes beyond one round of register rows keep the three launches)
-            rm, rv = torch.zeros(D, device=DEV), torch.ones(D, device=DEV)
-            y, dx = torch.empty_like(x), torch.empty_like(x)
-            mean, rstd, dw, db = (torch.empty(D, device=DEV) for _ in range(4))
-            _lib.launch("gt_batchnorm_fwd_bcast", 0, ptr(x), ptr(w), ptr(b), ptr(rm), ptr(rv), None, mom, eps, 1, 1, None,
-                        ptr(vn), ptr(idx), None, rows, D, ptr(y), ptr(mean), ptr(rstd), p, seed, ptr(ws), wsb, st)
-            _lib.launch("gt_batchnorm_bwd", 0, ptr(x), ptr(g), ptr(w), ptr(b), ptr(mean), ptr(rstd), 1, 1, rows, D, ptr(dx), ptr(dw), ptr(db),
-                        p, seed, ptr(ws), wsb, st)
-            torch.cuda.synchronize()
-            off = ((ws.data_ptr() + wsb - 64) & ~63) - ws.data_ptr()   # a call without a slot pool keeps its counter at the workspace's tail
-            tail = ws[off:off + 8].view(torch.int32)
-            return [t.clone() for t in (y, mean, rstd, rm, rv, dx, dw, db)], tail.clone()
-        finally:
-            L.gt_bn_coop_set(prev)
-
-    one, tail = run(1)
-    again, _ = run(1)
-    three, _ = run(0)
-    assert int(tail[1]) == 0, "the grid barrier gave up"
-    for a, c in zip(one, again):
-        assert torch.equal(a, c)
-    names = ["y", "mean", "rstd", "running_mean", "running_var", "dx", "dweight", "dbias"]
-    for n, a, c in zip(names, one, three):
-        if n in ("y", "dx"):   # a ReLU gate within rounding of 0 may flip between two summation orders: compare where it did not
-            same = (one[0] != vn[idx.long()]) == (three[0] != vn[idx.long()]) if n == "y" else torch.ones_like(a, dtype=torch.bool)
-            assert float((~same).float().mean()) < 1e-4
-            assert_close(a[same].cpu(), c[same].cpu(), atol=2e-4, rtol=1e-4, what=n)
-        else:
-            assert_close(a.cpu(), c.cpu(), atol=1e-3 if n in ("dweight", "dbias") else 1e-5, rtol=1e-4, what=n)

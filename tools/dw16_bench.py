@@ -1,5 +1,5 @@
 """Micro-benchmark: bf16 weight gradient dW = dY^T X (+ db) at the encoder shapes (csrc/linear_dw16.h against the tiled k_linear_dw;
-GT_DW16=0 in the environment selects the old kernel, GT_DW16_BLOCKS the block target).  python tools/dw16_bench.py [M]"""
+A/B against another build: GT_LIB_PATH).  python tools/dw16_bench.py [M]"""
 import sys
 import torch
 sys.path.insert(0, ".")

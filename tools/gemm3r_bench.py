@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """k_lin3r (rows straight into MFMA fragments, csrc/linear3r.h) against k_lin3 (both operands through the LDS): forward and un-gated dX
-on the shapes of the benchmarked configurations.  usage: python tools/gemm3r_bench.py   (GPU box; re-runs itself with GT_LIN3R=0)"""
+on the shapes of the benchmarked configurations.  usage: python tools/gemm3r_bench.py   (GPU box; A/B against another build: GT_LIB_PATH)"""
 import os
 import subprocess
 import sys
@@ -30,9 +30,7 @@ def timeit(fn, n=100):
 
 
 def main():
-    tag = "k_lin3r" if os.environ.get("GT_LIN3R", "1") != "0" else "k_lin3 "
-    if tag == "k_lin3 ":
-        os.environ["GT_LIN3R_DW"] = "0"
+    tag = "k_lin3r"
     for M, N, K in [(31598, 300, 300), (131072, 256, 256), (16000, 272, 272), (31598, 600, 300), (31598, 300, 600), (12800, 300, 300)]:
         x = torch.randn(M, K, device=DEV)
         W = torch.randn(N, K, device=DEV) / K ** 0.5
@@ -51,5 +49,3 @@ def main():
 
 if __name__ == "__main__":
     main()
-    if os.environ.get("GT_LIN3R") is None:
-        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GT_LIN3R="0", GT_LIN3R_DW="0"))

@@ -1,5 +1,5 @@
 """usage (GPU box): PYTHONPATH=. python tools/heads_bench.py   -- the prediction heads (256 x 25 010 x 128) forward / dX / dW alone,
-exact fp32 and bf16 operands; GT_HEADS_KERNELS=0 in a second process = the kernels they replaced"""
+exact fp32 and bf16 operands (A/B against another build of the library: GT_LIB_PATH)"""
 import ctypes as C, os, subprocess, sys, torch
 def run():
     from graphtrans_amd import _lib
@@ -23,12 +23,9 @@ def run():
             e0.record()
             for _ in range(100): f()
             e1.record(); torch.cuda.synchronize()
-            print(f"heads={os.environ.get('GT_HEADS_KERNELS', '1')} {cname} {name}: {e0.elapsed_time(e1) * 10:.2f} us")
+            print(f"{cname} {name}: {e0.elapsed_time(e1) * 10:.2f} us")
         if comp == 0:
             ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
             print("  max |y - ref|", float((y[:, :N].double() - ref).abs().max()), " max |dx - ref|", float((dx.double() - dy[:, :N].double() @ w.double()).abs().max()))
 if __name__ == "__main__":
-    if len(sys.argv) > 1: run()
-    else:
-        for env in ({}, {"GT_HEADS_KERNELS": "0"}):
-            subprocess.run([sys.executable, __file__, "x"], env={**os.environ, **env})
+    run()

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r05_timeline.sh <tag> [workload=code2] [mode=mixed] [extra bench args]
+# usage (GPU box): bash tools/timeline_round.sh <tag> [workload=code2] [mode=mixed] [extra bench args]
 # rocprofv3 kernel trace of the clean bench loop -> kernel summary, per-step text timeline, and the per-stream busy / gap /
 # critical-path JSON (tools/timeline_json.py); the trace db travels back (gzip) so the tools can be re-run off the box.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; TAG=${1:-r05a}; W=${2:-code2}; M=${3:-mixed}; shift; shift; shift
