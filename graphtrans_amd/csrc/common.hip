@@ -63,7 +63,7 @@ void gt_prof_end(int64_t id, hipStream_t stream) {
 // ---- named runtime options ----------------------------------------------------------------------------------------------------
 namespace {
 std::atomic<int> g_options[GT_OPT_COUNT];   // zero-initialised = every default
-const char* const OPTION_NAMES[GT_OPT_COUNT] = {"attn_f32_exact", "bnstats_rows_kernel"};
+const char* const OPTION_NAMES[GT_OPT_COUNT] = {"attn_f32_exact", "bnstats_rows_kernel", "attn_split_groups"};
 int option_id(const char* name) {
   if (name)
     for (int i = 0; i < GT_OPT_COUNT; ++i)
@@ -75,7 +75,7 @@ int gt_opt(int id) { return g_options[id].load(std::memory_order_relaxed); }
 extern "C" int gt_option_set(const char* name, int value) {
   const int id = option_id(name);
   if (id < 0) { gt_set_error("gt_option_set: unknown option '%s'", name ? name : "(null)"); return GT_ERR_INVALID_ARG; }
-  return g_options[id].exchange(value != 0 ? 1 : 0);
+  return g_options[id].exchange(value < 0 ? 0 : value);
 }
 extern "C" int gt_option_get(const char* name) {
   const int id = option_id(name);

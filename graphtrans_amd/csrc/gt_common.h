@@ -22,9 +22,19 @@ static inline bool gt_dbg_skip(const char* kernel) {
   }
   return false;
 }
+// GT_EMPTY=1: every launch becomes ONE empty 64-thread block on the same stream -- the step's exact stream / event topology with no
+// work in it: the floor of the launch chain (tools/launch_floor.sh)
+static __global__ void gt_dbg_empty_kernel() {}
+static inline bool gt_dbg_empty() {
+  static const bool on = [] { const char* e = getenv("GT_EMPTY"); return e && *e && *e != '0'; }();
+  return on;
+}
 #undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(k, g, b, l, s, ...) \
-  do { if (!gt_dbg_skip(#k)) hipLaunchKernelGGLInternal((k), (g), (b), (l), (s), __VA_ARGS__); } while (0)
+#define hipLaunchKernelGGL(k, g, b, l, s, ...)                                                              \
+  do {                                                                                                      \
+    if (gt_dbg_empty()) hipLaunchKernelGGLInternal(gt_dbg_empty_kernel, dim3(1), dim3(64), 0, (s));        \
+    else if (!gt_dbg_skip(#k)) hipLaunchKernelGGLInternal((k), (g), (b), (l), (s), __VA_ARGS__);           \
+  } while (0)
 #endif
 #include <stdint.h>
 #include <stdio.h>
@@ -64,7 +74,7 @@ enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF
 unsigned gt_prof_mask();
 // named runtime options (gt_option_set / gt_option_get, csrc/common.hip): alternative implementations that stay in the library as
 // TESTED yardsticks (tests/test_hip_options.py runs each non-default value against the oracle).  Process-wide, read at every call.
-enum { GT_OPT_ATTN_F32_EXACT = 0, GT_OPT_BNSTATS_ROWS_KERNEL = 1, GT_OPT_COUNT };
+enum { GT_OPT_ATTN_F32_EXACT = 0, GT_OPT_BNSTATS_ROWS_KERNEL = 1, GT_OPT_ATTN_SPLIT_GROUPS = 2, GT_OPT_COUNT };
 int gt_opt(int id);
 int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims);
 void gt_prof_end(int64_t id, hipStream_t stream);

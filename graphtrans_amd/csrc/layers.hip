@@ -540,7 +540,7 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   if (d_x) GT_TRY(gt_segment_bcast_add(GT_F32, d_x_add, w.d_t0, L->node_graph, L->N, B, D, d_x, st));
   if (L->residual)
     GT_TRY(gt_segment_bcast_add(GT_F32, w.d_t0, d_vn_out, L->identity_graph, B, B, D, d_vn, st));
-  else
+  else if (d_vn != w.d_t0)   // (a caller that passes gt_vn_update_bwd_dt0() as d_vn reads d_t0 where it lies: no copy launch)
     (void)hipMemcpyAsync(d_vn, w.d_t0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
   if (defer) {
     GT_TRY(gt_event_record(L->ev_dx_done, st));

@@ -935,6 +935,7 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
     for (int l = L - 1; l >= 0; --l) {
       const void* extra = (l == 0 && m->jk_cat) ? Q(c->q_dJ) : nullptr;
       const bool upd = m->has_vn && l < L - 1;
+      void* d_vn_upd = Q(c->q_dvn[2]);   // d vn_l through update l (its pooled + residual inputs)
       const float* dt0 = nullptr;   // the update's gradient per GRAPH, added per node in the dX GEMM's epilogue (no N x D broadcast pass)
       if (upd) {   // vn_{l+1} = update(x_l, vn_l): d x_l = pooled gradient (+ the JK slab at l = 0)
         const bool bc = m->conv == GT_CONV_GCN && gt_linear_bwd_bcast_ok(compute, GT_F32, GT_F32, c->gcn[l].lin_w, N, D, D);
@@ -942,7 +943,9 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
         if (side) {   // beside layer l's BatchNorm / aggregate backward; joined before its dX GEMM (ev_dx_wait)
           GT_TRY(gt_event_record(m->ev_dvn[l], st));
           GT_TRY(gt_stream_wait_event(side, m->ev_dvn[l]));
-          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, dxl, Q(c->q_dvn[2]), G + m->off_vn[l], Q(c->q_ws2),
+          // without a residual branch d vn_l IS d_t0: read where the update's last GEMM wrote it (no copy launch)
+          d_vn_upd = m->residual ? Q(c->q_dvn[2]) : (void*)gt_vn_update_bwd_dt0(&c->vn[l], Q(c->q_ws2));
+          GT_TRY(gt_vn_update_bwd(&c->vn[l], d_vn_next, P(c->o_vn_saved[l]), extra, dxl, d_vn_upd, G + m->off_vn[l], Q(c->q_ws2),
                                   c->ws2_bytes, side));
           if (!m->vn_defer_dw) GT_TRY(gt_event_record(m->ev_extra[l], side));
           if (bc) dt0 = gt_vn_update_bwd_dt0(&c->vn[l], Q(c->q_ws2));
@@ -972,14 +975,16 @@ extern "C" int gt_model_backward(const gt_model* m, void* ctx_, const float* dlo
       }
       if (m->has_vn) {   // d vn_l = per-graph sum of d x_l (+ update l's pooled + residual inputs): off the main chain
         gt_stream_t vst = pool_on_side ? side : st;
-        if (pool_on_side) {
+        void* tgt = Q(c->q_dvn[l % 2]);
+        if (pool_on_side) {   // the pooled gradient + update l's share in ONE pass (the sum's `add` rows): no bcast_add / copy launch
           GT_TRY(gt_event_record(m->ev_pool[l], st));
           GT_TRY(gt_stream_wait_event(side, m->ev_pool[l]));
-          GT_TRY(gt_segment_sum_ws(GT_F32, out, nullptr, c->graph_ptr, N, B, D, Q(c->q_dvn[3]), Q(c->q_ws3), c->seg_ws_bytes, side));
+          GT_TRY(gt_segment_sum_ws(GT_F32, out, upd ? d_vn_upd : nullptr, c->graph_ptr, N, B, D, tgt, Q(c->q_ws3), c->seg_ws_bytes, side));
+        } else if (upd) {
+          GT_TRY(gt_segment_bcast_add(GT_F32, Q(c->q_dvn[3]), d_vn_upd, b.ident_B, B, B, D, tgt, vst));
+        } else {
+          GT_TRY(gt_copy2d(tgt, D * 4, Q(c->q_dvn[3]), D * 4, D * 4, B, vst));
         }
-        void* tgt = Q(c->q_dvn[l % 2]);
-        if (upd) GT_TRY(gt_segment_bcast_add(GT_F32, Q(c->q_dvn[3]), Q(c->q_dvn[2]), b.ident_B, B, B, D, tgt, vst));
-        else GT_TRY(gt_copy2d(tgt, D * 4, Q(c->q_dvn[3]), D * 4, D * 4, B, vst));
         d_vn_next = tgt;
       }
       dy = out;

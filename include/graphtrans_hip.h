@@ -64,10 +64,12 @@ int gt_stream_wait_event(gt_stream_t stream, void* event);
 
 /* Named runtime options: alternative implementations kept in the library as tested yardsticks (tests/test_hip_options.py runs each
  * non-default value against the oracle).  Process-wide, read at every call.  gt_option_set returns the previous value (0 / 1) or a
- * negative status for an unknown name.
+ * negative status for an unknown name; values are small non-negative integers (0 / 1 unless stated).
  *   "attn_f32_exact"       1: fp32 token rows run attention on the exact v_mfma_f32_16x16x4_f32 chains instead of bf16x6 products
  *   "bnstats_rows_kernel"  1: a gt_linear_bwd_bnstats request is also taken by the register-row bf16x6 dX kernel (one partial row per
- *                             128 rows; measured slower than the separate partial pass, off by default) */
+ *                             128 rows; measured slower than the separate partial pass, off by default)
+ *   "attn_split_groups"    0: the library's rule, 1 / 2: that many split groups per attention block (csrc/attention.hip: KS -- a block's
+ *                             walk over a sequence's key / query tiles divided over groups of four waves that meet at the end) */
 int gt_option_set(const char* name, int value);
 int gt_option_get(const char* name);
 
