@@ -64,6 +64,9 @@ SIGNATURES = {
     "gt_segment_sum_ws": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),
     "gt_seq_scatter": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
+    "gt_linear_bn_slab_ok": (_i, [_i, _i64, _i64, _i64, _i]),
+    "gt_linear_bn_slab_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _i64, _i64, _i64, _p, _p, _p, _f, _u64, _p]),
+    "gt_linear_bn_slab_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _p, _p, _p]),
     "gt_batchnorm_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_batchnorm_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_batchnorm_apply": (_i, [_i, _p, _p, _p, _p, _p, _i, _p, _i64, _i64, _p, _f, _u64, _p]),
@@ -227,7 +230,12 @@ def lib():
                 "(graphtrans_amd has no CPU or eager fallback)")
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            try:
+                fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            except AttributeError:
+                if not os.environ.get("GT_LIB_PATH"):
+                    raise
+                continue   # an A/B build of another revision (GT_LIB_PATH, tools/ab.sh) may predate an entry point
             fn.restype = res
             fn.argtypes = args
         if os.environ.get("GT_F32_GEMM", "split") == "exact":   # the parity yardstick everywhere: w3.ENABLED keeps the GEMMs' images

@@ -28,15 +28,9 @@
 namespace {
 using namespace gtf;
 
-constexpr int ATT_THREADS = 256;   // one split group: 4 waves x 16 queries (keys); a block is KS groups
-constexpr int TILE = 32;    // keys (fwd, dQ) or queries (dK/dV) per inner step of ONE wave
+constexpr int ATT_THREADS = 256;
+constexpr int TILE = 32;    // keys (fwd, dQ) or queries (dK/dV) per inner step
 constexpr int BLOCK_N = 64; // queries (fwd, dQ) or keys (dK/dV) per block: 4 waves x 16
-// KS (r6): the walk over the key (query) tiles of a sequence is a chain of dependent steps -- LDS fragments -> MFMA -> softmax -> MFMA ->
-// barrier, ~0.7 us each -- and a block walks ALL tiles of its sequence: the longest sequence of the batch was the kernel time (one
-// sequence of 1001 tokens alone: 24 us forward, the whole Code2 batch: 26 us; tools/attn_bench.py).  A block is now KS groups of 4 waves;
-// group s takes every KS-th tile (s, s + KS, ...) with its own running (max, sum, accumulators), a step stages KS tiles behind ONE
-// barrier, and the groups meet at the end through the LDS the tiles lived in (flash-decoding's split-K inside the block, fixed order:
-// results do not depend on scheduling).  Half (a quarter) as many dependent steps per block for the same work.
 constexpr float LOG2E = 1.4426950408889634f;
 
 // v_exp_f32 directly: the arguments here are <= 0 (scores minus the running max), where the library
@@ -127,9 +121,10 @@ struct Lds {
 
 // zero the LDS columns [HD, LD) that load_tile never writes (only needed when HD < 32)
 template <typename T, int HD>
-__device__ __forceinline__ void zero_pad_cols(T* lds, int elems) {
+__device__ __forceinline__ void zero_pad_cols(T* lds) {
+  constexpr int LD = Lds<HD, T>::LD;
   if constexpr (HD < 32) {
-    for (int i = threadIdx.x; i < elems; i += blockDim.x) lds[i] = (T)0;
+    for (int i = threadIdx.x; i < TILE * LD; i += ATT_THREADS) lds[i] = (T)0;
   }
 }
 
@@ -139,12 +134,27 @@ __device__ __forceinline__ Frag<T> frag_load_head(const T* head_row, int c0, boo
   return (valid && c0 < HD) ? frag_load(head_row + c0) : frag_zero<T>();
 }
 
+// cooperative load of a [TILE][HD] tile of rows (pos0 + r) into LDS, zero-filled outside [lo, hi)
+template <typename T, int HD>
+__device__ __forceinline__ void load_tile(T* lds, const T* src, int64_t src_ld, int64_t row0, int64_t row_stride,
+                                          int pos0, int lo, int hi) {
+  constexpr int LD = Lds<HD, T>::LD;
+  constexpr int CH = HD / 8;
+  for (int c = threadIdx.x; c < TILE * CH; c += ATT_THREADS) {
+    int r = c / CH, col = (c % CH) * 8;
+    int pos = pos0 + r;
+    Frag<T> f = frag_zero<T>();
+    if (pos >= lo && pos < hi) f = frag_load(src + (row0 + (int64_t)pos * row_stride) * src_ld + col);
+    frag_store_lds(lds + r * LD + col, f);
+  }
+}
+
 // Register-staged pair of [TILE][HD] tiles (K and V, or Q and dO): load() issues this thread's two 16-byte chunks of
 // the NEXT key / query tile before the current tile's MFMAs, store() parks them in the other LDS buffer behind them --
 // one barrier per 32-position step and the global latency off the step (the step of a 1000-token sequence is walked 32
 // times in a row by one block: with a synchronous load between two barriers per step that block WAS the kernel time).
-template <typename T, int HD, int KS = 1>
-struct TilePair {   // KS consecutive tiles per step: rows [pos0, pos0 + KS * TILE), tile t of a buffer at t * TO::ELEMS
+template <typename T, int HD>
+struct TilePair {
   static constexpr int LD = Lds<HD, T>::LD;
   static constexpr int CH = HD / 8;
   Frag<T> fa, fb;
@@ -155,7 +165,7 @@ struct TilePair {   // KS consecutive tiles per step: rows [pos0, pos0 + KS * TI
   int64_t sa, sb;   // elements per position (wave-uniform)
   __device__ __forceinline__ void init(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride) {
     const int c = threadIdx.x;
-    has = c < KS * TILE * CH;
+    has = c < TILE * CH;
     r = c / CH;
     col = (c % CH) * 8;
     pa = srcA + (row0 + (int64_t)r * row_stride) * ldA + col;
@@ -175,8 +185,8 @@ struct TilePair {   // KS consecutive tiles per step: rows [pos0, pos0 + KS * TI
   template <typename TO>
   __device__ __forceinline__ void store(typename TO::LT* sA, typename TO::LT* sB) const {
     if (has) {
-      TO::store(sA + (r / TILE) * TO::ELEMS, r % TILE, col, fa);
-      TO::store(sB + (r / TILE) * TO::ELEMS, r % TILE, col, fb);
+      TO::store(sA, r, col, fa);
+      TO::store(sB, r, col, fb);
     }
   }
 };
@@ -237,17 +247,15 @@ struct TileOps<float, HD, true> {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <typename T, int HD, bool DENSE, bool SP = false, int KS = 1>
-__global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
+template <typename T, int HD, bool DENSE, bool SP = false>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;  // 32-deep steps over head_dim
   constexpr int DT = (HD + 15) / 16;        // 16-wide output dim tiles
-  constexpr int MS = 4 + 4 * DT;            // floats a lane of a split group hands over at the end: max, sum, (pad), accumulators
-  // ONE array: [K | V][stage][split group][tile]; the groups' hand-over at the end reuses it
-  __shared__ __attribute__((aligned(16))) LT sT[2 * 2 * KS * TO::ELEMS];
-  static_assert(KS == 1 || sizeof(LT) * 2 * 2 * KS * TO::ELEMS >= sizeof(float) * (KS - 1) * 4 * 64 * MS, "hand-over area");
+  __shared__ __attribute__((aligned(16))) LT sKb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sVb[2][TO::ELEMS];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -255,7 +263,7 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
   if (a.last_only) tile_ = npos > 0 ? (npos - 1) / BLOCK_N : 0;
   const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
-  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & 3, ks = threadIdx.x / ATT_THREADS;   // query group, key-split group
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int qp = q_base + wid * 16 + n;
   const bool qvalid = qp < npos;
@@ -267,7 +275,10 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
     bq[kk] = TO::reg(frag_load_head<T, HD>(qkv + qrow * ld3 + head * HD, kk * 32 + g * 8, qvalid));
-  if constexpr (!SP) zero_pad_cols<T, HD>(sT, 2 * 2 * KS * TO::ELEMS);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[1]);
 
   float m = -INFINITY, lsum = 0.f;
   f32x4 acc[DT];
@@ -278,23 +289,21 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
   const uint32_t thr16 = a.drop_thr << 16;
-  TilePair<T, HD, KS> stg;
+  TilePair<T, HD> stg;
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
   stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();   // the zero fill above and the first store touch the same rows
   stg.load(k_first, kv_off, kv_end);
-  stg.template store<TO>((sT + (0) * (KS * TO::ELEMS)), (sT + (2 + (0)) * (KS * TO::ELEMS)));
+  stg.template store<TO>(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
-  for (int kb = k_first; kb < kv_end; kb += KS * TILE, cur ^= 1) {
-    const bool more = kb + KS * TILE < kv_end;
-    if (more) stg.load(kb + KS * TILE, kv_off, kv_end);
-    const int k0 = kb + ks * TILE;   // this group's tile of the step (wave-uniform)
-    if (k0 < kv_end) {   // (it holds >= 1 valid key: k0 >= k_first and k0 < kv_end)
-    const LT* sK = (sT + (cur) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
-    const LT* sV = (sT + (2 + (cur)) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
+  for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
+    const bool more = k0 + TILE < kv_end;
+    if (more) stg.load(k0 + TILE, kv_off, kv_end);
+    const LT* sK = sKb[cur];
+    const LT* sV = sVb[cur];
     // S^T: two 16-key tiles; row m of tile t <-> key (m>>2)*8 + t*4 + (m&3)
     float s[8];
 #pragma unroll
@@ -360,39 +369,11 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
       o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
       acc[dt] = TO::mm(TO::tr(sV, dt * 16, n, g), bp, o);
     }
-    }
-    if (more) stg.template store<TO>((sT + (cur ^ 1) * (KS * TO::ELEMS)), (sT + (2 + (cur ^ 1)) * (KS * TO::ELEMS)));
+    if (more) stg.template store<TO>(sKb[cur ^ 1], sVb[cur ^ 1]);
     __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
-  if constexpr (KS > 1) {   // the split groups meet: (max, sum, accumulators) of groups 1.. through the LDS the tiles lived in (the loop's
-                            // last barrier is behind every wave), merged by group 0 in group order
-    float* hand = reinterpret_cast<float*>(sT);
-    if (ks > 0) {
-      float* h = hand + (((ks - 1) * 4 + wid) * 64 + lane) * MS;
-      h[0] = m; h[1] = lsum;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(h + 4 + 4 * dt) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
-    }
-    __syncthreads();
-    if (ks > 0) return;
-#pragma unroll
-    for (int o = 1; o < KS; ++o) {
-      const float* h = hand + (((o - 1) * 4 + wid) * 64 + lane) * MS;
-      const float m2 = h[0], l2 = h[1];
-      const float m_new = fmaxf(m, m2);                 // m is finite (group 0 always holds the first tile), m2 may be -inf (no tile)
-      const float a1 = fast_exp2(m - m_new), a2 = fast_exp2(m2 - m_new);
-      lsum = lsum * a1 + l2 * a2;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const float4 v = *reinterpret_cast<const float4*>(h + 4 + 4 * dt);
-        acc[dt][0] = acc[dt][0] * a1 + v.x * a2; acc[dt][1] = acc[dt][1] * a1 + v.y * a2;
-        acc[dt][2] = acc[dt][2] * a1 + v.z * a2; acc[dt][3] = acc[dt][3] * a1 + v.w * a2;
-      }
-      m = m_new;
-    }
-  }
   if (!qvalid) return;
   const float inv_l = (a.drop_thr ? a.inv_keep : 1.0f) / lsum;
   T* ctx = reinterpret_cast<T*>(a.out);
@@ -411,16 +392,15 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_fwd(AttnArgs a) {
 // =================================================================================================
 // backward, pass 1: delta = rowsum(dO * O) and dQ      (block = 64 queries, loop over key tiles)
 // =================================================================================================
-template <typename T, int HD, bool DENSE, bool SP = false, int KS = 1>
-__global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
+template <typename T, int HD, bool DENSE, bool SP = false>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  constexpr int MS = 4 * DT;   // floats a lane of a split group hands over at the end: its dQ accumulators
-  __shared__ __attribute__((aligned(16))) LT sT[2 * 2 * KS * TO::ELEMS];   // [K | V][stage][split group][tile]
-  static_assert(KS == 1 || sizeof(LT) * 2 * 2 * KS * TO::ELEMS >= sizeof(float) * (KS - 1) * 4 * 64 * MS, "hand-over area");
+  __shared__ __attribute__((aligned(16))) LT sKb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sVb[2][TO::ELEMS];
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -428,7 +408,7 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
   if (a.last_only) tile_ = npos > 0 ? (npos - 1) / BLOCK_N : 0;
   const int q_base = tile_ * BLOCK_N;
   if (q_base >= npos) return;
-  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & 3, ks = threadIdx.x / ATT_THREADS;   // query group, key-split group
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int qp = q_base + wid * 16 + n;
   const bool qvalid = qp < npos;
@@ -462,8 +442,11 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
   const float logl = qvalid ? a.lse[((int64_t)a.nhead + head) * a.rows + qrow] : 0.f;
   const float negl = -(lse + logl);
   const uint32_t thr16 = a.drop_thr << 16;
-  if (qvalid && g == 0 && ks == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
-  if constexpr (!SP) zero_pad_cols<T, HD>(sT, 2 * 2 * KS * TO::ELEMS);
+  if (qvalid && g == 0) a.delta[(int64_t)head * a.rows + qrow] = delta;
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sKb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sVb[1]);
 
   f32x4 acc[DT];
 #pragma unroll
@@ -471,23 +454,21 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
   const int kv_end = kv_off + kv_len;
   const uint32_t bh = (uint32_t)(seq * a.nhead + head);
   const uint32_t hq = rng_qpart(a.seed1, bh, (uint32_t)qp);
-  TilePair<T, HD, KS> stg;
+  TilePair<T, HD> stg;
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
   stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();
   stg.load(k_first, kv_off, kv_end);
-  stg.template store<TO>((sT + (0) * (KS * TO::ELEMS)), (sT + (2 + (0)) * (KS * TO::ELEMS)));
+  stg.template store<TO>(sKb[0], sVb[0]);
   __syncthreads();
   int cur = 0;
-  for (int kb = k_first; kb < kv_end; kb += KS * TILE, cur ^= 1) {
-    const bool more = kb + KS * TILE < kv_end;
-    if (more) stg.load(kb + KS * TILE, kv_off, kv_end);
-    const int k0 = kb + ks * TILE;   // this group's tile of the step (wave-uniform)
-    if (k0 < kv_end) {
-    const LT* sK = (sT + (cur) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
-    const LT* sV = (sT + (2 + (cur)) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
+  for (int k0 = k_first; k0 < kv_end; k0 += TILE, cur ^= 1) {
+    const bool more = k0 + TILE < kv_end;
+    if (more) stg.load(k0 + TILE, kv_off, kv_end);
+    const LT* sK = sKb[cur];
+    const LT* sV = sVb[cur];
     float ds[8];
     const uint32_t kpart0 = rng_kpart(a.seed0, (uint32_t)(k0 + g * 8));
     bool full_tile = false;
@@ -528,28 +509,8 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
     const Op bds = TO::from(ds);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = TO::mm(TO::tr(sK, dt * 16, n, g), bds, acc[dt]);
-    }
-    if (more) stg.template store<TO>((sT + (cur ^ 1) * (KS * TO::ELEMS)), (sT + (2 + (cur ^ 1)) * (KS * TO::ELEMS)));
+    if (more) stg.template store<TO>(sKb[cur ^ 1], sVb[cur ^ 1]);
     __syncthreads();
-  }
-  if constexpr (KS > 1) {   // dQ = the sum over the key-split groups, added by group 0 in group order
-    float* hand = reinterpret_cast<float*>(sT);
-    if (ks > 0) {
-      float* h = hand + (((ks - 1) * 4 + wid) * 64 + lane) * MS;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(h + 4 * dt) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
-    }
-    __syncthreads();
-    if (ks > 0) return;
-#pragma unroll
-    for (int o = 1; o < KS; ++o) {
-      const float* h = hand + (((o - 1) * 4 + wid) * 64 + lane) * MS;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const float4 v = *reinterpret_cast<const float4*>(h + 4 * dt);
-        acc[dt][0] += v.x; acc[dt][1] += v.y; acc[dt][2] += v.z; acc[dt][3] += v.w;
-      }
-    }
   }
   if (!qvalid) return;
   T* dqkv = reinterpret_cast<T*>(a.out);
@@ -564,24 +525,23 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dq(AttnArgs a) {
 // =================================================================================================
 // backward, pass 2: dK, dV                              (block = 64 keys, loop over query tiles)
 // =================================================================================================
-template <typename T, int HD, bool DENSE, bool SP = false, int KS = 1>
-__global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dkv(AttnArgs a) {
+template <typename T, int HD, bool DENSE, bool SP = false>
+__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
   constexpr int KK = Lds<HD, T>::HDP / 32;
   constexpr int DT = (HD + 15) / 16;
-  constexpr int MS = 8 * DT;   // floats a lane of a split group hands over at the end: its dK and dV accumulators
-  __shared__ __attribute__((aligned(16))) LT sT[2 * 2 * KS * TO::ELEMS];   // [Q | dO][stage][split group][tile]
-  static_assert(KS == 1 || sizeof(LT) * 2 * 2 * KS * TO::ELEMS >= sizeof(float) * (KS - 1) * 4 * 64 * MS, "hand-over area");
-  __shared__ float sAux[2][KS][3 * TILE];   // per query of a tile: running max, log2(sum), delta
+  __shared__ __attribute__((aligned(16))) LT sQb[2][TO::ELEMS];
+  __shared__ __attribute__((aligned(16))) LT sDOb[2][TO::ELEMS];
+  __shared__ float sAux[2][3 * TILE];   // per query of the tile: running max, log2(sum), delta
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
             kv_len = a.desc[seq * 4 + 3];
   const int k_base = tile_ * BLOCK_N;
   if (k_base >= npos) return;
-  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & 3, ks = threadIdx.x / ATT_THREADS;   // key group, query-split group
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int kp = k_base + wid * 16 + n;
   const int kv_end = kv_off + kv_len;
@@ -598,7 +558,10 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dkv(AttnArgs a) {
     bk[kk] = TO::reg(frag_load_head<T, HD>(qkv + krow * ld3 + a.d_model + head * HD, kk * 32 + g * 8, kvalid));
     bv[kk] = TO::reg(frag_load_head<T, HD>(qkv + krow * ld3 + 2 * a.d_model + head * HD, kk * 32 + g * 8, kvalid));
   }
-  if constexpr (!SP) zero_pad_cols<T, HD>(sT, 2 * 2 * KS * TO::ELEMS);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sQb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sDOb[0]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sQb[1]);
+  if constexpr (!SP) zero_pad_cols<T, HD>(sDOb[1]);
   f32x4 dk[DT], dv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -612,22 +575,20 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dkv(AttnArgs a) {
   const uint32_t half_shift = (kp & 1) ? 0u : 16u;  // masked_fill masks are a separate instantiation: the common kernel carries none of it
   // a block whose 64 keys are all padding only writes zeros
   const bool any_valid = (k_base < kv_end) && (k_base + BLOCK_N > kv_off);
-  TilePair<T, HD, KS> stg;
+  TilePair<T, HD> stg;
   const T* srcQ = qkv + head * HD;
   const T* srcDO = dctx + head * HD;
   stg.init(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride);
-  // threads 0 .. KS * 96 - 1 also carry one statistic of one query of the step's tiles (0: running max, 1: log2(sum), 2: delta)
-  const int aux_t = threadIdx.x / (3 * TILE), aux_i = threadIdx.x % (3 * TILE);   // tile of the step, slot inside its aux row
-  const int aux_r = aux_i & (TILE - 1), aux_which = aux_i / TILE;
-  const bool aux_on = threadIdx.x < KS * 3 * TILE;
+  // threads 0..95 also carry one statistic of one query of the tile (0: running max, 1: log2(sum), 2: delta)
+  const int aux_r = threadIdx.x & (TILE - 1), aux_which = threadIdx.x / TILE;
   const float* aux_src = aux_which == 0 ? a.lse : (aux_which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
   float aux_v = 0.f;
   auto load_aux = [&](int q0) {
-    const int pos = q0 + aux_t * TILE + aux_r;
+    const int pos = q0 + aux_r;
     const int64_t o = (int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride;
-    aux_v = (aux_on && pos < npos) ? aux_src[o] : 0.f;
+    aux_v = (threadIdx.x < 3 * TILE && pos < npos) ? aux_src[o] : 0.f;
     if constexpr (!DENSE) {   // slot 0 carries -(max + log2 sum), the addend of the exponent's fma (slot 1 is not read)
-      if (aux_on && aux_which == 0 && pos < npos) aux_v = -(aux_v + a.lse[(int64_t)a.nhead * a.rows + o]);
+      if (aux_which == 0 && pos < npos) aux_v = -(aux_v + a.lse[(int64_t)a.nhead * a.rows + o]);
     }
   };
   const int q_begin = (a.q_last_only && npos > 0) ? ((npos - 1) / TILE) * TILE : 0;   // pooled mode: only the last position's gradient is non-zero
@@ -635,24 +596,22 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dkv(AttnArgs a) {
   if (any_valid) {
     stg.load(q_begin, 0, npos);
     load_aux(q_begin);
-    stg.template store<TO>((sT + (0) * (KS * TO::ELEMS)), (sT + (2 + (0)) * (KS * TO::ELEMS)));
-    if (aux_on) sAux[0][aux_t][aux_i] = aux_v;
+    stg.template store<TO>(sQb[0], sDOb[0]);
+    if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
   }
   __syncthreads();
   int cur = 0;
-  for (int qb = q_begin; any_valid && qb < npos; qb += KS * TILE, cur ^= 1) {
-    const bool more = qb + KS * TILE < npos;
+  for (int q0 = q_begin; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
+    const bool more = q0 + TILE < npos;
     if (more) {
-      stg.load(qb + KS * TILE, 0, npos);
-      load_aux(qb + KS * TILE);
+      stg.load(q0 + TILE, 0, npos);
+      load_aux(q0 + TILE);
     }
-    const int q0 = qb + ks * TILE;   // this group's query tile of the step (wave-uniform)
-    if (q0 < npos) {
-    const LT* sQ = (sT + (cur) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
-    const LT* sDO = (sT + (2 + (cur)) * (KS * TO::ELEMS)) + ks * TO::ELEMS;
-    const float* sLse = sAux[cur][ks];
-    const float* sLogl = sAux[cur][ks] + TILE;
-    const float* sDelta = sAux[cur][ks] + 2 * TILE;
+    const LT* sQ = sQb[cur];
+    const LT* sDO = sDOb[cur];
+    const float* sLse = sAux[cur];
+    const float* sLogl = sAux[cur] + TILE;
+    const float* sDelta = sAux[cur] + 2 * TILE;
     float pd[8], ds[8];
     // (Sharing the pair's hash between lanes n and n ^ 1 -- each computes four of the eight and takes the rest by DPP -- was built
     // and measured: 45 us against 43 us for this form on the Code2 batch; the kernel is not bound by its VALU instruction count.)
@@ -701,35 +660,11 @@ __global__ void __launch_bounds__(ATT_THREADS * KS) k_attn_bwd_dkv(AttnArgs a) {
       dv[dt] = TO::mm(TO::tr(sDO, dt * 16, n, g), bp, dv[dt]);
       dk[dt] = TO::mm(TO::tr(sQ, dt * 16, n, g), bds, dk[dt]);
     }
-    }
     if (more) {
-      stg.template store<TO>((sT + (cur ^ 1) * (KS * TO::ELEMS)), (sT + (2 + (cur ^ 1)) * (KS * TO::ELEMS)));
-      if (aux_on) sAux[cur ^ 1][aux_t][aux_i] = aux_v;
+      stg.template store<TO>(sQb[cur ^ 1], sDOb[cur ^ 1]);
+      if (threadIdx.x < 3 * TILE) sAux[cur ^ 1][threadIdx.x] = aux_v;
     }
     __syncthreads();
-  }
-  if constexpr (KS > 1) {   // dK, dV = the sums over the query-split groups, added by group 0 in group order
-    float* hand = reinterpret_cast<float*>(sT);
-    if (ks > 0) {
-      float* h = hand + (((ks - 1) * 4 + wid) * 64 + lane) * MS;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        *reinterpret_cast<float4*>(h + 8 * dt) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
-        *reinterpret_cast<float4*>(h + 8 * dt + 4) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-      }
-    }
-    __syncthreads();
-    if (ks > 0) return;
-#pragma unroll
-    for (int o = 1; o < KS; ++o) {
-      const float* h = hand + (((o - 1) * 4 + wid) * 64 + lane) * MS;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const float4 u = *reinterpret_cast<const float4*>(h + 8 * dt), v = *reinterpret_cast<const float4*>(h + 8 * dt + 4);
-        dk[dt][0] += u.x; dk[dt][1] += u.y; dk[dt][2] += u.z; dk[dt][3] += u.w;
-        dv[dt][0] += v.x; dv[dt][1] += v.y; dv[dt][2] += v.z; dv[dt][3] += v.w;
-      }
-    }
   }
   if (!kin) return;
   T* dqkv = reinterpret_cast<T*>(a.out);
@@ -778,16 +713,6 @@ AttnArgs make_args(const void* qkv, const void* ctx, const void* d_ctx, float* l
 // yardstick (graphtrans_amd/w3.py sets it together with the exact fp32 GEMMs: GT_F32_GEMM=exact; tests/test_hip_options.py)
 bool attn_f32_split() { return !gt_opt(GT_OPT_ATTN_F32_EXACT); }
 
-// split groups per block (KS, see the top of the file): 2 when the sequences average >= 48 positions -- shorter ones have one or two
-// 32-position tiles and a second group would idle (Molpcba: 27 nodes, NCI1: 30) -- on the range-mask kernels of head dims 32 / 64;
-// gt_option_set("attn_split_groups", 1 | 2) forces it (0 = this rule)
-int attn_split_groups(int64_t total_rows, int64_t num_seqs, int hd, bool dense) {
-  if (dense || (hd != 32 && hd != 64)) return 1;
-  const int forced = gt_opt(GT_OPT_ATTN_SPLIT_GROUPS);
-  if (forced == 1 || forced == 2) return forced;
-  return total_rows >= 48 * (num_seqs > 0 ? num_seqs : 1) ? 2 : 1;
-}
-
 }  // namespace
 
 static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, float* lse, int64_t total_rows, int64_t d_model,
@@ -811,22 +736,14 @@ static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, floa
                                       : dim3(pooled ? 1u : (unsigned)gt_cdiv(max_npos, BLOCK_N), (unsigned)nhead, (unsigned)num_seqs);
   const int hd = (int)(d_model / nhead);
   const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
-  const int ks = attn_split_groups(total_rows, num_seqs, hd, dense_launch);
 #define GT_LAUNCH(T, HD)                                                                                     \
   do {                                                                                                       \
     if (dense_launch) hipLaunchKernelGGL((k_attn_fwd<T, HD, true>), grid, dim3(ATT_THREADS), 0, stream, a);  \
     else hipLaunchKernelGGL((k_attn_fwd<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);              \
   } while (0)
-#define GT_LAUNCH2(T, HD, SP)                                                                                          \
-  do {                                                                                                                 \
-    if (ks == 2) hipLaunchKernelGGL((k_attn_fwd<T, HD, false, SP, 2>), grid, dim3(2 * ATT_THREADS), 0, stream, a);     \
-    else hipLaunchKernelGGL((k_attn_fwd<T, HD, false, SP, 1>), grid, dim3(ATT_THREADS), 0, stream, a);                 \
-  } while (0)
   if (dtype == GT_F32 && !dense_launch && attn_f32_split() && (hd == 32 || hd == 64)) {   // bf16x6 products (TileOps<float, HD, true>)
-    if (hd == 32) GT_LAUNCH2(float, 32, true); else GT_LAUNCH2(float, 64, true);
-  } else if (!dense_launch && (hd == 32 || hd == 64)) {
-    if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH2(float, 32, false); else GT_LAUNCH2(float, 64, false); }
-    else { if (hd == 32) GT_LAUNCH2(gt_bf16, 32, false); else GT_LAUNCH2(gt_bf16, 64, false); }
+    if (hd == 32) hipLaunchKernelGGL((k_attn_fwd<float, 32, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((k_attn_fwd<float, 64, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
   } else if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
     else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
@@ -834,7 +751,6 @@ static int attn_fwd_impl(int pooled, int dtype, const void* qkv, void* ctx, floa
     if (hd == 8) GT_LAUNCH(gt_bf16, 8); else if (hd == 16) GT_LAUNCH(gt_bf16, 16);
     else if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64);
   }
-#undef GT_LAUNCH2
 #undef GT_LAUNCH
   GT_CHECK_LAUNCH();
   return GT_OK;
@@ -886,7 +802,6 @@ static int attn_bwd_impl(int pooled, int dtype, const void* qkv, const void* ctx
   }
   const int hd = (int)(d_model / nhead);
   const bool dense_launch = dense_mask != nullptr || key_valid != nullptr;
-  const int ks = attn_split_groups(total_rows, num_seqs, hd, dense_launch);
 #define GT_LAUNCH(T, HD)                                                                        \
   do {                                                                                          \
     if (dense_launch) {                                                                         \
@@ -897,21 +812,14 @@ static int attn_bwd_impl(int pooled, int dtype, const void* qkv, const void* ctx
       hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false>), grid, dim3(ATT_THREADS), 0, stream, a);\
     }                                                                                           \
   } while (0)
-#define GT_LAUNCH2(T, HD, SP)                                                                                              \
-  do {                                                                                                                     \
-    if (ks == 2) {                                                                                                         \
-      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, false, SP, 2>), grid_q, dim3(2 * ATT_THREADS), 0, stream, aq);              \
-      hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false, SP, 2>), grid, dim3(2 * ATT_THREADS), 0, stream, a);                \
-    } else {                                                                                                               \
-      hipLaunchKernelGGL((k_attn_bwd_dq<T, HD, false, SP, 1>), grid_q, dim3(ATT_THREADS), 0, stream, aq);                  \
-      hipLaunchKernelGGL((k_attn_bwd_dkv<T, HD, false, SP, 1>), grid, dim3(ATT_THREADS), 0, stream, a);                    \
-    }                                                                                                                      \
-  } while (0)
   if (dtype == GT_F32 && !dense_launch && attn_f32_split() && (hd == 32 || hd == 64)) {   // bf16x6 products (TileOps<float, HD, true>)
-    if (hd == 32) GT_LAUNCH2(float, 32, true); else GT_LAUNCH2(float, 64, true);
-  } else if (!dense_launch && (hd == 32 || hd == 64)) {
-    if (dtype == GT_F32) { if (hd == 32) GT_LAUNCH2(float, 32, false); else GT_LAUNCH2(float, 64, false); }
-    else { if (hd == 32) GT_LAUNCH2(gt_bf16, 32, false); else GT_LAUNCH2(gt_bf16, 64, false); }
+    if (hd == 32) {
+      hipLaunchKernelGGL((k_attn_bwd_dq<float, 32, false, true>), grid_q, dim3(ATT_THREADS), 0, stream, aq);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<float, 32, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((k_attn_bwd_dq<float, 64, false, true>), grid_q, dim3(ATT_THREADS), 0, stream, aq);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<float, 64, false, true>), grid, dim3(ATT_THREADS), 0, stream, a);
+    }
   } else if (dtype == GT_F32) {
     if (hd == 8) GT_LAUNCH(float, 8); else if (hd == 16) GT_LAUNCH(float, 16);
     else if (hd == 32) GT_LAUNCH(float, 32); else GT_LAUNCH(float, 64);
@@ -919,7 +827,6 @@ static int attn_bwd_impl(int pooled, int dtype, const void* qkv, const void* ctx
     if (hd == 8) GT_LAUNCH(gt_bf16, 8); else if (hd == 16) GT_LAUNCH(gt_bf16, 16);
     else if (hd == 32) GT_LAUNCH(gt_bf16, 32); else GT_LAUNCH(gt_bf16, 64);
   }
-#undef GT_LAUNCH2
 #undef GT_LAUNCH
   GT_CHECK_LAUNCH();
   return GT_OK;

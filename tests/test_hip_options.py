@@ -3,8 +3,7 @@ implementation that stays in the product library is reachable from a test and is
 environment switches latched in function-local statics that no test could flip; they are gone, these two remain.
 
   attn_f32_exact       fp32 token rows on the exact v_mfma_f32_16x16x4_f32 chains instead of bf16x6 products
-  bnstats_rows_kernel  BatchNorm-backward statistics in the register-row bf16x6 dX kernel's epilogue (k_lin3r)
-  attn_split_groups    1 / 2 split groups per attention block (0 = the library's rule by average sequence length)"""
+  bnstats_rows_kernel  BatchNorm-backward statistics in the register-row bf16x6 dX kernel's epilogue (k_lin3r)"""
 import copy
 import os
 import sys
@@ -22,7 +21,7 @@ def test_option_api_without_a_gpu():
     """set returns the previous value, get reads it, unknown names are an error with a message (no GPU needed)"""
     from graphtrans_amd import _lib
     L = _lib.lib()
-    for name in ("attn_f32_exact", "bnstats_rows_kernel", "attn_split_groups"):
+    for name in ("attn_f32_exact", "bnstats_rows_kernel"):
         start = _lib.option_get(name)
         assert start in (0, 1)
         assert _lib.option_set(name, 1) == start
@@ -71,49 +70,6 @@ def test_attn_f32_exact_option_against_float64(hd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("hd", [32, 64])
-@pytest.mark.parametrize("p", [0.0, 0.3])
-def test_attn_split_groups_option_against_float64(dtype, tol, hd, p):
-    """One and two split groups per block (csrc/attention.hip KS: the walk over a sequence's key / query tiles divided over groups of
-    four waves that meet at the end) on ragged lengths -- sequences with fewer tiles than groups, tile counts that do not divide,
-    a 1001-token sequence: both against the float64 reference; with dropout the two draw the SAME mask (a function of seed, sequence,
-    head, query, key only), so their outputs agree to summation order there too."""
-    from graphtrans_amd import _lib, ops
-    from test_hip_attention import make_layout, reference
-
-    torch.manual_seed(3)
-    nhead = 4 if hd == 32 else 2
-    d = nhead * hd
-    lay = make_layout("packed", [1, 7, 31, 32, 33, 64, 65, 96, 97, 130, 517, 1001])
-    qkv = torch.randn(lay.rows, 3 * d)
-    w = torch.randn(lay.rows, d)
-    ref = ref_in = None
-    if p == 0.0:
-        qq = qkv.to(dtype).float()
-        ref_in = qq.clone().requires_grad_(True)
-        ref = reference(ref_in, lay, nhead, hd ** -0.5)
-        (ref * w.double()).sum().backward()
-    got = {}
-    prev = _lib.option_get("attn_split_groups")
-    try:
-        for groups in (1, 2):
-            _lib.option_set("attn_split_groups", groups)
-            x = qkv.to(DEV).to(dtype).requires_grad_(True)
-            out = ops.attention(x, lay, nhead, dropout_p=p, seed=99) if p else ops.attention(x, lay, nhead)
-            (out.float() * w.to(DEV)).sum().backward()
-            if ref is not None:
-                assert_close(out.float().cpu(), ref.detach(), atol=tol, rtol=tol, what=f"ctx groups={groups}")
-                assert_close(x.grad.float().cpu(), ref_in.grad, atol=tol, rtol=tol, what=f"d_qkv groups={groups}")
-            got[groups] = (out.detach().float().clone(), x.grad.detach().float().clone())
-    finally:
-        _lib.option_set("attn_split_groups", prev)
-    assert_close(got[2][0].cpu(), got[1][0].cpu(), atol=tol, rtol=tol, what="ctx, two groups vs one")
-    assert_close(got[2][1].cpu(), got[1][1].cpu(), atol=tol, rtol=tol, what="d_qkv, two groups vs one")
-    assert not torch.equal(got[1][0], got[2][0]), "the option did not change the kernels"
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("vn", [False, True])
 def test_bnstats_rows_kernel_option_against_the_module_path(vn):
     """GCN at >= 12288 nodes, D = 160 (ten 16-column tiles: the register-row kernel's shape): with the option the previous layer's
@@ -146,9 +102,11 @@ def test_bnstats_rows_kernel_option_against_the_module_path(vn):
             m = copy.deepcopy(model)
             l1, g1, _ = _run(m, b, y, True, 7)
             assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
-            for n in g0:
-                scale = max(1.0, float(g0[n].abs().max()))
-                assert torch.allclose(g0[n] / scale, g1[n] / scale, rtol=2e-4, atol=2e-5), (on, n, float((g0[n] - g1[n]).abs().max()))
+            top = max(float(v.norm()) / v.numel() ** 0.5 for v in g0.values())
+            for n in g0:   # (ReLU gates at fp32 rounding of zero flip between two summation orders: a relative-L2 bar per tensor)
+                den = float(g0[n].norm())
+                if den / g0[n].numel() ** 0.5 >= 1e-3 * top:   # (a bias in front of a train-mode BatchNorm has NO gradient: rounding noise only)
+                    assert float((g0[n] - g1[n]).norm()) / den < 5e-3, (on, n, float((g0[n] - g1[n]).norm()) / den)
             res[on] = g1
     finally:
         _lib.option_set("bnstats_rows_kernel", prev)

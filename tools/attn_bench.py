@@ -62,10 +62,6 @@ def case(name, lens, d=128, nhead=4, dtype=torch.bfloat16, lpt=None, p=0.0):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:   # python tools/attn_bench.py <groups>: force the split groups per block (csrc/attention.hip KS)
-        from graphtrans_amd import _lib as _l
-        _l.option_set("attn_split_groups", int(sys.argv[1]))
-        print("== attn_split_groups", sys.argv[1])
     case("one sequence of 1001", [1001])
     case("one sequence of 513", [513])
     case("one sequence of 126", [126])
