@@ -64,9 +64,6 @@ SIGNATURES = {
     "gt_segment_sum_ws": (_i, [_i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gt_seq_gather": (_i, [_i, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p]),
     "gt_seq_scatter": (_i, [_i, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _p]),
-    "gt_linear_bn_slab_ok": (_i, [_i, _i64, _i64, _i64, _i]),
-    "gt_linear_bn_slab_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _i64, _i64, _i64, _p, _p, _p, _f, _u64, _p]),
-    "gt_linear_bn_slab_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _p, _p, _p, _p]),
     "gt_batchnorm_workspace_bytes": (_sz, [_i64, _i64]),
     "gt_batchnorm_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _i64, _p, _p, _p, _f, _u64, _p, _sz, _p]),
     "gt_batchnorm_apply": (_i, [_i, _p, _p, _p, _p, _p, _i, _p, _i64, _i64, _p, _f, _u64, _p]),

@@ -504,15 +504,6 @@ extern "C" int gt_vn_update_fwd(const gt_vn_update* L, const void* x, const void
   // global_add_pool(h_list[layer], batch) + vn   (gnn_module.py:219)
   GT_TRY(gt_segment_sum_ws(GT_F32, x, vn, L->graph_ptr, L->N, B, D, s.t0, w.seg_ws, w.seg_ws_bytes, st));
   // mlp_virtualnode_list[layer]: Linear(D,2D) BN ReLU Linear(2D,D) BN ReLU   (gnn_module.py:161-170)
-  if (gt_linear_bn_slab_ok(L->compute, B, 2 * D, D, L->training) && gt_linear_bn_slab_ok(L->compute, B, D, 2 * D, L->training)) {
-    // each Linear + its BatchNorm (+ ReLU, dropout, residual) as ONE launch: a block owns 16 output columns x all B rows (linear_bn_slab.h)
-    GT_TRY(gt_linear_bn_slab_fwd(L->compute, (const float*)s.t0, L->w1, L->b1, (float*)s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->bn1_nbt,
-                                 L->bn_momentum, L->bn_eps, 1, nullptr, B, 2 * D, D, (float*)s.a1, s.st1, s.st1 + 2 * D, 0.f, 0, st));
-    GT_TRY(gt_linear_bn_slab_fwd(L->compute, (const float*)s.a1, L->w2, L->b2, (float*)s.z2, L->bn2_w, L->bn2_b, L->bn2_rm, L->bn2_rv, L->bn2_nbt,
-                                 L->bn_momentum, L->bn_eps, 1, L->residual ? (const float*)vn : nullptr, B, D, 2 * D, (float*)vn_out, s.st2,
-                                 s.st2 + D, L->dropout_p, L->seed, st));   // vn (+)= drop(mlp(t))   (:222)
-    return GT_OK;
-  }
   GT_TRY(gt_linear_fwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, L->b1, s.z1, B, 2 * D, D, 0, 0.f, 0, st));
   GT_TRY(gt_batchnorm_fwd(GT_F32, s.z1, L->bn1_w, L->bn1_b, L->bn1_rm, L->bn1_rv, L->training ? L->bn1_nbt : nullptr,
                           L->bn_momentum, L->bn_eps, L->training, 1, nullptr, B, 2 * D, s.a1, s.st1, s.st1 + 2 * D, 0.f, 0,
@@ -538,19 +529,10 @@ extern "C" int gt_vn_update_bwd(const gt_vn_update* L, const void* d_vn_out, con
   const bool defer = L->ev_dx_done != nullptr;
   GT_TRY(gt_batchnorm_bwd(GT_F32, s.z2, d_vn_out, L->bn2_w, L->bn2_b, s.st2, s.st2 + D, L->training, 1, B, D, w.d_z2, g.bn2_w,
                           g.bn2_b, L->dropout_p, L->seed, w.bn_ws, w.bn_ws_bytes, st));
-  if (gt_linear_bn_slab_ok(L->compute, B, D, 2 * D, L->training)) {
-    // Linear2's dX + BatchNorm1's backward as ONE launch (d a1 stays in registers); Linear2's weight gradient on its own as before
-    GT_TRY(gt_linear_bn_slab_bwd(L->compute, (const float*)w.d_z2, L->w2, (const float*)s.z1, s.st1, s.st1 + 2 * D, L->bn1_w, L->bn1_b, 1, B, D,
-                                 2 * D, (float*)w.d_z1, g.bn1_w, g.bn1_b, st));
-    if (!defer)
-      GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, nullptr, g.w2, g.b2, B, D, 2 * D, 0.f,
-                           w.lin_ws, w.lin_ws_bytes, st));
-  } else {
-    GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, defer ? nullptr : g.w2,
-                         defer ? nullptr : g.b2, B, D, 2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
-    GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, B, 2 * D, w.d_z1,
-                            g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
-  }
+  GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.a1, L->w2, w.d_z2, nullptr, nullptr, nullptr, w.d_a1, defer ? nullptr : g.w2,
+                       defer ? nullptr : g.b2, B, D, 2 * D, 0.f, w.lin_ws, w.lin_ws_bytes, st));
+  GT_TRY(gt_batchnorm_bwd(GT_F32, s.z1, w.d_a1, L->bn1_w, L->bn1_b, s.st1, s.st1 + 2 * D, L->training, 1, B, 2 * D, w.d_z1,
+                          g.bn1_w, g.bn1_b, 0.f, 0, w.bn_ws, w.bn_ws_bytes, st));
   // d_t0 = d_z1 W1 ; d_vn = d_t0 (+ d_vn_out through the residual branch)
   GT_TRY(gt_linear_bwd(GT_F32, GT_F32, L->compute, s.t0, L->w1, w.d_z1, nullptr, nullptr, nullptr, w.d_t0, defer ? nullptr : g.w1,
                        defer ? nullptr : g.b1, B, 2 * D, D, 0.f, w.lin_ws, w.lin_ws_bytes, st));

@@ -14,7 +14,6 @@
 #include <stdlib.h>
 
 #include "gt_common.h"
-#include "mfma_frag.h"
 
 namespace {
 
@@ -305,8 +304,6 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const T* __restrict__ x, co
   }
 }
 
-
-#include "linear_bn_slab.h"
 
 // ---- few rows (the virtual-node MLP normalises B = 256 graph rows, modules/gnn_module.py:161-170): ONE launch
 // per direction instead of three.  A block owns 32 columns x all rows (8 row lanes); statistics and apply in
@@ -1218,54 +1215,6 @@ extern "C" int gt_batchnorm_bwd_apply(int dtype, const void* x, const void* dy, 
   else
     hipLaunchKernelGGL(k_bn_bwd_apply<gt_bf16>, dim3(g), dim3(NT), 0, stream, (const gt_bf16*)x, (const gt_bf16*)dy, mean, rstd,
                        weight, bias, sum_dy, sum_dy_xhat, relu, inv_n, drop, rows, dim, (gt_bf16*)dx, (const float*)nullptr);
-  GT_CHECK_LAUNCH();
-  return GT_OK;
-}
-
-// ---- Linear + BatchNorm over few rows as one launch per direction (linear_bn_slab.h; the virtual-node MLP, modules/gnn_module.py:161-170)
-// 1 when the pair runs fused: training-mode statistics of THIS rank's rows (no gt_bn_sync_set hook), 2 <= M <= 512 rows, fp32 rows
-extern "C" int gt_linear_bn_slab_ok(int compute, int64_t M, int64_t N, int64_t K, int training) {
-  if (!training || (g_bn_sync.fn && g_bn_sync.world > 1)) return 0;
-  if (compute != GT_F32 && compute != GT_BF16) return 0;
-  return slab::slab_shape_ok(M, N, K) ? 1 : 0;
-}
-// z [M][N] = x W^T + b (the BatchNorm's saved input); y = [drop(relu(BN(z)))] (+ resid); save_mean / save_rstd [N]; running statistics
-// and num_batches_tracked updated like gt_batchnorm_fwd in training mode (same dropout mask: bn_hash(seed, row, column))
-extern "C" int gt_linear_bn_slab_fwd(int compute, const float* x, const float* w, const float* bias, float* z, const float* bn_w,
-                                     const float* bn_b, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                     float momentum, float eps, int relu, const float* resid, int64_t M, int64_t N, int64_t K, float* y,
-                                     float* save_mean, float* save_rstd, float dropout_p, uint64_t seed, gt_stream_t stream_) {
-  GT_CHECK_ARG(x && w && z && bn_w && bn_b && y && save_mean && save_rstd, "null buffer");
-  GT_CHECK_ARG(gt_linear_bn_slab_ok(compute, M, N, K, 1), "not covered (ask gt_linear_bn_slab_ok)");
-  GT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0,1)");
-  GT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)z | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)bn_w | (uintptr_t)bn_b |
-                 (uintptr_t)save_mean | (uintptr_t)save_rstd) & 15) == 0, "16-byte aligned buffers");
-  slab::SlabArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.z = z; a.y = y; a.resid = resid; a.bn_w = bn_w; a.bn_b = bn_b; a.mean = save_mean; a.rstd = save_rstd;
-  a.rmean = running_mean; a.rvar = running_mean ? running_var : nullptr; a.nbt = num_batches_tracked;
-  a.M = M; a.N = N; a.K = K; a.momentum = momentum; a.eps = eps; a.relu = relu; a.drop = make_bn_drop(dropout_p, seed);
-  const dim3 grid((unsigned)gt_cdiv(N, slab::SL_COLS));
-  if (compute == GT_F32) hipLaunchKernelGGL(slab::k_slab_lin_bn_fwd<float>, grid, dim3(slab::SL_THREADS), 0, (hipStream_t)stream_, a);
-  else hipLaunchKernelGGL(slab::k_slab_lin_bn_fwd<gt_bf16>, grid, dim3(slab::SL_THREADS), 0, (hipStream_t)stream_, a);
-  GT_CHECK_LAUNCH();
-  return GT_OK;
-}
-// The dX of the UPPER Linear (dz_up [M][N], w_up [N][K]) and the backward of the BatchNorm(+ReLU) BELOW it (saved input z [M][K],
-// statistics, affine parameters) as one launch: dz [M][K], d gamma / d beta [K]; the intermediate d a = dz_up W_up never reaches memory.
-extern "C" int gt_linear_bn_slab_bwd(int compute, const float* dz_up, const float* w_up, const float* z, const float* mean,
-                                     const float* rstd, const float* bn_w, const float* bn_b, int relu, int64_t M, int64_t N, int64_t K,
-                                     float* dz, float* dgamma, float* dbeta, gt_stream_t stream_) {
-  GT_CHECK_ARG(dz_up && w_up && z && mean && rstd && bn_w && bn_b && dz && dgamma && dbeta, "null buffer");
-  GT_CHECK_ARG(gt_linear_bn_slab_ok(compute, M, N, K, 1), "not covered (ask gt_linear_bn_slab_ok)");
-  GT_CHECK_ARG((((uintptr_t)dz_up | (uintptr_t)w_up | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)bn_w | (uintptr_t)bn_b |
-                 (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0, "16-byte aligned buffers");
-  slab::SlabArgs a{};
-  a.x = dz_up; a.w = w_up; a.zin = z; a.y = dz; a.bn_w = bn_w; a.bn_b = bn_b; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
-  a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.N = N; a.K = K; a.relu = relu;
-  const dim3 grid((unsigned)gt_cdiv(K, slab::SL_COLS));
-  const size_t lds = (size_t)slab::SL_COLS * ((size_t)gt_cdiv(N, 32) * 32 + 4) * sizeof(float);
-  if (compute == GT_F32) hipLaunchKernelGGL(slab::k_slab_dx_bn_bwd<float>, grid, dim3(slab::SL_THREADS), lds, (hipStream_t)stream_, a);
-  else hipLaunchKernelGGL(slab::k_slab_dx_bn_bwd<gt_bf16>, grid, dim3(slab::SL_THREADS), lds, (hipStream_t)stream_, a);
   GT_CHECK_LAUNCH();
   return GT_OK;
 }

@@ -385,23 +385,6 @@ int gt_batchnorm_bwd_parts(int dtype, const void* x, const void* dy, const float
  * on `stream` (stream-ordered, no host sync required); returns 0 or an error.  The collective itself is the caller's. */
 typedef int (*gt_bn_sync_fn)(void* user, int kind, float* buf, int64_t n, gt_stream_t stream);
 int gt_bn_sync_set(gt_bn_sync_fn fn, void* user, int world);
-/* Linear + BatchNorm over FEW rows as one launch per direction (csrc/linear_bn_slab.h; the virtual-node MLP on one row per graph,
- * modules/gnn_module.py:161-170): a block owns 16 output columns x all M rows -- the GEMM for its slab and the whole BatchNorm on the
- * accumulators, no cross-block step.  fp32 rows, 2 <= M <= 512, N, K multiples of 4, training-mode statistics of the local rows (not
- * under gt_bn_sync_set): ask gt_linear_bn_slab_ok.  compute = GT_F32 (exact fp32 MFMA) or GT_BF16.
- *   fwd: z [M][N] = x W^T + b (saved for the backward); y = [drop(relu(BN(z)))] (+ resid); save_mean / save_rstd [N]; running statistics
- *        and num_batches_tracked as gt_batchnorm_fwd (same dropout mask for the same seed).
- *   bwd: dz_up [M][N] is the gradient of the UPPER Linear's output, w_up [N][K] its weight: d a = dz_up w_up stays in registers and goes
- *        through the backward of the BatchNorm(+ReLU) BELOW (saved input z [M][K], mean / rstd, affine parameters): dz [M][K],
- *        dgamma / dbeta [K]. */
-int gt_linear_bn_slab_ok(int compute, int64_t M, int64_t N, int64_t K, int training);
-int gt_linear_bn_slab_fwd(int compute, const float* x, const float* w, const float* bias, float* z, const float* bn_w, const float* bn_b,
-                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu,
-                          const float* resid, int64_t M, int64_t N, int64_t K, float* y, float* save_mean, float* save_rstd,
-                          float dropout_p, uint64_t seed, gt_stream_t stream);
-int gt_linear_bn_slab_bwd(int compute, const float* dz_up, const float* w_up, const float* z, const float* mean, const float* rstd,
-                          const float* bn_w, const float* bn_b, int relu, int64_t M, int64_t N, int64_t K, float* dz, float* dgamma,
-                          float* dbeta, gt_stream_t stream);
 /* The apply passes on their own, for BatchNorm statistics synchronised over data-parallel ranks (the reference
  * normalises over the whole single-device batch, modules/gnn_module.py:204): y = drop(bn(x; mean, rstd) [relu]) [+ resid]
  * with caller-provided statistics; dx from caller-provided (all-rank) sums of dy' and dy' * xhat over `count` rows. */
