@@ -777,54 +777,82 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd(LnArgs a) {
 // 16-byte load per operand -- four rows per wave and trip instead of two, half the trips and half the dependent shuffle steps of the
 // generic kernel (19 us for 40 MB at Code2's 32 k token rows: a chain of round trips, not bandwidth).  Same arithmetic, same dropout
 // hash, same partial layout ([block][2][D]) for k_ln_bwd_finish.
-template <int NTB, int DD>
+// eight consecutive row elements as they travel in registers: bf16 = one 16-byte load, fp32 (r6: the fp32 contract mode's token rows ran the
+// generic kernel, 37 us per call against 12 for this one) = two
+template <typename T>
+struct Row8;
+template <>
+struct Row8<gt_bf16> {
+  uint4 v;
+  __device__ __forceinline__ void load(const gt_bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void get(float* f) const {
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(u[e] << 16); f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(gt_bf16* p, const float* z) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(gt_pack_bf16(z[0], z[1]), gt_pack_bf16(z[2], z[3]), gt_pack_bf16(z[4], z[5]), gt_pack_bf16(z[6], z[7]));
+  }
+};
+template <>
+struct Row8<float> {
+  float4 lo, hi;
+  __device__ __forceinline__ void load(const float* p) { lo = *reinterpret_cast<const float4*>(p); hi = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void zero() { lo = gt_zero4(); hi = gt_zero4(); }
+  __device__ __forceinline__ void get(float* f) const {
+    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float* z) {
+    *reinterpret_cast<float4*>(p) = make_float4(z[0], z[1], z[2], z[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(z[4], z[5], z[6], z[7]);
+  }
+};
+
+template <typename T, int NTB, int DD>
 __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
   static_assert(DD == 128 || DD == 256, "8 columns per lane, 16 or 32 lanes per row");
   constexpr int LPR = DD / 8, RPW = 64 / LPR;   // lanes per row, rows per wave and trip
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [waves][2][DD]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int sub = lane / LPR, sl = lane % LPR, col = sl * 8;
-  const gt_bf16* dy = reinterpret_cast<const gt_bf16*>(a.dy);
-  const gt_bf16* xin = reinterpret_cast<const gt_bf16*>(a.x);
-  const gt_bf16* rin = reinterpret_cast<const gt_bf16*>(a.resid);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const T* xin = reinterpret_cast<const T*>(a.x);
+  const T* rin = reinterpret_cast<const T*>(a.resid);
   float gw[8], aw[8], ab[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gw[e] = a.w[col + e]; aw[e] = 0.f; ab[e] = 0.f; }
   const int64_t stride = (int64_t)gridDim.x * (NTB / 64) * RPW;
   int64_t row = ((int64_t)blockIdx.x * (NTB / 64) + wid) * RPW + sub;
   // the next trip's operands are in flight while this trip is reduced
-  uint4 cx, cr, cd, nx, nr, nd;
+  Row8<T> cx, cr, cd, nx, nr, nd;
   float cmu, crs, nmu, nrs;
   auto clampr = [&](int64_t r) { return r < a.rows ? r : a.rows - 1; };
+  cr.zero();
+  nr.zero();
   {
     const int64_t q = clampr(row) * DD + col;
-    cx = *reinterpret_cast<const uint4*>(xin + q);
-    cr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
-    cd = *reinterpret_cast<const uint4*>(dy + q);
+    cx.load(xin + q);
+    if (rin) cr.load(rin + q);
+    cd.load(dy + q);
     cmu = a.mean[clampr(row)];
     crs = a.rstd[clampr(row)];
   }
   for (; row - sub < a.rows; row += stride) {   // (uniform per wave: its four rows start at row - sub)
     {
       const int64_t rn = clampr(row + stride), q = rn * DD + col;
-      nx = *reinterpret_cast<const uint4*>(xin + q);
-      nr = rin ? *reinterpret_cast<const uint4*>(rin + q) : make_uint4(0, 0, 0, 0);
-      nd = *reinterpret_cast<const uint4*>(dy + q);
+      nx.load(xin + q);
+      if (rin) nr.load(rin + q);
+      nd.load(dy + q);
       nmu = a.mean[rn];
       nrs = a.rstd[rn];
     }
     const bool live = row < a.rows;
     const float cnt = live ? 1.f : 0.f;
     float d[8], x[8], r[8];
-    {
-      const uint32_t ud[4] = {cd.x, cd.y, cd.z, cd.w}, ux[4] = {cx.x, cx.y, cx.z, cx.w}, ur[4] = {cr.x, cr.y, cr.z, cr.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        d[2 * e] = __uint_as_float(ud[e] << 16); d[2 * e + 1] = __uint_as_float(ud[e] & 0xffff0000u);
-        x[2 * e] = __uint_as_float(ux[e] << 16); x[2 * e + 1] = __uint_as_float(ux[e] & 0xffff0000u);
-        r[2 * e] = __uint_as_float(ur[e] << 16); r[2 * e + 1] = __uint_as_float(ur[e] & 0xffff0000u);
-      }
-    }
+    cd.get(d);
+    cx.get(x);
+    cr.get(r);
     bool keep[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -850,16 +878,13 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dz[e] = crs * (g[e] - m1 - xh[e] * m2);
     if (live) {
-      if (a.dresid)
-        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dresid) + row * DD + col) =
-            make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+      if (a.dresid) Row8<T>::store(reinterpret_cast<T*>(a.dresid) + row * DD + col, dz);
       if (a.dx) {
         if (a.thr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dz[e] = keep[e] ? dz[e] * a.inv_keep : 0.f;
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<gt_bf16*>(a.dx) + row * DD + col) =
-            make_uint4(gt_pack_bf16(dz[0], dz[1]), gt_pack_bf16(dz[2], dz[3]), gt_pack_bf16(dz[4], dz[5]), gt_pack_bf16(dz[6], dz[7]));
+        Row8<T>::store(reinterpret_cast<T*>(a.dx) + row * DD + col, dz);
       }
     }
     cx = nx; cr = nr; cd = nd; cmu = nmu; crs = nrs;
@@ -903,13 +928,13 @@ constexpr int LN_BWD_BLOCKS = 256;   // (512 blocks for the d = 128 kernel -- on
 template <typename T, bool BWD>
 void ln_launch(const LnArgs& a, int grid_bwd, hipStream_t stream) {
   const int64_t D = a.D;
-  if constexpr (BWD && sizeof(T) == 2) {
+  if constexpr (BWD) {
     if (D == 128) {
-      hipLaunchKernelGGL((k_ln_bwd_d128<1024, 128>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
+      hipLaunchKernelGGL((k_ln_bwd_d128<T, 1024, 128>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 128 * 4, stream, a);
       return;
     }
     if (D == 256) {   // the same scheme at 32 lanes per row (the Erdos-Renyi stress: d_model 256, 131 k token rows)
-      hipLaunchKernelGGL((k_ln_bwd_d128<1024, 256>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 256 * 4, stream, a);
+      hipLaunchKernelGGL((k_ln_bwd_d128<T, 1024, 256>), dim3(grid_bwd), dim3(1024), (size_t)16 * 2 * 256 * 4, stream, a);
       return;
     }
   }
@@ -1282,7 +1307,7 @@ extern "C" int gt_layernorm_bwd(int dtype, const void* x, const void* resid, con
   a.x = x; a.resid = resid; a.w = weight; a.dy = dy; a.dx = dx; a.dresid = dresid; a.mean = const_cast<float*>(save_mean);
   a.rstd = const_cast<float*>(save_rstd); a.rows = rows; a.D = dim; a.part = (float*)workspace;
   fill_drop(a, dropout_p, seed);
-  const bool d128 = dtype == GT_BF16 && dim == 128;   // k_ln_bwd_d128: four rows per wave and trip
+  const bool d128 = dim == 128;   // k_ln_bwd_d128: four rows per wave and trip
   const int64_t npw = d128 ? 4 : (dim <= 64 ? 4 : (dim <= 128 ? 2 : 1));
   const int bwd_waves = dim <= 256 ? 16 : NT / 64;   // waves per block of the launch below
   int64_t want = gt_cdiv(gt_cdiv(rows > 0 ? rows : 1, npw), bwd_waves);
