@@ -5,6 +5,8 @@ Replaces the reference's per-layer `degree(row)` (modules/conv.py:57), its unsor
 `gt_graph_prep`, plus the sequence layouts (`SeqLayout`) that describe how node rows map to
 transformer token rows (padded = the reference's (S,B,d) layout; packed = no padding rows at all).
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -116,13 +118,20 @@ class _StageRing:
         return self.buf[i * self.SLOT_BYTES:(i + 1) * self.SLOT_BYTES], self.events[i]
 
 
-_RING = []
+_RINGS = {}   # one ring per device: its events belong to that device's streams (one process-global ring reused events across devices)
+_RINGS_LOCK = threading.Lock()
 
 
-def _staging(nbytes):
-    if not _RING:
-        _RING.append(_StageRing())
-    return _RING[0].take(nbytes)
+def _staging(nbytes, device):
+    """(pinned slot, event to record behind the copy that reads it) from the ring of `device`; (None, None) if it does not fit a slot"""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _RINGS_LOCK:   # (autograd's backward threads and data-loader threads build layouts too)
+        ring = _RINGS.get(key)
+        if ring is None:
+            ring = _RINGS[key] = _StageRing()
+        with torch.cuda.device(key):   # a new slot's event is created on the ring's device
+            return ring.take(nbytes)
 
 
 class SeqLayout:
@@ -226,7 +235,7 @@ class SeqLayout:
             o_l = (nd + 15) // 16 * 16
             o_w = (o_l + nl + 15) // 16 * 16
             nbytes = max(o_w + nw, 16)
-            pinned, event = _staging(nbytes)
+            pinned, event = _staging(nbytes, gs.device)
             if pinned is None:   # (larger than a ring slot: its own pinned buffer)
                 pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
             hb = pinned.numpy()

@@ -13,6 +13,7 @@ for w in code2 molpcba er code2-pna; do
   for m in $modes; do
     [ $w = er ] && [ $m != mixed ] && continue   # the stress workload: the headline mode only
     [ $w = code2-pna ] && [ $m != mixed ] && continue
+    [ $w = molpcba ] && [ $m = fp32 ] && continue
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_${w}_${m}_$c
       timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_${w}_${m}_$c -o res -- python bench.py --workload $w --mode $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_${w}_${m}_$c.log 2>&1 || true
