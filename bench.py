@@ -879,9 +879,15 @@ def main():
     ap.add_argument("--from-store", action="store_true",
                     help="assemble every batch on the device from an HBM graph store inside the timed step "
                          "(gt_collate: sampling + augment_edge + collation; code2 / molpcba / code2-pna)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B only: a named runtime option of the library (include/graphtrans_hip.h, gt_option_set), e.g. lin_ring=1")
     opt = ap.parse_args()
     if opt.dtype is not None:
         opt.mode = opt.dtype
+    for kv in opt.lib_option:
+        from graphtrans_amd import _lib
+        name, _, val = kv.partition("=")
+        _lib.option_set(name, int(val))
 
     if "WORLD_SIZE" not in os.environ and opt.gpus > 1:
         self_spawn(opt)

@@ -63,7 +63,7 @@ void gt_prof_end(int64_t id, hipStream_t stream) {
 // ---- named runtime options ----------------------------------------------------------------------------------------------------
 namespace {
 std::atomic<int> g_options[GT_OPT_COUNT];   // zero-initialised = every default
-const char* const OPTION_NAMES[GT_OPT_COUNT] = {"attn_f32_exact", "bnstats_rows_kernel"};
+const char* const OPTION_NAMES[GT_OPT_COUNT] = {"attn_f32_exact", "bnstats_rows_kernel", "lin_ring"};
 int option_id(const char* name) {
   if (name)
     for (int i = 0; i < GT_OPT_COUNT; ++i)

@@ -74,7 +74,7 @@ enum { GT_PROF_AGGREGATE = 1, GT_PROF_ATTENTION = 2, GT_PROF_LINEAR = 4, GT_PROF
 unsigned gt_prof_mask();
 // named runtime options (gt_option_set / gt_option_get, csrc/common.hip): alternative implementations that stay in the library as
 // TESTED yardsticks (tests/test_hip_options.py runs each non-default value against the oracle).  Process-wide, read at every call.
-enum { GT_OPT_ATTN_F32_EXACT = 0, GT_OPT_BNSTATS_ROWS_KERNEL = 1, GT_OPT_COUNT };
+enum { GT_OPT_ATTN_F32_EXACT = 0, GT_OPT_BNSTATS_ROWS_KERNEL = 1, GT_OPT_LIN_RING = 2, GT_OPT_COUNT };
 int gt_opt(int id);
 int64_t gt_prof_begin(const char* name, hipStream_t stream, const int64_t* dims, int ndims);
 void gt_prof_end(int64_t id, hipStream_t stream);

@@ -205,6 +205,7 @@ __device__ __forceinline__ float4 bias_chunk(const float* bias, int64_t col, int
 #include "linear3x.h"
 #include "linear3r.h"
 #include "linear1.h"
+#include "linear2.h"
 #include "linear_small.h"
 #include "linear_heads.h"
 #include "linear_dw16.h"
@@ -1069,10 +1070,12 @@ static int linear_fwd_impl(int x_dtype, int y_dtype, int compute, const void* x,
       l.a = (const gt_bf16*)x; l.img = (const unsigned char*)img; l.bias = bias; l.out = (gt_bf16*)y;
       l.M = M; l.lda = ldx; l.ldo = ldy; l.N = (int)N; l.K = (int)K; l.act = act;
       l.inv_keep = a.inv_keep; l.thr = a.thr; l.s0 = a.s0; l.s1 = a.s1;
+      // many rows, or a contraction the registers cannot hold: both operands through the LDS ring (linear2.h)
+      const bool ring = w2_take(l, w1_pick_ntw(N, K) != 0);
       bool ok;
       {
-        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
-        ok = w1_launch(stream, l);
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, ring ? "k_lin2[fwd]" : "k_lin1[fwd]", stream, {M, N, K, x_dtype, y_dtype, compute});
+        ok = ring ? w2_launch(stream, l) : w1_launch(stream, l);
       }
       if (ok) { GT_CHECK_LAUNCH(); return GT_OK; }
     }
@@ -1520,9 +1523,10 @@ extern "C" int gt_linear_bwd_grouped(int x_dtype, int y_dtype, int compute, cons
       l.gate = g_opt.gate_out ? (const gt_bf16*)y_for_mask : nullptr; l.gate_inv_keep = a.inv_keep;
       l.add1 = (const gt_bf16*)dx_add1; l.add2 = (const gt_bf16*)dx_add2;
       l.M = M; l.lda = ldy; l.ldo = ldx; l.N = (int)K; l.K = (int)N;
+      const bool ring = w2_take(l, w1_pick_ntw(K, N) != 0);
       {
-        GtProfScope pk__(GT_PROF_GEMM_KERNEL, "k_lin1[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
-        dx_done = w1_launch(stream, l);
+        GtProfScope pk__(GT_PROF_GEMM_KERNEL, ring ? "k_lin2[dx]" : "k_lin1[dx]", stream, {M, N, K, x_dtype, y_dtype, compute});
+        dx_done = ring ? w2_launch(stream, l) : w1_launch(stream, l);
       }
     }
   }
@@ -1743,7 +1747,7 @@ extern "C" int gt_w3_unbind(void) {
 // ---- fragment-order bf16 images for the encoder layers' GEMMs (linear1.h) ------------------------------------------------
 // 0 when the (rows, contraction) GEMM is not covered by the weight-stationary kernel (rows % 64, contraction % 128, <= 1024)
 extern "C" size_t gt_w1_image_bytes(int64_t rows, int64_t contraction) {
-  return w1_pick_ntw(rows, contraction) ? w1_image_bytes(rows, contraction) : 0;
+  return (w1_pick_ntw(rows, contraction) || w2_covered(rows, contraction)) ? w1_image_bytes(rows, contraction) : 0;
 }
 // Job i as gt_w3_images: weight[i] = fp32 [N[i]][K[i]]; transposed[i] == 0 -> image of W (rows N, contraction K), != 0 -> image of W^T;
 // image[i] has gt_w1_image_bytes(rows, contraction) bytes (non-zero), 16-byte aligned.
@@ -1758,7 +1762,7 @@ extern "C" int gt_w1_images(int n, const float* const* weight, const int64_t* N,
       const int s = i0 + i;
       GT_CHECK_ARG(weight[s] && image[s] && N[s] > 0 && K[s] > 0 && ((uintptr_t)image[s] & 15) == 0, "null / unaligned buffer");
       const int64_t rows = transposed[s] ? K[s] : N[s], contr = transposed[s] ? N[s] : K[s];
-      GT_CHECK_ARG(w1_pick_ntw(rows, contr) != 0, "shape not covered (gt_w1_image_bytes == 0)");
+      GT_CHECK_ARG(w1_pick_ntw(rows, contr) != 0 || w2_covered(rows, contr), "shape not covered (gt_w1_image_bytes == 0)");
       W1Job& J = jobs.j[i];
       J.w = weight[s]; J.img = (unsigned char*)image[s]; J.R = (int)rows; J.C = (int)contr; J.ldw = (int)K[s];
       J.transposed = transposed[s] ? 1 : 0; J.block0 = blocks;

@@ -88,6 +88,7 @@ struct L1Args {
   int ncb;                    // column blocks of 64 * NTW columns
   int sgroups;                // row-tile groups in flight: grid = 8 * ncb * sgroups
   int row_tiles;              // ceil(M / 64)
+  int tm;                     // k_lin2 (linear2.h): rows per work item
 };
 
 constexpr int W1_TM = 64;            // rows per tile

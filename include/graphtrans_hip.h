@@ -67,7 +67,10 @@ int gt_stream_wait_event(gt_stream_t stream, void* event);
  * negative status for an unknown name; values are small non-negative integers (0 / 1 unless stated).
  *   "attn_f32_exact"       1: fp32 token rows run attention on the exact v_mfma_f32_16x16x4_f32 chains instead of bf16x6 products
  *   "bnstats_rows_kernel"  1: a gt_linear_bwd_bnstats request is also taken by the register-row bf16x6 dX kernel (one partial row per
- *                             128 rows; measured slower than the separate partial pass, off by default) */
+ *                             128 rows; measured slower than the separate partial pass, off by default)
+ *   "lin_ring"             which bf16 GEMMs with a bound fragment image (gt_w1_bind) run the LDS-ring kernel k_lin2 (csrc/linear2.h):
+ *                             0 = from 65 536 rows on, and every covered shape the weight-stationary kernel does not take (default);
+ *                             1 = never (k_lin1 / the tiled kernels: the yardstick); 2 = every covered shape from 2 048 rows on */
 int gt_option_set(const char* name, int value);
 int gt_option_get(const char* name);
 

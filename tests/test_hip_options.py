@@ -21,7 +21,7 @@ def test_option_api_without_a_gpu():
     """set returns the previous value, get reads it, unknown names are an error with a message (no GPU needed)"""
     from graphtrans_amd import _lib
     L = _lib.lib()
-    for name in ("attn_f32_exact", "bnstats_rows_kernel"):
+    for name in ("attn_f32_exact", "bnstats_rows_kernel", "lin_ring"):
         start = _lib.option_get(name)
         assert start in (0, 1)
         assert _lib.option_set(name, 1) == start

@@ -51,11 +51,15 @@ def main():
                                 M, N, K, K, N, 0.0, _p(ws), ws_bytes, st)
         t_f0, t_d0 = timeit(f), timeit(d)
         with imgs.bound():
+            prev = _lib.option_set("lin_ring", 1)      # k_lin1 (the tiled kernel where it does not cover the shape)
             t_f1, t_d1 = timeit(f), timeit(d)
+            _lib.option_set("lin_ring", 2)             # k_lin2: both operands through the LDS ring
+            t_f2, t_d2 = timeit(f), timeit(d)
+            _lib.option_set("lin_ring", prev)
         gb_f = (M * K * 2 + M * N * 2) / 1e3
         gb_d = (M * N * 2 + 2 * M * K * 2) / 1e3
-        print(f"M={M} N={N} K={K}: fwd tiled {t_f0:7.1f} us  stationary {t_f1:7.1f} us ({gb_f / t_f1 / 1e3:.2f} TB/s) | "
-              f"dx tiled {t_d0:7.1f} us  stationary {t_d1:7.1f} us ({gb_d / t_d1 / 1e3:.2f} TB/s)")
+        print(f"M={M} N={N} K={K}: fwd tiled {t_f0:7.1f} us  stationary {t_f1:7.1f} us  ring {t_f2:7.1f} us ({gb_f / t_f2 / 1e3:.2f} TB/s) | "
+              f"dx tiled {t_d0:7.1f} us  stationary {t_d1:7.1f} us  ring {t_d2:7.1f} us ({gb_d / t_d2 / 1e3:.2f} TB/s)")
     t = timeit(lambda: imgs.build())
     print(f"image build (1 weight, both directions): {t:.1f} us")
 
