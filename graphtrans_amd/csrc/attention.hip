@@ -159,34 +159,46 @@ struct TilePair {
   static constexpr int CH = HD / 8;
   Frag<T> fa, fb;
   int r, col;
-  bool has;
+  bool has, ok;
   const T* pa;   // this thread's chunk of the tile at position 0 of the sequence
   const T* pb;
+  const T* za;   // this thread's chunk of a row that always exists: what a lane outside [lo, hi) fetches (and then zeroes)
+  const T* zb;
   int64_t sa, sb;   // elements per position (wave-uniform)
-  __device__ __forceinline__ void init(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride) {
+  __device__ __forceinline__ void init(const T* srcA, int64_t ldA, const T* srcB, int64_t ldB, int64_t row0, int64_t row_stride, int safe_pos) {
     const int c = threadIdx.x;
     has = c < TILE * CH;
     r = c / CH;
     col = (c % CH) * 8;
     pa = srcA + (row0 + (int64_t)r * row_stride) * ldA + col;
     pb = srcB + (row0 + (int64_t)r * row_stride) * ldB + col;
+    za = srcA + (row0 + (int64_t)safe_pos * row_stride) * ldA + col;
+    zb = srcB + (row0 + (int64_t)safe_pos * row_stride) * ldB + col;
     sa = row_stride * ldA;
     sb = row_stride * ldB;
+    ok = false;
   }
   // The tile at positions [pos0, pos0 + TILE): the per-thread row address is base + pos0 * (row_stride * ld) -- pos0 and the
   // stride are wave-uniform, so the 64-bit product is scalar work and the vector side is one 64-bit add per operand (the
-  // per-lane (row0 + pos * row_stride) * ld of the first version was five quarter-rate multiplies per operand and step)
+  // per-lane (row0 + pos * row_stride) * ld of the first version was five quarter-rate multiplies per operand and step).
+  // BRANCH-FREE: a lane whose position lies outside [lo, hi) loads the safe row instead and store() writes zeros for it.  With the
+  // loads under an exec-masked branch (`ok ? load : zero`) hipcc's wait-count pass lost track of them across the loop and put
+  // s_waitcnt vmcnt(0) in front of the step's FIRST MFMA -- every step waited out the latency of the prefetch it had just issued
+  // (forward and dK/dV: 0.7-1.1 us per 32-position step).
   __device__ __forceinline__ void load(int pos0, int lo, int hi) {
     const int pos = pos0 + r;
-    const bool ok = has && pos >= lo && pos < hi;
-    fa = ok ? frag_load(pa + (int64_t)pos0 * sa) : frag_zero<T>();
-    fb = ok ? frag_load(pb + (int64_t)pos0 * sb) : frag_zero<T>();
+    ok = has && pos >= lo && pos < hi;
+    fa = frag_load(ok ? pa + (int64_t)pos0 * sa : za);
+    fb = frag_load(ok ? pb + (int64_t)pos0 * sb : zb);
   }
-  template <typename TO>
+  template <typename TO, bool PIN = false>
   __device__ __forceinline__ void store(typename TO::LT* sA, typename TO::LT* sB) const {
+    // PIN (dK/dV): nothing of the store moves up across this point -- hipcc's scheduler otherwise hoists the zero-selects of fa / fb to
+    // right behind the loads, and the wait for the loads with them, in front of the step's MFMAs
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     if (has) {
-      TO::store(sA, r, col, fa);
-      TO::store(sB, r, col, fb);
+      TO::store(sA, r, col, ok ? fa : frag_zero<T>());
+      TO::store(sB, r, col, ok ? fb : frag_zero<T>());
     }
   }
 };
@@ -248,7 +260,7 @@ struct TileOps<float, HD, true> {
 // forward
 // =================================================================================================
 template <typename T, int HD, bool DENSE, bool SP = false>
-__global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
+__global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
@@ -292,7 +304,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
   TilePair<T, HD> stg;
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
-  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
+  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride, kv_off < npos ? kv_off : npos - 1);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();   // the zero fill above and the first store touch the same rows
   stg.load(k_first, kv_off, kv_end);
@@ -393,7 +405,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_fwd(AttnArgs a) {
 // backward, pass 1: delta = rowsum(dO * O) and dQ      (block = 64 queries, loop over key tiles)
 // =================================================================================================
 template <typename T, int HD, bool DENSE, bool SP = false>
-__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
+__global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_bwd_dq(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
@@ -457,7 +469,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
   TilePair<T, HD> stg;
   const T* srcK = qkv + a.d_model + head * HD;
   const T* srcV = qkv + 2 * a.d_model + head * HD;
-  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride);
+  stg.init(srcK, ld3, srcV, ld3, row0, a.row_stride, kv_off < npos ? kv_off : npos - 1);
   const int k_first = (kv_off / TILE) * TILE;
   if (HD < 32) __syncthreads();
   stg.load(k_first, kv_off, kv_end);
@@ -526,7 +538,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dq(AttnArgs a) {
 // backward, pass 2: dK, dV                              (block = 64 keys, loop over query tiles)
 // =================================================================================================
 template <typename T, int HD, bool DENSE, bool SP = false>
-__global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
+__global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_bwd_dkv(AttnArgs a) {
   using TO = TileOps<T, HD, SP>;
   using LT = typename TO::LT;
   using Op = typename TO::Op;
@@ -578,27 +590,36 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
   TilePair<T, HD> stg;
   const T* srcQ = qkv + head * HD;
   const T* srcDO = dctx + head * HD;
-  stg.init(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride);
-  // threads 0..95 also carry one statistic of one query of the tile (0: running max, 1: log2(sum), 2: delta)
-  const int aux_r = threadIdx.x & (TILE - 1), aux_which = threadIdx.x / TILE;
+  stg.init(srcQ, ld3, srcDO, a.d_model, row0, a.row_stride, 0);
+  // threads 0..95 also carry one statistic of one query of the tile (0: running max, 1: log2(sum), 2: delta).  Branch-free, and the
+  // two loads of slot 0 are COMBINED WHEN THEY ARE STORED: with `aux = -(m + lse2[..])` computed at load time the step waited for both
+  // loads (and with them for the Q / dO prefetch issued in front of them) before its first MFMA.
+  const int aux_r = threadIdx.x & (TILE - 1), aux_which = (threadIdx.x / TILE) % 3;
   const float* aux_src = aux_which == 0 ? a.lse : (aux_which == 1 ? a.lse + (int64_t)a.nhead * a.rows : a.delta);
-  float aux_v = 0.f;
+  const float* aux_src2 = a.lse + (int64_t)a.nhead * a.rows;
+  float aux_v = 0.f, aux_w = 0.f;
+  bool aux_ok = false;
   auto load_aux = [&](int q0) {
     const int pos = q0 + aux_r;
-    const int64_t o = (int64_t)head * a.rows + row0 + (int64_t)pos * a.row_stride;
-    aux_v = (threadIdx.x < 3 * TILE && pos < npos) ? aux_src[o] : 0.f;
-    if constexpr (!DENSE) {   // slot 0 carries -(max + log2 sum), the addend of the exponent's fma (slot 1 is not read)
-      if (aux_which == 0 && pos < npos) aux_v = -(aux_v + a.lse[(int64_t)a.nhead * a.rows + o]);
-    }
+    aux_ok = pos < npos;
+    const int64_t o = (int64_t)head * a.rows + row0 + (int64_t)(aux_ok ? pos : 0) * a.row_stride;
+    aux_v = aux_src[o];
+    aux_w = aux_src2[o];
+  };
+  auto aux_value = [&]() {   // slot 0 carries -(max + log2 sum), the addend of the exponent's fma, unless the masks are dense (slot 1 is read then)
+    float v = aux_v;
+    if constexpr (!DENSE) v = aux_which == 0 ? -(aux_v + aux_w) : aux_v;
+    return aux_ok ? v : 0.f;
   };
   const int q_begin = (a.q_last_only && npos > 0) ? ((npos - 1) / TILE) * TILE : 0;   // pooled mode: only the last position's gradient is non-zero
   if (HD < 32) __syncthreads();
-  if (any_valid) {
-    stg.load(q_begin, 0, npos);
-    load_aux(q_begin);
-    stg.template store<TO>(sQb[0], sDOb[0]);
-    if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_v;
-  }
+  // (unconditional, also for a block whose keys are all padding: every path into the loop passes this store and with it the wait for
+  // the bk / bv loads above -- behind `if (any_valid)` the wait-count pass kept them pending on the other path and put vmcnt(0) in
+  // front of every step's first MFMA)
+  stg.load(q_begin, 0, npos);
+  load_aux(q_begin);
+  stg.template store<TO, true>(sQb[0], sDOb[0]);
+  if (threadIdx.x < 3 * TILE) sAux[0][threadIdx.x] = aux_value();
   __syncthreads();
   int cur = 0;
   for (int q0 = q_begin; any_valid && q0 < npos; q0 += TILE, cur ^= 1) {
@@ -661,8 +682,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attn_bwd_dkv(AttnArgs a) {
       dk[dt] = TO::mm(TO::tr(sQ, dt * 16, n, g), bds, dk[dt]);
     }
     if (more) {
-      stg.template store<TO>(sQb[cur ^ 1], sDOb[cur ^ 1]);
-      if (threadIdx.x < 3 * TILE) sAux[cur ^ 1][threadIdx.x] = aux_v;
+      stg.template store<TO, true>(sQb[cur ^ 1], sDOb[cur ^ 1]);
+      if (threadIdx.x < 3 * TILE) sAux[cur ^ 1][threadIdx.x] = aux_value();
     }
     __syncthreads();
   }
