@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(W1_THREADS, 1) k_lin1(L1Args a) {
       ra0 = *W1_CHUNK_PTR(c2, sr0);
       ra1 = *W1_CHUNK_PTR(c2, sr1);
     }
+    // (the loads are ISSUED here: hipcc's scheduler otherwise sinks them below the chunk's MFMAs, and the next chunk's wait at the top of
+    // the loop then sees their whole latency -- every chunk of a K = 384 / 512 tile)
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned char* st = smem1 + cur * W1_STAGE;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
