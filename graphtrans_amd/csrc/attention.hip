@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_bwd_dkv(AttnArgs a) {
   constexpr int DT = (HD + 15) / 16;
   __shared__ __attribute__((aligned(16))) LT sQb[2][TO::ELEMS];
   __shared__ __attribute__((aligned(16))) LT sDOb[2][TO::ELEMS];
-  __shared__ float sAux[2][3 * TILE];   // per query of the tile: running max, log2(sum), delta
+  __shared__ __attribute__((aligned(16))) float sAux[2][3 * TILE];   // per query of the tile: running max, log2(sum), delta
   int seq, tile_, head;
   if (!block_item(a, seq, tile_, head)) return;
   const int row0 = a.desc[seq * 4 + 0], npos = a.desc[seq * 4 + 1], kv_off = a.desc[seq * 4 + 2],
@@ -637,6 +637,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_bwd_dkv(AttnArgs a) {
     // (Sharing the pair's hash between lanes n and n ^ 1 -- each computes four of the eight and takes the rest by DPP -- was built
     // and measured: 45 us against 43 us for this form on the Code2 batch; the kernel is not bound by its VALU instruction count.)
     const uint32_t qmul0 = (uint32_t)(q0 + g * 8) * RNG_CQ;
+    // this lane group's 8 queries' statistics as four 16-byte LDS reads (they were sixteen ds_read_b32)
+    float a0v[8], dlv[8];
+    *reinterpret_cast<float4*>(a0v) = *reinterpret_cast<const float4*>(sLse + g * 8);
+    *reinterpret_cast<float4*>(a0v + 4) = *reinterpret_cast<const float4*>(sLse + g * 8 + 4);
+    *reinterpret_cast<float4*>(dlv) = *reinterpret_cast<const float4*>(sDelta + g * 8);
+    *reinterpret_cast<float4*>(dlv + 4) = *reinterpret_cast<const float4*>(sDelta + g * 8 + 4);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -652,7 +658,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_bwd_dkv(AttnArgs a) {
         const int qi = g * 8 + i;  // query row inside the tile owned by this slot
         const int qpos = q0 + qi;
         const bool ok = kvalid && qpos < npos;
-        const float a0 = sLse[qi], dlt = sDelta[qi];
+        const float a0 = a0v[i], dlt = dlv[i];
         float p;
         bool filled = false;
         if constexpr (!DENSE) {
