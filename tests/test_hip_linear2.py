@@ -99,6 +99,7 @@ def test_default_policy_takes_the_ring_kernel_only_where_it_is_meant_to():
     assert any(n.startswith("k_lin2") for n in names(4096, 256, 1024))
     assert any(n.startswith("k_lin1") for n in names(4096, 512, 128))
     assert any(n.startswith("k_lin2") for n in names(65536, 512, 128))
+    assert any(n.startswith("k_lin1") for n in names(65536, 256, 256))    # out_proj at d_model 256: the weight-stationary kernel is as fast
     assert any(n.startswith("k_linear_fwd") for n in names(1024, 256, 1024))   # below 2 048 rows: the tiled kernel
 
 
