@@ -37,4 +37,9 @@ for m in $modes; do
   db=$(find /tmp/pmc_mfma_$m -name "*.db" | head -1)
   python tools/rocpd_pmc.py $db k_ > gpurun_out/$tag/${tag}_code2_${m}_pmc_mfma.txt 2>&1 || true
 done
+# the same counters on the ER stress (attention at head_dim 64 / 513 tokens, the ring GEMMs): the headline mode only
+rm -rf /tmp/pmc_mfma_er
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU -d /tmp/pmc_mfma_er -o res -- python bench.py --workload er --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra > gpurun_out/$tag/pmc_mfma_er.log 2>&1 || true
+db=$(find /tmp/pmc_mfma_er -name "*.db" | head -1)
+python tools/rocpd_pmc.py $db k_ > gpurun_out/$tag/${tag}_er_mixed_pmc_mfma.txt 2>&1 || true
 ls gpurun_out/$tag
