@@ -824,15 +824,12 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
   for (int e = 0; e < 8; ++e) { gw[e] = a.w[col + e]; aw[e] = 0.f; ab[e] = 0.f; }
   const int64_t stride = (int64_t)gridDim.x * (NTB / 64) * RPW;
   int64_t row = ((int64_t)blockIdx.x * (NTB / 64) + wid) * RPW + sub;
-  // the next trip's operands are in flight while this trip is reduced -- bf16 rows: the next TWO trips (96 KB per CU instead of 48: at
-  // the ER stress' 131 k rows x 256 the kernel ran at the rate of its loads in flight, 3.2 TB/s; fp32 rows would not fit 128 registers)
-  constexpr bool DEEP = sizeof(T) == 2;
-  Row8<T> cx, cr, cd, nx, nr, nd, mx, mr, md;
-  float cmu, crs, nmu, nrs, mmu = 0.f, mrs = 0.f;
+  // the next trip's operands are in flight while this trip is reduced
+  Row8<T> cx, cr, cd, nx, nr, nd;
+  float cmu, crs, nmu, nrs;
   auto clampr = [&](int64_t r) { return r < a.rows ? r : a.rows - 1; };
   cr.zero();
   nr.zero();
-  mr.zero();
   {
     const int64_t q = clampr(row) * DD + col;
     cx.load(xin + q);
@@ -841,23 +838,8 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
     cmu = a.mean[clampr(row)];
     crs = a.rstd[clampr(row)];
   }
-  if constexpr (DEEP) {
-    const int64_t rn = clampr(row + stride), q = rn * DD + col;
-    nx.load(xin + q);
-    if (rin) nr.load(rin + q);
-    nd.load(dy + q);
-    nmu = a.mean[rn];
-    nrs = a.rstd[rn];
-  }
   for (; row - sub < a.rows; row += stride) {   // (uniform per wave: its four rows start at row - sub)
-    if constexpr (DEEP) {
-      const int64_t rn = clampr(row + 2 * stride), q = rn * DD + col;
-      mx.load(xin + q);
-      if (rin) mr.load(rin + q);
-      md.load(dy + q);
-      mmu = a.mean[rn];
-      mrs = a.rstd[rn];
-    } else {
+    {
       const int64_t rn = clampr(row + stride), q = rn * DD + col;
       nx.load(xin + q);
       if (rin) nr.load(rin + q);
@@ -906,7 +888,6 @@ __global__ void __launch_bounds__(NTB) k_ln_bwd_d128(LnArgs a) {
       }
     }
     cx = nx; cr = nr; cd = nd; cmu = nmu; crs = nrs;
-    if constexpr (DEEP) { nx = mx; nr = mr; nd = md; nmu = mmu; nrs = mrs; }
   }
   // the four row groups of a wave -> the waves of the block -> one partial row per block
 #pragma unroll
