@@ -129,3 +129,42 @@ def test_ring_gate_on_the_dx_output(M):
     assert bool((dz[f1 <= 0] == 0).all())
     assert rel(dza, ref + add.double()) < 4e-3
     assert rel(dzm, (dy.double() @ Wb) * mul.double()) < 4e-3
+
+
+def test_ring_kernel_on_strided_operands():
+    """Row pitches larger than the row length on both sides (column slices of wider buffers, as gt_linear_fwd_ld2 / _bwd_ld2 allow): the
+    ring kernel's DMA source addresses and its epilogue's stores follow ldx / ldy; the columns outside the slice stay untouched."""
+    from graphtrans_amd import _lib
+    from graphtrans_amd.graph import _stream
+    from graphtrans_amd.w3 import W1Images
+    M, N, K, ldx, ldy = 4099, 256, 768, 1024, 384
+    torch.manual_seed(5)
+    xw = torch.randn(M, ldx, device=DEV).to(BF)
+    x = xw[:, 128:128 + K]                       # 16-byte aligned column slice
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    imgs = W1Images([W])
+    imgs.build()
+    yw = torch.full((M, ldy), 7.0, dtype=BF, device=DEV)
+    y = yw[:, 64:64 + N]
+    with ring(2), imgs.bound():
+        _lib.launch("gt_linear_fwd_ld2", GT_BF16, GT_BF16, GT_BF16, x.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, ldx, ldy, 0, 0.0, 0, _stream())
+    torch.cuda.synchronize()
+    ref = x.double() @ W.to(BF).double().t() + b.double()
+    assert rel(y, ref) < 4e-3
+    assert bool((yw[:, :64] == 7.0).all()) and bool((yw[:, 64 + N:] == 7.0).all())
+    # dX = dY W on the same pitches (dY a slice of yw's shape, dX into a slice of a wide buffer), one addend
+    dyw = torch.randn(M, ldy, device=DEV).to(BF)
+    dy = dyw[:, 64:64 + N]
+    dxw = torch.full((M, ldx), -3.0, dtype=BF, device=DEV)
+    dx = dxw[:, 128:128 + K]
+    addw = torch.randn(M, ldx, device=DEV).to(BF)
+    add = addw[:, 128:128 + K]
+    ws_bytes = _lib.lib().gt_linear_bwd_workspace_bytes(GT_BF16, M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    with ring(2), imgs.bound():
+        _lib.launch("gt_linear_bwd_ld2", GT_BF16, GT_BF16, GT_BF16, None, W.data_ptr(), dy.data_ptr(), None, add.data_ptr(), None, dx.data_ptr(), None, None,
+                    M, N, K, ldx, ldy, 0.0, ws.data_ptr(), ws_bytes, _stream())
+    torch.cuda.synchronize()
+    assert rel(dx, dy.double() @ W.to(BF).double() + add.double()) < 4e-3
+    assert bool((dxw[:, :128] == -3.0).all()) and bool((dxw[:, 128 + K:] == -3.0).all())
